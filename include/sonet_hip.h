@@ -1,0 +1,155 @@
+/*
+ * sonet_hip.h -- C ABI of libsonet_hip.so: the MI355X (gfx950 / CDNA4) implementation of SO-Net's
+ * "SOM assignment -> grouped point feature" hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain DEVICE pointers,
+ * sizes and a HIP stream, launches asynchronously on that stream (no device synchronisation, no
+ * allocation) and returns a status code; sonet_last_error() gives the message for the calling
+ * thread.  No torch types cross this boundary.  The reference interface each function replaces is
+ * cited as file:line under the lijx10/SO-Net tree.  Host-side bindings (the python modules that
+ * mirror the reference operator API, and the stub a reference maintainer would add) are described
+ * in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors are dense, row-major ("contiguous" in torch terms), batch outermost;
+ *   - B = clouds in the batch, N = points per cloud, k = SOM nodes per point, kN = k*N,
+ *     M = SOM nodes, C / Cin / Cout = feature channels, L = columns (points) per cloud;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - pointers marked "nullable" may be NULL to skip that output;
+ *   - workspaces are caller-allocated; the callee initialises them on `stream`.
+ */
+#ifndef SONET_HIP_H
+#define SONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sonet_stream_t;
+
+enum {
+    SONET_OK = 0,
+    SONET_ERR_INVALID_ARG = 1, /* NULL pointer, non-positive size, id out of range, misaligned   */
+    SONET_ERR_UNSUPPORTED = 2, /* shape outside what the kernels instantiate (e.g. K > 1024)     */
+    SONET_ERR_LAUNCH = 3,      /* hipGetLastError() after the launch was not hipSuccess          */
+    SONET_ERR_NO_DEVICE = 4    /* no gfx950 device is current                                    */
+};
+
+/* Library identity: ABI version (bumped on any signature change) and build target ("gfx950"). */
+int sonet_abi_version(void);
+const char *sonet_build_arch(void);
+/* Message of the last non-OK status returned to this thread ("" if none). */
+const char *sonet_last_error(void);
+/* SONET_OK iff the current HIP device reports gcnArchName gfx950*. */
+int sonet_check_device(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * index_max  -- replaces index_max.forward_cuda / forward_cuda_shared_mem
+ *   reference: models/index_max_ext/index_max.cpp:132-148 (wrappers), index_max_cuda.cu:10-26,66-82
+ *   caller:    models/networks.py:180-184
+ * data  [B][C][Np] f32 (bf16 twin: raw bfloat16 bits), index [B][Np] i32 with 0 <= index < K,
+ * out_idx [B][C][K] i32 (fully overwritten).
+ * out_idx[b][c][m] = the position n of the maximum of { data[b][c][n] : index[b][n] == m } under the
+ * reference's sequential semantics: running max starts at -1000, position at 0, ascending n,
+ * strict '>'  =>  ties keep the smallest n; NaN, values <= -1000 and empty segments yield 0.
+ * Bit-exact with index_max_forward_cpu on identical inputs.
+ * sonet_index_max_gather_* additionally writes out_val[b][c][m] = data[b][c][ out_idx * row_max[b][m] ]
+ * (the masked gather of models/networks.py:185; row_max nullable = all ones), saving one pass.
+ * ---------------------------------------------------------------------------------------------- */
+int sonet_index_max_f32(const float *data, const int32_t *index, int32_t *out_idx,
+                        int B, int C, int Np, int K, sonet_stream_t stream);
+int sonet_index_max_bf16(const uint16_t *data, const int32_t *index, int32_t *out_idx,
+                         int B, int C, int Np, int K, sonet_stream_t stream);
+int sonet_index_max_gather_f32(const float *data, const int32_t *index, const int32_t *row_max,
+                               int32_t *out_idx, float *out_val,
+                               int B, int C, int Np, int K, sonet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * som_assign  -- replaces the body of BatchSOM.query_topk (and BatchSOM.query for k = 1)
+ *   reference: util/som.py:237-269 (:245-250 distance, :253 top-k, :261-267 outputs)
+ *   caller:    models/networks.py:127-128
+ * x [B][3][N] f32, node [B][3][M] f32, 1 <= k <= 4, k <= M <= 1024.
+ * Distance is ((dx*dx + dy*dy) + dz*dz) in f32 with separate multiplies and adds (no FMA), which
+ * is what aten evaluates for (diff**2).sum(dim=1).  The k smallest nodes of every point are written
+ * in canonical slot order -- ascending (distance, node id) -- k-major:
+ *   min_idx_i32[b][s*N + n] (always), min_idx_i64 (nullable; the dtype query_topk returns).
+ * count [B][M] i32   = number of point copies assigned to each node (= mask.sum(1), networks.py:128)
+ * sum_ws [B][3][M] f64 workspace = per-node coordinate sums of the assigned copies (f64 accumulation),
+ *   consumed by sonet_som_group_f32.  Both are zeroed by the callee on `stream`.
+ * ---------------------------------------------------------------------------------------------- */
+int sonet_som_assign_f32(const float *x, const float *node, int B, int N, int M, int k,
+                         int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                         sonet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * som_group  -- replaces the dense grouping block of Encoder.forward
+ *   reference: models/networks.py:128-172 (cluster mean :140-144, centers :168-169,
+ *              de-centre :171, concat with normals :172)
+ * Inputs: x, sn (nullable) [B][3][N] f32, min_idx_i32 [B][kN], count [B][M], sum_ws [B][3][M] f64.
+ * Outputs (each nullable):
+ *   som_node     [B][3][M]  = sum / (count + 1e-5)          (f32 division as the reference)
+ *   row_max      [B][M] i32 = count > 0                     (util/som.py:267 mask_row_max)
+ *   centers      [B][3][kN] = som_node gathered by min_idx
+ *   x_decentered [B][3][kN] = x_stack - centers
+ *   x_augmented  [B][6][kN] = cat(x_decentered, sn_stack)   (requires sn)
+ * ---------------------------------------------------------------------------------------------- */
+int sonet_som_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32,
+                        const int32_t *count, const double *sum_ws, int B, int N, int M, int k,
+                        float *som_node, int32_t *row_max, float *centers, float *x_decentered,
+                        float *x_augmented, sonet_stream_t stream);
+
+/* one-hot mask [B][kN][M] i32 from min_idx (util/som.py:254-265); materialised only on request
+ * (the reference's Encoder.mask attribute, read by models/segmenter.py:90). */
+int sonet_som_mask_i32(const int32_t *min_idx_i32, int32_t *mask, int B, int kN, int M,
+                       sonet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * knn_gather  -- replaces knn_gather_by_indexing / knn_gather_wrapper
+ *   reference: models/operations.py:19-54;  caller: models/layers.py:346,360
+ * x [B][C][M] f32, knn_I [B][M][K] i64 (0 <= id < M), out [B][C][M][K] f32 = x[b][c][knn_I[b][m][j]].
+ * ---------------------------------------------------------------------------------------------- */
+int sonet_knn_gather_f32(const float *x, const int64_t *knn_I, float *out,
+                         int B, int C, int M, int K, sonet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * pointmlp  -- fused point-wise layer: Conv1d/Conv2d(kernel 1) + per-channel affine + ReLU
+ *   reference: models/layers.py:282-296 (EquivariantLayer.forward), :199-211 (MyConv2d.forward),
+ *              BN at :60-70 / :112-120 (F.batch_norm); concat of models/layers.py:431 fused as x2.
+ *   y[b][o][l] = act( (sum_i W[o][i] * xcat[b][i][l]) * scale[o] + shift[o] ),
+ *   xcat = concat(x1 [B][C1][L], x2 [B][C2][L] (nullable, C2 = 0)) along channels, Cin = C1 + C2.
+ * Eval mode folds bias and BatchNorm running statistics into (scale, shift) on the host side;
+ * a layer without BN passes scale = 1, shift = bias.  relu != 0 applies max(.,0) (NaN propagates).
+ * Arithmetic: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), i.e. an f32 fma chain over i.
+ * W is passed PACKED: sonet_pointmlp_pack_size(Cin, Cout) floats produced by
+ * sonet_pointmlp_pack_f32 from the row-major [Cout][Cin] weight (device to device, on `stream`).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sonet_pointmlp_pack_size(int Cin, int Cout);
+int sonet_pointmlp_pack_f32(const float *W, float *Wp, int Cin, int Cout, sonet_stream_t stream);
+int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const float *Wp,
+                       const float *scale, const float *shift, int relu, float *y,
+                       int B, int Cout, int L, sonet_stream_t stream);
+
+/* Per-channel batch statistics of y [B][C][L] for training-mode BatchNorm (F.batch_norm with
+ * training=True, models/layers.py:68): mean[c], biased var[c] over (B, L), f64 accumulation.
+ * stat_ws: 2*C doubles of workspace, zeroed by the callee. */
+int sonet_channel_stats_f32(const float *y, int B, int C, int L, double *stat_ws,
+                            float *mean, float *var_biased, sonet_stream_t stream);
+/* y = act(y * scale[c] + shift[c]) in place (the normalise + ReLU pass of training mode). */
+int sonet_channel_affine_act_f32(float *y, const float *scale, const float *shift, int relu,
+                                 int B, int C, int L, sonet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * chamfer_nn ("next" row) -- replaces the faiss GpuIndexFlatL2 1-NN search
+ *   reference: models/losses.py:220-235 (search), :260-276 (per-sample loop)
+ * q [B][3][Nq], db [B][3][Nd] f32 -> nn [B][Nq] i32 = argmin_j ((dx*dx+dy*dy)+dz*dz), ties -> lowest j.
+ * ---------------------------------------------------------------------------------------------- */
+int sonet_chamfer_nn_f32(const float *q, const float *db, int32_t *nn, int B, int Nq, int Nd,
+                         sonet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONET_HIP_H */

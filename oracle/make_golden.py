@@ -1,0 +1,204 @@
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE: generate tests/golden/*.npz from the LIVE reference.
+
+Run in the build container (needs /root/reference):   python oracle/make_golden.py
+Each fixture holds seeded inputs and the outputs of the unmodified reference code on them
+(imported through oracle/ref_harness.py).  Weights are NOT stored: both sides regenerate them
+with sonet_hip.synth.fill_state_dict_(seed).  The fixtures are the pin for oracle/sonet_oracle.c
+(tests/test_oracle_golden.py) and, on the GPU box where /root/reference does not exist, for the
+HIP path (tests/test_*_gpu.py).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != HERE]
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness  # noqa: E402
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location(
+        "sonet_synth", os.path.join(ROOT, "so-net_amd", "sonet_hip", "synth.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_synth()
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(path, **out)
+    print("%-40s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------ index_max
+def golden_index_max(ref):
+    fwd, fwd_mt = ref.index_max.forward_cpu, ref.index_max.forward_multi_thread_cpu
+    g = torch.Generator().manual_seed(11)
+    # (1) plain random
+    B, C, N, K = 3, 24, 700, 64
+    data = torch.randn(B, C, N, generator=g)
+    index = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32)
+    out = fwd(data, index, K)
+    assert torch.equal(out, fwd_mt(data, index, K, 4))
+    save("index_max_random", data=data, index=index, K=K, out=out)
+    # (2) adversarial: ties, NaN, -inf/+inf, values <= -1000, -0.0/+0.0, empty nodes, quantised values
+    B, C, N, K = 2, 16, 513, 64
+    data = torch.randn(B, C, N, generator=g)
+    data = (data * 4).round() / 4                                   # heavy exact ties
+    data[0, 0, :] = 0.0                                             # all equal -> smallest n per node
+    data[0, 1, :] = -1000.0                                         # never beats the init value
+    data[0, 2, :] = -2000.0
+    data[0, 3, :] = float("nan")
+    data[0, 4, ::2] = float("nan")
+    data[0, 5, :] = -0.0
+    data[0, 5, 1::2] = 0.0                                          # +0.0 after -0.0: no update
+    data[0, 6, :] = 0.0
+    data[0, 6, 1::2] = -0.0
+    data[0, 7, 7] = float("inf")
+    data[0, 8, :] = float("-inf")
+    data[0, 9, :] = -1000.0
+    data[0, 9, 100] = -999.99994
+    data[1, 0, :] = torch.arange(N, dtype=torch.float32)            # strictly increasing
+    data[1, 1, :] = -torch.arange(N, dtype=torch.float32)           # strictly decreasing
+    data[1, 2, :] = 1e-42                                           # subnormal
+    data[1, 3, :] = -1e-42
+    index = torch.randint(0, K - 8, (B, N), generator=g, dtype=torch.int32)   # nodes K-8.. stay empty
+    index[1, :] = 5                                                 # one node owns every point
+    out = fwd(data, index, K)
+    assert torch.equal(out, fwd_mt(data, index, K, 3))
+    save("index_max_adversarial", data=data, index=index, K=K, out=out)
+    # (3) odd sizes: N not a multiple of anything, K != 64, C == 1, single point
+    for tag, (B, C, N, K) in {"odd": (2, 5, 1021, 37), "tiny": (1, 1, 1, 4), "k256": (1, 3, 999, 256),
+                              "k1": (2, 2, 130, 1)}.items():
+        data = torch.randn(B, C, N, generator=g)
+        index = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32)
+        save("index_max_" + tag, data=data, index=index, K=K, out=fwd(data, index, K))
+
+
+# ------------------------------------------------------------------------------------------ query_topk
+def golden_query_topk(ref):
+    for tag, (B, N, rows, seed, kind) in {"a": (2, 257, 8, 21, "uniform"), "b": (3, 1024, 8, 22, "som"),
+                                          "c": (1, 100, 4, 23, "uniform")}.items():
+        M = rows * rows
+        inp = synth.make_inputs(B, N, M=M, som_k=min(9, M), seed=seed, node_kind=kind)
+        bs = ref.som.BatchSOM(rows, rows, 3, 0, B)
+        arrays = dict(x=inp["pc"], node=inp["node"])
+        for k in (1, 2, 3):
+            bs.node.resize_(inp["node"].size()).copy_(inp["node"])
+            mask_u, rmax_u, idx_u = bs.query_topk(inp["pc"], k)                  # reference, as is
+            with ref_harness.sorted_topk():
+                mask_s, rmax_s, idx_s = bs.query_topk(inp["pc"], k)              # canonical slot order
+            assert torch.equal(rmax_u, rmax_s)
+            assert torch.equal(mask_u.sum(1), mask_s.sum(1))
+            arrays["min_idx_unsorted_k%d" % k] = idx_u
+            arrays["min_idx_sorted_k%d" % k] = idx_s
+            arrays["mask_row_max_k%d" % k] = rmax_s
+            arrays["mask_row_sum_k%d" % k] = mask_s.sum(1)
+            arrays["mask_dtype_k%d" % k] = str(mask_s.dtype)
+        save("query_topk_" + tag, **arrays)
+
+
+# ------------------------------------------------------------------------------------------ model forward
+def golden_classifier(ref, tag, B, N, seed, node_kind, k=3, som_k=9, som_k_type="avg"):
+    opt = ref_harness.make_opt(batch_size=B, input_pc_num=N, k=k, som_k=som_k, som_k_type=som_k_type,
+                               classes=40)
+    model = ref.classifier.Model(opt)
+    synth.fill_state_dict_(model.encoder.state_dict(), seed=seed)       # tensors alias the parameters
+    synth.fill_state_dict_(model.classifier.state_dict(), seed=seed + 1)
+    inp = synth.make_inputs(B, N, M=opt.node_num, som_k=som_k, seed=seed, node_kind=node_kind)
+    model.set_input(inp["pc"], inp["sn"], inp["label"], inp["node"], inp["node_knn_I"])
+    with ref_harness.sorted_topk(), torch.no_grad():
+        model.test_model()
+    enc = model.encoder
+    min_idx = enc.mask.argmax(dim=2)                                     # segmenter.py:90
+    first = enc.first_pn_out
+    save("classifier_" + tag,
+         B=B, N=N, k=k, som_k=som_k, som_k_type=som_k_type, seed=seed, node_kind=node_kind,
+         pc=inp["pc"], sn=inp["sn"], node=inp["node"], node_knn_I=inp["node_knn_I"], label=inp["label"],
+         min_idx=min_idx, mask_row_sum=enc.mask.sum(1), som_node=enc.som_node, centers=enc.centers[:, :, ::7],
+         x_decentered=enc.x_decentered[:, :, ::7],
+         first_pn_out_sub=first[:, ::16, ::5], first_pn_out_rms=first.pow(2).mean().sqrt(),
+         first_pn_out_masked_max=enc.first_pn_out_masked_max,
+         knn_center_1=enc.knn_center_1, knn_feature_1=enc.knn_feature_1[:, ::4],
+         final_pn_out=enc.final_pn_out[:, ::4], feature=enc.feature, score=model.score, loss=model.loss)
+    return model, inp
+
+
+def golden_layers(ref):
+    """EquivariantLayer / PointResNet / KNNModule in isolation, eval and train mode."""
+    g = torch.Generator().manual_seed(31)
+    L = ref.layers
+    arrays = {}
+    # eval + train single layer 6 -> 64 with BN + relu
+    x = torch.randn(2, 6, 300, generator=g)
+    layer = L.EquivariantLayer(6, 64, "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(layer.state_dict(), seed=5)
+    layer.eval()
+    with torch.no_grad():
+        arrays["eq_eval_y"] = layer(x)
+    layer.train()
+    y = layer(x, epoch=None)
+    arrays["eq_x"] = x
+    arrays["eq_train_y"] = y
+    arrays["eq_train_running_mean"] = layer.norm.running_mean.clone()
+    arrays["eq_train_running_var"] = layer.norm.running_var.clone()
+    arrays["eq_train_num_batches_tracked"] = layer.norm.num_batches_tracked.clone()
+    gy = torch.randn(y.shape, generator=g)
+    xg = x.clone().requires_grad_(True)
+    synth.fill_state_dict_(layer.state_dict(), seed=5)
+    y2 = layer(xg)
+    y2.backward(gy)
+    arrays["eq_gy"] = gy
+    arrays["eq_train_gx"] = xg.grad
+    arrays["eq_train_gw"] = layer.conv.weight.grad
+    arrays["eq_train_gb"] = layer.conv.bias.grad
+    arrays["eq_train_ggamma"] = layer.norm.weight.grad
+    arrays["eq_train_gbeta"] = layer.norm.bias.grad
+    # momentum decay rule (layers.py:60-65)
+    layer2 = L.EquivariantLayer(6, 64, "relu", "batch", 0.5, 2, 0.6)
+    synth.fill_state_dict_(layer2.state_dict(), seed=6)
+    layer2.train()
+    layer2(x, epoch=5)
+    arrays["eq_decay_momentum"] = layer2.norm.momentum
+    arrays["eq_decay_running_mean"] = layer2.norm.running_mean.clone()
+    # PointResNet 6 -> [64,128,256,384] eval
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.eval()
+    with torch.no_grad():
+        arrays["prn_eval_y"] = pr(x)[:, ::8]
+    save("layers", **arrays)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = ref_harness.import_reference()
+    golden_index_max(ref)
+    golden_query_topk(ref)
+    golden_layers(ref)
+    golden_classifier(ref, "b2_n256", B=2, N=256, seed=101, node_kind="uniform")
+    golden_classifier(ref, "b8_n1024", B=8, N=1024, seed=102, node_kind="som")          # BASELINE configs[0]
+    golden_classifier(ref, "b2_n5000", B=2, N=5000, seed=103, node_kind="som")          # configs[1] shape
+    golden_classifier(ref, "b2_n300_k1_center", B=2, N=300, seed=104, node_kind="uniform", k=1,
+                      som_k=5, som_k_type="center")
+
+
+if __name__ == "__main__":
+    main()

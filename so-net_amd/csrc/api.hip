@@ -1,0 +1,39 @@
+// api.hip -- library identity and error plumbing of libsonet_hip.so.
+#include "common.hpp"
+#include <string.h>
+
+namespace sonet {
+
+char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace sonet
+
+extern "C" int sonet_abi_version(void) { return 1; }
+extern "C" const char *sonet_build_arch(void) { return "gfx950"; }
+extern "C" const char *sonet_last_error(void) { return sonet::err_buf(); }
+
+extern "C" int sonet_check_device(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+        (void)hipGetLastError();
+        return sonet::fail(SONET_ERR_NO_DEVICE, "sonet_check_device: no HIP device is current");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return sonet::fail(SONET_ERR_NO_DEVICE, "sonet_check_device: hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return sonet::fail(SONET_ERR_NO_DEVICE, "sonet_check_device: device %d is %s, this library is built for gfx950 only",
+                           dev, prop.gcnArchName);
+    return SONET_OK;
+}

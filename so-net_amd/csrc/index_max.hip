@@ -1,0 +1,176 @@
+// index_max.hip -- per-node segmented arg-max pool for gfx950 (MI355X).
+//
+// Replaces models/index_max_ext/index_max_cuda.cu:10-26 (one CUDA *thread* per (b,c) row, scanning
+// its N' values serially and uncoalesced) and its CPU twin index_max.cpp:73-112.
+//
+// Design (HBM-bound, 23.2 MB per cloud at C=384, N'=15000 -- DESIGN.md "index_max"):
+//   * one 256-thread workgroup owns R consecutive channel rows of ONE cloud; its 4 waves stream
+//     disjoint 256-element chunks of those rows with 16-byte loads (64 lanes x float4 = 1 KiB per
+//     instruction, fully coalesced along n).  The node-id chunk (int4) is loaded once per chunk and
+//     reused for the R rows, so the shared B x N' id row costs 1/R of the data traffic and stays in L2.
+//   * per row, K bins live in LDS as packed 64-bit keys  (orderable(value) << 32) | (0xFFFFFFFF - n).
+//     "key > bin" is exactly "this element beats the running maximum under the reference's sequential
+//     strict-'>' scan" (bigger value wins, equal value -> smaller n wins).  Each element does one
+//     ds_read_b64 of its bin and only the rare record-breakers (about ln(n) per bin) issue a
+//     ds_max_u64, so LDS atomics never limit the stream.  Integer max is order-independent, hence the
+//     result is deterministic and identical to the sequential scan.
+//   * bins start at (orderable(-1000) << 32 | 0xFFFFFFFF) == "value -1000 at position 0": values
+//     <= -1000, NaN (mapped to key 0) and empty segments leave position 0, as the reference does.
+//     -0.0 is canonicalised to +0.0 first because IEEE '>' treats them as equal.
+//   * epilogue: one coalesced store of the R x K positions (and, for the gather variant, the value at
+//     that position, masked by row_max -- models/networks.py:185).
+//   * workgroup ids are remapped so that the ~C/R workgroups of a cloud run on one XCD and share its
+//     L2 copy of the id row (speed only).
+#include "common.hpp"
+
+namespace {
+
+constexpr int IM_THREADS = 256;
+constexpr unsigned long long IM_INIT_KEY = (0x3B85FFFFull << 32) | 0xFFFFFFFFull;  // ord(-1000.0f) = ~0xC47A0000, n = 0
+
+__device__ __forceinline__ unsigned ord_f32(unsigned bits) {
+    // total order on floats as unsigned ints; -0.0 == +0.0; NaN -> 0 (never wins)
+    if (bits == 0x80000000u) bits = 0u;
+    const unsigned mag = bits & 0x7FFFFFFFu;
+    const unsigned o = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+    return mag > 0x7F800000u ? 0u : o;
+}
+static_assert((0xC47A0000u ^ 0xFFFFFFFFu) == 0x3B85FFFFu, "ord(-1000) check");
+
+__device__ __forceinline__ void im_update(unsigned long long *bins, int id, int K, unsigned vbits, unsigned n) {
+    if ((unsigned)id >= (unsigned)K) return;  // out-of-range id: ignored (the reference would corrupt memory)
+    const unsigned long long key = ((unsigned long long)ord_f32(vbits) << 32) | (unsigned long long)(0xFFFFFFFFu - n);
+    if (key > bins[id]) atomicMax(&bins[id], key);
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    using type = float4;
+    static __device__ __forceinline__ void bits(const float4 &v, unsigned (&o)[4]) {
+        o[0] = __float_as_uint(v.x); o[1] = __float_as_uint(v.y); o[2] = __float_as_uint(v.z); o[3] = __float_as_uint(v.w);
+    }
+    static __device__ __forceinline__ unsigned bits1(float v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+};
+template <> struct Vec4<uint16_t> {  // bfloat16 bits
+    using type = ushort4;
+    static __device__ __forceinline__ void bits(const ushort4 &v, unsigned (&o)[4]) {
+        o[0] = (unsigned)v.x << 16; o[1] = (unsigned)v.y << 16; o[2] = (unsigned)v.z << 16; o[3] = (unsigned)v.w << 16;
+    }
+    static __device__ __forceinline__ unsigned bits1(uint16_t v) { return (unsigned)v << 16; }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
+};
+
+// R rows per workgroup; VEC = true requires Np % 4 == 0 (16-byte aligned rows).
+template <typename T, int R, bool VEC>
+__global__ __launch_bounds__(IM_THREADS) void index_max_kernel(
+    const T *__restrict__ data, const int32_t *__restrict__ index, const int32_t *__restrict__ row_max,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_val, int C, int Np, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];  // [R][K]
+    const int tid = threadIdx.x;
+    const int grp = xcd_remap(blockIdx.x, gridDim.x);
+    const long long row0 = (long long)grp * R;        // flattened (b*C + c); R divides C
+    const int b = (int)(row0 / C);
+    const T *drow = data + row0 * (long long)Np;
+    const int32_t *irow = index + (long long)b * Np;
+
+    for (int i = tid; i < R * K; i += IM_THREADS) bins[i] = IM_INIT_KEY;
+    __syncthreads();
+
+    if constexpr (VEC) {
+        using V = typename Vec4<T>::type;
+        const int nvec = Np >> 2;
+#pragma unroll 2
+        for (int v = tid; v < nvec; v += IM_THREADS) {
+            const int4 id = reinterpret_cast<const int4 *>(irow)[v];
+            V d[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) d[r] = reinterpret_cast<const V *>(drow + (long long)r * Np)[v];
+            const unsigned n = (unsigned)v << 2;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                unsigned vb[4];
+                Vec4<T>::bits(d[r], vb);
+                unsigned long long *bb = bins + r * K;
+                im_update(bb, id.x, K, vb[0], n);
+                im_update(bb, id.y, K, vb[1], n + 1);
+                im_update(bb, id.z, K, vb[2], n + 2);
+                im_update(bb, id.w, K, vb[3], n + 3);
+            }
+        }
+    } else {
+        for (int n = tid; n < Np; n += IM_THREADS) {
+            const int id = irow[n];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                im_update(bins + r * K, id, K, Vec4<T>::bits1(drow[(long long)r * Np + n]), (unsigned)n);
+        }
+    }
+    __syncthreads();
+
+    for (int i = tid; i < R * K; i += IM_THREADS) {
+        const int r = i / K, m = i - r * K;
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(bins[i] & 0xFFFFFFFFull));
+        out_idx[(row0 + r) * K + m] = pos;
+        if (out_val != nullptr) {
+            const int g = (row_max == nullptr || row_max[(long long)b * K + m] != 0) ? pos : 0;
+            out_val[(row0 + r) * K + m] = Vec4<T>::to_f32(drow[(long long)r * Np + g]);
+        }
+    }
+}
+
+template <typename T>
+int launch_index_max(const T *data, const int32_t *index, const int32_t *row_max, int32_t *out_idx,
+                     float *out_val, int B, int C, int Np, int K, hipStream_t st, const char *what)
+{
+    SONET_REQUIRE(data && index && out_idx, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && Np > 0 && K > 0, "%s: non-positive size B=%d C=%d Np=%d K=%d", what, B, C, Np, K);
+    if (K > 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: K=%d > 1024 bins", what, K);
+    const bool vec = (Np % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(index) & 15) == 0);
+    // rows per workgroup: as many as divide C (id-chunk reuse), but keep >= ~4 workgroups per CU in flight
+    int R = 1;
+    const long long rows = (long long)B * C;
+    for (int cand : {8, 4, 2}) {
+        if (C % cand == 0 && rows / cand >= 1024 && (size_t)cand * K * 8 <= 32768) { R = cand; break; }
+    }
+    if (R == 1) for (int cand : {4, 2}) if (C % cand == 0 && (size_t)cand * K * 8 <= 32768) { R = cand; break; }
+    const long long nwg = rows / R;
+    if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many rows", what);
+    const size_t lds = (size_t)R * K * sizeof(unsigned long long);
+    dim3 grid((unsigned)nwg), block(IM_THREADS);
+#define IM_LAUNCH(RR, VV) \
+    hipLaunchKernelGGL((index_max_kernel<T, RR, VV>), grid, block, lds, st, data, index, row_max, out_idx, out_val, C, Np, K)
+    if (vec) {
+        switch (R) { case 8: IM_LAUNCH(8, true); break; case 4: IM_LAUNCH(4, true); break;
+                     case 2: IM_LAUNCH(2, true); break; default: IM_LAUNCH(1, true); }
+    } else {
+        switch (R) { case 8: IM_LAUNCH(8, false); break; case 4: IM_LAUNCH(4, false); break;
+                     case 2: IM_LAUNCH(2, false); break; default: IM_LAUNCH(1, false); }
+    }
+#undef IM_LAUNCH
+    return sonet::launched(what);
+}
+
+}  // namespace
+
+extern "C" int sonet_index_max_f32(const float *data, const int32_t *index, int32_t *out_idx,
+                                   int B, int C, int Np, int K, sonet_stream_t stream) {
+    return launch_index_max<float>(data, index, nullptr, out_idx, nullptr, B, C, Np, K, sonet::as_stream(stream),
+                                   "sonet_index_max_f32");
+}
+
+extern "C" int sonet_index_max_bf16(const uint16_t *data, const int32_t *index, int32_t *out_idx,
+                                    int B, int C, int Np, int K, sonet_stream_t stream) {
+    return launch_index_max<uint16_t>(data, index, nullptr, out_idx, nullptr, B, C, Np, K, sonet::as_stream(stream),
+                                      "sonet_index_max_bf16");
+}
+
+extern "C" int sonet_index_max_gather_f32(const float *data, const int32_t *index, const int32_t *row_max,
+                                          int32_t *out_idx, float *out_val, int B, int C, int Np, int K,
+                                          sonet_stream_t stream) {
+    SONET_REQUIRE(out_val, "sonet_index_max_gather_f32: out_val is NULL");
+    return launch_index_max<float>(data, index, row_max, out_idx, out_val, B, C, Np, K, sonet::as_stream(stream),
+                                   "sonet_index_max_gather_f32");
+}

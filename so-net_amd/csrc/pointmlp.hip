@@ -1,0 +1,288 @@
+// pointmlp.hip -- fused point-wise layer (Conv 1x1 + per-channel affine + ReLU) on exact-f32 MFMA.
+//
+// Replaces, per layer, the three aten launches of EquivariantLayer.forward (models/layers.py:282-296:
+// conv1d -> batch_norm -> relu) and MyConv2d.forward (:199-211); the channel concat of
+// PointResNet.forward (models/layers.py:431) is fused as a second input panel.
+//
+//   y[b][o][l] = act( (sum_i W[o][i] * xcat[b][i][l]) * scale[o] + shift[o] )
+//
+// GEMM view: D[Cout x P] = W[Cout x Cin] . X[Cin x P] with P = B*L points.  Cin is tiny (6..515) and
+// P is huge (960k at B=64, N=5000, k=3), so the layer is a "tall-skinny" GEMM whose X panel is read
+// once and whose W is shared by every workgroup.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact f32 = an fma chain, guide section 3):
+//   A (32 x 2)  <- W     lane l: A[i = l&31][k = l>>5]
+//   B (2 x 32)  <- X     lane l: B[k = l>>5][j = l&31]     j runs along POINTS -> the 32 lanes of a
+//                        half-wave read 128 contiguous bytes of one channel row (the B x C x L layout
+//                        is already "N-major" for this operand: no transpose, no LDS staging).
+//   D (32 x 32)          lane l, reg r: D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+//                        -> per register the half-waves store 128 contiguous bytes of one output row.
+// W is pre-packed once per weight update (sonet_pointmlp_pack_f32) into exactly the A-fragment order:
+//   Wp[ct][g][lane][s] = W[ct*32 + (lane&31)][8*g + 2*s + (lane>>5)],  s = 0..3, zero padded,
+// so one global_load_dwordx4 per lane feeds four K-steps and the whole wave reads 1 KiB contiguous.
+// W (<= 2 MB) is read by every wave and stays L1/L2-resident; HBM sees X once per cout pass and Y once.
+//
+// Work split: a wave owns NT groups of 32 consecutive points of one cloud and MT cout-tiles at a time
+// (MT*NT accumulators of 16 VGPRs); a 256-thread workgroup = 4 waves on 4 adjacent point groups (they
+// hit the same W lines together).  gridDim.y splits the cout tiles when there are too few point
+// groups to fill 256 CUs (the node-level layers with L = 64 or 576 columns per cloud).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PM_THREADS = 256;
+constexpr int PM_WAVES = PM_THREADS / 64;
+
+__global__ __launch_bounds__(256) void pointmlp_pack_kernel(const float *__restrict__ W, float *__restrict__ Wp,
+                                                             int Cin, int Cout, int G, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int s = (int)(t & 3);
+    const int lane = (int)((t >> 2) & 63);
+    const long long r = t >> 8;            // ct*G + g
+    const int g = (int)(r % G);
+    const int ct = (int)(r / G);
+    const int o = ct * 32 + (lane & 31);
+    const int i = 8 * g + 2 * s + (lane >> 5);
+    Wp[t] = (o < Cout && i < Cin) ? W[(long long)o * Cin + i] : 0.f;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void pm_accumulate(f32x16 (&acc)[MT][NT], const float *const (&xp)[NT], const bool (&pv)[NT],
+                                              int Cx, long long L, const float4 *__restrict__ wp4, int G, int g0, int ng, int h)
+{
+    // xp[nt] points at x[b][0][p] of this lane's point; channel stride is L floats
+    for (int g = 0; g < ng; ++g) {
+        float4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = wp4[((long long)mt * G + (g0 + g)) * 64];
+        float bv[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = 8 * g + 2 * s + h;
+                float v = 0.f;
+                if (pv[nt] && c < Cx) v = xp[nt][(long long)c * L];
+                bv[nt][s] = v;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float av = s == 0 ? a[mt].x : s == 1 ? a[mt].y : s == 2 ? a[mt].z : a[mt].w;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt][s], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_kernel(
+    const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const float *__restrict__ Wp,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
+    int Cout, int L, int gpc /*32-point groups per cloud*/, long long ngroups, int CT, int G, int ct_per_y)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int G1 = C2 > 0 ? C1 / 8 : G;                     // groups fed by x1 (C1 % 8 == 0 when C2 > 0)
+    const int G2 = G - G1;
+
+    const float *xp1[NT], *xp2[NT];
+    bool pv[NT];
+    long long ybase[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const long long q = ((long long)blockIdx.x * PM_WAVES + wave) * NT + nt;   // global 32-point group
+        const long long b = q / gpc;
+        const int l = (int)(q - b * gpc) * 32 + j;
+        pv[nt] = q < ngroups && l < L;
+        xp1[nt] = x1 + (b * C1) * (long long)L + l;
+        xp2[nt] = x2 ? x2 + (b * C2) * (long long)L + l : nullptr;
+        ybase[nt] = (b * Cout) * (long long)L + l;
+    }
+
+    const int ct_begin = blockIdx.y * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {     // CT and ct_per_y are multiples of MT
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+        const float4 *wp4 = reinterpret_cast<const float4 *>(Wp) + (long long)ct0 * G * 64 + lane;
+        pm_accumulate<MT, NT>(acc, xp1, pv, C1, L, wp4, G, 0, G1, h);
+        if (G2 > 0) pm_accumulate<MT, NT>(acc, xp2, pv, C2, L, wp4, G, G1, G2, h);
+
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (ct0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < Cout) {
+                    const float sc = scale[o], sh = shift[o];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = __fmaf_rn(acc[mt][nt][r], sc, sh);
+                        if (relu) v = (v < 0.f) ? 0.f : v;      // NaN propagates like aten's relu
+                        if (pv[nt]) y[ybase[nt] + (long long)o * L] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- training-mode BatchNorm support: per-channel statistics and the normalise + ReLU pass --------
+constexpr int ST_THREADS = 256;
+
+// grid (chunks, C): each workgroup reduces one chunk of one channel over (b, l); f64 partials are
+// combined with f64 atomics into stat_ws[2*C] = {sum[c], sumsq[c]}.
+__global__ __launch_bounds__(ST_THREADS) void channel_stats_kernel(const float *__restrict__ y, int B, int C, int L,
+                                                                    double *__restrict__ stat_ws)
+{
+    const int c = blockIdx.y;
+    const long long per_c = (long long)B * L;
+    const long long chunk = (per_c + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * chunk, end = min(per_c, beg + chunk);
+    double s = 0.0, s2 = 0.0;
+    for (long long t = beg + threadIdx.x; t < end; t += ST_THREADS) {
+        const long long b = t / L;
+        const float v = y[(b * C + c) * (long long)L + (t - b * L)];
+        s += (double)v;
+        s2 += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double red[2][ST_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, a2 = 0.0;
+        for (int w = 0; w < ST_THREADS / 64; ++w) { a += red[0][w]; a2 += red[1][w]; }
+        unsafeAtomicAdd(&stat_ws[c], a);
+        unsafeAtomicAdd(&stat_ws[C + c], a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_stats_finalize_kernel(const double *__restrict__ stat_ws, int C, double inv_n,
+                                                                      float *__restrict__ mean, float *__restrict__ var)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double m = stat_ws[c] * inv_n;
+    double v = stat_ws[C + c] * inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+}
+
+__global__ __launch_bounds__(256) void channel_affine_act_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift, int relu, int C, int L,
+                                                                  long long total)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int c = (int)((t / L) % C);
+        float v = __fmaf_rn(y[t], scale[c], shift[c]);
+        if (relu) v = (v < 0.f) ? 0.f : v;
+        y[t] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sonet_pointmlp_pack_size(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 8) * 256;
+}
+
+extern "C" int sonet_pointmlp_pack_f32(const float *W, float *Wp, int Cin, int Cout, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_pack_f32";
+    SONET_REQUIRE(W && Wp, "%s: NULL pointer", what);
+    SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
+    const long long total = (long long)sonet_pointmlp_pack_size(Cin, Cout);
+    hipLaunchKernelGGL(pointmlp_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0,
+                       sonet::as_stream(stream), W, Wp, Cin, Cout, sonet::ceil_div(Cin, 8), total);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const float *Wp,
+                                  const float *scale, const float *shift, int relu, float *y,
+                                  int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_f32";
+    SONET_REQUIRE(x1 && Wp && scale && shift && y, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
+    SONET_REQUIRE(C2 == 0 || C1 % 8 == 0, "%s: with a second input C1=%d must be a multiple of 8", what, C1);
+    const int Cin = C1 + C2;
+    const int CT = sonet::ceil_div(Cout, 32), G = sonet::ceil_div(Cin, 8);
+    const int gpc = sonet::ceil_div(L, 32);
+    const long long ngroups = (long long)B * gpc;
+    // cout tiles per accumulator pass
+    const int MT = (CT % 4 == 0) ? 4 : (CT % 2 == 0) ? 2 : 1;
+    const int NT = 1;
+    const long long nwg_x = sonet::ceil_div64(ngroups, (long long)PM_WAVES * NT);
+    // split the cout tiles over gridDim.y when the point axis alone cannot fill the chip
+    int ysplit = 1;
+    while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    const int ct_per_y = CT / ysplit;
+    if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+    dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(PM_THREADS);
+    hipStream_t st = sonet::as_stream(stream);
+#define PM_LAUNCH(MM, NN) \
+    hipLaunchKernelGGL((pointmlp_f32_kernel<MM, NN>), grid, block, 0, st, x1, C1, x2, C2, Wp, scale, shift, relu, y, \
+                       Cout, L, gpc, ngroups, CT, G, ct_per_y)
+    switch (MT) { case 4: PM_LAUNCH(4, 1); break; case 2: PM_LAUNCH(2, 1); break; default: PM_LAUNCH(1, 1); }
+#undef PM_LAUNCH
+    (void)NT;
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_channel_stats_f32(const float *y, int B, int C, int L, double *stat_ws, float *mean,
+                                       float *var_biased, sonet_stream_t stream)
+{
+    const char *what = "sonet_channel_stats_f32";
+    SONET_REQUIRE(y && stat_ws && mean && var_biased, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0, "%s: non-positive size", what);
+    if (C > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d > 65535", what, C);
+    hipStream_t st = sonet::as_stream(stream);
+    if (hipMemsetAsync(stat_ws, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    const long long per_c = (long long)B * L;
+    int chunks = (int)sonet::ceil_div64(per_c, 16384);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks, C), dim3(ST_THREADS), 0, st, y, B, C, L, stat_ws);
+    hipLaunchKernelGGL(channel_stats_finalize_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, st,
+                       stat_ws, C, 1.0 / (double)per_c, mean, var_biased);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_channel_affine_act_f32(float *y, const float *scale, const float *shift, int relu,
+                                            int B, int C, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_channel_affine_act_f32";
+    SONET_REQUIRE(y && scale && shift, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0, "%s: non-positive size", what);
+    const long long total = (long long)B * C * L;
+    long long blocks = sonet::ceil_div64(total, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(channel_affine_act_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
+                       y, scale, shift, relu, C, L, total);
+    return sonet::launched(what);
+}

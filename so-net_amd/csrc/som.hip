@@ -1,0 +1,255 @@
+// som.hip -- SOM assignment, grouping, one-hot mask and node-kNN gather kernels for gfx950.
+//
+//   som_assign : util/som.py:237-269 (BatchSOM.query_topk) + node counts (models/networks.py:128)
+//                + per-node coordinate sums (the numerator of the cluster mean, networks.py:140-142)
+//   som_group  : models/networks.py:140-172 (cluster mean, centers, de-centre, concat normals)
+//   som_mask   : util/som.py:254-265 (the one-hot B x kN x M mask, only when a caller asks for it)
+//   knn_gather : models/operations.py:38-54
+//
+// The reference materialises B x 3 x N x M and two B x 3 x kN x M f32 temporaries (11.5 MB per cloud
+// each at N=5000) to do this; here a point is read once (12 B), its k node ids are written once
+// (4 B each) and the only cross-point state -- 64 counts and 192 sums per cloud -- lives in LDS.
+//
+// Arithmetic contract (bit-exact node sets): d = (dx*dx + dy*dy) + dz*dz with separate f32 multiplies
+// and adds.  This file is compiled with -ffp-contract=off AND uses __fmul_rn/__fadd_rn so that no
+// FMA contraction can change a comparison.  Selection is a k-deep insertion list kept in VGPRs,
+// nodes visited in ascending id with strict '<', so ties keep the lower id and slots come out in
+// ascending (distance, id) order -- the canonical order of torch.topk(sorted=True).
+#include "common.hpp"
+
+namespace {
+
+constexpr int SA_THREADS = 256;
+
+__device__ __forceinline__ float sqdist(float px, float py, float pz, const float4 nd) {
+    const float dx = __fsub_rn(px, nd.x), dy = __fsub_rn(py, nd.y), dz = __fsub_rn(pz, nd.z);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// LDS layout (dynamic): float4 nodes[M] | double sums[3][M] | unsigned cnt[M]
+template <int KSEL>
+__global__ __launch_bounds__(SA_THREADS) void som_assign_kernel(
+    const float *__restrict__ x, const float *__restrict__ node, int N, int M,
+    int32_t *__restrict__ min32, int64_t *__restrict__ min64, int32_t *__restrict__ count,
+    double *__restrict__ sum_ws)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *nodes = reinterpret_cast<float4 *>(smem);
+    double *sums = reinterpret_cast<double *>(smem + (size_t)M * sizeof(float4));
+    unsigned *cnt = reinterpret_cast<unsigned *>(smem + (size_t)M * (sizeof(float4) + 3 * sizeof(double)));
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *nb = node + (size_t)b * 3 * M;
+    for (int m = tid; m < M; m += SA_THREADS) {
+        nodes[m] = make_float4(nb[m], nb[M + m], nb[2 * M + m], 0.f);
+        sums[m] = 0.0; sums[M + m] = 0.0; sums[2 * M + m] = 0.0;
+        cnt[m] = 0u;
+    }
+    __syncthreads();
+
+    const int n = blockIdx.x * SA_THREADS + tid;
+    if (n < N) {
+        const float px = xb[n], py = xb[N + n], pz = xb[2 * (size_t)N + n];
+        float bd[KSEL];
+        int bi[KSEL];
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) { bd[s] = __builtin_inff(); bi[s] = 0; }
+#pragma unroll 4
+        for (int m = 0; m < M; ++m) {
+            const float d = sqdist(px, py, pz, nodes[m]);
+            bool c[KSEL];
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) c[s] = d < bd[s];
+#pragma unroll
+            for (int s = KSEL - 1; s >= 1; --s) {
+                bd[s] = c[s - 1] ? bd[s - 1] : (c[s] ? d : bd[s]);
+                bi[s] = c[s - 1] ? bi[s - 1] : (c[s] ? m : bi[s]);
+            }
+            bd[0] = c[0] ? d : bd[0];
+            bi[0] = c[0] ? m : bi[0];
+        }
+        const size_t kN = (size_t)KSEL * N;
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) {
+            const size_t o = (size_t)b * kN + (size_t)s * N + n;
+            min32[o] = bi[s];
+            if (min64 != nullptr) min64[o] = bi[s];
+            atomicAdd(&cnt[bi[s]], 1u);
+            atomicAdd(&sums[bi[s]], (double)px);
+            atomicAdd(&sums[M + bi[s]], (double)py);
+            atomicAdd(&sums[2 * M + bi[s]], (double)pz);
+        }
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += SA_THREADS) {
+        const unsigned c = cnt[m];
+        if (c != 0u) {
+            atomicAdd(&count[(size_t)b * M + m], (int)c);
+            double *ws = sum_ws + (size_t)b * 3 * M;
+            unsafeAtomicAdd(&ws[m], sums[m]);
+            unsafeAtomicAdd(&ws[M + m], sums[M + m]);
+            unsafeAtomicAdd(&ws[2 * M + m], sums[2 * M + m]);
+        }
+    }
+}
+
+constexpr int SG_THREADS = 256;
+constexpr int SG_PER_THREAD = 4;
+
+__global__ __launch_bounds__(SG_THREADS) void som_group_kernel(
+    const float *__restrict__ x, const float *__restrict__ sn, const int32_t *__restrict__ min32,
+    const int32_t *__restrict__ count, const double *__restrict__ sum_ws, int N, int M, int k,
+    float *__restrict__ som_node, int32_t *__restrict__ row_max, float *__restrict__ centers,
+    float *__restrict__ x_dec, float *__restrict__ x_aug)
+{
+    extern __shared__ __attribute__((aligned(16))) float mean[];  // [3][M]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const double *ws = sum_ws + (size_t)b * 3 * M;
+    for (int m = tid; m < M; m += SG_THREADS) {
+        const int c = count[(size_t)b * M + m];
+        const float denom = __fadd_rn((float)c, 1e-5f);          // networks.py:142
+        const float mx = __fdiv_rn((float)ws[m], denom);
+        const float my = __fdiv_rn((float)ws[M + m], denom);
+        const float mz = __fdiv_rn((float)ws[2 * M + m], denom);
+        mean[m] = mx; mean[M + m] = my; mean[2 * M + m] = mz;
+        if (blockIdx.x == 0) {
+            if (som_node != nullptr) {
+                float *o = som_node + (size_t)b * 3 * M;
+                o[m] = mx; o[M + m] = my; o[2 * M + m] = mz;
+            }
+            if (row_max != nullptr) row_max[(size_t)b * M + m] = c > 0;
+        }
+    }
+    __syncthreads();
+    if (centers == nullptr && x_dec == nullptr && x_aug == nullptr) return;
+
+    const size_t kN = (size_t)k * N;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *snb = sn ? sn + (size_t)b * 3 * N : nullptr;
+    const int32_t *ib = min32 + (size_t)b * kN;
+    const size_t j0 = (size_t)blockIdx.x * (SG_THREADS * SG_PER_THREAD) + tid;
+#pragma unroll
+    for (int i = 0; i < SG_PER_THREAD; ++i) {
+        const size_t j = j0 + (size_t)i * SG_THREADS;
+        if (j >= kN) break;
+        const int n = (int)(j % (size_t)N);
+        const int m = ib[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ctr = mean[c * M + m];
+            const float d = __fsub_rn(xb[(size_t)c * N + n], ctr);
+            const size_t o = ((size_t)b * 3 + c) * kN + j;
+            if (centers != nullptr) centers[o] = ctr;
+            if (x_dec != nullptr) x_dec[o] = d;
+            if (x_aug != nullptr) {
+                x_aug[((size_t)b * 6 + c) * kN + j] = d;
+                x_aug[((size_t)b * 6 + 3 + c) * kN + j] = snb[(size_t)c * N + n];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void som_mask_kernel(const int32_t *__restrict__ min32, int32_t *__restrict__ mask,
+                                                        long long rows, int M)
+{
+    // one thread per 4 consecutive m of one (b, j) row when M % 4 == 0, else per element
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((M & 3) == 0) {
+        const int q = M >> 2;
+        const long long row = t / q;
+        if (row >= rows) return;
+        const int m0 = (int)(t - row * q) << 2;
+        const int id = min32[row];
+        reinterpret_cast<int4 *>(mask)[t] = make_int4(id == m0, id == m0 + 1, id == m0 + 2, id == m0 + 3);
+    } else {
+        const long long row = t / M;
+        if (row >= rows) return;
+        mask[t] = min32[row] == (int)(t - row * M);
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict__ x, const int64_t *__restrict__ I,
+                                                          float *__restrict__ out, int C, int M, int K, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int MK = M * K;
+    const long long bc = t / MK;                 // b*C + c
+    const int mk = (int)(t - bc * MK);
+    const long long b = bc / C;
+    const long long id = I[b * MK + mk];
+    out[t] = ((unsigned long long)id < (unsigned long long)M) ? x[bc * M + id] : 0.f;
+}
+
+}  // namespace
+
+extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, int N, int M, int k,
+                                    int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                    sonet_stream_t stream)
+{
+    const char *what = "sonet_som_assign_f32";
+    SONET_REQUIRE(x && node && min_idx_i32 && count && sum_ws, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && N > 0 && M > 0, "%s: non-positive size B=%d N=%d M=%d", what, B, N, M);
+    SONET_REQUIRE(k >= 1 && k <= 4 && k <= M, "%s: k=%d must be in [1, min(4, M=%d)]", what, k, M);
+    if (M > 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 1024 nodes", what, M);
+    if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
+    hipStream_t st = sonet::as_stream(stream);
+    if (hipMemsetAsync(count, 0, (size_t)B * M * sizeof(int32_t), st) != hipSuccess ||
+        hipMemsetAsync(sum_ws, 0, (size_t)B * 3 * M * sizeof(double), st) != hipSuccess)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    dim3 grid(sonet::ceil_div(N, SA_THREADS), B), block(SA_THREADS);
+    const size_t lds = (size_t)M * (sizeof(float4) + 3 * sizeof(double) + sizeof(unsigned));
+#define SA_LAUNCH(KK) hipLaunchKernelGGL((som_assign_kernel<KK>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws)
+    switch (k) { case 1: SA_LAUNCH(1); break; case 2: SA_LAUNCH(2); break; case 3: SA_LAUNCH(3); break; default: SA_LAUNCH(4); }
+#undef SA_LAUNCH
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_som_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,
+                                   const double *sum_ws, int B, int N, int M, int k, float *som_node, int32_t *row_max,
+                                   float *centers, float *x_decentered, float *x_augmented, sonet_stream_t stream)
+{
+    const char *what = "sonet_som_group_f32";
+    SONET_REQUIRE(x && min_idx_i32 && count && sum_ws, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && N > 0 && M > 0 && k >= 1, "%s: non-positive size", what);
+    SONET_REQUIRE(!(x_augmented != nullptr && sn == nullptr), "%s: x_augmented needs sn", what);
+    if (M > 4096) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 4096 nodes", what, M);
+    if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
+    const bool per_point = centers || x_decentered || x_augmented;
+    const long long kN = (long long)k * N;
+    dim3 grid(per_point ? (unsigned)sonet::ceil_div64(kN, SG_THREADS * SG_PER_THREAD) : 1u, B), block(SG_THREADS);
+    hipLaunchKernelGGL(som_group_kernel, grid, block, (size_t)3 * M * sizeof(float), sonet::as_stream(stream),
+                       x, sn, min_idx_i32, count, sum_ws, N, M, k, som_node, row_max, centers, x_decentered, x_augmented);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_som_mask_i32(const int32_t *min_idx_i32, int32_t *mask, int B, int kN, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_som_mask_i32";
+    SONET_REQUIRE(min_idx_i32 && mask, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && kN > 0 && M > 0, "%s: non-positive size", what);
+    const long long rows = (long long)B * kN;
+    const long long threads = (M & 3) == 0 ? rows * (M >> 2) : rows * M;
+    const long long blocks = sonet::ceil_div64(threads, 256);
+    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(som_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
+                       min_idx_i32, mask, rows, M);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_knn_gather_f32(const float *x, const int64_t *knn_I, float *out, int B, int C, int M, int K,
+                                    sonet_stream_t stream)
+{
+    const char *what = "sonet_knn_gather_f32";
+    SONET_REQUIRE(x && knn_I && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && K > 0, "%s: non-positive size", what);
+    const long long total = (long long)B * C * M * K;
+    const long long blocks = sonet::ceil_div64(total, 256);
+    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(knn_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
+                       x, knn_I, out, C, M, K, total);
+    return sonet::launched(what);
+}

@@ -1,0 +1,475 @@
+"""Point-wise layer blocks -- mirror of the reference's models/layers.py on the MI355X kernels.
+
+Class names, constructor signatures, ``forward(x, epoch=None)`` signatures and ``state_dict`` keys
+(``conv.weight``, ``conv.bias``, ``norm.weight``, ``norm.running_mean`` ..., ``layers.N.*``,
+``linear.*``) are those of the reference, so checkpoints and the unmodified
+heads (models/networks.py Classifier / Segmenter / Decoder*) load and run on top.
+
+What is different underneath: ``EquivariantLayer`` (Conv1d k=1 + BN + ReLU, models/layers.py:243-296)
+and ``MyConv2d`` with a 1x1 kernel (:169-211) execute as ONE fused gfx950 kernel
+(``sonet_pointmlp_f32``: exact-f32 MFMA GEMM with the bias / BatchNorm / ReLU epilogue) instead of
+three aten launches; ``PointResNet`` feeds its skip concat (:431) to that kernel as a second input
+panel instead of materialising it.  Training mode computes the batch statistics with
+``sonet_channel_stats_f32`` and normalises in place; gradients flow through a custom
+``autograd.Function``.  ``MyLinear`` / ``UpConv`` (classifier FCs, decoder convs) are outside the
+hot path and stay on PyTorch-ROCm ops.
+
+There is no CPU path: calling a fused layer on CPU tensors raises (modules can still be
+constructed on CPU, e.g. to build or load a ``state_dict``).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from sonet_hip import ops as _ops
+from . import operations
+
+
+class Swish(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+def _make_act(name):
+    if name == 'relu':
+        return nn.ReLU()
+    if name == 'elu':
+        return nn.ELU(alpha=1.0)
+    if name == 'swish':
+        return Swish()
+    if name == 'leakyrelu':
+        return nn.LeakyReLU(0.1)
+    return None
+
+
+class _DecayingBatchNorm(_BatchNorm):
+    """BatchNorm whose momentum decays with the epoch (models/layers.py:48-70, :99-120):
+    momentum = max(0.01, momentum_original * decay ** (epoch // step)) for epoch >= 1."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, momentum_decay_step=None, momentum_decay=1):
+        super().__init__(num_features, eps, momentum, affine)
+        self.momentum_decay_step = momentum_decay_step
+        self.momentum_decay = momentum_decay
+        self.momentum_original = self.momentum
+
+    def decay_momentum(self, epoch):
+        step = self.momentum_decay_step
+        if epoch is not None and epoch >= 1 and step is not None and step > 0:
+            self.momentum = max(0.01, self.momentum_original * (self.momentum_decay ** (epoch // step)))
+
+    def forward(self, input, epoch=None):
+        self._check_input_dim(input)
+        self.decay_momentum(epoch)
+        return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias,
+                            self.training, self.momentum, self.eps)
+
+
+class MyBatchNorm1d(_DecayingBatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() not in (2, 3):
+            raise ValueError('expected 2D or 3D input (got {}D input)'.format(input.dim()))
+
+
+class MyBatchNorm2d(_DecayingBatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 4:
+            raise ValueError('expected 4D input (got {}D input)'.format(input.dim()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused conv1x1 + affine + relu
+# ---------------------------------------------------------------------------------------------------
+class _PointwiseFn(torch.autograd.Function):
+    """Differentiable fused layer.  forward: HIP kernels; backward: dgrad / wgrad as dense GEMMs.
+
+    mode 'affine': y = act((W x) * scale + shift) with constant (scale, shift) (eval BN / no norm);
+    mode 'batch' : training BatchNorm -- statistics over (B, L) of raw = W x + bias.
+    """
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps):
+        Cout = weight2d.shape[0]
+        if mode == 'affine':
+            y = _ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
+            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, scale, y if relu else x1.new_empty(0))
+            ctx.stats = None
+        else:
+            ones = torch.ones(Cout, dtype=torch.float32, device=x1.device)
+            raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
+            mean, var = _ops.channel_stats(raw)
+            invstd = torch.rsqrt(var + eps)
+            sc = gamma * invstd
+            sh = beta - mean * sc
+            y = torch.empty_like(raw)
+            y.copy_(raw)
+            _ops.channel_affine_act_(y, sc.contiguous(), sh.contiguous(), relu)
+            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, y if relu else x1.new_empty(0),
+                                  raw, mean, invstd, gamma)
+            ctx.stats = (mean, var)
+            ctx.mark_non_differentiable(mean, var)
+        ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
+        if mode == 'affine':
+            return y
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, *unused):
+        saved = ctx.saved_tensors
+        x1, x2, weight2d, sc, y = saved[:5]
+        if ctx.relu:
+            gy = gy * (y > 0).to(gy.dtype)
+        g_gamma = g_beta = None
+        if ctx.mode == 'affine':
+            g_raw = gy * sc.view(1, -1, 1)
+            g_bias = g_raw.sum(dim=(0, 2)) if ctx.needs_input_grad[3] else None     # shift = bias*scale + ...
+        else:
+            raw, mean, invstd, gamma = saved[5:9]
+            n = raw.shape[0] * raw.shape[2]
+            xhat = (raw - mean.view(1, -1, 1)) * invstd.view(1, -1, 1)
+            g_beta = gy.sum(dim=(0, 2))
+            g_gamma = (gy * xhat).sum(dim=(0, 2))
+            g_raw = (gamma * invstd).view(1, -1, 1) * (gy - (g_beta / n).view(1, -1, 1) - xhat * (g_gamma / n).view(1, -1, 1))
+            g_bias = g_raw.sum(dim=(0, 2))
+        x = torch.cat((x1, x2), dim=1) if ctx.has_x2 else x1
+        g_w = torch.einsum('bol,bil->oi', g_raw, x) if ctx.needs_input_grad[2] else None
+        g_x1 = g_x2 = None
+        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
+            g_x = torch.matmul(weight2d.t().unsqueeze(0), g_raw)
+            if ctx.has_x2:
+                g_x1, g_x2 = g_x[:, :x1.shape[1]].contiguous(), g_x[:, x1.shape[1]:].contiguous()
+            else:
+                g_x1 = g_x
+        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
+
+
+class _FusedPointwise(nn.Module):
+    """Shared implementation of EquivariantLayer / MyConv2d(1x1): holds ``conv`` (+ ``norm``, ``act``)
+    exactly like the reference modules and runs them as one kernel."""
+
+    def _fusable(self):
+        ks = self.conv.kernel_size
+        return all(k == 1 for k in ks) and all(s == 1 for s in self.conv.stride) and all(p == 0 for p in self.conv.padding) \
+            and self.conv.groups == 1
+
+    def _weight2d(self):
+        w = self.conv.weight
+        return w.reshape(w.shape[0], w.shape[1])
+
+    def _packed(self):
+        w = self.conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        if getattr(self, '_wp_key', None) != key:
+            with torch.no_grad():
+                self._wp = _ops.pointmlp_pack(self._weight2d().detach().contiguous().float())
+            self._wp_key = key
+        return self._wp
+
+    def _bias(self):
+        if self.conv.bias is not None:
+            return self.conv.bias
+        return torch.zeros(self.conv.out_channels, dtype=torch.float32, device=self.conv.weight.device)
+
+    def _eval_affine(self):
+        """(scale, shift) folding the conv bias and the eval-mode BatchNorm (running statistics)."""
+        bn = self.norm if self.normalization == 'batch' else None
+        ts = [self.conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        key = tuple((t._version, t.data_ptr()) if t is not None else None for t in ts) + (self.conv.weight.device,)
+        if getattr(self, '_affine_key', None) != key:
+            with torch.no_grad():
+                b = self._bias().detach().float()
+                if bn is None:
+                    scale, shift = torch.ones_like(b), b.clone()
+                else:
+                    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+                    shift = (b - bn.running_mean) * scale + bn.bias.detach()
+                self._affine = (scale.contiguous(), shift.contiguous())
+            self._affine_key = key
+        return self._affine
+
+    def _run(self, x1, x2, epoch):
+        """x1 (and optional x2): B x C x L contiguous f32 CUDA tensors -> B x Cout x L."""
+        relu_fused = self.activation == 'relu'
+        norm = self.normalization
+        bn = self.norm if norm == 'batch' else None
+        if bn is not None:
+            bn.decay_momentum(epoch)
+        train_bn = bn is not None and bn.training
+        needs_grad = torch.is_grad_enabled() and (x1.requires_grad or (x2 is not None and x2.requires_grad)
+                                                  or self.conv.weight.requires_grad)
+        fuse_act = relu_fused and (norm in (None, 'batch'))
+        wp = self._packed()
+        if train_bn:
+            y, mean, var = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
+                                              fuse_act, 'batch', bn.eps)
+            with torch.no_grad():                                       # F.batch_norm running-stat update
+                n = y.shape[0] * y.shape[2]
+                m = bn.momentum
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                bn.num_batches_tracked += 1
+        else:
+            if norm in (None, 'batch'):
+                scale, shift = self._eval_affine()
+            else:                                                        # instance norm etc.: conv only
+                b = self._bias().detach().float()
+                scale, shift = torch.ones_like(b), b.contiguous()
+            if needs_grad:
+                y = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), None, None, wp, scale, shift, fuse_act,
+                                       'affine', 0.0)
+            else:
+                y = _ops.pointmlp(x1, wp, scale, shift, fuse_act, self.conv.out_channels, x2=x2)
+        return y, fuse_act
+
+    @staticmethod
+    def _prep(x):
+        if not x.is_cuda:
+            raise _ops.SonetHipError("fused point-wise layers run on the MI355X only (got a CPU tensor); "
+                                     "there is no CPU fallback")
+        if x.dtype != torch.float32:
+            x = x.float()
+        return x.contiguous()
+
+
+class EquivariantLayer(_FusedPointwise):
+    def __init__(self, num_in_channels, num_out_channels, activation='relu', normalization=None, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.num_in_channels = num_in_channels
+        self.num_out_channels = num_out_channels
+        self.activation = activation
+        self.normalization = normalization
+        self.conv = nn.Conv1d(num_in_channels, num_out_channels, kernel_size=1, stride=1, padding=0)
+        if normalization == 'batch':
+            self.norm = MyBatchNorm1d(num_out_channels, momentum=momentum, affine=True,
+                                      momentum_decay_step=bn_momentum_decay_step, momentum_decay=bn_momentum_decay)
+        elif normalization == 'instance':
+            self.norm = nn.InstanceNorm1d(num_out_channels, momentum=momentum, affine=True)
+        act = _make_act(activation)
+        if act is not None:
+            self.act = act
+        self.weight_init()
+
+    def weight_init(self):
+        n = self.conv.kernel_size[0] * self.conv.in_channels
+        self.conv.weight.data.normal_(0, math.sqrt(2. / n))             # models/layers.py:271-275
+        if self.conv.bias is not None:
+            self.conv.bias.data.fill_(0)
+        if self.normalization in ('batch', 'instance'):
+            self.norm.weight.data.fill_(1)
+            self.norm.bias.data.zero_()
+
+    def forward(self, x, epoch=None, x_skip=None):
+        """x: B x Cin x L.  ``x_skip`` (optional, B x C2 x L) is concatenated AFTER... before x along channels
+        inside the kernel: the layer computes conv(cat(x_skip, x)) without materialising the concat."""
+        if x_skip is not None:
+            y, act_done = self._run(self._prep(x_skip), self._prep(x), epoch)
+        else:
+            y, act_done = self._run(self._prep(x), None, epoch)
+        if self.normalization is not None and self.normalization != 'batch':
+            y = self.norm(y)
+        if self.activation is not None and not act_done:
+            y = self.act(y)
+        return y
+
+
+class MyLinear(nn.Module):
+    """FC + BN + act (models/layers.py:123-166).  Classifier-head layer: B x C only, stays on aten."""
+
+    def __init__(self, in_features, out_features, activation=None, normalization=None, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.activation = activation
+        self.normalization = normalization
+        self.linear = nn.Linear(in_features, out_features, bias=True)
+        if normalization == 'batch':
+            self.norm = MyBatchNorm1d(out_features, momentum=momentum, affine=True,
+                                      momentum_decay_step=bn_momentum_decay_step, momentum_decay=bn_momentum_decay)
+        elif normalization == 'instance':
+            self.norm = nn.InstanceNorm1d(out_features, momentum=momentum, affine=True)
+        act = _make_act(activation)
+        if act is not None:
+            self.act = act
+        self.weight_init()
+
+    def weight_init(self):
+        self.linear.weight.data.normal_(0, math.sqrt(2. / self.linear.in_features))
+        if self.linear.bias is not None:
+            self.linear.bias.data.fill_(0)
+        if self.normalization in ('batch', 'instance'):
+            self.norm.weight.data.fill_(1)
+            self.norm.bias.data.zero_()
+
+    def forward(self, x, epoch=None):
+        x = self.linear(x)
+        if self.normalization == 'batch':
+            x = self.norm(x, epoch)
+        elif self.normalization is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.act(x)
+        return x
+
+
+class MyConv2d(_FusedPointwise):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, activation=None,
+                 momentum=0.1, normalization=None, bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.activation = activation
+        self.normalization = normalization
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        if normalization == 'batch':
+            self.norm = MyBatchNorm2d(out_channels, momentum=momentum, affine=True,
+                                      momentum_decay_step=bn_momentum_decay_step, momentum_decay=bn_momentum_decay)
+        elif normalization == 'instance':
+            self.norm = nn.InstanceNorm2d(out_channels, momentum=momentum, affine=True)
+        act = _make_act(activation)
+        if act is not None:
+            self.act = act
+        self.weight_init()
+
+    def weight_init(self):
+        ks = self.conv.kernel_size
+        self.conv.weight.data.normal_(0, math.sqrt(2. / (ks[0] * ks[1] * self.conv.in_channels)))
+        if self.conv.bias is not None:
+            self.conv.bias.data.fill_(0)
+        if self.normalization in ('batch', 'instance'):
+            self.norm.weight.data.fill_(1)
+            self.norm.bias.data.zero_()
+
+    def forward(self, x, epoch=None):
+        if self._fusable() and x.is_cuda:
+            B, C, H, W = x.shape
+            y, act_done = self._run(self._prep(x).view(B, C, H * W), None, epoch)
+            y = y.view(B, -1, H, W)
+        else:                                               # 3x3 decoder convs (UpConv): outside the hot path
+            if not x.is_cuda and self._fusable():
+                raise _ops.SonetHipError("MyConv2d(1x1) runs on the MI355X only (got a CPU tensor)")
+            y, act_done = self.conv(x), False
+            if self.normalization == 'batch':
+                y = self.norm(y, epoch)
+        if self.normalization is not None and self.normalization != 'batch':
+            y = self.norm(y)
+        if self.activation is not None and not act_done:
+            y = self.act(y)
+        return y
+
+
+class UpConv(nn.Module):
+    """Upsample x2 + 3x3 conv (models/layers.py:214-240); decoder only, stays on aten."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, output_padding=0, bias=True,
+                 activation=None, normalization=None):
+        super().__init__()
+        self.activation = activation
+        self.normalization = normalization
+        self.up_sample = nn.Upsample(scale_factor=2)
+        self.conv = MyConv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True,
+                             activation=activation, normalization=normalization)
+        self.weight_init()
+
+    def weight_init(self):
+        for m in self.modules():
+            if isinstance(m, (nn.ConvTranspose2d, nn.Conv2d)):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+                if m.bias is not None:
+                    m.bias.data.fill_(0.001)
+
+    def forward(self, x):
+        return self.conv(self.up_sample(x))
+
+
+class KNNModule(nn.Module):
+    """Node-level grouping (models/layers.py:299-367): gather the K' neighbours of every SOM node
+    (coordinates + features), de-centre, two fused 1x1 conv layers, max over the neighbourhood."""
+
+    def __init__(self, in_channels, out_channels_list, activation, normalization, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        prev = in_channels
+        for c_out in out_channels_list:
+            self.layers.append(MyConv2d(prev, c_out, kernel_size=1, stride=1, padding=0, bias=True,
+                                        activation=activation, normalization=normalization, momentum=momentum,
+                                        bn_momentum_decay_step=bn_momentum_decay_step,
+                                        bn_momentum_decay=bn_momentum_decay))
+            prev = c_out
+
+    def forward(self, coordinate, x, precomputed_knn_I, K, center_type, epoch=None):
+        coord = coordinate.detach()                                        # B x 3 x M
+        if precomputed_knn_I is not None:
+            assert precomputed_knn_I.size()[2] >= K
+            knn_I = precomputed_knn_I[:, :, 0:K].contiguous()
+        else:                                                              # fallback M x M kNN (layers.py:333-337)
+            d = ((coord.unsqueeze(3) - coord.unsqueeze(2)) ** 2).sum(dim=1)
+            _, knn_I = torch.topk(d, k=K, dim=2, largest=False, sorted=True)
+        neighbors = operations.knn_gather_wrapper(coord, knn_I)            # B x 3 x M x K
+        if center_type == 'avg':
+            center = neighbors.mean(dim=3, keepdim=True)
+        elif center_type == 'center':
+            center = coord.unsqueeze(3)
+        else:
+            raise ValueError(center_type)
+        decentered = (neighbors - center).detach()
+        x_neighbors = operations.knn_gather_by_indexing(x, knn_I)          # B x C x M x K
+        h = torch.cat((decentered, x_neighbors), dim=1)
+        for layer in self.layers:
+            h = layer(h, epoch)
+        feature, _ = torch.max(h, dim=3, keepdim=False)
+        return center.squeeze(3).detach(), feature
+
+
+class PointNet(nn.Module):
+    """Stack of EquivariantLayers, last one without norm / activation (models/layers.py:370-387)."""
+
+    def __init__(self, in_channels, out_channels_list, activation, normalization, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        prev = in_channels
+        last = len(out_channels_list) - 1
+        for i, c_out in enumerate(out_channels_list):
+            if i != last:
+                self.layers.append(EquivariantLayer(prev, c_out, activation, normalization, momentum,
+                                                    bn_momentum_decay_step, bn_momentum_decay))
+            else:
+                self.layers.append(EquivariantLayer(prev, c_out, None, None))
+            prev = c_out
+
+    def forward(self, x, epoch=None):
+        for layer in self.layers:
+            x = layer(x, epoch)
+        return x
+
+
+class PointResNet(nn.Module):
+    """in -> c0 -> c1 -> ... -> c[k-2]; the last layer sees cat(c0 output, c[k-2] output)
+    (models/layers.py:390-432).  The concat is never materialised: both panels go to the kernel."""
+
+    def __init__(self, in_channels, out_channels_list, activation, normalization, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        self.out_channels_list = out_channels_list
+        self.layers = nn.ModuleList()
+        prev = in_channels
+        last = len(out_channels_list) - 1
+        for i, c_out in enumerate(out_channels_list):
+            if i != last:
+                self.layers.append(EquivariantLayer(prev, c_out, activation, normalization, momentum,
+                                                    bn_momentum_decay_step, bn_momentum_decay))
+            else:
+                self.layers.append(EquivariantLayer(prev + out_channels_list[0], c_out, None, None))
+            prev = c_out
+
+    def forward(self, x, epoch=None):
+        n = len(self.out_channels_list)
+        skip = self.layers[0](x, epoch)
+        t = skip
+        for l in range(1, n - 1):
+            t = self.layers[l](t, epoch)
+        if skip.shape[1] % 8 == 0:
+            return self.layers[n - 1](t, epoch, x_skip=skip)              # fused concat (skip first)
+        return self.layers[n - 1](torch.cat((skip, t), dim=1), epoch)

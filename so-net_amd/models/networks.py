@@ -1,0 +1,187 @@
+"""Level-2 drop-in of the reference's models/networks.py: ``Encoder`` (the hot path) and the
+``Classifier`` head used by the ModelNet40 benchmark.
+
+``Encoder(opt)`` keeps the reference constructor, ``forward(x, sn, node, node_knn_I, is_train, epoch)
+-> B x feature_num``, the post-call attributes the heads read (``mask`` [lazy], ``som_node``,
+``centers``, ``x_decentered``, ``first_pn_out``, ``first_pn_out_masked_max``, ``knn_center_1``,
+``knn_feature_1``, ``final_pn_out``, ``feature``, ``som_builder.node``; models/segmenter.py:90-109)
+and the ``state_dict`` keys -- including the never-called ``transformer.*`` (models/networks.py:78,
+147-164) -- so reference checkpoints load and the Classifier / Segmenter / Decoder heads of a
+reference checkout run on top unchanged ("two drop-in levels").
+
+What changes is the data flow of models/networks.py:111-199:
+
+  reference                                              here
+  ---------------------------------------------------   ------------------------------------------
+  query_topk -> dense one-hot mask B x kN x M            som_assign kernel: int32 node ids + per-node
+  masked broadcast-multiply-sum for the cluster mean      counts / f64 coordinate sums (LDS atomics)
+  (two B x 3 x kN x M f32 temporaries, :141, :169)        som_group kernel: mean, de-centre, concat sn
+  4 x (conv1d, batch_norm, relu) + cat                    4 fused pointmlp launches (MFMA), skip concat
+                                                          read in place
+  index_max ext + torch.gather                            index_max_gather kernel (arg-max + value)
+  KNNModule / final PointNet on aten                      same modules on the fused kernels
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from sonet_hip import ops as _ops
+from util import som
+from .layers import EquivariantLayer, KNNModule, MyLinear, PointNet, PointResNet  # noqa: F401
+
+
+def _bn_kwargs(opt):
+    return dict(momentum=opt.bn_momentum, bn_momentum_decay_step=opt.bn_momentum_decay_step,
+                bn_momentum_decay=opt.bn_momentum_decay)
+
+
+class Transformer(nn.Module):
+    """Rotation regressor that the reference constructs but never calls (models/networks.py:20-68,
+    forward use commented out at :147-164).  Kept so that ``state_dict`` keys match; 184,449
+    parameters that never receive a gradient (the data-parallel wrapper skips them)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        kw = _bn_kwargs(opt)
+        self.first_pointnet = PointNet(3, (32, 64, 128), activation=opt.activation, normalization=opt.normalization, **kw)
+        self.second_pointnet = PointNet(128 + 128, (256, 256), activation=opt.activation, normalization=opt.normalization, **kw)
+        self.fc1 = MyLinear(256, 128, activation=opt.activation, normalization=opt.normalization, **kw)
+        self.fc2 = MyLinear(128, 64, activation=opt.activation, normalization=opt.normalization, **kw)
+        self.fc3 = MyLinear(64, 1, activation=None, normalization=None)
+        self.dropout1 = nn.Dropout(p=opt.dropout)
+        self.dropout2 = nn.Dropout(p=opt.dropout)
+
+    def forward(self, x, sn=None, epoch=None):
+        h = self.first_pointnet(x, epoch)
+        g1, _ = torch.max(h, dim=2, keepdim=True)
+        h = self.second_pointnet(torch.cat((h, g1.expand_as(h)), dim=1), epoch)
+        g2, _ = torch.max(h, dim=2)
+        h = self.fc1(g2, epoch)
+        if self.opt.dropout > 0.1:
+            h = self.dropout1(h)
+        self.fc2_out = self.fc2(h, epoch)
+        if self.opt.dropout > 0.1:
+            self.fc2_out = self.dropout2(self.fc2_out)
+        return torch.tanh(self.fc3(self.fc2_out, epoch))
+
+
+class Encoder(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.feature_num = opt.feature_num
+        kw = _bn_kwargs(opt)
+        act, norm = opt.activation, opt.normalization
+        self.transformer = Transformer(opt)
+        self.first_pointnet = PointResNet(6 if opt.surface_normal else 3, [64, 128, 256, 384],
+                                          activation=act, normalization=norm, **kw)
+        if opt.som_k >= 2:
+            self.knnlayer = KNNModule(3 + 384, (512, 512), activation=act, normalization=norm, **kw)
+            self.final_pointnet = PointNet(3 + 512, (768, self.feature_num), activation=act, normalization=norm, **kw)
+        else:
+            self.final_pointnet = PointResNet(3 + 384, (512, 512, 768, self.feature_num),
+                                              activation=act, normalization=norm, **kw)
+        rows = int(math.sqrt(opt.node_num))
+        self.som_builder = som.BatchSOM(rows, rows, 3, opt.gpu_id, opt.batch_size)
+        self.zero_pad = torch.nn.ZeroPad2d(padding=1)
+        self._lazy = None
+
+    # ---- attributes the segmenter / autoencoder read after forward; built on demand -----------------
+    @property
+    def mask(self):
+        """B x kN x M int32 one-hot assignment (models/segmenter.py:90 takes its argmax)."""
+        st = self._lazy
+        if st is None:
+            raise AttributeError("Encoder.mask: call forward first")
+        if st.get("mask") is None:
+            st["mask"] = _ops.som_mask(st["a"].min_idx_i32, st["a"].M)
+        return st["mask"]
+
+    @property
+    def min_idx(self):
+        """B x kN int64 node id of every point copy (what the segmenter recovers with argmax(mask))."""
+        st = self._lazy
+        if st.get("min_idx") is None:
+            st["min_idx"] = st["a"].min_idx_i32.long()
+        return st["min_idx"]
+
+    def _per_point(self, name):
+        st = self._lazy
+        if st is None:
+            raise AttributeError("Encoder.%s: call forward first" % name)
+        if st.get(name) is None:
+            g = _ops.som_group(st["x"], None, st["a"], want_centers=True, want_decentered=True)
+            st["centers"], st["x_decentered"] = g["centers"], g["x_decentered"]
+        return st[name]
+
+    @property
+    def centers(self):
+        return self._per_point("centers")
+
+    @property
+    def x_decentered(self):
+        return self._per_point("x_decentered")
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x, sn, node, node_knn_I, is_train=False, epoch=None):
+        """x, sn: B x 3 x N; node: B x 3 x M; node_knn_I: B x M x K' int64 -> B x feature_num."""
+        opt = self.opt
+        M = node.size()[2]
+        xd = x.detach().float().contiguous()
+        sb = self.som_builder
+        sb.node = node.detach().float().contiguous()                     # networks.py:124
+        a = sb.assign(xd, opt.k)                                         # :127-128 (ids, counts, sums)
+        use_sn = bool(opt.surface_normal)
+        g = _ops.som_group(xd, sn.detach().float().contiguous() if use_sn else None, a,
+                           want_decentered=not use_sn, want_augmented=use_sn)            # :140-172
+        sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes
+        self.som_node = sb.node
+        row_max = g["row_max"]
+        self._lazy = dict(a=a, x=xd, mask=None, min_idx=None,
+                          centers=None, x_decentered=None if use_sn else g["x_decentered"])
+        pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
+
+        self.first_pn_out = self.first_pointnet(pn_in, epoch)            # :175-178  B x 384 x kN
+
+        if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
+            gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
+            self.first_pn_out_masked_max = self.first_pn_out.gather(
+                dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
+        else:
+            _, self.first_pn_out_masked_max = _ops.index_max_gather(self.first_pn_out, a.min_idx_i32, M, row_max)
+
+        if opt.som_k >= 2:
+            self.knn_center_1, self.knn_feature_1 = self.knnlayer(self.som_node, self.first_pn_out_masked_max,
+                                                                  node_knn_I, opt.som_k, opt.som_k_type, epoch)
+            self.final_pn_out = self.final_pointnet(torch.cat((self.knn_center_1, self.knn_feature_1), dim=1), epoch)
+        else:
+            self.final_pn_out = self.final_pointnet(torch.cat((self.som_node, self.first_pn_out_masked_max), dim=1), epoch)
+        self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)
+        return self.feature
+
+
+class Classifier(nn.Module):
+    """feature_num -> 512 -> 256 -> classes (models/networks.py:202-227).  Three B x C FC layers:
+    not part of the hot path, plain PyTorch-ROCm."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.feature_num = opt.feature_num
+        kw = _bn_kwargs(opt)
+        self.fc1 = MyLinear(self.feature_num, 512, activation=opt.activation, normalization=opt.normalization, **kw)
+        self.fc2 = MyLinear(512, 256, activation=opt.activation, normalization=opt.normalization, **kw)
+        self.fc3 = MyLinear(256, opt.classes, activation=None, normalization=None)
+        self.dropout1 = nn.Dropout(p=opt.dropout)
+        self.dropout2 = nn.Dropout(p=opt.dropout)
+
+    def forward(self, feature, epoch=None):
+        h = self.fc1(feature, epoch)
+        if self.opt.dropout > 0.1:
+            h = self.dropout1(h)
+        self.fc2_out = self.fc2(h, epoch)
+        if self.opt.dropout > 0.1:
+            self.fc2_out = self.dropout2(self.fc2_out)
+        return self.fc3(self.fc2_out, epoch)

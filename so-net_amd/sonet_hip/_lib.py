@@ -1,0 +1,101 @@
+"""ctypes binding of libsonet_hip.so (the C ABI declared in include/sonet_hip.h).
+
+There is no CPU fallback: if the library is missing, cannot be loaded, or the current device is not
+a gfx950, every op raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64.so first so the library binds to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsonet_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+# name -> argtypes; every function returns int status unless listed in _RESTYPES
+SIGNATURES = {
+    "sonet_abi_version": [],
+    "sonet_build_arch": [],
+    "sonet_last_error": [],
+    "sonet_check_device": [],
+    "sonet_index_max_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_index_max_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_index_max_gather_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sonet_som_mask_i32": [_vp, _vp, _i, _i, _i, _vp],
+    "sonet_knn_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_pointmlp_pack_size": [_i, _i],
+    "sonet_pointmlp_pack_f32": [_vp, _vp, _i, _i, _vp],
+    "sonet_pointmlp_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+}
+_RESTYPES = {
+    "sonet_build_arch": ctypes.c_char_p,
+    "sonet_last_error": ctypes.c_char_p,
+    "sonet_pointmlp_pack_size": ctypes.c_size_t,
+}
+
+_lib = None
+
+
+class SonetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises SonetHipError when it is not built / not loadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SonetHipError(
+            "libsonet_hip.so is not built (%s).  Build it with `make -C so-net_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SonetHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sonet_last_error().decode("utf-8", "replace")
+
+
+def check(status, what=""):
+    if status != 0:
+        raise SonetHipError("%s failed (status %d): %s" % (what or "libsonet_hip", status, last_error()))
+
+
+_device_ok = {}
+
+
+def require_device(device):
+    """The ops run only on an MI355X: fail loudly otherwise."""
+    if not torch.cuda.is_available():
+        raise SonetHipError("sonet_hip needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False "
+                            "and there is no CPU fallback")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ok = _device_ok.get(idx)
+    if ok is None:
+        with torch.cuda.device(idx):
+            check(load().sonet_check_device(), "sonet_check_device")
+        _device_ok[idx] = True
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None

@@ -1,0 +1,219 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch, launch on the
+current stream.  Everything here requires CUDA (ROCm) tensors on an MI355X and raises otherwise
+(mirroring the reference's CHECK_CUDA / CHECK_CONTIGUOUS -> RuntimeError convention,
+models/index_max_ext/index_max.cpp:119-121)."""
+import torch
+
+from . import _lib
+from ._lib import SonetHipError, check, ptr, stream_ptr
+
+
+def _chk(t, name, dtype=None, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise SonetHipError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise SonetHipError("%s must be a CUDA tensor/variable" % name)          # CHECK_CUDA
+    if not t.is_contiguous():
+        raise SonetHipError("%s must be contiguous" % name)                      # CHECK_CONTIGUOUS
+    if dtype is not None and t.dtype != dtype:
+        raise SonetHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise SonetHipError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t is not None and t.device != dev:
+            raise SonetHipError("tensors are on different devices: %s vs %s" % (dev, t.device))
+    _lib.require_device(dev)
+    return dev
+
+
+# ------------------------------------------------------------------------------------------ index_max
+def index_max(data, index, K):
+    """data BxCxN' f32|bf16, index BxN' i32 -> BxCxK i32 (include/sonet_hip.h: sonet_index_max_*)."""
+    _chk(data, "data", dim=3)
+    _chk(index, "index", torch.int32, 2)
+    if data.dtype not in (torch.float32, torch.bfloat16):
+        raise SonetHipError("data must be float32 or bfloat16, got %s" % data.dtype)
+    B, C, Np = data.shape
+    if tuple(index.shape) != (B, Np):
+        raise SonetHipError("index must be B x N' = %s, got %s" % ((B, Np), tuple(index.shape)))
+    dev = _same_device(data, index)
+    out = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
+    if out.numel() == 0 or Np == 0:
+        return out.zero_()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        fn = lib.sonet_index_max_f32 if data.dtype == torch.float32 else lib.sonet_index_max_bf16
+        check(fn(ptr(data), ptr(index), ptr(out), B, C, Np, int(K), stream_ptr()), "sonet_index_max")
+    return out
+
+
+def index_max_gather(data, index, K, row_max=None):
+    """index_max + the masked gather of models/networks.py:185 in one pass -> (idx i32, val f32) BxCxK."""
+    _chk(data, "data", torch.float32, 3)
+    _chk(index, "index", torch.int32, 2)
+    B, C, Np = data.shape
+    if tuple(index.shape) != (B, Np):
+        raise SonetHipError("index must be B x N' = %s, got %s" % ((B, Np), tuple(index.shape)))
+    if row_max is not None:
+        _chk(row_max, "row_max", torch.int32, 2)
+    dev = _same_device(data, index, row_max)
+    idx = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
+    val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_index_max_gather_f32(ptr(data), ptr(index), ptr(row_max), ptr(idx), ptr(val),
+                                                     B, C, Np, int(K), stream_ptr()), "sonet_index_max_gather_f32")
+    return idx, val
+
+
+# ------------------------------------------------------------------------------------------ SOM
+class SomAssignment:
+    """Result of som_assign: node ids per point copy plus the per-node count / sum state."""
+    __slots__ = ("B", "N", "M", "k", "min_idx_i32", "min_idx_i64", "count", "sum_ws")
+
+
+def som_assign(x, node, k, want_i64=False):
+    _chk(x, "x", torch.float32, 3)
+    _chk(node, "node", torch.float32, 3)
+    B, D, N = x.shape
+    if D != 3 or node.shape[0] != B or node.shape[1] != 3:
+        raise SonetHipError("x must be B x 3 x N and node B x 3 x M, got %s and %s" % (tuple(x.shape), tuple(node.shape)))
+    M = node.shape[2]
+    dev = _same_device(x, node)
+    r = SomAssignment()
+    r.B, r.N, r.M, r.k = B, N, M, int(k)
+    r.min_idx_i32 = torch.empty((B, r.k * N), dtype=torch.int32, device=dev)
+    r.min_idx_i64 = torch.empty((B, r.k * N), dtype=torch.int64, device=dev) if want_i64 else None
+    r.count = torch.empty((B, M), dtype=torch.int32, device=dev)
+    r.sum_ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_som_assign_f32(ptr(x), ptr(node), B, N, M, r.k, ptr(r.min_idx_i32), ptr(r.min_idx_i64),
+                                               ptr(r.count), ptr(r.sum_ws), stream_ptr()), "sonet_som_assign_f32")
+    return r
+
+
+def som_group(x, sn, a, want_centers=False, want_decentered=False, want_augmented=False):
+    """-> dict(som_node Bx3xM, row_max BxM i32, [centers], [x_decentered] Bx3xkN, [x_augmented] Bx6xkN)."""
+    _chk(x, "x", torch.float32, 3)
+    if sn is not None:
+        _chk(sn, "sn", torch.float32, 3)
+        if sn.shape != x.shape:
+            raise SonetHipError("sn must have the shape of x")
+    dev = _same_device(x, sn, a.min_idx_i32)
+    B, N, M, k = a.B, a.N, a.M, a.k
+    kN = k * N
+    out = dict(som_node=torch.empty((B, 3, M), dtype=torch.float32, device=dev),
+               row_max=torch.empty((B, M), dtype=torch.int32, device=dev))
+    out["centers"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_centers else None
+    out["x_decentered"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_decentered else None
+    out["x_augmented"] = torch.empty((B, 6, kN), dtype=torch.float32, device=dev) if want_augmented else None
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_som_group_f32(ptr(x), ptr(sn), ptr(a.min_idx_i32), ptr(a.count), ptr(a.sum_ws),
+                                              B, N, M, k, ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["centers"]),
+                                              ptr(out["x_decentered"]), ptr(out["x_augmented"]), stream_ptr()),
+              "sonet_som_group_f32")
+    return out
+
+
+def som_mask(min_idx_i32, M):
+    _chk(min_idx_i32, "min_idx", torch.int32, 2)
+    dev = _same_device(min_idx_i32)
+    B, kN = min_idx_i32.shape
+    mask = torch.empty((B, kN, int(M)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_som_mask_i32(ptr(min_idx_i32), ptr(mask), B, kN, int(M), stream_ptr()), "sonet_som_mask_i32")
+    return mask
+
+
+def knn_gather(x, knn_I):
+    """x BxCxM f32, knn_I BxMxK i64 -> BxCxMxK (models/operations.py:38-54)."""
+    _chk(x, "som_node", torch.float32, 3)
+    _chk(knn_I, "som_node_knn_I", torch.int64, 3)
+    B, C, M = x.shape
+    if knn_I.shape[0] != B or knn_I.shape[1] != M:
+        raise SonetHipError("knn_I must be B x M x K, got %s for x %s" % (tuple(knn_I.shape), tuple(x.shape)))
+    K = knn_I.shape[2]
+    dev = _same_device(x, knn_I)
+    out = torch.empty((B, C, M, K), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_knn_gather_f32(ptr(x), ptr(knn_I), ptr(out), B, C, M, K, stream_ptr()), "sonet_knn_gather_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ pointmlp
+def pointmlp_pack(weight2d):
+    """[Cout][Cin] f32 -> packed A-fragment order (device tensor)."""
+    _chk(weight2d, "weight", torch.float32, 2)
+    dev = _same_device(weight2d)
+    Cout, Cin = weight2d.shape
+    lib = _lib.load()
+    wp = torch.empty((lib.sonet_pointmlp_pack_size(Cin, Cout),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.sonet_pointmlp_pack_f32(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_pack_f32")
+    return wp
+
+
+def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
+    """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32."""
+    _chk(x1, "x", torch.float32, 3)
+    B, C1, L = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2", torch.float32, 3)
+        if x2.shape[0] != B or x2.shape[2] != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.shape[1]
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    dev = _same_device(x1, x2, wp, scale, shift)
+    lib = _lib.load()
+    if wp.numel() != lib.sonet_pointmlp_pack_size(C1 + C2, Cout):
+        raise SonetHipError("packed weight has %d floats, expected %d for Cin=%d Cout=%d"
+                            % (wp.numel(), lib.sonet_pointmlp_pack_size(C1 + C2, Cout), C1 + C2, Cout))
+    y = out if out is not None else torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(dev):
+        check(lib.sonet_pointmlp_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
+                                     B, Cout, L, stream_ptr()), "sonet_pointmlp_f32")
+    return y
+
+
+def channel_stats(y):
+    """per-channel (mean, biased var) over (B, L) of y B x C x L."""
+    _chk(y, "y", torch.float32, 3)
+    dev = _same_device(y)
+    B, C, L = y.shape
+    ws = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+    mean = torch.empty((C,), dtype=torch.float32, device=dev)
+    var = torch.empty((C,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_channel_stats_f32(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()),
+              "sonet_channel_stats_f32")
+    return mean, var
+
+
+def channel_affine_act_(y, scale, shift, relu):
+    _chk(y, "y", torch.float32, 3)
+    dev = _same_device(y, scale, shift)
+    B, C, L = y.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_channel_affine_act_f32(ptr(y), ptr(scale), ptr(shift), int(bool(relu)), B, C, L, stream_ptr()),
+              "sonet_channel_affine_act_f32")
+    return y
+
+
+def chamfer_nn(q, db):
+    """q B x 3 x Nq, db B x 3 x Nd -> B x Nq i32 nearest database index."""
+    _chk(q, "q", torch.float32, 3)
+    _chk(db, "db", torch.float32, 3)
+    dev = _same_device(q, db)
+    B, _, Nq = q.shape
+    Nd = db.shape[2]
+    nn = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_chamfer_nn_f32(ptr(q), ptr(db), ptr(nn), B, Nq, Nd, stream_ptr()), "sonet_chamfer_nn_f32")
+    return nn

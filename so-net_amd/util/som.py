@@ -1,0 +1,125 @@
+"""BatchSOM -- mirror of the reference's util/som.py:175-366 on the MI355X kernels.
+
+Constructor, attributes (``node``, ``node_idx_list``, ``rows/cols/dim/node_num``, ``sigma``,
+``learning_rate``, ``max_iteration``) and method signatures follow the reference so that
+models/networks.py:104-106,124-144 runs on it unchanged.  What differs is underneath:
+
+* ``query_topk`` / ``query`` call one fused gfx950 kernel (``sonet_som_assign_f32``) instead of
+  materialising B x 3 x N x M differences, a B x N x M distance matrix and a B x N x M x k compare;
+* the k winners of a point are returned in canonical order -- ascending (distance, node id) -- which
+  is one of the orders ``torch.topk(sorted=False)`` (util/som.py:253) is allowed to return;
+* ``assign`` exposes the compact result (int32 ids, per-node counts and coordinate sums) that the
+  level-2 Encoder consumes directly; the dense one-hot ``mask`` of the reference API is only built
+  when ``query_topk`` / ``query`` is called.
+
+The SOM *trainer* (``batch_update`` / ``optimize``, util/som.py:295-366) is restated on top of the
+same kernel in closed form: for the Gaussian neighbourhood weights w[i, j] the reference's
+B x 3 x M x rows x cols broadcast reduces to two M x M products,
+    node[:, :, j] += lr * ( sum_i w[i,j] r[b,i] mean[b,:,i]  -  node[b,:,j] * sum_i w[i,j] r[b,i] ).
+"""
+import math
+
+import numpy as np
+import torch
+
+from sonet_hip import ops as _ops
+
+
+class BatchSOM():
+    def __init__(self, rows=4, cols=4, dim=3, gpu_id=None, batch_size=10):
+        self.rows, self.cols, self.dim = rows, cols, dim
+        self.node_num = rows * cols
+        self.sigma = 0.4
+        self.learning_rate = 0.5
+        self.max_iteration = 60
+        self.gpu_id = gpu_id
+        assert gpu_id >= 0                                              # util/som.py:187
+        self.device = torch.device("cuda:%d" % gpu_id if torch.cuda.is_available() else "cpu")
+        self.batch_size = batch_size
+        self.node = torch.zeros(batch_size, dim, self.node_num, dtype=torch.float32, device=self.device)
+        self.node_idx_list = torch.arange(self.node_num, dtype=torch.int64, device=self.device)
+        self.init_weighting_matrix = self._gaussian_table(self.sigma).to(self.device)   # M x rows x cols
+        self._node_init_value = None
+        self.last_assignment = None
+
+    # ------------------------------------------------------------------ neighbourhood weights
+    def idx2multi(self, i):
+        return (i // self.cols, i % self.cols)
+
+    def gaussian(self, c, sigma):
+        d = 2 * np.pi * sigma * sigma
+        ax = np.exp(-np.power(np.arange(self.rows) - c[0], 2) / d)
+        ay = np.exp(-np.power(np.arange(self.cols) - c[1], 2) / d)
+        return torch.from_numpy(np.outer(ax, ay).astype(np.float32))
+
+    def _gaussian_table(self, sigma):
+        return torch.stack([self.gaussian(self.idx2multi(i), sigma) for i in range(self.node_num)])
+
+    def get_init_weighting_matrix(self):
+        self.init_weighting_matrix = self._gaussian_table(self.sigma).to(self.device)
+
+    def get_weighting_matrix(self, sigma):
+        scale = 1.0 / ((sigma / self.sigma) ** 2)
+        return torch.exp(torch.log(self.init_weighting_matrix) * scale)
+
+    # ------------------------------------------------------------------ node initialisation
+    @property
+    def node_init_value(self):
+        """dim x M initial node layout from the repulsive potential field (util/potential_field.py).
+
+        Built lazily: the models overwrite ``node`` with dataset nodes on every forward
+        (models/networks.py:124), so the 5 s initialiser only runs if ``node_init`` is used.  The
+        initialiser itself is outside the hot path and is taken from a reference checkout on sys.path.
+        """
+        if self._node_init_value is None:
+            from util import potential_field      # resolved through the overlay package path
+            pf = potential_field.PotentialField(self.node_num, self.dim)
+            pf.optimize()
+            self._node_init_value = torch.from_numpy(pf.node.transpose().astype(np.float32))
+        return self._node_init_value
+
+    def node_init(self, batch_size):
+        self.batch_size = batch_size
+        self.node = self.node_init_value.to(self.device).unsqueeze(0).repeat(batch_size, 1, 1).contiguous()
+
+    # ------------------------------------------------------------------ assignment (the hot path)
+    def assign(self, x, k, want_i64=False):
+        """Compact SOM assignment of x (B x 3 x N) against ``self.node`` (B x 3 x M)."""
+        node = self.node
+        if node.dtype != torch.float32 or not node.is_contiguous():
+            node = node.float().contiguous()
+        a = _ops.som_assign(x.contiguous(), node, int(k), want_i64=want_i64)
+        self.last_assignment = a
+        return a
+
+    def query_topk(self, x, k):
+        """-> mask B x kN x M int32, mask_row_max B x M int32, min_idx B x kN int64 (k-major)."""
+        a = self.assign(x, k, want_i64=True)
+        mask = _ops.som_mask(a.min_idx_i32, a.M)
+        mask_row_max = (a.count > 0).to(torch.int32)
+        return mask, mask_row_max, a.min_idx_i64
+
+    def query(self, x):
+        """k = 1 variant with float mask (util/som.py:271-293) -> mask B x N x M f32, mask_row_max B x M f32."""
+        a = self.assign(x, 1)
+        mask = _ops.som_mask(a.min_idx_i32, a.M).float()
+        return mask, (a.count > 0).float()
+
+    # ------------------------------------------------------------------ batch-SOM training
+    def batch_update(self, x, learning_rate, sigma):
+        assert x.size()[1] == self.dim and x.size()[0] == self.batch_size
+        a = self.assign(x, 1)
+        g = _ops.som_group(x.contiguous(), None, a)               # mean = sum / (count + 1e-5)
+        mean, r = g["som_node"], g["row_max"].float()             # B x 3 x M, B x M
+        w = self.get_weighting_matrix(sigma).reshape(self.node_num, self.node_num)      # w[i, j]
+        pull = torch.matmul(mean * r.unsqueeze(1), w)                                    # sum_i w[i,j] r_i mean_i
+        mass = torch.matmul(r, w).unsqueeze(1)                                           # sum_i w[i,j] r_i
+        self.node = self.node + learning_rate * (pull - self.node * mass)
+
+    def optimize(self, x):
+        self.node_init(x.size()[0])
+        for _ in range(int(self.max_iteration / 3)):
+            self.batch_update(x, self.learning_rate, self.sigma)
+        for it in range(self.max_iteration):
+            decay = 1 + 2 * it / self.max_iteration
+            self.batch_update(x, self.learning_rate / decay, self.sigma / decay)

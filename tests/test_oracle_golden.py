@@ -1,0 +1,103 @@
+"""Pin the CPU oracle (oracle/sonet_oracle.c + oracle/cpu_oracle.py) against the golden fixtures
+that oracle/make_golden.py produced from the live, unmodified reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close_rms, golden
+from oracle import cpu_oracle as O
+from sonet_hip import synth
+
+
+INDEX_MAX_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "index_max_*.npz")))
+
+
+@pytest.mark.parametrize("case", INDEX_MAX_CASES)
+def test_index_max_restatement_matches_reference(case):
+    g = golden(case)
+    out = O.index_max(g["data"], g["index"], int(g["K"]))
+    np.testing.assert_array_equal(out, g["out"])
+
+
+@pytest.mark.parametrize("case", INDEX_MAX_CASES)
+def test_compiled_reference_matches_its_own_golden(case):
+    if O.ref_module() is None:
+        pytest.skip("oracle/_ref/index_max.so not built")
+    g = golden(case)
+    np.testing.assert_array_equal(O.ref_index_max(g["data"], g["index"], int(g["K"])), g["out"])
+    np.testing.assert_array_equal(O.ref_index_max(g["data"], g["index"], int(g["K"]), threads=3), g["out"])
+
+
+@pytest.mark.parametrize("case", ["query_topk_a", "query_topk_b", "query_topk_c"])
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_query_topk_restatement(case, k):
+    g = golden(case)
+    x, node = g["x"], g["node"]
+    B, _, N = x.shape
+    M = node.shape[2]
+    min_idx, count, row_max = O.som_query_topk(x, node, k)
+    # canonical slot order == reference with topk(sorted=True): bit exact
+    np.testing.assert_array_equal(min_idx, g["min_idx_sorted_k%d" % k])
+    # unmodified reference (sorted=False): same SET of k nodes per point
+    ref_u = g["min_idx_unsorted_k%d" % k].reshape(B, k, N)
+    np.testing.assert_array_equal(np.sort(min_idx.reshape(B, k, N), axis=1), np.sort(ref_u, axis=1))
+    np.testing.assert_array_equal(count, g["mask_row_sum_k%d" % k])
+    np.testing.assert_array_equal(row_max, g["mask_row_max_k%d" % k])
+    mask = O.mask_from_min_idx(min_idx, M)
+    assert mask.dtype == np.int32 and str(g["mask_dtype_k%d" % k]) == "torch.int32"
+    np.testing.assert_array_equal(mask.sum(1), g["mask_row_sum_k%d" % k])
+
+
+def test_pointwise_layer_restatement_eval():
+    g = golden("layers")
+    from models import layers as L          # product mirror: only used here for state_dict key names
+    layer = L.EquivariantLayer(6, 64, "relu", "batch", 0.1, None, 1)
+    sd = synth.fill_state_dict_(layer.state_dict(), seed=5)
+    y = O.pointwise_layer(g["eq_x"], sd["conv.weight"].numpy(), sd["conv.bias"].numpy(),
+                          bn=(sd["norm.weight"].numpy(), sd["norm.bias"].numpy(),
+                              sd["norm.running_mean"].numpy(), sd["norm.running_var"].numpy()), relu=True)
+    assert_close_rms(y, g["eq_eval_y"], 1e-5, "EquivariantLayer eval")
+
+
+CLS_CASES = ["classifier_b2_n256", "classifier_b8_n1024", "classifier_b2_n5000", "classifier_b2_n300_k1_center"]
+
+
+def _models_sd(seed):
+    """state_dicts with the reference key names, from the product mirror's module definitions."""
+    from argparse import Namespace
+    from models import networks as NW
+    opt = Namespace(gpu_id=0, device=torch.device("cpu"), batch_size=2, input_pc_num=256, surface_normal=True,
+                    feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3,
+                    som_k=9, som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None,
+                    bn_momentum_decay=0.6, classes=40)
+    enc_sd = NW.Encoder(opt).state_dict()
+    cls_sd = NW.Classifier(opt).state_dict()
+    synth.fill_state_dict_(enc_sd, seed)
+    synth.fill_state_dict_(cls_sd, seed + 1)
+    return enc_sd, cls_sd
+
+
+@pytest.mark.parametrize("case", CLS_CASES)
+def test_encoder_restatement_matches_reference_forward(case):
+    g = golden(case)
+    enc_sd, cls_sd = _models_sd(int(g["seed"]))
+    k, som_k = int(g["k"]), int(g["som_k"])
+    r = O.encoder_forward(enc_sd, torch.from_numpy(g["pc"]), torch.from_numpy(g["sn"]),
+                          torch.from_numpy(g["node"]), torch.from_numpy(g["node_knn_I"]),
+                          k=k, som_k=som_k, som_k_type=str(g["som_k_type"]))
+    np.testing.assert_array_equal(r["min_idx"], g["min_idx"])
+    np.testing.assert_array_equal(r["count"], g["mask_row_sum"])
+    assert_close_rms(r["som_node"], g["som_node"], 1e-5, "som_node")
+    assert_close_rms(r["centers"][:, :, ::7], g["centers"], 1e-5, "centers")
+    assert_close_rms(r["x_decentered"][:, :, ::7], g["x_decentered"], 1e-5, "x_decentered")
+    assert_close_rms(r["first_pn_out"][:, ::16, ::5].numpy(), g["first_pn_out_sub"], 1e-5, "first_pn_out")
+    assert_close_rms(r["first_pn_out_masked_max"].numpy(), g["first_pn_out_masked_max"], 1e-5, "masked_max")
+    assert_close_rms(r["knn_center_1"].numpy(), g["knn_center_1"], 1e-5, "knn_center_1")
+    assert_close_rms(r["knn_feature_1"][:, ::4].numpy(), g["knn_feature_1"], 1e-5, "knn_feature_1")
+    assert_close_rms(r["final_pn_out"][:, ::4].numpy(), g["final_pn_out"], 1e-5, "final_pn_out")
+    assert_close_rms(r["feature"].numpy(), g["feature"], 1e-5, "feature")
+    score = O.classifier_forward(cls_sd, r["feature"])
+    assert_close_rms(score.numpy(), g["score"], 1e-5, "score")
