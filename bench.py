@@ -1,0 +1,194 @@
+"""bench.py -- point-clouds/sec forward, ModelNet40 5k-pt 8x8 SOM (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run)
+
+A "step" is one forward pass of the SO-Net ModelNet40 classifier (level-2 Encoder + Classifier
+head, eval mode) over one batch of synthetic clouds already resident in HBM: B clouds per GPU,
+5000 points, 8x8 SOM, k=3, som_k=9, surface normals on (BASELINE.json configs[1] shape; forward is
+the metric).  The batch is sharded over ranks with no data-path collective ("weak" scaling: per-GPU
+work fixed).  W untimed warm-up steps, then exactly K steps bracketed by barrier +
+torch.cuda.synchronize(); the time is the MAX over ranks; rank 0 prints ONE JSON line.
+
+Extra objects on the line (task contract (4)):
+  roofline      -- for the dominant kernel of the step (largest share of kernel time): algorithmic
+                   flops (or bytes) per launch / its mean launch duration, measured live with HIP
+                   events recorded on the launch stream inside the timed region.
+  kernels       -- the same figure for every hand-written kernel of the step.
+  cpu_baseline  -- the CPU oracle (oracle/cpu_oracle.py: C restatement + the reference's own compiled
+                   index_max + the aten CPU calls the reference makes) timed on this box's host
+                   cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "so-net_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (BASELINE configs[4]: 512 / 8 GPUs)")
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_opt(dev, B, N):
+    from argparse import Namespace
+    return Namespace(gpu_id=dev.index or 0, device=dev, batch_size=B, input_pc_num=N, surface_normal=True,
+                     feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3,
+                     som_k=9, som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6,
+                     classes=40)
+
+
+def algorithmic(name, B, N, k=3, M=64, C=384):
+    """(kind, amount per launch): algorithmic bytes for the HBM-bound kernels, flops for the MFMA ones
+    (per-cloud figures of SURVEY.md 8(d) / DESIGN.md x the B clouds one launch processes)."""
+    kN = k * N
+    if name == "index_max_gather":
+        return "hbm", B * (C * kN * 4 + kN * 4 + 2 * C * M * 4 + M * 4)
+    if name == "index_max":
+        return "hbm", B * (C * kN * 4 + kN * 4 + C * M * 4)
+    if name == "som_assign":
+        return "hbm", B * (3 * N * 4 + 3 * M * 4 + kN * 4 + M * 4 + 3 * M * 8)
+    if name == "som_group":
+        return "hbm", B * (6 * N * 4 + kN * 4 + M * 4 + 3 * M * 8 + 6 * kN * 4 + 3 * M * 4 + M * 4)
+    if name == "knn_gather":
+        return "hbm", None
+    if name.startswith("pointmlp_"):
+        dims, L = name[len("pointmlp_"):].split("_L")
+        cin, cout = dims.split("x")
+        return "mfma", 2.0 * int(cin) * int(cout) * B * int(L)
+    return "hbm", None
+
+
+def cpu_baseline(args, enc_sd, cls_sd):
+    """Oracle forward on the host cores, bounded sample (about 10-30 s)."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = args.cpu_clouds
+    inp = synth.make_inputs(Bc, args.points, seed=1234)
+    use_ref = O.ref_module() is not None
+
+    def run():
+        r = O.encoder_forward(enc_sd, inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"],
+                              index_max_threads=cores, use_ref_index_max=use_ref)
+        return O.classifier_forward(cls_sd, r["feature"])
+
+    with torch.no_grad():
+        run()                                            # warm-up
+        best, reps, t_start = float("inf"), 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t_start < 10.0 and reps < 10):
+            t0 = time.perf_counter()
+            run()
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+    return {"value": Bc / best, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": "%d clouds x %d pts, full classifier forward (oracle/cpu_oracle.py: C restatement of the SOM "
+                      "assignment/grouping, %s index_max with %d threads, aten CPU conv/BN as the reference calls), "
+                      "best of %d after 1 warm-up" % (Bc, args.points,
+                                                       "the reference's own compiled" if use_ref else "restated", cores, reps)}
+
+
+def main():
+    args = parse()
+    from models import networks as NW
+    from sonet_hip import dp, ops, synth
+
+    world, rank, local_rank = dp.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, N = args.batch, args.points
+    opt = make_opt(dev, B, N)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    enc_sd = synth.fill_state_dict_(enc.state_dict(), 0)          # identical weights on every rank
+    cls_sd = synth.fill_state_dict_(cls.state_dict(), 1)
+    enc_cpu = {k: v.clone() for k, v in enc_sd.items()}
+    cls_cpu = {k: v.clone() for k, v in cls_sd.items()}
+    enc.to(dev).eval()
+    cls.to(dev).eval()
+    inp = synth.make_inputs(B, N, seed=100 + rank, device=dev)   # this rank's shard, resident in HBM
+
+    def step():
+        feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+        return cls(feat)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        dp.barrier()
+        torch.cuda.synchronize()
+        with ops.kernel_timing() as rec:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = step()
+            dp.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    elapsed = dp.all_reduce_max(elapsed, dev)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * args.steps / elapsed
+
+    if rank != 0:
+        return
+    summ = rec.summary()
+    kernels = []
+    for name, s in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+        bound, amount = algorithmic(name, B, N)
+        k = {"name": name, "launches_per_step": s["count"] // args.steps, "mean_ms": round(s["mean_ms"], 5),
+             "ms_per_step": round(s["total_ms"] / args.steps, 5), "bound": bound}
+        if amount:
+            if bound == "mfma":
+                ach = amount / (s["mean_ms"] * 1e-3) / 1e12
+                k.update(achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+            else:
+                ach = amount / (s["mean_ms"] * 1e-3) / 1e9
+                k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+        kernels.append(k)
+    dom = next((k for k in kernels if "achieved" in k), None)
+    roofline = None
+    if dom is not None:
+        roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": None}
+    line = {
+        "metric": "point-clouds/sec forward, ModelNet40 5k-pt 8x8 SOM",
+        "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ModelNet40 classifier forward (level-2 Encoder + Classifier head, eval), %d pts, 8x8 SOM, "
+                               "k=3, som_k=9, surface normals" % N,
+                   "batch_per_gpu": B, "global_batch": B * world, "points": N,
+                   "parallelism": "dp%d: batch shards, no data-path collective" % world},
+        "roofline": roofline,
+        "kernel_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 4),
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

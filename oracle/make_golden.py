@@ -185,11 +185,27 @@ def golden_layers(ref):
     save("layers", **arrays)
 
 
+def golden_state_dict_keys(ref):
+    """Key names and shapes of the reference modules: the checkpoint compatibility contract."""
+    import json
+    opt = ref_harness.make_opt(batch_size=2, input_pc_num=256)
+    out = {}
+    for name, mod in (("encoder", ref.networks.Encoder(opt)), ("classifier", ref.networks.Classifier(opt))):
+        out[name] = {k: list(v.shape) for k, v in mod.state_dict().items()}
+    L = ref.layers
+    out["knnmodule"] = {k: list(v.shape) for k, v in L.KNNModule(387, (512, 512), "relu", "batch").state_dict().items()}
+    out["myconv2d"] = {k: list(v.shape) for k, v in L.MyConv2d(4, 8, 1, activation="relu", normalization="batch").state_dict().items()}
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("state_dict_keys.json  encoder %d keys, classifier %d keys" % (len(out["encoder"]), len(out["classifier"])))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = ref_harness.import_reference()
+    golden_state_dict_keys(ref)
     golden_index_max(ref)
     golden_query_topk(ref)
     golden_layers(ref)

@@ -8,6 +8,54 @@ from . import _lib
 from ._lib import SonetHipError, check, ptr, stream_ptr
 
 
+# ---- optional per-launch timing with HIP events on the launch stream (used by bench.py) ----------
+_TIMING = None
+
+
+class kernel_timing:
+    """``with ops.kernel_timing() as rec:`` records one (name, start, end) event pair per C-ABI launch
+    on the current stream; ``rec.summary()`` (after a synchronize) gives per-name count and mean ms."""
+
+    def __enter__(self):
+        global _TIMING
+        self.records = []
+        _TIMING = self.records
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMING
+        _TIMING = None
+        return False
+
+    def summary(self):
+        out = {}
+        for name, e0, e1 in self.records:
+            d = out.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return {k: dict(count=v[0], total_ms=v[1], mean_ms=v[1] / v[0]) for k, v in out.items()}
+
+
+class _timed:
+    __slots__ = ("name", "e0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMING.append((self.name, self.e0, e1))
+        return False
+
+
 def _chk(t, name, dtype=None, dim=None):
     if not isinstance(t, torch.Tensor):
         raise SonetHipError("%s must be a torch.Tensor" % name)
@@ -45,7 +93,7 @@ def index_max(data, index, K):
     if out.numel() == 0 or Np == 0:
         return out.zero_()
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("index_max"):
         fn = lib.sonet_index_max_f32 if data.dtype == torch.float32 else lib.sonet_index_max_bf16
         check(fn(ptr(data), ptr(index), ptr(out), B, C, Np, int(K), stream_ptr()), "sonet_index_max")
     return out
@@ -63,7 +111,7 @@ def index_max_gather(data, index, K, row_max=None):
     dev = _same_device(data, index, row_max)
     idx = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
     val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("index_max_gather"):
         check(_lib.load().sonet_index_max_gather_f32(ptr(data), ptr(index), ptr(row_max), ptr(idx), ptr(val),
                                                      B, C, Np, int(K), stream_ptr()), "sonet_index_max_gather_f32")
     return idx, val
@@ -89,7 +137,7 @@ def som_assign(x, node, k, want_i64=False):
     r.min_idx_i64 = torch.empty((B, r.k * N), dtype=torch.int64, device=dev) if want_i64 else None
     r.count = torch.empty((B, M), dtype=torch.int32, device=dev)
     r.sum_ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("som_assign"):
         check(_lib.load().sonet_som_assign_f32(ptr(x), ptr(node), B, N, M, r.k, ptr(r.min_idx_i32), ptr(r.min_idx_i64),
                                                ptr(r.count), ptr(r.sum_ws), stream_ptr()), "sonet_som_assign_f32")
     return r
@@ -110,7 +158,7 @@ def som_group(x, sn, a, want_centers=False, want_decentered=False, want_augmente
     out["centers"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_centers else None
     out["x_decentered"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_decentered else None
     out["x_augmented"] = torch.empty((B, 6, kN), dtype=torch.float32, device=dev) if want_augmented else None
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("som_group"):
         check(_lib.load().sonet_som_group_f32(ptr(x), ptr(sn), ptr(a.min_idx_i32), ptr(a.count), ptr(a.sum_ws),
                                               B, N, M, k, ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["centers"]),
                                               ptr(out["x_decentered"]), ptr(out["x_augmented"]), stream_ptr()),
@@ -123,7 +171,7 @@ def som_mask(min_idx_i32, M):
     dev = _same_device(min_idx_i32)
     B, kN = min_idx_i32.shape
     mask = torch.empty((B, kN, int(M)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("som_mask"):
         check(_lib.load().sonet_som_mask_i32(ptr(min_idx_i32), ptr(mask), B, kN, int(M), stream_ptr()), "sonet_som_mask_i32")
     return mask
 
@@ -138,7 +186,7 @@ def knn_gather(x, knn_I):
     K = knn_I.shape[2]
     dev = _same_device(x, knn_I)
     out = torch.empty((B, C, M, K), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("knn_gather"):
         check(_lib.load().sonet_knn_gather_f32(ptr(x), ptr(knn_I), ptr(out), B, C, M, K, stream_ptr()), "sonet_knn_gather_f32")
     return out
 
@@ -176,7 +224,7 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
     y = out if out is not None else torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
     if y.numel() == 0:
         return y
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("pointmlp_%dx%d_L%d" % (C1 + C2, Cout, L)):
         check(lib.sonet_pointmlp_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
                                      B, Cout, L, stream_ptr()), "sonet_pointmlp_f32")
     return y
@@ -190,7 +238,7 @@ def channel_stats(y):
     ws = torch.empty((2 * C,), dtype=torch.float64, device=dev)
     mean = torch.empty((C,), dtype=torch.float32, device=dev)
     var = torch.empty((C,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("channel_stats"):
         check(_lib.load().sonet_channel_stats_f32(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()),
               "sonet_channel_stats_f32")
     return mean, var
@@ -200,7 +248,7 @@ def channel_affine_act_(y, scale, shift, relu):
     _chk(y, "y", torch.float32, 3)
     dev = _same_device(y, scale, shift)
     B, C, L = y.shape
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("channel_affine_act"):
         check(_lib.load().sonet_channel_affine_act_f32(ptr(y), ptr(scale), ptr(shift), int(bool(relu)), B, C, L, stream_ptr()),
               "sonet_channel_affine_act_f32")
     return y
@@ -214,6 +262,6 @@ def chamfer_nn(q, db):
     B, _, Nq = q.shape
     Nd = db.shape[2]
     nn = torch.empty((B, Nq), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("chamfer_nn"):
         check(_lib.load().sonet_chamfer_nn_f32(ptr(q), ptr(db), ptr(nn), B, Nq, Nd, stream_ptr()), "sonet_chamfer_nn_f32")
     return nn

@@ -1,0 +1,93 @@
+"""world_size-2 tests of the data-parallel helpers on CPU with the gloo backend."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "so-net_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import torch.nn as nn
+    from sonet_hip import dp
+    w, r, _ = dp.init_distributed(backend="gloo")
+    assert (w, r) == (world, rank) and dp.world_size() == world
+    # shards: contiguous, disjoint, cover the batch
+    lo, hi = dp.shard_range(7, world, rank)
+    ranges = [None] * world
+    dist.all_gather_object(ranges, (lo, hi))
+    assert ranges == [(0, 4), (4, 7)]
+    batch = {"pc": torch.arange(7 * 3).float().view(7, 3), "label": torch.arange(7)}
+    mine = dp.shard_batch(batch, world, rank)
+    assert mine["label"].tolist() == list(range(lo, hi))
+    # parameter broadcast from rank 0 (the reference's init is unseeded)
+    torch.manual_seed(100 + rank)
+    live = nn.Sequential(nn.Linear(4, 3), nn.BatchNorm1d(3))
+    dead = nn.Linear(5, 5)                                       # never used: grads stay None (the dead Transformer)
+    dp.broadcast_parameters([live, dead])
+    flat = torch.cat([p.detach().reshape(-1) for p in list(live.parameters()) + list(dead.parameters())])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1])
+    # gradient averaging == gradient of the global-batch loss (sum-reduced loss / world)
+    x = torch.arange(8 * 4).float().view(8, 4) / 10.0
+    xs = x[rank * 4:(rank + 1) * 4]
+    red = dp.GradientAllReducer([live, dead])
+    live[0](xs).pow(2).sum().backward()
+    nbytes = red.reduce()
+    assert nbytes == sum(p.numel() for p in live[0].parameters()) * 4       # BN affine got no grad here, dead skipped
+    ref = nn.Linear(4, 3)
+    ref.load_state_dict(live[0].state_dict())
+    (ref(x).pow(2).sum() / world).backward()
+    assert torch.allclose(live[0].weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(live[0].bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-6)
+    assert all(p.grad is None for p in dead.parameters())
+    # second step reuses the bucket
+    live.zero_grad()
+    live[0](xs).sum().backward()
+    red.reduce()
+    assert dp.all_reduce_max(float(rank), torch.device("cpu")) == float(world - 1)
+    dp.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.timeout(180)
+def test_dp_helpers_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_single_process_is_a_no_op():
+    import torch.nn as nn
+    from sonet_hip import dp
+    assert dp.world_size() == 1 and dp.shard_range(5, 1, 0) == (0, 5)
+    m = nn.Linear(2, 2)
+    m(torch.ones(1, 2)).sum().backward()
+    g = m.weight.grad.clone()
+    assert dp.GradientAllReducer([m]).reduce() == 0 and torch.equal(m.weight.grad, g)
+    dp.broadcast_parameters([m])
+    dp.barrier()

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the python mirror of the reference API)
+against the golden fixtures of the live reference and against the CPU oracle on seeded inputs.
+
+Integer / index outputs: bit-exact.  Float outputs: |got-ref| <= 1e-5 * max(|ref|, rms(ref))
+(BASELINE.json north_star tolerance, metric of SURVEY.md section 7 hard part 4)."""
+import glob
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close_rms, golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def test_library_loaded_and_device_is_gfx950():
+    from sonet_hip import _lib
+    lib = _lib.load()
+    assert lib.sonet_abi_version() == 1
+    assert lib.sonet_build_arch() == b"gfx950"
+    _lib.require_device(torch.device(DEV))
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ------------------------------------------------------------------------------------------ index_max
+INDEX_MAX_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "index_max_*.npz")))
+
+
+@pytest.mark.parametrize("case", INDEX_MAX_CASES)
+def test_index_max_golden(case):
+    import index_max
+    g = golden(case)
+    K = int(g["K"])
+    data, index = cu(g["data"]), cu(g["index"])
+    out = index_max.forward_cuda(data, index, K)
+    assert out.dtype == torch.int32 and out.device == data.device and tuple(out.shape) == g["out"].shape
+    np.testing.assert_array_equal(out.cpu().numpy(), g["out"])
+    np.testing.assert_array_equal(index_max.forward_cuda_shared_mem(data, index, K).cpu().numpy(), g["out"])
+    # CPU-tensor entry points keep the reference signature (staged through the GPU)
+    np.testing.assert_array_equal(index_max.forward_cpu(torch.from_numpy(g["data"]), torch.from_numpy(g["index"]), K).numpy(),
+                                  g["out"])
+    np.testing.assert_array_equal(index_max.forward_multi_thread_cpu(torch.from_numpy(g["data"]),
+                                                                     torch.from_numpy(g["index"]), K, 4).numpy(), g["out"])
+
+
+@pytest.mark.parametrize("shape", [(8, 384, 15000, 64), (4, 384, 3072, 64), (3, 30, 1023, 64), (2, 7, 4097, 100),
+                                   (1, 64, 20000, 1024)])
+def test_index_max_vs_oracle_random(shape):
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    B, C, N, K = shape
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    data = torch.randn(B, C, N, generator=g)
+    index = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32)
+    ref = O.index_max(data.numpy(), index.numpy(), K)
+    out = ops.index_max(data.to(DEV), index.to(DEV), K)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # gather variant: positions identical, values = data at (position * row_max)
+    row_max = (torch.bincount(index[0].long(), minlength=K) > 0)
+    row_max = torch.stack([(torch.bincount(index[b].long(), minlength=K) > 0) for b in range(B)]).to(torch.int32)
+    idx, val = ops.index_max_gather(data.to(DEV), index.to(DEV), K, row_max.to(DEV))
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    exp = torch.gather(data, 2, torch.from_numpy(ref).long() * row_max.unsqueeze(1).long())
+    np.testing.assert_array_equal(val.cpu().numpy(), exp.numpy())
+
+
+def test_index_max_bf16_ties():
+    """bf16 features make exact ties common: the tie rule (smallest n) is load-bearing."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(4, 48, 6000, generator=g).to(torch.bfloat16)
+    index = torch.randint(0, 64, (4, 6000), generator=g, dtype=torch.int32)
+    ref = O.index_max(data.float().numpy(), index.numpy(), 64)
+    out = ops.index_max(data.to(DEV), index.to(DEV), 64)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_index_max_error_behaviour():
+    import index_max
+    data = torch.randn(2, 4, 64)
+    index = torch.zeros(2, 64, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        index_max.forward_cuda(data, index.to(DEV), 8)                       # CHECK_CUDA
+    with pytest.raises(RuntimeError, match="contiguous"):
+        index_max.forward_cuda(data.to(DEV).transpose(1, 2), index.to(DEV), 8)   # CHECK_CONTIGUOUS
+    with pytest.raises(RuntimeError):
+        index_max.forward_cuda(data.to(DEV), index.to(DEV).long(), 8)
+
+
+# ------------------------------------------------------------------------------------------ SOM assignment
+@pytest.mark.parametrize("case", ["query_topk_a", "query_topk_b", "query_topk_c"])
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_query_topk_golden(case, k):
+    from util import som
+    g = golden(case)
+    x, node = cu(g["x"]), cu(g["node"])
+    B, _, N = x.shape
+    M = node.shape[2]
+    rows = int(round(M ** 0.5))
+    bs = som.BatchSOM(rows, rows, 3, 0, B)
+    bs.node.resize_(node.size()).copy_(node)                                  # as models/networks.py:124 does
+    mask, mask_row_max, min_idx = bs.query_topk(x, k)
+    assert mask.dtype == torch.int32 and mask_row_max.dtype == torch.int32 and min_idx.dtype == torch.int64
+    assert tuple(mask.shape) == (B, k * N, M) and tuple(min_idx.shape) == (B, k * N)
+    np.testing.assert_array_equal(min_idx.cpu().numpy(), g["min_idx_sorted_k%d" % k])        # canonical order: exact
+    ref_u = np.sort(g["min_idx_unsorted_k%d" % k].reshape(B, k, N), axis=1)                   # reference as-is: same sets
+    np.testing.assert_array_equal(np.sort(min_idx.cpu().numpy().reshape(B, k, N), axis=1), ref_u)
+    np.testing.assert_array_equal(mask_row_max.cpu().numpy(), g["mask_row_max_k%d" % k])
+    np.testing.assert_array_equal(mask.sum(1).cpu().numpy(), g["mask_row_sum_k%d" % k])
+    np.testing.assert_array_equal(mask.argmax(dim=2).cpu().numpy(), g["min_idx_sorted_k%d" % k])
+    if k == 1:
+        fmask, frow = bs.query(x)
+        assert fmask.dtype == torch.float32
+        np.testing.assert_array_equal(fmask.argmax(dim=2).cpu().numpy(), g["min_idx_sorted_k1"])
+
+
+@pytest.mark.parametrize("B,N,M,k", [(64, 5000, 64, 3), (3, 777, 16, 2), (2, 1, 64, 1), (1, 300, 256, 4)])
+def test_som_assign_and_group_vs_oracle(B, N, M, k):
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops, synth
+    inp = synth.make_inputs(B, N, M=M, som_k=min(9, M), seed=N + M, node_kind="uniform" if N < M else "som")
+    a = ops.som_assign(inp["pc"].to(DEV), inp["node"].to(DEV), k, want_i64=True)
+    ref_idx, ref_cnt, ref_rm = O.som_query_topk(inp["pc"].numpy(), inp["node"].numpy(), k)
+    np.testing.assert_array_equal(a.min_idx_i64.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(a.min_idx_i32.cpu().numpy(), ref_idx.astype(np.int32))
+    np.testing.assert_array_equal(a.count.cpu().numpy(), ref_cnt)
+    g = ops.som_group(inp["pc"].to(DEV), inp["sn"].to(DEV), a, want_centers=True, want_decentered=True, want_augmented=True)
+    node_ref, ctr_ref, xd_ref = O.som_group(inp["pc"].numpy(), ref_idx, M, k)
+    np.testing.assert_array_equal(g["row_max"].cpu().numpy(), ref_rm)
+    assert_close_rms(g["som_node"].cpu().numpy(), node_ref, 1e-6, "som_node")
+    assert_close_rms(g["centers"].cpu().numpy(), ctr_ref, 1e-6, "centers")
+    assert_close_rms(g["x_decentered"].cpu().numpy(), xd_ref, 1e-6, "x_decentered")
+    aug = g["x_augmented"].cpu()
+    np.testing.assert_array_equal(aug[:, :3].numpy(), g["x_decentered"].cpu().numpy())
+    np.testing.assert_array_equal(aug[:, 3:].numpy(), torch.cat([inp["sn"]] * k, dim=2).numpy())
+    # run-to-run reproducibility of the f64-accumulated means
+    a2 = ops.som_assign(inp["pc"].to(DEV), inp["node"].to(DEV), k)
+    g2 = ops.som_group(inp["pc"].to(DEV), None, a2)
+    np.testing.assert_array_equal(g2["som_node"].cpu().numpy(), g["som_node"].cpu().numpy())
+
+
+def test_knn_gather_vs_oracle():
+    from models import operations
+    from oracle import cpu_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 387, 64, generator=g)
+    I = torch.randint(0, 64, (5, 64, 9), generator=g)
+    out = operations.knn_gather_by_indexing(x.to(DEV), I.to(DEV))
+    np.testing.assert_array_equal(out.cpu().numpy(), O.knn_gather(x.numpy(), I.numpy()))
+    out3 = operations.knn_gather_wrapper(x[:, :3].contiguous().to(DEV), I.to(DEV))
+    np.testing.assert_array_equal(out3.cpu().numpy(), O.knn_gather(x[:, :3].numpy(), I.numpy()))
+
+
+def test_chamfer_nn_vs_oracle():
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(4)
+    q = torch.rand(3, 3, 1280, generator=g) * 2 - 1
+    db = torch.rand(3, 3, 5000, generator=g) * 2 - 1
+    np.testing.assert_array_equal(ops.chamfer_nn(q.to(DEV), db.to(DEV)).cpu().numpy(), O.chamfer_nn(q.numpy(), db.numpy()))
+    np.testing.assert_array_equal(ops.chamfer_nn(db.to(DEV), q.to(DEV)).cpu().numpy(), O.chamfer_nn(db.numpy(), q.numpy()))
+
+
+# ------------------------------------------------------------------------------------------ pointmlp
+@pytest.mark.parametrize("B,C1,C2,Cout,L,bn,relu", [
+    (2, 6, 0, 64, 300, True, True), (2, 64, 0, 128, 768, True, True), (1, 64, 256, 384, 1000, False, False),
+    (3, 387, 0, 512, 576, True, True), (4, 515, 0, 768, 64, True, True), (2, 768, 0, 1024, 64, False, False),
+    (2, 128, 0, 50, 77, False, False), (1, 3, 0, 32, 1, True, True)])
+def test_pointmlp_vs_oracle(B, C1, C2, Cout, L, bn, relu):
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, L, generator=g)
+    W = torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5
+    bias = torch.rand(Cout, generator=g) * 0.2 - 0.1
+    if bn:
+        gamma, beta = 0.5 + torch.rand(Cout, generator=g), torch.rand(Cout, generator=g) * 0.4 - 0.2
+        mean, var = 0.2 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)
+        scale = gamma / torch.sqrt(var + 1e-5)
+        shift = (bias - mean) * scale + beta
+        ref = O.pointwise_layer(x.numpy(), W.numpy(), bias.numpy(), bn=(gamma.numpy(), beta.numpy(), mean.numpy(), var.numpy()),
+                                relu=relu)
+    else:
+        scale, shift = torch.ones(Cout), bias
+        ref = O.pointwise_layer(x.numpy(), W.numpy(), bias.numpy(), bn=None, relu=relu)
+    wp = ops.pointmlp_pack(W.to(DEV))
+    x1 = x[:, :C1].contiguous().to(DEV)
+    x2 = x[:, C1:].contiguous().to(DEV) if C2 else None
+    y = ops.pointmlp(x1, wp, scale.to(DEV), shift.to(DEV), relu, Cout, x2=x2)
+    assert_close_rms(y.cpu().numpy(), ref, 1e-5, "pointmlp")
+
+
+def test_channel_stats_and_affine():
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(3, 70, 1234, generator=g) * 3 + 1
+    mean, var = ops.channel_stats(y.to(DEV))
+    y64 = y.double()
+    assert_close_rms(mean.cpu().numpy(), y64.mean(dim=(0, 2)).numpy(), 1e-6, "mean")
+    assert_close_rms(var.cpu().numpy(), y64.var(dim=(0, 2), unbiased=False).numpy(), 1e-6, "var")
+    sc, sh = torch.rand(70, generator=g), torch.randn(70, generator=g)
+    out = ops.channel_affine_act_(y.to(DEV).clone(), sc.to(DEV), sh.to(DEV), True)
+    assert_close_rms(out.cpu().numpy(), torch.relu(y * sc.view(1, -1, 1) + sh.view(1, -1, 1)).numpy(), 1e-6, "affine")
+
+
+# ------------------------------------------------------------------------------------------ layers (golden)
+def test_equivariant_layer_eval_and_train_golden():
+    from models import layers as L
+    from sonet_hip import synth
+    g = golden("layers")
+    x = cu(g["eq_x"])
+    layer = L.EquivariantLayer(6, 64, "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(layer.state_dict(), seed=5)
+    layer.to(DEV).eval()
+    with torch.no_grad():
+        assert_close_rms(layer(x).cpu().numpy(), g["eq_eval_y"], 1e-5, "eval y")
+    layer.train()
+    y = layer(x, epoch=None)
+    assert_close_rms(y.detach().cpu().numpy(), g["eq_train_y"], 1e-5, "train y")
+    assert_close_rms(layer.norm.running_mean.cpu().numpy(), g["eq_train_running_mean"], 1e-5, "running_mean")
+    assert_close_rms(layer.norm.running_var.cpu().numpy(), g["eq_train_running_var"], 1e-5, "running_var")
+    assert int(layer.norm.num_batches_tracked) == int(g["eq_train_num_batches_tracked"])
+    # backward (fresh statistics, same weights)
+    layer2 = L.EquivariantLayer(6, 64, "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(layer2.state_dict(), seed=5)
+    layer2.to(DEV).train()
+    xg = x.clone().requires_grad_(True)
+    layer2(xg).backward(cu(g["eq_gy"]))
+    assert_close_rms(xg.grad.cpu().numpy(), g["eq_train_gx"], 1e-4, "gx")
+    assert_close_rms(layer2.conv.weight.grad.cpu().numpy(), g["eq_train_gw"], 1e-4, "gw")
+    assert_close_rms(layer2.norm.weight.grad.cpu().numpy(), g["eq_train_ggamma"], 1e-4, "ggamma")
+    assert_close_rms(layer2.norm.bias.grad.cpu().numpy(), g["eq_train_gbeta"], 1e-4, "gbeta")
+    # momentum decay rule (models/layers.py:60-65)
+    layer3 = L.EquivariantLayer(6, 64, "relu", "batch", 0.5, 2, 0.6)
+    synth.fill_state_dict_(layer3.state_dict(), seed=6)
+    layer3.to(DEV).train()
+    layer3(x, epoch=5)
+    assert abs(layer3.norm.momentum - float(g["eq_decay_momentum"])) < 1e-12
+    assert_close_rms(layer3.norm.running_mean.cpu().numpy(), g["eq_decay_running_mean"], 1e-5, "decayed running_mean")
+
+
+def test_point_resnet_eval_golden():
+    from models import layers as L
+    from sonet_hip import synth
+    g = golden("layers")
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    with torch.no_grad():
+        y = pr(cu(g["eq_x"]))
+    assert_close_rms(y[:, ::8].cpu().numpy(), g["prn_eval_y"], 1e-5, "PointResNet eval")
+
+
+# ------------------------------------------------------------------------------------------ encoder + classifier (golden)
+def make_opt(g, B, N):
+    return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True,
+                     feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64,
+                     k=int(g["k"]), som_k=int(g["som_k"]), som_k_type=str(g["som_k_type"]), bn_momentum=0.1,
+                     bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+
+
+@pytest.mark.parametrize("case", ["classifier_b2_n256", "classifier_b8_n1024", "classifier_b2_n5000",
+                                  "classifier_b2_n300_k1_center"])
+def test_encoder_classifier_forward_golden(case):
+    from models import networks as NW
+    from sonet_hip import synth
+    g = golden(case)
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = make_opt(g, B, N)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(cls.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    with torch.no_grad():
+        feat = enc(cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]), is_train=False)
+        score = cls(feat)
+    # integer outputs: bit exact
+    np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), g["min_idx"])
+    np.testing.assert_array_equal(enc.mask.argmax(dim=2).cpu().numpy(), g["min_idx"])       # models/segmenter.py:90
+    np.testing.assert_array_equal(enc.mask.sum(1).cpu().numpy(), g["mask_row_sum"])
+    # float outputs
+    tol = 1e-5
+    assert_close_rms(enc.som_node.cpu().numpy(), g["som_node"], tol, "som_node")
+    assert_close_rms(enc.som_builder.node.cpu().numpy(), g["som_node"], tol, "som_builder.node")
+    assert_close_rms(enc.centers[:, :, ::7].cpu().numpy(), g["centers"], tol, "centers")
+    assert_close_rms(enc.x_decentered[:, :, ::7].cpu().numpy(), g["x_decentered"], tol, "x_decentered")
+    assert_close_rms(enc.first_pn_out[:, ::16, ::5].cpu().numpy(), g["first_pn_out_sub"], tol, "first_pn_out")
+    assert_close_rms(enc.first_pn_out_masked_max.cpu().numpy(), g["first_pn_out_masked_max"], tol, "masked_max")
+    assert_close_rms(enc.knn_center_1.cpu().numpy(), g["knn_center_1"], tol, "knn_center_1")
+    assert_close_rms(enc.knn_feature_1[:, ::4].cpu().numpy(), g["knn_feature_1"], tol, "knn_feature_1")
+    assert_close_rms(enc.final_pn_out[:, ::4].cpu().numpy(), g["final_pn_out"], tol, "final_pn_out")
+    assert_close_rms(feat.cpu().numpy(), g["feature"], tol, "feature")
+    assert_close_rms(score.cpu().numpy(), g["score"], tol, "score")

@@ -1,0 +1,140 @@
+"""CPU-side tests (no GPU needed): the C-ABI library loads and exports every symbol the header
+declares, the python mirror keeps the reference's module / state_dict surface, the product fails
+loudly without a GPU (no CPU fallback), and nothing under so-net_amd/ touches oracle/."""
+import ctypes
+import json
+import os
+import re
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG, ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "sonet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sonet_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from sonet_hip import _lib
+    names = header_functions()
+    assert len(names) >= 15 and "sonet_index_max_f32" in names and "sonet_som_assign_f32" in names
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libsonet_hip.so does not export %s" % n
+    assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
+    lib = _lib.load()
+    assert lib.sonet_abi_version() == 1
+    assert lib.sonet_build_arch() == b"gfx950"
+    assert lib.sonet_pointmlp_pack_size(320, 384) == 12 * 40 * 256
+    assert lib.sonet_pointmlp_pack_size(6, 64) == 2 * 1 * 256
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Status codes and messages for bad arguments are produced before any launch."""
+    from sonet_hip import _lib
+    lib = _lib.load()
+    st = lib.sonet_index_max_f32(None, None, None, 1, 1, 1, 1, None)
+    assert st == 1 and "NULL" in _lib.last_error()
+    buf = (ctypes.c_float * 4)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.sonet_index_max_f32(p, p, p, 1, 1, 4, 2000, None) == 2 and "1024" in _lib.last_error()
+    assert lib.sonet_index_max_f32(p, p, p, 0, 1, 4, 4, None) == 1
+    assert lib.sonet_som_assign_f32(p, p, 1, 4, 8, 9, p, None, p, p, None) == 1 and "k=9" in _lib.last_error()
+    assert lib.sonet_pointmlp_f32(p, 6, p, 3, p, p, p, 1, p, 1, 8, 4, None) == 1       # C1 % 8 with a second input
+    assert lib.sonet_som_group_f32(p, None, p, p, p, 1, 4, 8, 3, None, None, None, None, p, None) == 1  # x_aug needs sn
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_fails_loudly_without_gpu():
+    import index_max
+    from models import layers as L
+    from sonet_hip import ops
+    from sonet_hip._lib import SonetHipError
+    from util import som
+    data, index = torch.randn(1, 2, 8), torch.zeros(1, 8, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        index_max.forward_cuda(data, index, 4)
+    with pytest.raises(SonetHipError, match="MI355X"):
+        index_max.forward_cpu(data, index, 4)
+    with pytest.raises(RuntimeError):
+        L.EquivariantLayer(6, 8, "relu", "batch")(torch.randn(1, 6, 5))
+    bs = som.BatchSOM(8, 8, 3, 0, 2)
+    with pytest.raises(RuntimeError):
+        bs.query_topk(torch.randn(2, 3, 10), 3)
+    with pytest.raises(RuntimeError):
+        ops.knn_gather(torch.randn(1, 3, 4), torch.zeros(1, 4, 2, dtype=torch.int64))
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        if os.path.basename(dirpath) in ("build", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|oracle/|cpu_oracle|sonet_oracle", txt, flags=re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, "product files reference oracle/: %s" % bad
+
+
+def test_state_dict_keys_match_the_reference():
+    from models import layers as L
+    from models import networks as NW
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    opt = Namespace(gpu_id=0, device=torch.device("cpu"), batch_size=2, input_pc_num=256, surface_normal=True,
+                    feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9,
+                    som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+    mods = {"encoder": NW.Encoder(opt), "classifier": NW.Classifier(opt),
+            "knnmodule": L.KNNModule(387, (512, 512), "relu", "batch"),
+            "myconv2d": L.MyConv2d(4, 8, 1, activation="relu", normalization="batch")}
+    for name, mod in mods.items():
+        got = {k: list(v.shape) for k, v in mod.state_dict().items()}
+        assert got == ref[name], name
+    n_enc = sum(p.numel() for p in mods["encoder"].parameters())
+    n_cls = sum(p.numel() for p in mods["classifier"].parameters())
+    assert (n_enc, n_cls) == (1999041, 667944)
+
+
+def test_reference_module_surface():
+    import index_max
+    from models import layers as L, operations
+    from util import som
+    for fn in ("forward_cpu", "forward_multi_thread_cpu", "forward_cuda", "forward_cuda_shared_mem"):
+        assert callable(getattr(index_max, fn))                     # index_max.cpp:154-159
+    for cls in ("Swish", "MyBatchNorm1d", "MyBatchNorm2d", "MyLinear", "MyConv2d", "UpConv", "EquivariantLayer",
+                "KNNModule", "PointNet", "PointResNet"):
+        assert hasattr(L, cls)
+    assert callable(operations.knn_gather_wrapper) and callable(operations.knn_gather_by_indexing)
+    bs = som.BatchSOM(8, 8, 3, 0, 4)
+    assert tuple(bs.node.shape) == (4, 3, 64) and bs.node_num == 64 and tuple(bs.init_weighting_matrix.shape) == (64, 8, 8)
+    for m in ("query_topk", "query", "batch_update", "optimize", "node_init", "get_weighting_matrix", "idx2multi"):
+        assert callable(getattr(bs, m))
+    with pytest.raises(AssertionError):
+        som.BatchSOM(8, 8, 3, -1, 4)                                 # util/som.py:187
+
+
+def test_bn_momentum_decay_rule():
+    from models import layers as L
+    bn = L.MyBatchNorm1d(4, momentum=0.5, momentum_decay_step=2, momentum_decay=0.6)
+    bn.decay_momentum(None); assert bn.momentum == 0.5
+    bn.decay_momentum(0); assert bn.momentum == 0.5
+    bn.decay_momentum(5); assert abs(bn.momentum - 0.5 * 0.6 ** 2) < 1e-12
+    bn.decay_momentum(100); assert bn.momentum == 0.01
+    y = bn(torch.randn(8, 4, 5), epoch=3)                           # BN module itself is plain aten (CPU ok)
+    assert y.shape == (8, 4, 5)
+
+
+def test_synth_inputs_are_deterministic_and_shaped():
+    from sonet_hip import synth
+    a, b = synth.make_inputs(3, 100, seed=5), synth.make_inputs(3, 100, seed=5)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert a["pc"].shape == (3, 3, 100) and a["node"].shape == (3, 3, 64) and a["node_knn_I"].shape == (3, 64, 9)
+    assert a["node_knn_I"].dtype == torch.int64 and torch.equal(a["node_knn_I"][:, :, 0], torch.arange(64).expand(3, 64))
+    assert torch.allclose(a["sn"].norm(dim=1), torch.ones(3, 100), atol=1e-5)
