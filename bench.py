@@ -80,30 +80,38 @@ def cpu_baseline(args, enc_sd, cls_sd):
     """Oracle forward on the host cores, bounded sample (about 10-30 s)."""
     from oracle import cpu_oracle as O
     from sonet_hip import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     Bc = args.cpu_clouds
     inp = synth.make_inputs(Bc, args.points, seed=1234)
     use_ref = O.ref_module() is not None
 
-    def run():
+    def run(threads):
         r = O.encoder_forward(enc_sd, inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"],
-                              index_max_threads=cores, use_ref_index_max=use_ref)
+                              index_max_threads=threads, use_ref_index_max=use_ref)
         return O.classifier_forward(cls_sd, r["feature"])
 
+    # all host cores is rarely the fastest for these small convolutions: try a few thread counts within
+    # the time bound and report the best (cores = the thread count of the reported number)
+    best, cores, reps = float("inf"), 1, 0
     with torch.no_grad():
-        run()                                            # warm-up
-        best, reps, t_start = float("inf"), 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - t_start < 10.0 and reps < 10):
-            t0 = time.perf_counter()
-            run()
-            best = min(best, time.perf_counter() - t0)
-            reps += 1
+        for threads in sorted({min(ncpu, 8), min(ncpu, 32), ncpu}):
+            torch.set_num_threads(threads)
+            run(threads)                                     # warm-up
+            t_start = time.perf_counter()
+            for _ in range(3):
+                t0 = time.perf_counter()
+                run(threads)
+                dt = time.perf_counter() - t0
+                reps += 1
+                if dt < best:
+                    best, cores = dt, threads
+                if time.perf_counter() - t_start > 8.0:
+                    break
     return {"value": Bc / best, "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": "%d clouds x %d pts, full classifier forward (oracle/cpu_oracle.py: C restatement of the SOM "
                       "assignment/grouping, %s index_max with %d threads, aten CPU conv/BN as the reference calls), "
-                      "best of %d after 1 warm-up" % (Bc, args.points,
-                                                       "the reference's own compiled" if use_ref else "restated", cores, reps)}
+                      "best of %d timed runs over thread counts {8, 32, all=%d}" % (Bc, args.points,
+                                                       "the reference's own compiled" if use_ref else "restated", cores, reps, ncpu)}
 
 
 def main():

@@ -50,36 +50,93 @@ __global__ __launch_bounds__(256) void pointmlp_pack_kernel(const float *__restr
     Wp[t] = (o < Cout && i < Cin) ? W[(long long)o * Cin + i] : 0.f;
 }
 
+// Operands of one K-group (8 input channels = 4 MFMA K-steps) for MT cout tiles x NT point groups.
 template <int MT, int NT>
-__device__ __forceinline__ void pm_accumulate(f32x16 (&acc)[MT][NT], const float *const (&xp)[NT], const bool (&pv)[NT],
-                                              int Cx, long long L, const float4 *__restrict__ wp4, int G, int g0, int ng, int h)
+struct PmFrag {
+    float4 a[MT];
+    float b[NT][4];
+};
+
+// Loads are UNCONDITIONAL (addresses are clamped by the caller; hipcc would otherwise branch around
+// every guarded load and drain vmcnt per element).  TAIL handles the last, partially filled group of
+// a panel: channel index clamped into range, value zeroed by a select after the load.
+template <int MT, int NT, bool TAIL>
+__device__ __forceinline__ void pm_load(PmFrag<MT, NT> &f, const float4 *__restrict__ wp4, long long wstride,
+                                        const float *const (&xp)[NT], long long L, int c0 /*first channel of the group*/,
+                                        int Cx, int h)
 {
-    // xp[nt] points at x[b][0][p] of this lane's point; channel stride is L floats
-    for (int g = 0; g < ng; ++g) {
-        float4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = wp4[((long long)mt * G + (g0 + g)) * 64];
-        float bv[NT][4];
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = wp4[(long long)mt * wstride];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int c = 8 * g + 2 * s + h;
-                float v = 0.f;
-                if (pv[nt] && c < Cx) v = xp[nt][(long long)c * L];
-                bv[nt][s] = v;
-            }
-        }
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float av = s == 0 ? a[mt].x : s == 1 ? a[mt].y : s == 2 ? a[mt].z : a[mt].w;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt][s], acc[mt][nt], 0, 0, 0);
+            const int c = c0 + 2 * s + h;
+            if constexpr (TAIL) {
+                const int cc = c < Cx ? c : Cx - 1;
+                const float v = xp[nt][(long long)cc * L];
+                f.b[nt][s] = c < Cx ? v : 0.f;
+            } else {
+                f.b[nt][s] = xp[nt][(long long)c * L];
             }
         }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void pm_mfma(f32x16 (&acc)[MT][NT], const PmFrag<MT, NT> &f)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float av = s == 0 ? f.a[mt].x : s == 1 ? f.a[mt].y : s == 2 ? f.a[mt].z : f.a[mt].w;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b[nt][s], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+// Both input panels as ONE sequence of K-groups (x1's groups, then x2's), software-pipelined with two
+// named operand sets in ping-pong: the loads of group g+1 are issued BEFORE the MFMAs of group g and
+// stay in flight across them (hipcc then emits a counted s_waitcnt vmcnt(N), not a drain), so L2/HBM
+// latency hides under 4*MT*NT MFMAs of 64 cycles each even at 1-2 waves per SIMD.  A single-set
+// "load next; compute current; current = next" loop gets rotated back into load-then-wait by hipcc.
+// Only the very last group can be partial (C1 % 8 == 0 whenever x2 exists): it runs as the TAIL.
+template <int MT, int NT>
+__device__ __forceinline__ void pm_accumulate(f32x16 (&acc)[MT][NT], const float *const (&xp1)[NT], int C1,
+                                              const float *const (&xp2)[NT], int C2, long long L,
+                                              const float4 *__restrict__ wp4 /*cout tile ct0, group 0, + lane*/,
+                                              long long wstride /*float4 stride between cout tiles = G*64*/, int h)
+{
+    const int G1 = C1 >> 3;                                   // full groups of x1
+    const int nfull = G1 + (C2 >> 3);
+    const int Clast = C2 > 0 ? C2 : C1;
+    auto load_full = [&](PmFrag<MT, NT> &f, int g) {
+        const bool second = g >= G1;
+        const float *xp[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xp[nt] = second ? xp2[nt] : xp1[nt];
+        pm_load<MT, NT, false>(f, wp4 + (long long)g * 64, wstride, xp, L, 8 * (second ? g - G1 : g), 0, h);
+    };
+    PmFrag<MT, NT> fa, fb;
+    int g = 0;
+    if (nfull > 0) {
+        load_full(fa, 0);
+        for (; g + 2 <= nfull; g += 2) {
+            load_full(fb, g + 1);
+            pm_mfma<MT, NT>(acc, fa);
+            load_full(fa, g + 2 < nfull ? g + 2 : g + 1);      // clamped re-load on the last trip (branch-free)
+            pm_mfma<MT, NT>(acc, fb);
+        }
+        if (g < nfull) pm_mfma<MT, NT>(acc, fa);
+    }
+    if (Clast & 7) {
+        const int gl = nfull;                                  // the partial group
+        if (C2 > 0) pm_load<MT, NT, true>(fb, wp4 + (long long)gl * 64, wstride, xp2, L, 8 * (gl - G1), C2, h);
+        else        pm_load<MT, NT, true>(fb, wp4 + (long long)gl * 64, wstride, xp1, L, 8 * gl, C1, h);
+        pm_mfma<MT, NT>(acc, fb);
     }
 }
 
@@ -91,8 +148,6 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_kernel(
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int G1 = C2 > 0 ? C1 / 8 : G;                     // groups fed by x1 (C1 % 8 == 0 when C2 > 0)
-    const int G2 = G - G1;
 
     const float *xp1[NT], *xp2[NT];
     bool pv[NT];
@@ -103,9 +158,11 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_kernel(
         const long long b = q / gpc;
         const int l = (int)(q - b * gpc) * 32 + j;
         pv[nt] = q < ngroups && l < L;
-        xp1[nt] = x1 + (b * C1) * (long long)L + l;
-        xp2[nt] = x2 ? x2 + (b * C2) * (long long)L + l : nullptr;
-        ybase[nt] = (b * Cout) * (long long)L + l;
+        const long long bc = pv[nt] ? b : 0;               // invalid lanes read cloud 0 / point 0, never store
+        const int lc = pv[nt] ? l : 0;
+        xp1[nt] = x1 + (bc * C1) * (long long)L + lc;
+        xp2[nt] = x2 ? x2 + (bc * C2) * (long long)L + lc : x1;
+        ybase[nt] = (bc * Cout) * (long long)L + lc;
     }
 
     const int ct_begin = blockIdx.y * ct_per_y;
@@ -120,8 +177,7 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_kernel(
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
         const float4 *wp4 = reinterpret_cast<const float4 *>(Wp) + (long long)ct0 * G * 64 + lane;
-        pm_accumulate<MT, NT>(acc, xp1, pv, C1, L, wp4, G, 0, G1, h);
-        if (G2 > 0) pm_accumulate<MT, NT>(acc, xp2, pv, C2, L, wp4, G, G1, G2, h);
+        pm_accumulate<MT, NT>(acc, xp1, C1, xp2, C2, L, wp4, (long long)G * 64, h);
 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {

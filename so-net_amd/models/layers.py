@@ -209,7 +209,7 @@ class _FusedPointwise(nn.Module):
                 m = bn.momentum
                 bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
                 bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-                bn.num_batches_tracked += 1
+                # (F.batch_norm does not touch num_batches_tracked; the reference never increments it)
         else:
             if norm in (None, 'batch'):
                 scale, shift = self._eval_affine()
@@ -262,8 +262,8 @@ class EquivariantLayer(_FusedPointwise):
             self.norm.bias.data.zero_()
 
     def forward(self, x, epoch=None, x_skip=None):
-        """x: B x Cin x L.  ``x_skip`` (optional, B x C2 x L) is concatenated AFTER... before x along channels
-        inside the kernel: the layer computes conv(cat(x_skip, x)) without materialising the concat."""
+        """x: B x Cin x L.  ``x_skip`` (optional, B x C_skip x L, C_skip % 8 == 0) goes first in the channel
+        order: the layer computes conv(cat(x_skip, x)) without materialising the concat."""
         if x_skip is not None:
             y, act_done = self._run(self._prep(x_skip), self._prep(x), epoch)
         else:
