@@ -27,6 +27,7 @@
 // hit the same W lines together).  gridDim.y splits the cout tiles when there are too few point
 // groups to fill 256 CUs (the node-level layers with L = 64 or 576 columns per cloud).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,6 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PM_THREADS = 256;
 constexpr int PM_WAVES = PM_THREADS / 64;
+constexpr int PM_S = 4;             // K-groups (of 8 input channels) per LDS stage of the W-through-LDS kernel
 
 __global__ __launch_bounds__(256) void pointmlp_pack_kernel(const float *__restrict__ W, float *__restrict__ Wp,
                                                              int Cin, int Cout, int G, long long total)
@@ -198,6 +200,153 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v2: W through LDS, staged S K-groups at a time.
+// In the kernel above every wave streams its own copy of the packed W from L1/L2 (MT KB per K-group per
+// wave): identical data for all waves of a CU.  Here the 4 waves of a workgroup share ONE copy per
+// STAGE of S K-groups (8*S input channels):
+//   * each wave loads 1/4 of the next-next stage's S*MT W slices into registers (async-STAGE split:
+//     issue early, ds_write after the next barrier), so global latency hides under a whole stage of
+//     MFMAs (S*4*MT MFMAs = 256*S*MT cycles per wave);
+//   * LDS holds two stages (2 x S x MT KB); all waves read their A fragments with conflict-free
+//     lane-linear ds_read_b128; ONE __syncthreads per stage, not per K-group (measured: with a barrier
+//     per group the loop reached only 67 % of the MFMA rate even with stores and X loads ablated);
+//   * X (the B operand) stays a direct register load -- it is private to the wave (its own 32 points)
+//     and already coalesced -- prefetched a whole stage ahead (4*S dword loads in flight per wave),
+//     ping-ponged between two named register sets so hipcc keeps the loads in flight (counted vmcnt).
+// ABL: bench-only ablation mask (tools/microbench.py): 1 = skip the epilogue stores, 2 = skip the X loads.
+template <int MT, int S, int ABL = 0>
+__global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
+    const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const float *__restrict__ Wp,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
+    int Cout, int L, int gpc, long long ngroups, int CT, int G, int ct_per_y)
+{
+    __shared__ float4 wsm[2][S * MT][64];
+    constexpr int NSL = S * MT;                               // W slices per stage
+    constexpr int NS = (NSL + PM_WAVES - 1) / PM_WAVES;      // ... staged per wave
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const long long q = (long long)blockIdx.x * PM_WAVES + wave;
+    const long long b = q / gpc;
+    const int l = (int)(q - b * gpc) * 32 + j;
+    const bool pv = q < ngroups && l < L;
+    const long long bc = pv ? b : 0;
+    const int lc = pv ? l : 0;
+    const float *xp1 = x1 + (bc * C1) * (long long)L + lc;
+    const float *xp2 = x2 ? x2 + (bc * C2) * (long long)L + lc : x1;
+    const long long ybase = (bc * Cout) * (long long)L + lc;
+    const int G1 = C2 > 0 ? (C1 >> 3) : G;                   // K-groups fed by x1
+    const int nstage = (G + S - 1) / S;
+
+    // B operands of stage st: S groups x 4 values per lane.  Channels past the panel (and the padded
+    // groups g >= G of the last stage) are clamped for the load and zeroed by a select afterwards.
+    auto load_b = [&](float (&bv)[S][4], int st) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int g = st * S + i;
+            const bool second = g >= G1;
+            const float *xp = second ? xp2 : xp1;
+            const int Cx = (g < G) ? (second ? C2 : C1) : 0;
+            const int c0 = 8 * (second ? g - G1 : g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = c0 + 2 * s + h;
+                int cc = c < Cx ? c : Cx - 1;
+                cc = cc < 0 ? 0 : cc;
+                if constexpr (ABL & 2) { bv[i][s] = (float)(cc + lane) * 1e-3f; continue; }
+                const float v = xp[(long long)cc * L];
+                bv[i][s] = c < Cx ? v : 0.f;
+            }
+        }
+    };
+
+    const int ct_begin = blockIdx.y * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+        const float4 *wsrc = reinterpret_cast<const float4 *>(Wp) + (long long)ct0 * G * 64 + lane;
+        // slice index sl in [0, S*MT): group i = sl / MT of the stage, cout tile mt = sl % MT
+        auto stage_load = [&](float4 (&w)[NS], int st) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                int sl = wave + t * PM_WAVES;
+                sl = sl < NSL ? sl : NSL - 1;                  // surplus lanes of the last round re-load a valid slice
+                const int i = sl / MT, mt = sl - i * MT;
+                int g = st * S + i;
+                g = g < G ? g : G - 1;                          // padded groups: any valid slice (their B is zero)
+                w[t] = wsrc[((long long)mt * G + g) * 64];
+            }
+        };
+        auto stage_write = [&](const float4 (&w)[NS], int slot) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int sl = wave + t * PM_WAVES;
+                if (sl < NSL) wsm[slot][sl][lane] = w[t];
+            }
+        };
+        auto compute = [&](const float (&bv)[S][4], int slot) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = wsm[slot][i * MT + mt][lane];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float av = s == 0 ? a[mt].x : s == 1 ? a[mt].y : s == 2 ? a[mt].z : a[mt].w;
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i][s], acc[mt], 0, 0, 0);
+                    }
+            }
+        };
+
+        float4 wreg[NS];
+        float b0[S][4], b1[S][4];
+        __syncthreads();                                       // previous pass finished reading both slots
+        stage_load(wreg, 0);
+        load_b(b0, 0);
+        stage_write(wreg, 0);
+        stage_load(wreg, nstage > 1 ? 1 : 0);
+        // one stage: barrier; publish W(st+1); prefetch W(st+2) and X(st+1); compute stage st
+#define PM_STAGE(st, bcur, bnxt, slot)                                       \
+        {                                                                    \
+            __syncthreads();                                                 \
+            if ((st) + 1 < nstage) stage_write(wreg, (slot) ^ 1);            \
+            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
+            load_b(bnxt, (st) + 1 < nstage ? (st) + 1 : nstage - 1);         \
+            compute(bcur, slot);                                             \
+        }
+        int st = 0;
+        for (; st + 2 <= nstage; st += 2) {
+            PM_STAGE(st, b0, b1, 0)
+            PM_STAGE(st + 1, b1, b0, 1)
+        }
+        if (st < nstage) PM_STAGE(st, b0, b1, 0)
+#undef PM_STAGE
+
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);                 // keep the epilogue tile-by-tile (bounds VGPR live ranges)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (ct0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < Cout) {
+                    float v = __fmaf_rn(acc[mt][r], scale[o], shift[o]);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    if constexpr (ABL & 1) { asm volatile("" ::"v"(v)); continue; }
+                    if (pv) y[ybase + (long long)o * L] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- training-mode BatchNorm support: per-channel statistics and the normalise + ReLU pass --------
 constexpr int ST_THREADS = 256;
 
@@ -289,23 +438,53 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
     const int CT = sonet::ceil_div(Cout, 32), G = sonet::ceil_div(Cin, 8);
     const int gpc = sonet::ceil_div(L, 32);
     const long long ngroups = (long long)B * gpc;
-    // cout tiles per accumulator pass
-    const int MT = (CT % 4 == 0) ? 4 : (CT % 2 == 0) ? 2 : 1;
-    const int NT = 1;
-    const long long nwg_x = sonet::ceil_div64(ngroups, (long long)PM_WAVES * NT);
-    // split the cout tiles over gridDim.y when the point axis alone cannot fill the chip
+    hipStream_t st = sonet::as_stream(stream);
+    // Tile policy, measured on MI355X (tools/microbench.py, profiles/r01_microbench.log): the loop is latency-
+    // bound, not bandwidth-bound, so the configuration with the most resident waves wins almost everywhere:
+    // MT = 2 cout tiles per pass (32 AGPR accumulators -> 3-4 waves/SIMD) with S = 2 K-groups per LDS stage.
+    // Exception: the node-level 515->768 layer (64 columns per cloud, too few point groups to fill the chip).
+    const long long nwg_x = sonet::ceil_div64(ngroups, (long long)PM_WAVES);
+    int MT = 1, S = 2;
+    if (CT % 2 == 0) MT = 2;
+    if (CT % 6 == 0 && nwg_x < 512) { MT = 6; S = 1; }
+    if (G == 1) S = 1;
+    if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
+        const int want = atoi(e);
+        if ((want == 8 || want == 6 || want == 4 || want == 2) && CT % want == 0) MT = want;
+    }
+    if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+    // split the cout passes over gridDim.y when the point axis alone cannot fill the chip
     int ysplit = 1;
     while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
     const int ct_per_y = CT / ysplit;
-    if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(PM_THREADS);
-    hipStream_t st = sonet::as_stream(stream);
-#define PM_LAUNCH(MM, NN) \
-    hipLaunchKernelGGL((pointmlp_f32_kernel<MM, NN>), grid, block, 0, st, x1, C1, x2, C2, Wp, scale, shift, relu, y, \
-                       Cout, L, gpc, ngroups, CT, G, ct_per_y)
-    switch (MT) { case 4: PM_LAUNCH(4, 1); break; case 2: PM_LAUNCH(2, 1); break; default: PM_LAUNCH(1, 1); }
+    if (const char *e = getenv("SONET_POINTMLP_S")) {       // tuning knob (bench experiments only)
+        const int want = atoi(e);
+        if (want == 1 || want == 2 || want == 4) S = want;
+    }
+    int abl = 0;
+    if (const char *e = getenv("SONET_POINTMLP_ABLATE")) abl = atoi(e);   // bench-only: no stores / no X loads
+#define PM_ARGS grid, block, 0, st, x1, C1, x2, C2, Wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, G, ct_per_y
+#define PM_LAUNCH_V2(MM)                                                                              \
+    do {                                                                                              \
+        if (abl == 1 && S == 4)      hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 1>), PM_ARGS); \
+        else if (abl == 2 && S == 4) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 2>), PM_ARGS); \
+        else if (abl == 3 && S == 4) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 3>), PM_ARGS); \
+        else if (S == 4)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 0>), PM_ARGS); \
+        else if (S == 2)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 0>), PM_ARGS); \
+        else                         hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 1, 0>), PM_ARGS); \
+    } while (0)
+#define PM_LAUNCH(MM, NN) hipLaunchKernelGGL((pointmlp_f32_kernel<MM, NN>), PM_ARGS)
+    switch (MT) {
+        case 8: PM_LAUNCH_V2(8); break;
+        case 6: PM_LAUNCH_V2(6); break;
+        case 4: PM_LAUNCH_V2(4); break;
+        case 2: PM_LAUNCH_V2(2); break;
+        default: PM_LAUNCH(1, 1);                       // odd CT (Cout <= 32 or not a multiple of 64)
+    }
 #undef PM_LAUNCH
-    (void)NT;
+#undef PM_LAUNCH_V2
+#undef PM_ARGS
     return sonet::launched(what);
 }
 

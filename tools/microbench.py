@@ -1,0 +1,112 @@
+"""tools/microbench.py -- per-kernel timing on one MI355X (HIP events, random data, within-process A/B).
+
+    python tools/microbench.py pointmlp        # all layer shapes of the classifier forward x MT variants
+    python tools/microbench.py index_max
+    python tools/microbench.py som
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "so-net_amd"))
+
+import torch  # noqa: E402
+from sonet_hip import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_pointmlp(B=64):
+    shapes = [(6, 0, 64, 15000), (64, 0, 128, 15000), (128, 0, 256, 15000), (64, 256, 384, 15000),
+              (387, 0, 512, 576), (512, 0, 512, 576), (515, 0, 768, 64), (768, 0, 1024, 64)]
+    for C1, C2, Cout, L in shapes:
+        Cin = C1 + C2
+        x1 = torch.randn(B, C1, L, device=DEV)
+        x2 = torch.randn(B, C2, L, device=DEV) if C2 else None
+        W = torch.randn(Cout, Cin, device=DEV) * (2.0 / Cin) ** 0.5
+        wp = ops.pointmlp_pack(W)
+        sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+        y = torch.empty(B, Cout, L, device=DEV)
+        flops = 2.0 * Cin * Cout * B * L
+        row = []
+        for mt in (0, 2, 4, 6, 8):
+            if mt and (Cout // 32) % mt:
+                continue
+            for S in ((4,) if mt == 0 else (1, 2, 4)):
+                if mt:
+                    os.environ["SONET_POINTMLP_MT"] = str(mt)
+                    os.environ["SONET_POINTMLP_S"] = str(S)
+                else:
+                    os.environ.pop("SONET_POINTMLP_MT", None)
+                    os.environ.pop("SONET_POINTMLP_S", None)
+                ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
+                row.append("MT=%s,S=%d %.3f ms %.1f TF" % (mt or "auto", S, ms, flops / ms / 1e9))
+        os.environ.pop("SONET_POINTMLP_MT", None)
+        os.environ.pop("SONET_POINTMLP_S", None)
+        print("pointmlp %4d->%4d L=%5d B=%d : %s" % (Cin, Cout, L, B, " | ".join(row)), flush=True)
+
+
+def bench_index_max():
+    for B, C, N, K in [(64, 384, 15000, 64), (8, 384, 15000, 64), (64, 384, 3072, 64)]:
+        data = torch.randn(B, C, N, device=DEV)
+        index = torch.randint(0, K, (B, N), device=DEV, dtype=torch.int32)
+        ms = timeit(lambda: ops.index_max(data, index, K))
+        byt = B * (C * N * 4 + N * 4 + C * K * 4)
+        print("index_max f32 B=%d C=%d N'=%d : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (B, C, N, ms, byt / ms / 1e6, byt / ms / 1e6 / 80), flush=True)
+        d16 = data.to(torch.bfloat16)
+        ms = timeit(lambda: ops.index_max(d16, index, K))
+        byt = B * (C * N * 2 + N * 4 + C * K * 4)
+        print("index_max bf16 B=%d C=%d N'=%d : %.4f ms  %.0f GB/s" % (B, C, N, ms, byt / ms / 1e6), flush=True)
+
+
+def bench_som():
+    from sonet_hip import synth
+    for B, N in [(64, 5000), (8, 5000), (512, 5000)]:
+        inp = synth.make_inputs(B, N, seed=1, device=DEV)
+        ms_a = timeit(lambda: ops.som_assign(inp["pc"], inp["node"], 3))
+        a = ops.som_assign(inp["pc"], inp["node"], 3)
+        ms_g = timeit(lambda: ops.som_group(inp["pc"], inp["sn"], a, want_augmented=True))
+        print("som B=%d N=%d : assign %.4f ms (%.1f Mclouds/s)  group %.4f ms" % (B, N, ms_a, B / ms_a / 1e3, ms_g), flush=True)
+
+
+def bench_ablate(B=64):
+    C1, C2, Cout, L = 64, 256, 384, 15000
+    x1, x2 = torch.randn(B, C1, L, device=DEV), torch.randn(B, C2, L, device=DEV)
+    wp = ops.pointmlp_pack(torch.randn(Cout, C1 + C2, device=DEV) * 0.08)
+    sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+    y = torch.empty(B, Cout, L, device=DEV)
+    flops = 2.0 * (C1 + C2) * Cout * B * L
+    os.environ["SONET_POINTMLP_S"] = "4"
+    for mt in (6, 2):
+        os.environ["SONET_POINTMLP_MT"] = str(mt)
+        for abl, what in ((0, "full"), (1, "no stores"), (2, "no X loads"), (3, "no stores, no X loads")):
+            os.environ["SONET_POINTMLP_ABLATE"] = str(abl)
+            ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
+            print("ablate 320->384 MT=%d %-24s %.4f ms %.1f TF" % (mt, what, ms, flops / ms / 1e9), flush=True)
+    os.environ.pop("SONET_POINTMLP_MT", None)
+    os.environ.pop("SONET_POINTMLP_ABLATE", None)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pointmlp", "index_max", "som"]
+    if "pointmlp" in which:
+        bench_pointmlp()
+    if "index_max" in which:
+        bench_index_max()
+    if "som" in which:
+        bench_som()
+    if "ablate" in which:
+        bench_ablate()
