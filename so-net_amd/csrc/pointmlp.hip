@@ -222,6 +222,7 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
     int Cout, int L, int gpc, long long ngroups, int CT, int G, int ct_per_y)
 {
     __shared__ float4 wsm[2][S * MT][64];
+    __shared__ float2 affine[1024];                          // (scale, shift) of this workgroup's cout range
     constexpr int NSL = S * MT;                               // W slices per stage
     constexpr int NS = (NSL + PM_WAVES - 1) / PM_WAVES;      // ... staged per wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,6 +264,9 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
 
     const int ct_begin = blockIdx.y * ct_per_y;
     const int ct_end = min(CT, ct_begin + ct_per_y);
+    // epilogue constants into LDS once: the epilogue must not start with a dependent global load
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32 && o - ct_begin * 32 < 1024; o += PM_THREADS)
+        affine[o - ct_begin * 32] = o < Cout ? make_float2(scale[o], shift[o]) : make_float2(0.f, 0.f);
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
         f32x16 acc[MT];
 #pragma unroll
@@ -295,7 +299,10 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
             for (int i = 0; i < S; ++i) {
                 float4 a[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = wsm[slot][i * MT + mt][lane];
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (ABL & 4) a[mt] = make_float4(bv[i][0] + mt, bv[i][1], bv[i][2], bv[i][3] + slot);
+                    else a[mt] = wsm[slot][i * MT + mt][lane];
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -316,9 +323,10 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
         // one stage: barrier; publish W(st+1); prefetch W(st+2) and X(st+1); compute stage st
 #define PM_STAGE(st, bcur, bnxt, slot)                                       \
         {                                                                    \
+            if constexpr (!(ABL & 4)) {                                      \
             __syncthreads();                                                 \
             if ((st) + 1 < nstage) stage_write(wreg, (slot) ^ 1);            \
-            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
+            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1); }   \
             load_b(bnxt, (st) + 1 < nstage ? (st) + 1 : nstage - 1);         \
             compute(bcur, slot);                                             \
         }
@@ -337,10 +345,169 @@ __global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_wlds_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int o = (ct0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (o < Cout) {
-                    float v = __fmaf_rn(acc[mt][r], scale[o], shift[o]);
+                    const float2 ss = affine[o - ct_begin * 32];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
                     if (relu) v = (v < 0.f) ? 0.f : v;
                     if constexpr (ABL & 1) { asm volatile("" ::"v"(v)); continue; }
                     if (pv) y[ybase + (long long)o * L] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v3 ("lean"): same data flow as v2 (W through LDS in stages, X prefetched a stage ahead), but the
+// steady-state loop carries NO ordinary VALU instructions.
+// Measured on MI355X (tools/mfma_issue.hip, profiles/r01_mfma_issue.log): v_mfma_f32_32x32x2_f32 runs at
+// the f32 VECTOR rate and every ordinary VALU instruction of a resident wave takes matrix-pipe time:
+// 0 / 4 / 8 / 16 filler VALU per MFMA -> 155 / 126 / 112 / 90 TFLOP/s at 4 waves per SIMD.  v2 carried
+// ~5 VALU per MFMA (64-bit address mads, clamps, selects) and topped out at 117 TFLOP/s even with all
+// memory traffic ablated.  Here every address is  <buffer descriptor> + <lane offset VGPR, computed once>
+// + <wave-uniform SGPR offset>  (raw buffer loads / stores; SALU arithmetic is free), and LDS addresses
+// are one VGPR plus compile-time immediates.  The descriptor of an X panel covers exactly the Cx*L floats
+// of this wave's cloud, so rows past the panel (the zero-padded channels of a partial K-group, padded
+// groups of the last stage) read as 0 in hardware: no clamps, no selects, one loader for every stage.
+// Requires Cout % 32 == 0 and panels < 4 GiB per cloud (all layers of the path); other shapes use v2.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+template <int MT, int S>
+__global__ __launch_bounds__(PM_THREADS) void pointmlp_f32_lean_kernel(
+    const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const float *__restrict__ Wp,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
+    int Cout, int L, int gpc, long long ngroups, int CT, int G, int ct_per_y)
+{
+    constexpr int NSL = S * MT;                               // W slices (1 KiB each) per stage
+    constexpr int NS = (NSL + PM_WAVES - 1) / PM_WAVES;      // ... staged per wave
+    __shared__ float4 wsm[2][NS * PM_WAVES][64];             // rounded up: surplus slices land in unused rows
+    __shared__ float2 affine[1024];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    // wave-uniform placement: this wave's 32 points of cloud b
+    long long q = (long long)blockIdx.x * PM_WAVES + wave;
+    const bool wave_valid = q < ngroups;
+    q = wave_valid ? q : 0;
+    const long long b = q / gpc;
+    const int l0 = (int)(q - b * gpc) * 32;
+    const bool pv = wave_valid && (l0 + j < L);
+    const int lc = (l0 + j < L) ? l0 + j : l0;               // clamped point (never stored when invalid)
+
+    const unsigned rowB = (unsigned)L * 4u;                   // bytes per channel row
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x1 + b * (long long)C1 * L), 0, (int)((unsigned)C1 * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Wp), 0, (int)((unsigned)CT * (unsigned)G * 1024u), 0x00020000);
+    const unsigned vox = (unsigned)(h * L + lc) * 4u;          // lane byte offset inside a channel-pair of rows
+    const unsigned voy = (unsigned)(4 * h * L + lc) * 4u;      // ... inside an output row quad (D rows r and r+4)
+    const unsigned vow = (unsigned)lane * 16u;
+
+    const int G1 = C2 > 0 ? (C1 >> 3) : G;                   // K-groups fed by x1 (C1 % 8 == 0 when x2 exists)
+    const int nstage = (G + S - 1) / S;
+
+    auto load_b = [&](float (&bv)[S][4], int st) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int g = st * S + i;
+            const bool second = g >= G1;
+            const unsigned row0 = (unsigned)(8 * (second ? g - G1 : g)) * rowB;     // scalar
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned so = row0 + (unsigned)(2 * s) * rowB;
+                bv[i][s] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
+                                                            : __builtin_amdgcn_raw_buffer_load_b32(r1, vox, so, 0));
+            }
+        }
+    };
+
+    const int ct_begin = blockIdx.y * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += PM_THREADS)
+        affine[o - ct_begin * 32] = make_float2(scale[o], shift[o]);
+
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+        // slice sl of a stage: K-group i = sl / MT, cout tile mt = sl % MT  (all scalar)
+        auto stage_load = [&](i32x4_t (&w)[NS], int st) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                int sl = wave + t * PM_WAVES;
+                sl = sl < NSL ? sl : NSL - 1;
+                const int i = sl / MT, mt = sl - i * MT;
+                int g = st * S + i;
+                g = g < G ? g : G - 1;
+                w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)((ct0 + mt) * G + g) * 1024u, 0);
+            }
+        };
+        auto stage_write = [&](const i32x4_t (&w)[NS], int slot) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                wsm[slot][wave + t * PM_WAVES][lane] = __builtin_bit_cast(float4, w[t]);
+        };
+        auto compute = [&](const float (&bv)[S][4], int slot) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = wsm[slot][i * MT + mt][lane];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float av = s == 0 ? a[mt].x : s == 1 ? a[mt].y : s == 2 ? a[mt].z : a[mt].w;
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i][s], acc[mt], 0, 0, 0);
+                    }
+            }
+        };
+
+        i32x4_t wreg[NS];
+        float b0[S][4], b1[S][4];
+        __syncthreads();                                       // previous pass done with both slots / affine ready
+        stage_load(wreg, 0);
+        load_b(b0, 0);
+        stage_write(wreg, 0);
+        stage_load(wreg, nstage > 1 ? 1 : 0);
+        // one stage: barrier; publish W(st+1) (unconditionally: a guarded ds_write lets LLVM sink the W load
+        // next to it and expose its latency); prefetch W(st+2) and X(st+1); compute stage st
+#define PM_STAGE(st, bcur, bnxt, slot)                                        \
+        {                                                                    \
+            __syncthreads();                                                 \
+            stage_write(wreg, (slot) ^ 1);                                   \
+            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
+            load_b(bnxt, (st) + 1);                                          \
+            compute(bcur, slot);                                             \
+        }
+        int st = 0;
+        for (; st + 2 <= nstage; st += 2) {
+            PM_STAGE(st, b0, b1, 0)
+            PM_STAGE(st + 1, b1, b0, 1)
+        }
+        if (st < nstage) PM_STAGE(st, b0, b1, 0)
+#undef PM_STAGE
+
+        if (pv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);             // + 4h is folded into voy / aff
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
                 }
             }
         }
@@ -439,14 +606,16 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
     const int gpc = sonet::ceil_div(L, 32);
     const long long ngroups = (long long)B * gpc;
     hipStream_t st = sonet::as_stream(stream);
-    // Tile policy, measured on MI355X (tools/microbench.py, profiles/r01_microbench.log): the loop is latency-
-    // bound, not bandwidth-bound, so the configuration with the most resident waves wins almost everywhere:
-    // MT = 2 cout tiles per pass (32 AGPR accumulators -> 3-4 waves/SIMD) with S = 2 K-groups per LDS stage.
-    // Exception: the node-level 515->768 layer (64 columns per cloud, too few point groups to fill the chip).
+    // Tile policy, measured on MI355X (tools/microbench.py, profiles/r01_microbench_pointmlp_lean.log) for the
+    // lean kernel: as many cout tiles per pass as divide CT (6, else 4, else 2) -- fewer passes over the X
+    // panel -- with one K-group per LDS stage; two per stage for the short-K / few-tile layers.
+    // The 32-tile node-level layer (768->1024 on 64 columns per cloud) prefers MT = 2 (more workgroups).
     const long long nwg_x = sonet::ceil_div64(ngroups, (long long)PM_WAVES);
-    int MT = 1, S = 2;
-    if (CT % 2 == 0) MT = 2;
-    if (CT % 6 == 0 && nwg_x < 512) { MT = 6; S = 1; }
+    int MT = 1, S = 1;
+    if (CT % 6 == 0) MT = 6;
+    else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
+    else if (CT % 2 == 0) MT = 2;
+    if (MT == 2 || (MT == 4 && CT <= 8)) S = 2;
     if (G == 1) S = 1;
     if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
         const int want = atoi(e);
@@ -456,7 +625,9 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
     // split the cout passes over gridDim.y when the point axis alone cannot fill the chip
     int ysplit = 1;
     while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;   // LDS affine table holds 1024 channels
     const int ct_per_y = CT / ysplit;
+    if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large for one pass table", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(PM_THREADS);
     if (const char *e = getenv("SONET_POINTMLP_S")) {       // tuning knob (bench experiments only)
         const int want = atoi(e);
@@ -467,14 +638,31 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
 #define PM_ARGS grid, block, 0, st, x1, C1, x2, C2, Wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, G, ct_per_y
 #define PM_LAUNCH_V2(MM)                                                                              \
     do {                                                                                              \
-        if (abl == 1 && S == 4)      hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 1>), PM_ARGS); \
-        else if (abl == 2 && S == 4) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 2>), PM_ARGS); \
-        else if (abl == 3 && S == 4) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 3>), PM_ARGS); \
+        if (abl == 1 && S == 2)      hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 1>), PM_ARGS); \
+        else if (abl == 2 && S == 2) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 2>), PM_ARGS); \
+        else if (abl == 3 && S == 2) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 3>), PM_ARGS); \
+        else if (abl == 4 && S == 2) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 4>), PM_ARGS); \
+        else if (abl == 7 && S == 2) hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 7>), PM_ARGS); \
         else if (S == 4)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 0>), PM_ARGS); \
         else if (S == 2)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 0>), PM_ARGS); \
         else                         hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 1, 0>), PM_ARGS); \
     } while (0)
 #define PM_LAUNCH(MM, NN) hipLaunchKernelGGL((pointmlp_f32_kernel<MM, NN>), PM_ARGS)
+    const char *kenv = getenv("SONET_POINTMLP_KERNEL");      // "wlds" forces v2 (bench A/B only)
+    const bool fits32 = (double)(C1 > C2 ? C1 : C2) * L * 4.0 < 4.0e9 && (double)Cout * L * 4.0 < 4.0e9 &&
+                        (double)CT * G * 1024.0 < 4.0e9;
+    const bool lean = (Cout % 32 == 0) && (ct_per_y <= 32) && fits32 && !(kenv && kenv[0] == 'w') && abl == 0;
+#define PM_LAUNCH_LEAN(MM)                                                                            \
+    do {                                                                                              \
+        if (S == 4)      hipLaunchKernelGGL((pointmlp_f32_lean_kernel<MM, 4>), PM_ARGS);              \
+        else if (S == 2) hipLaunchKernelGGL((pointmlp_f32_lean_kernel<MM, 2>), PM_ARGS);              \
+        else             hipLaunchKernelGGL((pointmlp_f32_lean_kernel<MM, 1>), PM_ARGS);              \
+    } while (0)
+    if (lean && (MT == 2 || MT == 4 || MT == 6)) {
+        if (MT == 2) PM_LAUNCH_LEAN(2); else if (MT == 4) PM_LAUNCH_LEAN(4); else PM_LAUNCH_LEAN(6);
+        return sonet::launched(what);
+    }
+#undef PM_LAUNCH_LEAN
     switch (MT) {
         case 8: PM_LAUNCH_V2(8); break;
         case 6: PM_LAUNCH_V2(6); break;

@@ -418,7 +418,7 @@ class KNNModule(nn.Module):
         h = torch.cat((decentered, x_neighbors), dim=1)
         for layer in self.layers:
             h = layer(h, epoch)
-        feature, _ = torch.max(h, dim=3, keepdim=False)
+        feature = torch.amax(h, dim=3)                                     # values only (torch.max also builds indices)
         return center.squeeze(3).detach(), feature
 
 

@@ -158,7 +158,7 @@ class Encoder(nn.Module):
             self.final_pn_out = self.final_pointnet(torch.cat((self.knn_center_1, self.knn_feature_1), dim=1), epoch)
         else:
             self.final_pn_out = self.final_pointnet(torch.cat((self.som_node, self.first_pn_out_masked_max), dim=1), epoch)
-        self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)
+        self.feature = torch.amax(self.final_pn_out, dim=2)               # :197 (values only)
         return self.feature
 
 

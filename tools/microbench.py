@@ -42,10 +42,10 @@ def bench_pointmlp(B=64):
         y = torch.empty(B, Cout, L, device=DEV)
         flops = 2.0 * Cin * Cout * B * L
         row = []
-        for mt in (0, 2, 4, 6, 8):
+        for mt in (0, 2, 4, 6):
             if mt and (Cout // 32) % mt:
                 continue
-            for S in ((4,) if mt == 0 else (1, 2, 4)):
+            for S in ((0,) if mt == 0 else (1, 2, 4)):
                 if mt:
                     os.environ["SONET_POINTMLP_MT"] = str(mt)
                     os.environ["SONET_POINTMLP_S"] = str(S)
@@ -54,6 +54,12 @@ def bench_pointmlp(B=64):
                     os.environ.pop("SONET_POINTMLP_S", None)
                 ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
                 row.append("MT=%s,S=%d %.3f ms %.1f TF" % (mt or "auto", S, ms, flops / ms / 1e9))
+        os.environ.pop("SONET_POINTMLP_MT", None)
+        os.environ.pop("SONET_POINTMLP_S", None)
+        os.environ["SONET_POINTMLP_KERNEL"] = "wlds"
+        ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
+        row.append("v2(wlds) auto %.3f ms %.1f TF" % (ms, flops / ms / 1e9))
+        os.environ.pop("SONET_POINTMLP_KERNEL", None)
         os.environ.pop("SONET_POINTMLP_MT", None)
         os.environ.pop("SONET_POINTMLP_S", None)
         print("pointmlp %4d->%4d L=%5d B=%d : %s" % (Cin, Cout, L, B, " | ".join(row)), flush=True)
@@ -89,15 +95,36 @@ def bench_ablate(B=64):
     sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
     y = torch.empty(B, Cout, L, device=DEV)
     flops = 2.0 * (C1 + C2) * Cout * B * L
-    os.environ["SONET_POINTMLP_S"] = "4"
-    for mt in (6, 2):
+    os.environ["SONET_POINTMLP_S"] = "2"
+    for mt in (2, 6):
         os.environ["SONET_POINTMLP_MT"] = str(mt)
-        for abl, what in ((0, "full"), (1, "no stores"), (2, "no X loads"), (3, "no stores, no X loads")):
+        for abl, what in ((0, "full"), (1, "no stores"), (2, "no X loads"), (3, "no stores, no X loads"), (4, "no LDS/barrier"), (7, "MFMA loop only")):
             os.environ["SONET_POINTMLP_ABLATE"] = str(abl)
             ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
             print("ablate 320->384 MT=%d %-24s %.4f ms %.1f TF" % (mt, what, ms, flops / ms / 1e9), flush=True)
     os.environ.pop("SONET_POINTMLP_MT", None)
     os.environ.pop("SONET_POINTMLP_ABLATE", None)
+
+
+def bench_shape_probe(B=64, L=15000):
+    """Same MFMA count per workgroup, different pass structure: many cout passes x short K vs one pass x long K."""
+    os.environ["SONET_POINTMLP_MT"] = "2"
+    os.environ["SONET_POINTMLP_S"] = "2"
+    for Cin, Cout in ((320, 384), (1920, 64), (960, 128), (160, 768), (64, 128), (256, 128), (1024, 128)):
+        x1 = torch.randn(B, Cin, L if Cin <= 1024 else L // 4, device=DEV)
+        Lx = x1.shape[2]
+        wp = ops.pointmlp_pack(torch.randn(Cout, Cin, device=DEV) * 0.05)
+        sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+        y = torch.empty(B, Cout, Lx, device=DEV)
+        flops = 2.0 * Cin * Cout * B * Lx
+        row = []
+        for abl in (0, 3, 7):
+            os.environ["SONET_POINTMLP_ABLATE"] = str(abl)
+            ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, out=y))
+            row.append("abl=%d %.3f ms %.1f TF" % (abl, ms, flops / ms / 1e9))
+        print("probe %4d->%4d L=%d : %s" % (Cin, Cout, Lx, " | ".join(row)), flush=True)
+    for k in ("SONET_POINTMLP_MT", "SONET_POINTMLP_S", "SONET_POINTMLP_ABLATE"):
+        os.environ.pop(k, None)
 
 
 if __name__ == "__main__":
@@ -110,3 +137,5 @@ if __name__ == "__main__":
         bench_som()
     if "ablate" in which:
         bench_ablate()
+    if "probe" in which:
+        bench_shape_probe()
