@@ -33,6 +33,9 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
+# the 3xbf16-split path issues 6 bf16 MFMAs per algorithmic f32 product: its ceiling in algorithmic flops
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -43,6 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (BASELINE configs[4]: 512 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["x3", "f32"], default=None,
+                    help="point-wise layer arithmetic: x3 = 3xbf16 split on bf16 MFMA (default), f32 = exact f32 MFMA")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -69,8 +75,8 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
         return "hbm", B * (6 * N * 4 + kN * 4 + M * 4 + 3 * M * 8 + 6 * kN * 4 + 3 * M * 4 + M * 4)
     if name == "knn_gather":
         return "hbm", None
-    if name.startswith("pointmlp_"):
-        dims, L = name[len("pointmlp_"):].split("_L")
+    if name.startswith("pointmlp"):
+        dims, L = name.split("_", 1)[1].split("_L")
         cin, cout = dims.split("x")
         return "mfma", 2.0 * int(cin) * int(cout) * B * int(L)
     return "hbm", None
@@ -119,6 +125,8 @@ def main():
     from models import networks as NW
     from sonet_hip import dp, ops, synth
 
+    if args.precision:
+        ops.POINTMLP_PRECISION = args.precision
     world, rank, local_rank = dp.init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -142,25 +150,47 @@ def main():
         feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
         return cls(feat)
 
+    # The step is shape-static: replay it as ONE HIP graph (sonet_hip/graph.py).  `value` is timed on the
+    # replays; the per-kernel durations for the roofline come from a second, eagerly launched region of
+    # the same K steps with HIP events around every C-ABI launch (events cannot be read inside a graph).
+    use_graph = not args.no_graph
     with torch.no_grad():
+        if use_graph:
+            from sonet_hip.graph import GraphedForward
+            graphed = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False)),
+                                     (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"]), warmup=max(1, args.warmup))
+            run = lambda: graphed(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])   # noqa: E731
+        else:
+            run = step
         for _ in range(args.warmup):
-            step()
+            run()
         dp.barrier()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = run()
+        dp.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        # instrumented eager region (same K steps) for the per-kernel figures
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
         with ops.kernel_timing() as rec:
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             for _ in range(args.steps):
-                out = step()
-            dp.barrier()
+                step()
             torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
+            eager_ms = (time.perf_counter() - t1) * 1e3 / args.steps
     elapsed = dp.all_reduce_max(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
 
     if rank != 0:
         return
+    dtype = ("f32 (3xbf16-split operands on bf16 MFMA, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "x3"
+             else "f32 (exact f32 MFMA)")
     summ = rec.summary()
     kernels = []
     for name, s in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
@@ -170,7 +200,8 @@ def main():
         if amount:
             if bound == "mfma":
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e12
-                k.update(achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+                peak = PEAK_X3_TFLOPS if name.startswith("pointmlpx3") else PEAK_F32_MFMA_TFLOPS
+                k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
             else:
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e9
                 k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
@@ -184,11 +215,13 @@ def main():
         "metric": "point-clouds/sec forward, ModelNet40 5k-pt 8x8 SOM",
         "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier forward (level-2 Encoder + Classifier head, eval), %d pts, 8x8 SOM, "
                                "k=3, som_k=9, surface normals" % N,
                    "batch_per_gpu": B, "global_batch": B * world, "points": N,
                    "parallelism": "dp%d: batch shards, no data-path collective" % world},
+        "launch_mode": "hip-graph replay" if use_graph else "eager",
+        "eager_instrumented_ms_per_step": round(eager_ms, 4),
         "roofline": roofline,
         "kernel_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 4),
         "kernels": kernels,

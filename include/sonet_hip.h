@@ -132,6 +132,16 @@ int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const f
                        const float *scale, const float *shift, int relu, float *y,
                        int B, int Cout, int L, sonet_stream_t stream);
 
+/* The same layer on bf16 MFMA with a 3-way bf16 split of both operands (6 MFMAs per product term set):
+ * f32-class accuracy (classifier forward within 3e-6 * max(|ref|, rms) of the reference; tolerance 1e-5) at
+ * 6/16 of the f32-MFMA cost.  Requires Cout % 32 == 0 and, with a second input, C1 % 16 == 0.
+ * Wp3 = sonet_pointmlp_x3_pack_size(Cin, Cout) BYTES produced by sonet_pointmlp_x3_pack. */
+size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout);
+int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream);
+int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
+                          const float *scale, const float *shift, int relu, float *y,
+                          int B, int Cout, int L, sonet_stream_t stream);
+
 /* Per-channel batch statistics of y [B][C][L] for training-mode BatchNorm (F.batch_norm with
  * training=True, models/layers.py:68): mean[c], biased var[c] over (B, L), f64 accumulation.
  * stat_ws: 2*C doubles of workspace, zeroed by the callee. */

@@ -1,0 +1,293 @@
+// pointmlp_x3.hip -- the fused point-wise layer on bf16 MFMA with a 3-way bf16 split of BOTH operands.
+//
+// Why: on gfx950 the f32-input MFMA (pointmlp.hip) runs at the f32 vector rate (157 TFLOP/s) and shares the
+// VALU pipe; the bf16 MFMA runs on the matrix cores at 16x that rate.  Splitting an f32 value into three
+// bf16 terms  x = xh + xm + xl  (each the round-to-nearest bf16 of the remaining residual: 3 x 8 = 24
+// significand bits) and keeping the six products of weight <= 2^-16
+//      W.x  ~=  Wh.xh + Wh.xm + Wm.xh + Wh.xl + Wl.xh + Wm.xm        (f32 accumulate inside the MFMA)
+// reproduces the f32 product to ~2^-23 relative (the dropped terms Wm.xl, Wl.xm, Wl.xl are <= 2^-24),
+// i.e. f32-class accuracy at 6/16 of the f32-MFMA cost.  Against the reference's fixtures the whole
+// classifier forward stays within 3e-6 * max(|ref|, rms) (tolerance 1e-5); a 2-way split does not (4e-5).
+//
+// Same data flow as the lean f32 kernel: W (pre-split, pre-packed in A-fragment order) goes through LDS in
+// stages shared by the 4 waves; X rows are raw-buffer loads (scalar row offsets, hardware zero fill past
+// the panel) prefetched one stage ahead as f32 and split in registers right before use:
+//   v_mfma_f32_32x32x16_bf16:  A lane l: W[i = l&31][k = 8*(l>>5) .. +7]   (8 bf16 = 4 VGPRs)
+//                              B lane l: X[k = 8*(l>>5) .. +7][j = l&31]   -> 8 dword loads per 16-channel chunk
+//                              D as in pointmlp.hip (rows = output channels, columns = points).
+// Split cost: 11 VALU per value pair (v_cvt_pk_bf16_f32, unpack, exact f32 subtract) = 44 per chunk per lane,
+// on the VALU pipe, while the 6*MT MFMAs of the chunk run on the matrix pipe.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int X3_THREADS = 256;
+constexpr int X3_WAVES = 4;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// (x0, x1) -> three packed bf16 pairs (hi, mid, lo), round-to-nearest at each level, residuals exact in f32
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = cvt_pk_bf16(q0, q1);
+}
+
+// Wp3[ct][kc][term][lane] (uint4 = 8 bf16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
+                                                       int Cin, int Cout, int KC, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int kc = (int)(r % KC), ct = (int)(r / KC);
+    const int o = ct * 32 + (lane & 31);
+    const int c0 = kc * 16 + 8 * (lane >> 5);
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + 2 * p;
+        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
+        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
+        split3_pair(w0, w1, h[p], m[p], l[p]);
+    }
+    uint4 *dst = Wp3 + (r * 3) * 64 + lane;
+    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    dst[64] = make_uint4(m[0], m[1], m[2], m[3]);
+    dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int MT, int S>
+__global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
+    const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
+    int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y)
+{
+    constexpr int NSL = S * MT * 3;                           // 1 KiB W slices per stage (3 split terms)
+    constexpr int NS = (NSL + X3_WAVES - 1) / X3_WAVES;
+    __shared__ uint4 wsm[2][NS * X3_WAVES][64];
+    __shared__ float2 affine[1024];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    long long q = (long long)blockIdx.x * X3_WAVES + wave;
+    const bool wave_valid = q < ngroups;
+    q = wave_valid ? q : 0;
+    const long long b = q / gpc;
+    const int l0 = (int)(q - b * gpc) * 32;
+    const bool pv = wave_valid && (l0 + j < L);
+    const int lc = (l0 + j < L) ? l0 + j : l0;
+
+    const unsigned rowB = (unsigned)L * 4u;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x1 + b * (long long)C1 * L), 0, (int)((unsigned)C1 * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(Wp3), 0, (int)((unsigned)CT * (unsigned)KC * 3072u), 0x00020000);
+    const unsigned vox = (unsigned)(8 * h * L + lc) * 4u;      // lane byte offset inside a 16-channel chunk
+    const unsigned voy = (unsigned)(4 * h * L + lc) * 4u;
+    const unsigned vow = (unsigned)lane * 16u;
+
+    const int KC1 = C2 > 0 ? (C1 >> 4) : KC;                  // chunks fed by x1 (C1 % 16 == 0 when x2 exists)
+    const int nstage = (KC + S - 1) / S;
+
+    auto load_b = [&](float (&raw)[S][8], int st) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int kc = st * S + i;
+            const bool second = kc >= KC1;
+            const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rowB;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned so = row0 + (unsigned)t * rowB;
+                raw[i][t] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
+                                                              : __builtin_amdgcn_raw_buffer_load_b32(r1, vox, so, 0));
+            }
+        }
+    };
+
+    const int ct_begin = blockIdx.y * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
+        affine[o - ct_begin * 32] = make_float2(scale[o], shift[o]);
+
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+        // slice sl of a stage: chunk i = sl / (3*MT), cout tile mt = (sl / 3) % MT, term = sl % 3
+        auto stage_load = [&](i32x4_t (&w)[NS], int st) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                int sl = wave + t * X3_WAVES;
+                sl = sl < NSL ? sl : NSL - 1;
+                const int i = sl / (3 * MT), rem = sl - i * (3 * MT);
+                const int mt = rem / 3, term = rem - mt * 3;
+                int kc = st * S + i;
+                kc = kc < KC ? kc : KC - 1;
+                w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(((ct0 + mt) * KC + kc) * 3 + term) * 1024u, 0);
+            }
+        };
+        auto stage_write = [&](const i32x4_t (&w)[NS], int slot) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                wsm[slot][wave + t * X3_WAVES][lane] = __builtin_bit_cast(uint4, w[t]);
+        };
+        auto compute = [&](const float (&raw)[S][8], int slot) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) split3_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
+                const bf16x8 Bh = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const bf16x8 Bm = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+                const bf16x8 Bl = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, wsm[slot][(i * MT + mt) * 3 + 0][lane]);
+                    const bf16x8 Am = __builtin_bit_cast(bf16x8, wsm[slot][(i * MT + mt) * 3 + 1][lane]);
+                    const bf16x8 Al = __builtin_bit_cast(bf16x8, wsm[slot][(i * MT + mt) * 3 + 2][lane]);
+                    // smallest terms first
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[mt], 0, 0, 0);
+                }
+            }
+        };
+
+        i32x4_t wreg[NS];
+        float b0[S][8], b1[S][8];
+        __syncthreads();
+        stage_load(wreg, 0);
+        load_b(b0, 0);
+        stage_write(wreg, 0);
+        stage_load(wreg, nstage > 1 ? 1 : 0);
+#define X3_STAGE(st, bcur, bnxt, slot)                                        \
+        {                                                                    \
+            __syncthreads();                                                 \
+            stage_write(wreg, (slot) ^ 1);                                   \
+            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
+            load_b(bnxt, (st) + 1);                                          \
+            compute(bcur, slot);                                             \
+        }
+        int st = 0;
+        for (; st + 2 <= nstage; st += 2) {
+            X3_STAGE(st, b0, b1, 0)
+            X3_STAGE(st + 1, b1, b0, 1)
+        }
+        if (st < nstage) X3_STAGE(st, b0, b1, 0)
+#undef X3_STAGE
+
+        if (pv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 3 * 64 * 16;     // bytes
+}
+
+extern "C" int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_x3_pack";
+    SONET_REQUIRE(W && Wp3, "%s: NULL pointer", what);
+    SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
+    const int KC = sonet::ceil_div(Cin, 16);
+    const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
+                                     const float *scale, const float *shift, int relu, float *y,
+                                     int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_x3_f32";
+    SONET_REQUIRE(x1 && Wp3 && scale && shift && y, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
+    SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
+    if (Cout % 32 != 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 32", what, Cout);
+    const int Cin = C1 + C2;
+    const int CT = Cout / 32, KC = sonet::ceil_div(Cin, 16);
+    const int gpc = sonet::ceil_div(L, 32);
+    const long long ngroups = (long long)B * gpc;
+    if ((double)(C1 > C2 ? C1 : C2) * L * 4.0 >= 4.0e9 || (double)Cout * L * 4.0 >= 4.0e9 || (double)CT * KC * 3072.0 >= 4.0e9)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
+    const long long nwg_x = sonet::ceil_div64(ngroups, (long long)X3_WAVES);
+    if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+    int MT = 1, S = 1;
+    if (CT % 6 == 0) MT = 6;
+    else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
+    else if (CT % 2 == 0) MT = 2;
+    if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
+        const int want = atoi(e);
+        if ((want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
+    }
+    if (const char *e = getenv("SONET_POINTMLP_S")) {
+        const int want = atoi(e);
+        if (want == 1 || want == 2) S = want;
+    }
+    if (KC == 1) S = 1;
+    int ysplit = 1;
+    while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    const int ct_per_y = CT / ysplit;
+    if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
+    dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
+    hipStream_t st = sonet::as_stream(stream);
+    const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y
+#define X3_LAUNCH(MM) do { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2>), X3_ARGS); \
+                           else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1>), X3_ARGS); } while (0)
+    switch (MT) {
+        case 6: X3_LAUNCH(6); break;
+        case 4: X3_LAUNCH(4); break;
+        case 2: X3_LAUNCH(2); break;
+        default: X3_LAUNCH(1);
+    }
+#undef X3_LAUNCH
+#undef X3_ARGS
+    return sonet::launched(what);
+}

@@ -158,12 +158,16 @@ class _FusedPointwise(nn.Module):
         w = self.conv.weight
         return w.reshape(w.shape[0], w.shape[1])
 
-    def _packed(self):
+    def _packed(self, C1=None, C2=0):
+        """Packed weight for the current arithmetic mode (``sonet_hip.ops.POINTMLP_PRECISION``)."""
         w = self.conv.weight
-        key = (w._version, w.data_ptr(), w.device)
+        mode = _ops.POINTMLP_PRECISION
+        if mode == "x3" and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
+            mode = "f32"
+        key = (w._version, w.data_ptr(), w.device, mode)
         if getattr(self, '_wp_key', None) != key:
             with torch.no_grad():
-                self._wp = _ops.pointmlp_pack(self._weight2d().detach().contiguous().float())
+                self._wp = _ops.pointmlp_pack(self._weight2d().detach().contiguous().float(), mode)
             self._wp_key = key
         return self._wp
 
@@ -200,7 +204,7 @@ class _FusedPointwise(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x1.requires_grad or (x2 is not None and x2.requires_grad)
                                                   or self.conv.weight.requires_grad)
         fuse_act = relu_fused and (norm in (None, 'batch'))
-        wp = self._packed()
+        wp = self._packed(x1.shape[1], x2.shape[1] if x2 is not None else 0)
         if train_bn:
             y, mean, var = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
                                               fuse_act, 'batch', bn.eps)

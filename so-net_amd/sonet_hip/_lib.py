@@ -30,6 +30,9 @@ SIGNATURES = {
     "sonet_pointmlp_pack_size": [_i, _i],
     "sonet_pointmlp_pack_f32": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_x3_pack_size": [_i, _i],
+    "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
+    "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -38,6 +41,7 @@ _RESTYPES = {
     "sonet_build_arch": ctypes.c_char_p,
     "sonet_last_error": ctypes.c_char_p,
     "sonet_pointmlp_pack_size": ctypes.c_size_t,
+    "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
 }
 
 _lib = None

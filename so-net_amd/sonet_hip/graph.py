@@ -1,0 +1,39 @@
+"""HIP-graph capture of a fixed-shape forward pass.
+
+The level-2 forward is ~40 short launches (11 hand-written kernels plus the aten glue of the heads);
+eagerly launched from Python it is partly launch-bound (about 0.3-0.7 ms of a 4 ms step at B=64).
+Static shapes make it a textbook case for a HIP graph: capture once, replay with one host call.
+The C-ABI launches go to ``torch.cuda.current_stream()``, which is the capture stream inside
+``torch.cuda.graph``, so they are recorded as kernel / memset nodes like any aten op.
+
+    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), (pc, sn, node, knn))
+    out = fwd(pc, sn, node, knn)          # copies into the static inputs (no-op for the same tensors), replays
+
+Inference only (no autograd through a replay); the callable must be shape-static and must not
+synchronise or allocate outside the caching allocator.
+"""
+import torch
+
+
+class GraphedForward:
+    def __init__(self, fn, example_inputs, warmup=3):
+        self.fn = fn
+        self.static_inputs = tuple(t for t in example_inputs)
+        dev = self.static_inputs[0].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):            # builds every lazy cache (packed weights, folded BN)
+                fn(*self.static_inputs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_output = fn(*self.static_inputs)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            if dst is not src and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_output

@@ -306,3 +306,101 @@ def test_encoder_classifier_forward_golden(case):
     assert_close_rms(enc.final_pn_out[:, ::4].cpu().numpy(), g["final_pn_out"], tol, "final_pn_out")
     assert_close_rms(feat.cpu().numpy(), g["feature"], tol, "feature")
     assert_close_rms(score.cpu().numpy(), g["score"], tol, "score")
+
+
+def test_graphed_forward_equals_eager():
+    """HIP-graph replay of the classifier forward is bit-identical to the eager launch sequence."""
+    from models import networks as NW
+    from sonet_hip import synth
+    from sonet_hip.graph import GraphedForward
+    g = golden("classifier_b8_n1024")
+    opt = make_opt(g, 8, 1024)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), 3)
+    synth.fill_state_dict_(cls.state_dict(), 4)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    args = (cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
+    with torch.no_grad():
+        eager = cls(enc(*args)).clone()
+    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), args)
+    out1 = fwd(*args).clone()
+    # new data through the same graph
+    args2 = (args[0].flip(0).contiguous(), args[1].flip(0).contiguous(), args[2].flip(0).contiguous(), args[3].flip(0).contiguous())
+    out2 = fwd(*args2).clone()
+    with torch.no_grad():
+        eager2 = cls(enc(*args2))
+    assert torch.equal(out1, eager)
+    assert torch.equal(out2, eager2)
+    assert torch.equal(out2.flip(0), eager)
+
+
+# ------------------------------------------------------------------------------------------ 3 x bf16 split path
+@pytest.fixture
+def x3_mode():
+    from sonet_hip import ops
+    old = ops.POINTMLP_PRECISION
+    ops.POINTMLP_PRECISION = "x3"
+    yield
+    ops.POINTMLP_PRECISION = old
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L,bn,relu", [
+    (2, 6, 0, 64, 300, True, True), (2, 64, 0, 128, 768, True, True), (1, 64, 256, 384, 1000, False, False),
+    (3, 387, 0, 512, 576, True, True), (4, 515, 0, 768, 64, True, True), (2, 768, 0, 1024, 64, False, False),
+    (2, 100, 0, 96, 77, False, True), (1, 3, 0, 32, 1, True, True), (2, 16, 16, 64, 40, False, False)])
+def test_pointmlp_x3_vs_oracle(B, C1, C2, Cout, L, bn, relu):
+    """bf16x3 split MFMA path: f32-class accuracy (same 1e-5 tolerance as the exact-f32 path)."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    Cin = C1 + C2
+    x = torch.randn(B, Cin, L, generator=g)
+    W = torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5
+    bias = torch.rand(Cout, generator=g) * 0.2 - 0.1
+    if bn:
+        gamma, beta = 0.5 + torch.rand(Cout, generator=g), torch.rand(Cout, generator=g) * 0.4 - 0.2
+        mean, var = 0.2 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)
+        scale = gamma / torch.sqrt(var + 1e-5)
+        shift = (bias - mean) * scale + beta
+        ref = O.pointwise_layer(x.numpy(), W.numpy(), bias.numpy(), bn=(gamma.numpy(), beta.numpy(), mean.numpy(), var.numpy()),
+                                relu=relu)
+    else:
+        scale, shift = torch.ones(Cout), bias
+        ref = O.pointwise_layer(x.numpy(), W.numpy(), bias.numpy(), bn=None, relu=relu)
+    wp = ops.pointmlp_pack(W.to(DEV), "x3")
+    assert wp.dtype == torch.uint8
+    x1 = x[:, :C1].contiguous().to(DEV)
+    x2 = x[:, C1:].contiguous().to(DEV) if C2 else None
+    y = ops.pointmlp(x1, wp, scale.to(DEV), shift.to(DEV), relu, Cout, x2=x2)
+    assert_close_rms(y.cpu().numpy(), ref, 1e-5, "pointmlp x3")
+
+
+@pytest.fixture
+def f32_mode():
+    from sonet_hip import ops
+    old = ops.POINTMLP_PRECISION
+    ops.POINTMLP_PRECISION = "f32"
+    yield
+    ops.POINTMLP_PRECISION = old
+
+
+@pytest.mark.parametrize("case", ["classifier_b2_n256", "classifier_b8_n1024", "classifier_b2_n5000",
+                                  "classifier_b2_n300_k1_center"])
+def test_encoder_classifier_forward_golden_x3(case, x3_mode):
+    test_encoder_classifier_forward_golden(case)
+
+
+@pytest.mark.parametrize("case", ["classifier_b2_n256", "classifier_b8_n1024", "classifier_b2_n5000",
+                                  "classifier_b2_n300_k1_center"])
+def test_encoder_classifier_forward_golden_exact_f32(case, f32_mode):
+    test_encoder_classifier_forward_golden(case)
+
+
+def test_point_resnet_eval_golden_x3(x3_mode):
+    test_point_resnet_eval_golden()
+
+
+def test_point_resnet_and_layer_golden_exact_f32(f32_mode):
+    test_point_resnet_eval_golden()
+    test_equivariant_layer_eval_and_train_golden()

@@ -65,6 +65,36 @@ def bench_pointmlp(B=64):
         print("pointmlp %4d->%4d L=%5d B=%d : %s" % (Cin, Cout, L, B, " | ".join(row)), flush=True)
 
 
+def bench_x3(B=64):
+    shapes = [(6, 0, 64, 15000), (64, 0, 128, 15000), (128, 0, 256, 15000), (64, 256, 384, 15000),
+              (387, 0, 512, 576), (512, 0, 512, 576), (515, 0, 768, 64), (768, 0, 1024, 64)]
+    for C1, C2, Cout, L in shapes:
+        Cin = C1 + C2
+        x1 = torch.randn(B, C1, L, device=DEV)
+        x2 = torch.randn(B, C2, L, device=DEV) if C2 else None
+        W = torch.randn(Cout, Cin, device=DEV) * (2.0 / Cin) ** 0.5
+        sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+        y = torch.empty(B, Cout, L, device=DEV)
+        flops = 2.0 * Cin * Cout * B * L
+        row = []
+        wp = ops.pointmlp_pack(W, "f32")
+        ms = timeit(lambda: ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y))
+        row.append("f32 %.3f ms %.1f TF" % (ms, flops / ms / 1e9))
+        wp3 = ops.pointmlp_pack(W, "x3")
+        for mt in (0, 1, 2, 4, 6):
+            if mt and (Cout // 32) % mt:
+                continue
+            for S in ((0,) if mt == 0 else (1, 2)):
+                if mt:
+                    os.environ["SONET_POINTMLP_MT"] = str(mt)
+                    os.environ["SONET_POINTMLP_S"] = str(S)
+                ms = timeit(lambda: ops.pointmlp(x1, wp3, sc, sh, True, Cout, x2=x2, out=y))
+                row.append("x3 MT=%s,S=%d %.3f ms %.1f TF-eq" % (mt or "auto", S, ms, flops / ms / 1e9))
+        os.environ.pop("SONET_POINTMLP_MT", None)
+        os.environ.pop("SONET_POINTMLP_S", None)
+        print("x3 %4d->%4d L=%5d B=%d : %s" % (Cin, Cout, L, B, " | ".join(row)), flush=True)
+
+
 def bench_index_max():
     for B, C, N, K in [(64, 384, 15000, 64), (8, 384, 15000, 64), (64, 384, 3072, 64)]:
         data = torch.randn(B, C, N, device=DEV)
@@ -137,5 +167,7 @@ if __name__ == "__main__":
         bench_som()
     if "ablate" in which:
         bench_ablate()
+    if "x3" in which:
+        bench_x3()
     if "probe" in which:
         bench_shape_probe()
