@@ -142,6 +142,22 @@ int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, cons
                           const float *scale, const float *shift, int relu, float *y,
                           int B, int Cout, int L, sonet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * pointresnet_fused -- the encoder's first PointNet as ONE kernel (eval mode, 3xbf16-split arithmetic)
+ *   reference: models/layers.py:419-432 (PointResNet.forward) as built at models/networks.py:82-83:
+ *              Cin0 (<= 16) -> 64 -> 128 -> 256 -> [64 + 256] -> 384, BN + ReLU on the first three layers.
+ * x [B][Cin0][L] f32 -> y [B][384][L] f32; intermediate activations never leave the registers.
+ * wstream: sonet_pointresnet_pack_size() bytes from sonet_pointresnet_pack (the four row-major weights
+ *   [64][Cin0], [128][64], [256][128], [384][320] split into bf16 terms and laid out in MFMA consumption order);
+ * affine: 832 (scale, shift) float pairs, channels of layer 1, 2, 3, 4 concatenated (eval BN + bias folded;
+ *   layer 4: scale 1, shift bias).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sonet_pointresnet_pack_size(void);
+int sonet_pointresnet_pack(const float *W1, const float *W2, const float *W3, const float *W4, int Cin0,
+                           void *wstream, sonet_stream_t stream);
+int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void *wstream, const float *affine,
+                                float *y, int B, int L, sonet_stream_t stream);
+
 /* Per-channel batch statistics of y [B][C][L] for training-mode BatchNorm (F.batch_norm with
  * training=True, models/layers.py:68): mean[c], biased var[c] over (B, L), f64 accumulation.
  * stat_ws: 2*C doubles of workspace, zeroed by the callee. */

@@ -468,7 +468,36 @@ class PointResNet(nn.Module):
                 self.layers.append(EquivariantLayer(prev + out_channels_list[0], c_out, None, None))
             prev = c_out
 
+    def _fusable_eval(self, x):
+        """One-kernel path: standard first-PointNet shape, eval BatchNorm + ReLU, no autograd, x3 arithmetic."""
+        if self.training or torch.is_grad_enabled():             # training BN / autograd: layer-by-layer path
+            return False
+        if _ops.POINTMLP_PRECISION != "x3" or not _ops.FUSE_POINTRESNET or not x.is_cuda:
+            return False
+        if list(self.out_channels_list) != [64, 128, 256, 384] or x.shape[1] > 16:
+            return False
+        ls = self.layers
+        hidden_ok = all(l.normalization == 'batch' and l.activation == 'relu' for l in ls[:3])
+        return hidden_ok and ls[3].normalization is None and ls[3].activation is None and x.shape[2] * 384 * 4 < 4e9
+
+    def _fused_state(self):
+        ws = [l.conv.weight for l in self.layers]
+        key = tuple((w._version, w.data_ptr()) for w in ws) + (ws[0].device,)
+        if getattr(self, '_fused_key', None) != key:
+            with torch.no_grad():
+                self._fused_w = _ops.pointresnet_pack(*[l._weight2d().detach().contiguous().float() for l in self.layers])
+            self._fused_key = key
+        aff = [l._eval_affine() for l in self.layers]                   # cached per layer
+        akey = tuple(id(a[0]) for a in aff)
+        if getattr(self, '_fused_akey', None) != akey:
+            self._fused_aff = torch.stack((torch.cat([a[0] for a in aff]), torch.cat([a[1] for a in aff])), dim=1).contiguous()
+            self._fused_akey = akey
+        return self._fused_w, self._fused_aff
+
     def forward(self, x, epoch=None):
+        if self._fusable_eval(x):
+            wstream, affine = self._fused_state()
+            return _ops.pointresnet_fused(_FusedPointwise._prep(x), wstream, affine)
         n = len(self.out_channels_list)
         skip = self.layers[0](x, epoch)
         t = skip

@@ -33,6 +33,9 @@ SIGNATURES = {
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointresnet_pack_size": [],
+    "sonet_pointresnet_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "sonet_pointresnet_fused_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -42,6 +45,7 @@ _RESTYPES = {
     "sonet_last_error": ctypes.c_char_p,
     "sonet_pointmlp_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
+    "sonet_pointresnet_pack_size": ctypes.c_size_t,
 }
 
 _lib = None

@@ -201,6 +201,10 @@ import os as _os
 POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "x3")
 
 
+# run the encoder's first PointNet (eval mode, "x3" arithmetic) as one fused kernel
+FUSE_POINTRESNET = _os.environ.get("SONET_FUSE_POINTRESNET", "1") != "0"
+
+
 def x3_supported(C1, C2, Cout):
     return Cout % 32 == 0 and (C2 == 0 or C1 % 16 == 0)
 
@@ -246,6 +250,38 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
     with torch.cuda.device(dev), _timed("pointmlp%s_%dx%d_L%d" % ("x3" if x3 else "", C1 + C2, Cout, L)):
         check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
                  B, Cout, L, stream_ptr()), "sonet_pointmlp")
+    return y
+
+
+def pointresnet_pack(w1, w2, w3, w4):
+    """Pack the four [Cout][Cin] f32 weights of the first PointNet into the fused kernel's weight stream."""
+    for i, w in enumerate((w1, w2, w3, w4)):
+        _chk(w, "w%d" % (i + 1), torch.float32, 2)
+    if (w1.shape[0], tuple(w2.shape), tuple(w3.shape), tuple(w4.shape)) != (64, (128, 64), (256, 128), (384, 320)) or w1.shape[1] > 16:
+        raise SonetHipError("pointresnet_fused supports Cin0<=16 -> 64 -> 128 -> 256 -> [320] -> 384 only")
+    dev = _same_device(w1, w2, w3, w4)
+    lib = _lib.load()
+    ws = torch.empty((lib.sonet_pointresnet_pack_size(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.sonet_pointresnet_pack(ptr(w1), ptr(w2), ptr(w3), ptr(w4), w1.shape[1], ptr(ws), stream_ptr()),
+              "sonet_pointresnet_pack")
+    return ws
+
+
+def pointresnet_fused(x, wstream, affine):
+    """x B x Cin0 x L f32 -> B x 384 x L f32 (whole first PointNet, eval BN folded into ``affine`` 832 x 2)."""
+    _chk(x, "x", torch.float32, 3)
+    _chk(affine, "affine", torch.float32, 2)
+    if tuple(affine.shape) != (832, 2):
+        raise SonetHipError("affine must be 832 x 2 (scale, shift)")
+    dev = _same_device(x, wstream, affine)
+    B, Cin0, L = x.shape
+    y = torch.empty((B, 384, L), dtype=torch.float32, device=dev)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(dev), _timed("pointresnet_fused_L%d" % L):
+        check(_lib.load().sonet_pointresnet_fused_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
+              "sonet_pointresnet_fused_f32")
     return y
 
 

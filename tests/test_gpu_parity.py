@@ -404,3 +404,34 @@ def test_point_resnet_eval_golden_x3(x3_mode):
 def test_point_resnet_and_layer_golden_exact_f32(f32_mode):
     test_point_resnet_eval_golden()
     test_equivariant_layer_eval_and_train_golden()
+
+
+def test_pointresnet_fused_vs_layerwise_and_golden():
+    """One-kernel first PointNet (register-chained layers) == the four-launch path == the reference fixture."""
+    from models import layers as L
+    from sonet_hip import ops, synth
+    g = golden("layers")
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    old = (ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET)
+    try:
+        ops.POINTMLP_PRECISION = "x3"
+        for shape in [(2, 6, 300), (3, 6, 15000), (1, 6, 1), (2, 3, 129)]:
+            gen = torch.Generator().manual_seed(shape[2])
+            x = torch.randn(shape, generator=gen).to(DEV)
+            prn = pr if shape[1] == 6 else L.PointResNet(3, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1).to(DEV).eval()
+            with torch.no_grad():
+                ops.FUSE_POINTRESNET = True
+                with ops.kernel_timing() as rec:
+                    y_fused = prn(x)
+                assert any(n.startswith("pointresnet_fused") for n, _, _ in rec.records), "fused kernel did not run"
+                ops.FUSE_POINTRESNET = False
+                y_layer = prn(x)
+            assert_close_rms(y_fused.cpu().numpy(), y_layer.cpu().numpy(), 1e-5, "fused vs layerwise %s" % (shape,))
+        with torch.no_grad():
+            ops.FUSE_POINTRESNET = True
+            y = pr(cu(g["eq_x"]))
+        assert_close_rms(y[:, ::8].cpu().numpy(), g["prn_eval_y"], 1e-5, "fused PointResNet vs reference")
+    finally:
+        ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET = old

@@ -95,6 +95,29 @@ def bench_x3(B=64):
         print("x3 %4d->%4d L=%5d B=%d : %s" % (Cin, Cout, L, B, " | ".join(row)), flush=True)
 
 
+def bench_fused(B=64, L=15000):
+    from models import layers as Lm
+    from sonet_hip import synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    x = torch.randn(B, 6, L, device=DEV)
+    flops = 2.0 * (6 * 64 + 64 * 128 + 128 * 256 + 320 * 384) * B * L
+    with torch.no_grad():
+        for fuse in (True, False):
+            ops.FUSE_POINTRESNET = fuse
+            ms = timeit(lambda: pr(x))
+            print("first PointNet B=%d L=%d %s : %.3f ms  %.1f TF-eq (%.1f%% of 2500/6)" % (
+                B, L, "FUSED" if fuse else "4 launches", ms, flops / ms / 1e9, flops / ms / 1e9 / (2500 / 6) * 100), flush=True)
+        ops.FUSE_POINTRESNET = True
+        for abl, what in ((1, "no stores"), (2, "no bf16 split"), (4, "no W streaming/barriers"), (7, "MFMA stream only")):
+            os.environ["SONET_FUSED_ABLATE"] = str(abl)
+            ms = timeit(lambda: pr(x))
+            print("   fused ablation %-26s : %.3f ms  %.1f TF-eq" % (what, ms, flops / ms / 1e9), flush=True)
+        os.environ.pop("SONET_FUSED_ABLATE", None)
+    ops.FUSE_POINTRESNET = True
+
+
 def bench_index_max():
     for B, C, N, K in [(64, 384, 15000, 64), (8, 384, 15000, 64), (64, 384, 3072, 64)]:
         data = torch.randn(B, C, N, device=DEV)
@@ -169,5 +192,7 @@ if __name__ == "__main__":
         bench_ablate()
     if "x3" in which:
         bench_x3()
+    if "fused" in which:
+        bench_fused()
     if "probe" in which:
         bench_shape_probe()

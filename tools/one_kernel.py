@@ -19,6 +19,16 @@ if name == "pointmlp":
     y = torch.empty(B, Cout, L, device=DEV)
     for _ in range(iters):
         ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2, out=y)
+elif name == "fused":
+    from models import layers as Lm
+    from sonet_hip import synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    x = torch.randn(B, 6, 15000, device=DEV)
+    with torch.no_grad():
+        for _ in range(iters):
+            pr(x)
 elif name == "index_max":
     data = torch.randn(B, 384, 15000, device=DEV)
     index = torch.randint(0, 64, (B, 15000), device=DEV, dtype=torch.int32)
