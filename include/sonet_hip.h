@@ -106,6 +106,12 @@ int sonet_som_group_f32(const float *x, const float *sn, const int32_t *min_idx_
 int sonet_som_mask_i32(const int32_t *min_idx_i32, int32_t *mask, int B, int kN, int M,
                        sonet_stream_t stream);
 
+/* node_gather -- the segmenter's back-broadcast of node-level features to the kN point copies
+ *   reference: models/segmenter.py:90-98 (argmax(mask) -> min_idx, three torch.gather calls)
+ * feat [B][C][M] f32, min_idx_i32 [B][kN] -> out [B][C][kN] = feat[b][c][min_idx[b][j]]. */
+int sonet_node_gather_f32(const float *feat, const int32_t *min_idx_i32, float *out,
+                          int B, int C, int M, int kN, sonet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * knn_gather  -- replaces knn_gather_by_indexing / knn_gather_wrapper
  *   reference: models/operations.py:19-54;  caller: models/layers.py:346,360

@@ -200,6 +200,96 @@ def golden_state_dict_keys(ref):
     print("state_dict_keys.json  encoder %d keys, classifier %d keys" % (len(out["encoder"]), len(out["classifier"])))
 
 
+GRAD_KEYS = ["first_pointnet.layers.0.conv.weight", "first_pointnet.layers.0.norm.weight", "first_pointnet.layers.2.conv.weight",
+             "first_pointnet.layers.3.conv.weight", "first_pointnet.layers.3.conv.bias", "knnlayer.layers.0.conv.weight",
+             "knnlayer.layers.1.norm.bias", "final_pointnet.layers.0.conv.weight", "final_pointnet.layers.1.conv.bias"]
+
+
+def golden_train_step(ref, tag, B, N, seed):
+    """One classifier training step of the reference (models/classifier.py:78-99), dropout off so it is
+    deterministic: loss, selected gradients, BN running statistics and parameters after the Adam steps.
+
+    Gradients are stored twice: from the reference as it is (float32 on CPU) and from the SAME reference code run
+    in float64 (``grad64/``).  The float32 CPU backward of train-mode BatchNorm under the very sparse gradients of
+    the arg-max pools loses ~3 digits to cancellation (its deviation from the float64 run is stored as
+    ``ref32_dev/``), so the float64 run is the ground truth the HIP path is held to."""
+    def run(dtype):
+        opt = ref_harness.make_opt(batch_size=B, input_pc_num=N, dropout=0.0, classes=40)
+        model = ref.classifier.Model(opt)
+        synth.fill_state_dict_(model.encoder.state_dict(), seed=seed)
+        synth.fill_state_dict_(model.classifier.state_dict(), seed=seed + 1)
+        inp = synth.make_inputs(B, N, M=opt.node_num, som_k=opt.som_k, seed=seed, node_kind="som")
+        if dtype == torch.float64:
+            model.encoder.double(); model.classifier.double()
+            model.input_pc, model.input_sn, model.input_node = model.input_pc.double(), model.input_sn.double(), model.input_node.double()
+            model.encoder.som_builder.node = model.encoder.som_builder.node.double()
+            model.optimizer_encoder = torch.optim.Adam(model.encoder.parameters(), lr=0.001)
+            model.optimizer_classifier = torch.optim.Adam(model.classifier.parameters(), lr=0.001)
+            # the reference's index_max extension reads float32 only (index_max.cpp:92): cast at the shim, indices only
+            ext = ref.index_max
+            fwd = ext.forward_cpu
+            ref.networks.index_max = type(ext)("index_max")
+            ref.networks.index_max.forward_cuda = lambda d, i, K: fwd(d.float().contiguous(), i, K)
+        model.set_input(inp["pc"].to(dtype), inp["sn"].to(dtype), inp["label"], inp["node"].to(dtype), inp["node_knn_I"])
+        try:
+            with ref_harness.sorted_topk():
+                model.optimize(epoch=0)
+        finally:
+            ref.networks.index_max = ref.index_max
+        return model, inp
+
+    model, inp = run(torch.float32)
+    model64, _ = run(torch.float64)
+    enc = dict(model.encoder.named_parameters())
+    enc64 = dict(model64.encoder.named_parameters())
+    arrays = dict(B=B, N=N, seed=seed, pc=inp["pc"], sn=inp["sn"], node=inp["node"], node_knn_I=inp["node_knn_I"],
+                  label=inp["label"], loss=model.loss.detach(), loss64=model64.loss.detach(), feature=model.feature.detach(),
+                  score=model.score.detach())
+
+    def sub(t):                                   # strided subsample keeps the fixture small (<= ~16k values per tensor)
+        f = t.detach().flatten()
+        return f[::max(1, f.numel() // 16384)]
+    for k in GRAD_KEYS:
+        arrays["grad/" + k] = sub(enc[k].grad)
+        arrays["grad64/" + k] = sub(enc64[k].grad)
+        arrays["after/" + k] = sub(enc[k])
+        a, r = enc[k].grad.double(), enc64[k].grad
+        arrays["ref32_dev/" + k] = ((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+        print("   %-45s float32 reference vs its own float64 run: rel-rms %.2e" % (k, arrays["ref32_dev/" + k]))
+    cls = dict(model.classifier.named_parameters())
+    arrays["grad/cls.fc1.linear.weight"] = sub(cls["fc1.linear.weight"].grad)
+    arrays["grad64/cls.fc1.linear.weight"] = sub(dict(model64.classifier.named_parameters())["fc1.linear.weight"].grad)
+    arrays["dead_grad_count"] = sum(1 for p in model.encoder.parameters() if p.grad is None)
+    sd = model.encoder.state_dict()
+    for k in ("first_pointnet.layers.1.norm.running_mean", "first_pointnet.layers.1.norm.running_var",
+              "knnlayer.layers.0.norm.running_var", "final_pointnet.layers.0.norm.running_mean"):
+        arrays["bn/" + k] = sd[k]
+    save("train_step_" + tag, **arrays)
+
+
+def golden_segmenter(ref, tag, B, N, seed):
+    """Reference part-segmentation forward (models/segmenter.py:79-109 + networks.Segmenter), eval mode."""
+    opt = ref_harness.make_opt(batch_size=B, input_pc_num=N, classes=50, dropout=0.6, som_k_type="center")
+    model = ref.segmenter.Model(opt)
+    synth.fill_state_dict_(model.encoder.state_dict(), seed=seed)
+    synth.fill_state_dict_(model.segmenter.state_dict(), seed=seed + 1)
+    inp = synth.make_inputs(B, N, M=opt.node_num, som_k=opt.som_k, seed=seed, node_kind="som")
+    g = torch.Generator().manual_seed(seed)
+    label = torch.randint(0, 16, (B,), generator=g)
+    seg = torch.randint(0, 50, (B, N), generator=g)
+    model.set_input(inp["pc"], inp["sn"], label, seg, inp["node"], inp["node_knn_I"])
+    model.encoder.eval(); model.segmenter.eval()
+    with ref_harness.sorted_topk(), torch.no_grad():
+        model.forward(is_train=False)
+    enc = model.encoder
+    min_idx = enc.mask.argmax(dim=2)
+    idx384 = min_idx.unsqueeze(1).expand(B, 384, min_idx.shape[1])
+    bb = torch.gather(enc.first_pn_out_masked_max, 2, idx384)
+    save("segmenter_" + tag, B=B, N=N, seed=seed, pc=inp["pc"], sn=inp["sn"], node=inp["node"], node_knn_I=inp["node_knn_I"],
+         label=label, min_idx=min_idx, feature_max_first_pn_out=bb[:, ::8], score_segmenter=model.score_segmenter,
+         segmenter_keys=np.array(sorted(model.segmenter.state_dict().keys())))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -212,6 +302,8 @@ def main():
     golden_classifier(ref, "b2_n256", B=2, N=256, seed=101, node_kind="uniform")
     golden_classifier(ref, "b8_n1024", B=8, N=1024, seed=102, node_kind="som")          # BASELINE configs[0]
     golden_classifier(ref, "b2_n5000", B=2, N=5000, seed=103, node_kind="som")          # configs[1] shape
+    golden_train_step(ref, "b16_n512", B=16, N=512, seed=201)   # B=16: BN over 4 samples is too ill-conditioned to compare gradients
+    golden_segmenter(ref, "b2_n256", B=2, N=256, seed=301)
     golden_classifier(ref, "b2_n300_k1_center", B=2, N=300, seed=104, node_kind="uniform", k=1,
                       som_k=5, som_k_type="center")
 

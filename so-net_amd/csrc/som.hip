@@ -184,7 +184,51 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict
     out[t] = ((unsigned long long)id < (unsigned long long)M) ? x[bc * M + id] : 0.f;
 }
 
+// out[b][c][j] = feat[b][c][ idx[b][j] ]   (models/segmenter.py:90-98: node features broadcast back to the
+// kN point copies).  One thread per 4 consecutive j of one (b, c) row: coalesced 16-byte stores, the 256-byte
+// feature row and the id row stay in L1/L2.
+__global__ __launch_bounds__(256) void node_gather_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                           float *__restrict__ out, int C, int M, int kN, long long total4)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int q = (kN + 3) >> 2;                  // 4-wide groups per row
+    const long long bc = t / q;
+    const int j0 = (int)(t - bc * q) << 2;
+    const long long b = bc / C;
+    const float *frow = feat + bc * M;
+    const int32_t *irow = idx + b * kN;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        const int id = j < kN ? irow[j] : 0;
+        v[e] = ((unsigned)id < (unsigned)M) ? frow[id] : 0.f;
+    }
+    float *orow = out + bc * kN + j0;
+    if (j0 + 3 < kN && ((reinterpret_cast<uintptr_t>(orow) & 15) == 0)) {
+        *reinterpret_cast<float4 *>(orow) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (j0 + e < kN) orow[e] = v[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int sonet_node_gather_f32(const float *feat, const int32_t *min_idx_i32, float *out, int B, int C, int M, int kN,
+                                     sonet_stream_t stream)
+{
+    const char *what = "sonet_node_gather_f32";
+    SONET_REQUIRE(feat && min_idx_i32 && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && kN > 0, "%s: non-positive size", what);
+    const long long total4 = (long long)B * C * ((kN + 3) / 4);
+    const long long blocks = sonet::ceil_div64(total4, 256);
+    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(node_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
+                       feat, min_idx_i32, out, C, M, kN, total4);
+    return sonet::launched(what);
+}
 
 extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, int N, int M, int k,
                                     int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,

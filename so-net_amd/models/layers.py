@@ -422,7 +422,10 @@ class KNNModule(nn.Module):
         h = torch.cat((decentered, x_neighbors), dim=1)
         for layer in self.layers:
             h = layer(h, epoch)
-        feature = torch.amax(h, dim=3)                                     # values only (torch.max also builds indices)
+        if torch.is_grad_enabled() and h.requires_grad:
+            feature, _ = torch.max(h, dim=3, keepdim=False)            # autograd must route to ONE arg-max like the reference
+        else:
+            feature = torch.amax(h, dim=3)                             # values only (torch.max also builds indices)
         return center.squeeze(3).detach(), feature
 
 

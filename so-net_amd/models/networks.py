@@ -158,7 +158,10 @@ class Encoder(nn.Module):
             self.final_pn_out = self.final_pointnet(torch.cat((self.knn_center_1, self.knn_feature_1), dim=1), epoch)
         else:
             self.final_pn_out = self.final_pointnet(torch.cat((self.som_node, self.first_pn_out_masked_max), dim=1), epoch)
-        self.feature = torch.amax(self.final_pn_out, dim=2)               # :197 (values only)
+        if torch.is_grad_enabled() and self.final_pn_out.requires_grad:
+            self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)     # :197; amax would split the gradient over ties
+        else:
+            self.feature = torch.amax(self.final_pn_out, dim=2)
         return self.feature
 
 
@@ -185,3 +188,76 @@ class Classifier(nn.Module):
         if self.opt.dropout > 0.1:
             self.fc2_out = self.dropout2(self.fc2_out)
         return self.fc3(self.fc2_out, epoch)
+
+
+class Segmenter(nn.Module):
+    """Per-point part-segmentation head (models/networks.py:230-344): five EquivariantLayers on the
+    3356-channel concat of per-point, per-node (broadcast back) and global features; the k copies of a
+    point are averaged after layer 3.  All layers run on the fused point-wise kernels."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.feature_num = opt.feature_num
+        c = 3 + 3 + 3 + 16 + 384 + 384 + self.feature_num * 2
+        if opt.surface_normal:
+            c += 3
+        if opt.som_k >= 2:
+            c += 512
+        act, norm = opt.activation, opt.normalization
+        self.layer1 = EquivariantLayer(c, 1024, activation=act, normalization=norm)
+        self.layer2 = EquivariantLayer(1024, 512, activation=act, normalization=norm)
+        self.layer3 = EquivariantLayer(512, 256, activation=act, normalization=norm)
+        self.drop3 = nn.Dropout(p=opt.dropout)
+        self.layer4 = EquivariantLayer(256, 128, activation=act, normalization=norm)
+        self.drop4 = nn.Dropout(p=opt.dropout)
+        self.layer5 = EquivariantLayer(128, opt.classes, activation=None, normalization=None)
+
+    def forward(self, x_decentered, x, centers, sn, label, first_pn_out, feature_max_first_pn_out,
+                feature_max_knn_feature_1, feature_max_final_pn_out, feature):
+        B, N, k = x.size()[0], x.size()[2], self.opt.k
+        kN = k * N
+        x = torch.cat([x] * k, dim=2)
+        sn = torch.cat([sn] * k, dim=2)
+        onehot = torch.zeros(B, 16, dtype=torch.float32, device=x.device)
+        onehot.scatter_(1, label.unsqueeze(1), 1)
+        parts = [x_decentered, x, centers]
+        if self.opt.surface_normal:
+            parts.append(sn)
+        parts += [onehot.unsqueeze(2).expand(B, 16, kN), first_pn_out, feature_max_first_pn_out]
+        if self.opt.som_k >= 2:
+            parts.append(feature_max_knn_feature_1)
+        parts += [feature_max_final_pn_out, feature.unsqueeze(2).expand(B, self.feature_num, kN)]
+        h = self.layer3(self.layer2(self.layer1(torch.cat(parts, dim=1))))
+        chunks = torch.split(h, self.opt.input_pc_num, dim=2)
+        assert len(chunks) == k
+        h = chunks[0]
+        for c in chunks[1:]:
+            h = h + c
+        if k > 1:
+            h = (1.0 / k) * h if k == 3 else 0.5 * h          # networks.py:331-336 (k in {2, 3})
+        h = self.layer4(h)
+        if self.opt.dropout > 0.1:
+            h = self.drop4(h)
+        return self.layer5(h)
+
+
+def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is_train=False, epoch=None):
+    """Model.forward of the part-segmentation task (models/segmenter.py:79-109) on the level-2 encoder:
+    the reference recovers the node of every point copy with argmax over the one-hot mask and gathers three
+    node-level feature maps back to the kN copies; here the int32 ids are already there and one kernel does
+    each gather (autograd falls back to torch.gather when gradients are needed)."""
+    feature = encoder(pc, sn, node, node_knn_I, is_train, epoch)
+    st = encoder._lazy
+    need_grad = torch.is_grad_enabled() and encoder.first_pn_out_masked_max.requires_grad
+    if need_grad:
+        idx = encoder.min_idx.unsqueeze(1)
+        g1 = torch.gather(encoder.first_pn_out_masked_max, 2, idx.expand(-1, 384, -1))
+        g2 = torch.gather(encoder.knn_feature_1, 2, idx.expand(-1, encoder.knn_feature_1.shape[1], -1))
+        g3 = torch.gather(encoder.final_pn_out, 2, idx.expand(-1, encoder.final_pn_out.shape[1], -1))
+    else:
+        ids = st["a"].min_idx_i32
+        g1 = _ops.node_gather(encoder.first_pn_out_masked_max.contiguous(), ids)
+        g2 = _ops.node_gather(encoder.knn_feature_1.contiguous(), ids)
+        g3 = _ops.node_gather(encoder.final_pn_out.contiguous(), ids)
+    return segmenter(encoder.x_decentered, pc, encoder.centers, sn, label, encoder.first_pn_out, g1, g2, g3, feature)

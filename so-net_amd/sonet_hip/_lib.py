@@ -26,6 +26,7 @@ SIGNATURES = {
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_mask_i32": [_vp, _vp, _i, _i, _i, _vp],
+    "sonet_node_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_knn_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_pack_size": [_i, _i],
     "sonet_pointmlp_pack_f32": [_vp, _vp, _i, _i, _vp],

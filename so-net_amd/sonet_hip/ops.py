@@ -176,6 +176,20 @@ def som_mask(min_idx_i32, M):
     return mask
 
 
+def node_gather(feat, min_idx_i32):
+    """feat B x C x M f32, min_idx B x kN i32 -> B x C x kN (models/segmenter.py:90-98)."""
+    _chk(feat, "feat", torch.float32, 3)
+    _chk(min_idx_i32, "min_idx", torch.int32, 2)
+    dev = _same_device(feat, min_idx_i32)
+    B, C, M = feat.shape
+    kN = min_idx_i32.shape[1]
+    out = torch.empty((B, C, kN), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("node_gather"):
+        check(_lib.load().sonet_node_gather_f32(ptr(feat), ptr(min_idx_i32), ptr(out), B, C, M, kN, stream_ptr()),
+              "sonet_node_gather_f32")
+    return out
+
+
 def knn_gather(x, knn_I):
     """x BxCxM f32, knn_I BxMxK i64 -> BxCxMxK (models/operations.py:38-54)."""
     _chk(x, "som_node", torch.float32, 3)
