@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["x3", "f32"], default=None,
                     help="point-wise layer arithmetic: x3 = 3xbf16 split on bf16 MFMA (default), f32 = exact f32 MFMA")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = the BASELINE metric (default); train = forward+backward+gradient all-reduce+Adam "
+                         "(BASELINE configs[4], reported under its own metric name)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     return ap.parse_args()
@@ -75,6 +78,9 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
         return "hbm", B * (6 * N * 4 + kN * 4 + M * 4 + 3 * M * 8 + 6 * kN * 4 + 3 * M * 4 + M * 4)
     if name == "knn_gather":
         return "hbm", None
+    if name.startswith("pointresnet_fused"):
+        L = int(name.split("_L")[1])
+        return "mfma", 2.0 * (6 * 64 + 64 * 128 + 128 * 256 + 320 * 384) * B * L
     if name.startswith("pointmlp"):
         dims, L = name.split("_", 1)[1].split("_L")
         cin, cout = dims.split("x")
@@ -120,6 +126,53 @@ def cpu_baseline(args, enc_sd, cls_sd):
                                                        "the reference's own compiled" if use_ref else "restated", cores, reps, ncpu)}
 
 
+def train_bench(args, enc, cls, inp, world, rank, dev):
+    """Data-parallel training step (models/classifier.py:78-99 + one flat RCCL gradient all-reduce)."""
+    from sonet_hip import dp
+    enc.train()
+    cls.train()
+    dp.broadcast_parameters([enc, cls])
+    opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    reducer = dp.GradientAllReducer([enc, cls])
+    label = inp["label"]
+
+    def step():
+        feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+        score = cls(feat, 0)
+        enc.zero_grad(set_to_none=False)
+        cls.zero_grad(set_to_none=False)
+        loss = torch.nn.functional.cross_entropy(score, label)
+        loss.backward()
+        nbytes = reducer.reduce()
+        opt_e.step()
+        opt_c.step()
+        return loss, nbytes
+
+    for _ in range(max(1, args.warmup)):
+        loss, nbytes = step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, nbytes = step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = dp.all_reduce_max(time.perf_counter() - t0, dev)
+    assert torch.isfinite(loss)
+    if rank != 0:
+        return
+    B, N = args.batch, args.points
+    from sonet_hip import ops
+    print(json.dumps({
+        "metric": "point-clouds/sec training step (forward+backward+all-reduce+Adam), ModelNet40 5k-pt 8x8 SOM",
+        "value": round(world * B * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (%s forward; backward GEMMs on PyTorch-ROCm)" % ops.POINTMLP_PRECISION, "data": "synthetic",
+        "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
+                   "global_batch": B * world, "parallelism": "dp%d: batch shards + one flat %d-byte gradient all-reduce per step" % (world, nbytes)}}))
+
+
 def main():
     args = parse()
     from models import networks as NW
@@ -149,6 +202,9 @@ def main():
     def step():
         feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
         return cls(feat)
+
+    if args.mode == "train":
+        return train_bench(args, enc, cls, inp, world, rank, dev)
 
     # The step is shape-static: replay it as ONE HIP graph (sonet_hip/graph.py).  `value` is timed on the
     # replays; the per-kernel durations for the roofline come from a second, eagerly launched region of
@@ -200,17 +256,27 @@ def main():
         if amount:
             if bound == "mfma":
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e12
-                peak = PEAK_X3_TFLOPS if name.startswith("pointmlpx3") else PEAK_F32_MFMA_TFLOPS
+                peak = PEAK_X3_TFLOPS if name.startswith(("pointmlpx3", "pointresnet_fused")) else PEAK_F32_MFMA_TFLOPS
                 k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
             else:
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e9
                 k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
         kernels.append(k)
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("B%d_N%d" % (B, N), {})
+        except Exception:
+            traffic = {}
+    for k in kernels:
+        if k["name"] in traffic:
+            k["traffic"] = traffic[k["name"]]
     dom = next((k for k in kernels if "achieved" in k), None)
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": dom["unit"], "frac": dom["frac"], "traffic": None}
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": dom.get("traffic")}
     line = {
         "metric": "point-clouds/sec forward, ModelNet40 5k-pt 8x8 SOM",
         "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
