@@ -164,6 +164,25 @@ int sonet_pointresnet_pack(const float *W1, const float *W2, const float *W3, co
 int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void *wstream, const float *affine,
                                 float *y, int B, int L, sonet_stream_t stream);
 
+/* Fused first PointNet + per-node max-pool (the no-grad classifier / autoencoder path): nothing of the 23 MB/cloud
+ * first_pn_out reaches HBM.  Replaces models/networks.py:175-185 (PointResNet, index_max, masked gather) when only
+ * first_pn_out_masked_max is needed.  Inputs come from sonet_som_sort_group_f32 (point copies sorted by node):
+ *   x_sorted [B][Cin0][L], ids_sorted [B][L] (non-decreasing per cloud), pos0 [B] (sorted position of copy 0),
+ *   node_off [B][M] (first sorted position of each node), count [B][M].
+ * out [B][384][M] f32 = max over the node's copies (values > -1000), else the features of copy 0 (the reference's
+ * gather index 0).  Two kernels, no atomics on the common path: every 128-point tile stores the per-node maxima of
+ * the few nodes it touches, a second kernel combines the tiles of each node.  ws: sonet_pointresnet_pool_ws_size bytes. */
+size_t sonet_pointresnet_pool_ws_size(int B, int L, int M);
+int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                     const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                     const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream);
+/* som_sort_group: som_group with the kN point copies of every cloud counting-sorted by node id.
+ * x_aug_sorted [B][6][kN], ids_sorted [B][kN], pos0 [B], node_off [B][M]; cursor_ws: B*M i32 (zeroed by the callee). */
+int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,
+                             const double *sum_ws, int B, int N, int M, int k, float *som_node, int32_t *row_max,
+                             float *x_aug_sorted, int32_t *ids_sorted, int32_t *pos0, int32_t *node_off,
+                             int32_t *cursor_ws, sonet_stream_t stream);
+
 /* Per-channel batch statistics of y [B][C][L] for training-mode BatchNorm (F.batch_norm with
  * training=True, models/layers.py:68): mean[c], biased var[c] over (B, L), f64 accumulation.
  * stat_ws: 2*C doubles of workspace, zeroed by the callee. */

@@ -144,11 +144,50 @@ constexpr int NSLOT = 3;
 
 struct AF { bf16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
 
-template <int ABL>   // bench-only ablation: 1 = no stores, 2 = no bf16 split (constant B), 4 = no W streaming / barriers
+// SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
+constexpr int SEG_SLOTS = 16;                                 // nodes of a 128-point tile pre-reduced in LDS
+constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
+
+__device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
+    if (bits == 0x80000000u) bits = 0u;
+    const unsigned o = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+    return (bits & 0x7FFFFFFFu) > 0x7F800000u ? 0u : o;
+}
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_max(unsigned v) {
+    return umax_(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false));
+}
+
+// max over the 32 lanes of each half-wave, result in lanes 31 / 63, for four registers at once.  One v_max_f32 with a
+// DPP source per step (lanes without a source keep their value); the four independent chains are interleaved so a
+// dependent DPP read is always >= 2 instructions behind the write it needs (hipcc does not pad inline asm).
+__device__ __forceinline__ void dpp_halfwave_max4(float &a, float &b, float &c, float &d) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+template <int ABL, bool SEGMAX>   // ABL: bench-only ablation: 1 = no stores, 2 = no bf16 split, 4 = no W streaming / barriers
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
-    float *__restrict__ y, int L, int tpc /*128-point tiles per cloud*/, long long ntiles)
+    float *__restrict__ y, int L, int tpc /*128-point tiles per cloud*/, long long ntiles,
+    const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0, unsigned *__restrict__ pooled, float *__restrict__ v0, int M,
+    unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/)
 {
+    __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
+    __shared__ float4 segst[SEGMAX ? PF_WAVES : 1][SEGMAX ? 8 * MT4 : 1];   // per wave: one node's 192 reduced maxima
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 36 KiB
     __shared__ float2 aff[CH_TOTAL];
 
@@ -181,9 +220,31 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
     const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
     bool first_boundary = true;
+    int pend_n = 0;
+    // SEGMAX: partial-maxima block whose LDS bins are still to be stored.  The very first flush is a dry run (all
+    // INIT) into the block that the same lanes rewrite one pass later, which keeps the flush free of branches.
+    unsigned *pend = partial + (blockIdx.x * (long long)NPASS * SEG_SLOTS) * (32 * MT4);
+    // The bins of a pass are stored at the first stage boundary AFTER it, between the barrier (all lanes have
+    // published) and the next W loads: the stores are older than those loads, so the vmcnt wait that the next
+    // boundary needs anyway covers them a whole stage later.  Stored right after the epilogue they (or atomics)
+    // put a memory round trip in front of the next ds_write (vmcnt(0)): measured 0.2 ms per launch.
+    auto flush_bins = [&]() {                                   // branch-free on the common path (<= 4 nodes per tile)
+#pragma unroll
+        for (int i = 0; i < 4 * 32 * MT4 / PF_THREADS; ++i) {
+            const int e = i * PF_THREADS + threadIdx.x;
+            unsigned *bp = &bins[0][0] + e;
+            pend[e] = *bp;
+            *bp = SEG_INIT;
+        }
+        for (int e = 4 * 32 * MT4 + threadIdx.x; e < pend_n; e += PF_THREADS) {
+            unsigned *bp = &bins[0][0] + e;
+            pend[e] = *bp;
+            *bp = SEG_INIT;
+        }
+    };
 
     // boundary of the stage that the CURRENT step opens
-    auto boundary = [&]() {
+    auto boundary = [&](bool flush = false) {
         if constexpr (ABL & 4) return;
         __syncthreads();
         if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
@@ -192,6 +253,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         }
         first_boundary = false;
         stage_write(slot_fill);                                 // stage n_cur + 2
+        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
         stage_load(n_cur + 3);
         lds_cur = &wsm[slot_cur * NSTG][lane];
         lds_nxt = &wsm[slot_nxt * NSTG][lane];
@@ -242,6 +304,38 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
 
+        // per-node max-pool bookkeeping of this wave's 32 (node-sorted) points
+        int nid = -1, n0 = 0, jpos0 = -1, nslots = 0;
+        bool seg_uniform = false, seg_tail = false, tail_lds = true, segf[5] = {false, false, false, false, false};
+        unsigned *bins_lane = nullptr, *pool_lane = nullptr;
+        float *v0_lane = nullptr;
+        const float2 *aff_l4 = aff + 32 * (T0 + T1 + T2) + 4 * h;
+        if constexpr (SEGMAX) {
+            const int32_t *idb = ids_sorted + b * (long long)L;
+            nid = pv ? idb[l0 + j] : -1;
+            const int t0 = (int)(tile - b * tpc) * 128;
+            n0 = idb[t0];                                                          // first node of the workgroup's tile
+            const int nlast = idb[(t0 + 127 < L ? t0 + 127 : L - 1)];
+            nslots = nlast - n0 + 1 < SEG_SLOTS ? nlast - n0 + 1 : SEG_SLOTS;
+            const int nid_first = __builtin_amdgcn_readfirstlane(nid);
+            seg_uniform = __all(pv && nid == nid_first);
+            const int nxt = __shfl_down(nid, 1, 32);
+            seg_tail = pv && (j == 31 || nxt != nid);
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                const int up = __shfl_up(nid, 1 << d, 32);                         // every lane must execute the shuffle
+                segf[d] = pv && j >= (1 << d) && up == nid;
+            }
+            const int p0 = pos0[b] - l0;
+            jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
+            const int slot = nid - n0;
+            tail_lds = slot < SEG_SLOTS;
+            bins_lane = &bins[tail_lds && slot >= 0 ? slot : 0][4 * h];
+            pool_lane = pooled + ((long long)b * M + (nid >= 0 ? nid : 0)) * (32 * T3) + 4 * h;
+            v0_lane = v0 + b * (32 * T3) + 4 * h;
+            if (tile == blockIdx.x)                                               // first tile of this workgroup: clear the bins
+                for (int i = threadIdx.x; i < SEG_SLOTS * 32 * MT4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
+        }
         float xin[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -260,13 +354,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) act3[t][r] = 0.f;
 
-        AF af[2];
+        AF af[1];
         B3 bq[2];
         // ---- layer 1 (slice 0 opens stage 0 of this tile): no prefetch into it, prefetches layer 2's first step ----
         boundary();
         PF_LOAD_A(af[0], T0, OFF1, false)
         bq[0] = split_chunk_abl<ABL>(xin);
-        PF_LOAD_A(af[1], GS, MID_SIDX(0), (MID_SIDX(0) % NSTG) == 0)
         PF_MFMAS(act1, 0, T0, af[0], bq[0])
 #pragma unroll
         for (int t = 0; t < T0; ++t) PF_AFFINE_RELU(act1[t], 32 * t)
@@ -286,11 +379,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             const int grp = l2 ? i / KC2 : (i - KC2 * (T1 / GS)) / KC3; \
             if (sidx % NSTG == 0) boundary(); \
  \
-            if (i + 1 < NMID) { \
-                PF_LOAD_A(af[nxt], GS, MID_SIDX(i + 1), (MID_SIDX(i + 1) % NSTG) == 0) \
-            } else { \
-                PF_LOAD_A(af[nxt], MT4, PRE, (PRE % NSTG) == 0) \
-            } \
+            PF_LOAD_A(af[0], GS, sidx, false) \
  \
             const bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
             if (!last_of_l2 && !last_of_l3) { \
@@ -299,7 +388,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 if (l2) PF_CHUNK(v, act1, (l2 ? kcn : 0)) else PF_CHUNK(v, act2, (l2 ? 0 : kcn)) \
                 bq[nxt] = split_chunk_abl<ABL>(v); \
             } \
-            if (l2) PF_MFMAS(act2, grp * GS, GS, af[cur], bq[cur]) else PF_MFMAS(act3, grp * GS, GS, af[cur], bq[cur]) \
+            if (l2) PF_MFMAS(act2, grp * GS, GS, af[0], bq[cur]) else PF_MFMAS(act3, grp * GS, GS, af[0], bq[cur]) \
             if (last_of_l2) { \
 _Pragma("unroll") \
                 for (int t = 0; t < T1; ++t) PF_AFFINE_RELU(act2[t], 32 * T0 + 32 * t) \
@@ -330,21 +419,83 @@ _Pragma("unroll") \
                 constexpr int kc = (K_);                                    \
                 const int sidx = PRE + kc * MT4 * 3; \
                 const int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
-                if (sidx % NSTG == 0) boundary(); \
+                if (sidx % NSTG == 0) boundary(kc == 0); \
                 const int kn = (kc + 1) % KC4; \
-                const int sn = PRE + kn * MT4 * 3; \
-                PF_LOAD_A(af[nxt], MT4, sn, (sn % NSTG) == 0) \
+                PF_LOAD_A(af[0], MT4, sidx, false) \
                 { \
                     float v[8]; \
                     if (kn < KC2) PF_CHUNK(v, act1, (kn < KC2 ? kn : 0)) else PF_CHUNK(v, act3, (kn < KC2 ? 0 : kn - KC2)) \
                     bq[nxt] = split_chunk_abl<ABL>(v); \
                 } \
-                PF_MFMAS(acc, 0, MT4, af[cur], bq[cur]) \
+                PF_MFMAS(acc, 0, MT4, af[0], bq[cur]) \
             }
             static_assert(KC4 == 20, "expand PF_L4 to KC4 steps");
             PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
 #undef PF_L4
-            if (pv) {
+            if constexpr (SEGMAX) {
+                // ---- per-node max-pool of this pass's 192 channels (replaces index_max + masked gather,
+                //      models/networks.py:180-185, for the no-grad path: only the VALUES are needed) ----
+                // 1) affine in place, features of original copy 0 (wave-uniform branch: one wave per cloud)
+#pragma unroll
+                for (int mt = 0; mt < MT4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float2 ss = aff_l4[(pass * MT4 + mt) * 32 + (r & 3) + 8 * (r >> 2)];
+                        acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    }
+                if (jpos0 >= 0) {
+                    if (j == jpos0) {
+#pragma unroll
+                        for (int mt = 0; mt < MT4; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v0_lane[(pass * MT4 + mt) * 32 + (r & 3) + 8 * (r >> 2)] = acc[mt][r];
+                    }
+                }
+                // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted): mask the other
+                //    points to -inf, DPP-reduce the 32 lanes of each half-wave to lanes 31 / 63 (v_max_f32 ignores a NaN
+                //    operand, as the reference's '>' does), and let those two lanes publish -- to the LDS bins of the
+                //    workgroup's first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
+                if constexpr (!(ABL & 16)) {
+                unsigned long long remaining = __ballot(pv);
+                while (remaining != 0ull) {
+                    const int lead = __builtin_ctzll(remaining);
+                    const int node = __builtin_amdgcn_readlane(nid, lead);
+                    const unsigned long long segmask = __ballot(pv && nid == node);
+                    remaining &= ~segmask;
+                    const bool inseg = pv && nid == node;
+                    const int slot = node - n0;
+                    const bool to_lds = slot < SEG_SLOTS;
+                    unsigned *dst = to_lds ? &bins[slot][0] : pooled + ((long long)b * M + node) * (32 * T3) + pass * (32 * MT4);
+#pragma unroll
+                    for (int mt = 0; mt < MT4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 4) {
+                            float v0_ = inseg ? acc[mt][r] : -__builtin_inff(), v1_ = inseg ? acc[mt][r + 1] : -__builtin_inff();
+                            float v2_ = inseg ? acc[mt][r + 2] : -__builtin_inff(), v3_ = inseg ? acc[mt][r + 3] : -__builtin_inff();
+                            dpp_halfwave_max4(v0_, v1_, v2_, v3_);
+                            if constexpr (!(ABL & 32)) {
+                                // rows r..r+3 of this register quad are 4 consecutive channels: lanes 31 / 63 park them in LDS
+                                if (j == 31) segst[wave][mt * 8 + 2 * (r >> 2) + h] = make_float4(v0_, v1_, v2_, v3_);
+                            } else { asm volatile("" ::"v"(v0_), "v"(v1_), "v"(v2_), "v"(v3_)); }
+                        }
+                    if constexpr (!(ABL & 32)) {
+                        // ... and all 64 lanes publish them, 3 channels each (2 lanes x 96 LDS atomics cost 0.2 ms per launch)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const float *st = reinterpret_cast<const float *>(&segst[wave][0]);
+#pragma unroll
+                        for (int i = 0; i < 32 * MT4 / 64; ++i)
+                            atomicMax(dst + lane + 64 * i, ord_f32(__float_as_uint(st[lane + 64 * i])));
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                }
+                if constexpr (!(ABL & 8)) pend_n = nslots * (32 * MT4);
+                if constexpr (!(ABL & 8))
+                    pend = partial + ((tile * NPASS + pass) * SEG_SLOTS) * (long long)(32 * MT4);   // stored at the next boundary
+            } else if (pv) {
 #pragma unroll
                 for (int mt = 0; mt < MT4; ++mt) {
                     const int ct = pass * MT4 + mt;
@@ -362,11 +513,55 @@ _Pragma("unroll") \
             }
         }
     }
+    if constexpr (SEGMAX && !(ABL & 8)) {
+        __syncthreads();
+        if (blockIdx.x < ntiles) flush_bins();
+    }
 #undef PF_LOAD_A
 #undef PF_MFMAS
 #undef PF_AFFINE_RELU
 #undef PF_CHUNK
 #undef MID_SIDX
+}
+
+__global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__ pooled, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) pooled[t] = SEG_INIT;
+}
+
+// Second kernel of the pooled path: out[b][c][m] = max over the tiles that hold copies of node m of that tile's
+// partial (slot = m - first node of the tile), combined with the rare straight-to-memory fallback in `pooled`
+// (tiles spanning more than SEG_SLOTS nodes).  Nodes that never beat -1000 (empty, or all values <= -1000) take the
+// features of original point copy 0, as gather index 0 does in the reference (models/networks.py:185).
+__global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
+                                                             const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
+                                                             const int32_t *__restrict__ count, const float *__restrict__ v0,
+                                                             float *__restrict__ out, int M, int L, int tpc, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // over [B][M][384], c fastest (coalesced partial reads)
+    if (t >= total) return;
+    const int C = 32 * T3;
+    const int c = (int)(t % C);
+    const long long bm = t / C;
+    const int m = (int)(bm % M);
+    const long long b = bm / M;
+    unsigned key = pooled[t];
+    const int cnt = count[b * M + m];
+    if (cnt > 0) {
+        const int off = node_off[b * M + m];
+        const int pass = c / (32 * MT4), cl = c - pass * (32 * MT4);
+        for (int tl = off / 128; tl <= (off + cnt - 1) / 128; ++tl) {
+            const int slot = m - ids_sorted[b * L + tl * 128];
+            if (slot < SEG_SLOTS) {
+                const unsigned k2 = partial[((((b * tpc + tl) * NPASS + pass) * SEG_SLOTS) + slot) * (long long)(32 * MT4) + cl];
+                key = k2 > key ? k2 : key;
+            }
+        }
+    }
+    float v;
+    if (key > SEG_INIT) v = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+    else v = v0[b * C + c];
+    out[(b * C + c) * M + m] = v;
 }
 
 }  // namespace
@@ -401,9 +596,51 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
     int abl = 0;
     if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
-#define PF_LAUNCH(AA) hipLaunchKernelGGL(pointresnet_fused_kernel<AA>, dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream), \
-                       x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles)
+#define PF_LAUNCH(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream), \
+                       x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles, \
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr)
     switch (abl) { case 1: PF_LAUNCH(1); break; case 2: PF_LAUNCH(2); break; case 4: PF_LAUNCH(4); break; case 7: PF_LAUNCH(7); break; default: PF_LAUNCH(0); }
 #undef PF_LAUNCH
+    return sonet::launched(what);
+}
+
+extern "C" size_t sonet_pointresnet_pool_ws_size(int B, int L, int M)
+{
+    if (B <= 0 || L <= 0 || M <= 0) return 0;
+    const long long ntiles = (long long)B * sonet::ceil_div(L, 128);
+    return (size_t)((long long)B * M * (32 * T3) + ntiles * NPASS * SEG_SLOTS * (32 * MT4)) * 4 + (size_t)B * (32 * T3) * 4;
+}
+
+extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                                const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                                const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointresnet_fused_pool_f32";
+    SONET_REQUIRE(x_sorted && wstream && affine && ids_sorted && pos0 && node_off && count && ws && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && L > 0 && M > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d M=%d Cin0=%d", what, B, L, M, Cin0);
+    hipStream_t st = sonet::as_stream(stream);
+    const long long npool = (long long)B * M * (32 * T3);
+    const int tpc = sonet::ceil_div(L, 128);
+    const long long ntiles = (long long)B * tpc;
+    unsigned *pooled_ws = reinterpret_cast<unsigned *>(ws);
+    unsigned *partial_ws = pooled_ws + npool;
+    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * NPASS * SEG_SLOTS * (32 * MT4));
+    hipLaunchKernelGGL(pooled_init_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, npool);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const long long grid = ntiles < cus ? ntiles : cus;
+    int abl = 0;
+    if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
+#define PF_LAUNCH_POOL(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st, \
+                       x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr, \
+                       L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws)
+    switch (abl) { case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
+                   case 56: PF_LAUNCH_POOL(56); break; default: PF_LAUNCH_POOL(0); }
+#undef PF_LAUNCH_POOL
+    hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
+                       ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);
     return sonet::launched(what);
 }

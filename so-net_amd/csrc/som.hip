@@ -214,7 +214,98 @@ __global__ __launch_bounds__(256) void node_gather_kernel(const float *__restric
     }
 }
 
+// Node-sorted grouping for the fused eval path: the kN point copies of a cloud are counting-sorted by node id, so a
+// 128-point tile of the fused first PointNet spans only a couple of nodes and its per-node max-pool epilogue is a
+// wave-level reduction plus a handful of atomics.  Same arithmetic as som_group (mean = sum/(count+1e-5), x - mean).
+// Order inside a node is arbitrary (a max-pool does not care); pos0[b] = sorted position of original copy j = 0
+// (its features are the reference's fallback for empty nodes: gather index 0, models/networks.py:185).
+__global__ __launch_bounds__(SG_THREADS) void som_sort_group_kernel(
+    const float *__restrict__ x, const float *__restrict__ sn, const int32_t *__restrict__ min32,
+    const int32_t *__restrict__ count, const double *__restrict__ sum_ws, int N, int M, int k,
+    float *__restrict__ som_node, int32_t *__restrict__ row_max, float *__restrict__ x_aug_sorted,
+    int32_t *__restrict__ ids_sorted, int32_t *__restrict__ pos0, int32_t *__restrict__ cursor, int32_t *__restrict__ node_off)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];          // mean[3][M] | offs[M] | hist[M] | base[M]
+    float *mean = smem_f;
+    int *offs = reinterpret_cast<int *>(smem_f + 3 * M);
+    int *hist = offs + M;
+    int *base = hist + M;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const double *ws = sum_ws + (size_t)b * 3 * M;
+    for (int m = tid; m < M; m += SG_THREADS) {
+        const int c = count[(size_t)b * M + m];
+        const float denom = __fadd_rn((float)c, 1e-5f);
+        const float mx = __fdiv_rn((float)ws[m], denom), my = __fdiv_rn((float)ws[M + m], denom), mz = __fdiv_rn((float)ws[2 * M + m], denom);
+        mean[m] = mx; mean[M + m] = my; mean[2 * M + m] = mz;
+        hist[m] = 0;
+        if (blockIdx.x == 0) {
+            if (som_node != nullptr) { float *o = som_node + (size_t)b * 3 * M; o[m] = mx; o[M + m] = my; o[2 * M + m] = mz; }
+            if (row_max != nullptr) row_max[(size_t)b * M + m] = c > 0;
+        }
+    }
+    if (tid == 0) {                                                          // exclusive prefix of the node counts
+        int acc = 0;
+        for (int m = 0; m < M; ++m) {
+            offs[m] = acc;
+            if (blockIdx.x == 0 && node_off != nullptr) node_off[(size_t)b * M + m] = acc;
+            acc += count[(size_t)b * M + m];
+        }
+    }
+    __syncthreads();
+    const size_t kN = (size_t)k * N;
+    const int32_t *ib = min32 + (size_t)b * kN;
+    const size_t j0 = (size_t)blockIdx.x * (SG_THREADS * SG_PER_THREAD) + tid;
+    int id[SG_PER_THREAD], rk[SG_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SG_PER_THREAD; ++i) {
+        const size_t j = j0 + (size_t)i * SG_THREADS;
+        id[i] = j < kN ? ib[j] : -1;
+        rk[i] = id[i] >= 0 ? atomicAdd(&hist[id[i]], 1) : 0;
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += SG_THREADS) base[m] = hist[m] ? atomicAdd(&cursor[(size_t)b * M + m], hist[m]) : 0;
+    __syncthreads();
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *snb = sn + (size_t)b * 3 * N;
+#pragma unroll
+    for (int i = 0; i < SG_PER_THREAD; ++i) {
+        const size_t j = j0 + (size_t)i * SG_THREADS;
+        if (id[i] < 0) continue;
+        const int m = id[i];
+        const size_t pos = (size_t)(offs[m] + base[m] + rk[i]);
+        const int n = (int)(j % (size_t)N);
+        ids_sorted[(size_t)b * kN + pos] = m;
+        if (j == 0) pos0[b] = (int)pos;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            x_aug_sorted[((size_t)b * 6 + c) * kN + pos] = __fsub_rn(xb[(size_t)c * N + n], mean[c * M + m]);
+            x_aug_sorted[((size_t)b * 6 + 3 + c) * kN + pos] = snb[(size_t)c * N + n];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,
+                                        const double *sum_ws, int B, int N, int M, int k, float *som_node, int32_t *row_max,
+                                        float *x_aug_sorted, int32_t *ids_sorted, int32_t *pos0, int32_t *node_off,
+                                        int32_t *cursor_ws, sonet_stream_t stream)
+{
+    const char *what = "sonet_som_sort_group_f32";
+    SONET_REQUIRE(x && sn && min_idx_i32 && count && sum_ws && x_aug_sorted && ids_sorted && pos0 && node_off && cursor_ws, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && N > 0 && M > 0 && k >= 1, "%s: non-positive size", what);
+    if (M > 4096) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 4096 nodes", what, M);
+    if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
+    hipStream_t st = sonet::as_stream(stream);
+    if (hipMemsetAsync(cursor_ws, 0, (size_t)B * M * sizeof(int32_t), st) != hipSuccess)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    const long long kN = (long long)k * N;
+    dim3 grid((unsigned)sonet::ceil_div64(kN, SG_THREADS * SG_PER_THREAD), B), block(SG_THREADS);
+    hipLaunchKernelGGL(som_sort_group_kernel, grid, block, (size_t)M * (3 * sizeof(float) + 3 * sizeof(int)), st,
+                       x, sn, min_idx_i32, count, sum_ws, N, M, k, som_node, row_max, x_aug_sorted, ids_sorted, pos0, cursor_ws, node_off);
+    return sonet::launched(what);
+}
 
 extern "C" int sonet_node_gather_f32(const float *feat, const int32_t *min_idx_i32, float *out, int B, int C, int M, int kN,
                                      sonet_stream_t stream)

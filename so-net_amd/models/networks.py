@@ -87,6 +87,7 @@ class Encoder(nn.Module):
         self.som_builder = som.BatchSOM(rows, rows, 3, opt.gpu_id, opt.batch_size)
         self.zero_pad = torch.nn.ZeroPad2d(padding=1)
         self._lazy = None
+        self._first_pn_out = None
 
     # ---- attributes the segmenter / autoencoder read after forward; built on demand -----------------
     @property
@@ -117,6 +118,21 @@ class Encoder(nn.Module):
         return st[name]
 
     @property
+    def first_pn_out(self):
+        """B x 384 x kN output of the first PointNet.  On the fused no-grad path it is never written during
+        forward (only its per-node max is needed); it is materialised here if a caller (the segmenter) reads it."""
+        if self._first_pn_out is None and self._lazy is not None:
+            st = self._lazy
+            g = _ops.som_group(st["x"], st["sn"], st["a"], want_augmented=st["sn"] is not None, want_decentered=st["sn"] is None)
+            with torch.no_grad():
+                self._first_pn_out = self.first_pointnet(g["x_augmented"] if st["sn"] is not None else g["x_decentered"], None)
+        return self._first_pn_out
+
+    @first_pn_out.setter
+    def first_pn_out(self, v):
+        self._first_pn_out = v
+
+    @property
     def centers(self):
         return self._per_point("centers")
 
@@ -134,23 +150,35 @@ class Encoder(nn.Module):
         sb.node = node.detach().float().contiguous()                     # networks.py:124
         a = sb.assign(xd, opt.k)                                         # :127-128 (ids, counts, sums)
         use_sn = bool(opt.surface_normal)
-        g = _ops.som_group(xd, sn.detach().float().contiguous() if use_sn else None, a,
-                           want_decentered=not use_sn, want_augmented=use_sn)            # :140-172
-        sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes
-        self.som_node = sb.node
-        row_max = g["row_max"]
-        self._lazy = dict(a=a, x=xd, mask=None, min_idx=None,
-                          centers=None, x_decentered=None if use_sn else g["x_decentered"])
-        pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
-
-        self.first_pn_out = self.first_pointnet(pn_in, epoch)            # :175-178  B x 384 x kN
-
-        if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
-            gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
-            self.first_pn_out_masked_max = self.first_pn_out.gather(
-                dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
+        snd = sn.detach().float().contiguous() if use_sn else None
+        fused_pool = (use_sn and _ops.FUSE_POOL and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
+                      and a.k * a.N * 384 * 4 < 4e9)
+        if fused_pool:
+            # no-grad fast path: node-sorted grouping -> first PointNet + per-node max-pool in ONE kernel (:140-185)
+            g = _ops.som_sort_group(xd, snd, a)
+            sb.node = g["som_node"]
+            self.som_node = sb.node
+            self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None, centers=None, x_decentered=None)
+            self._first_pn_out = None                                    # lazy (property)
+            wstream, affine = self.first_pointnet._fused_state()
+            self.first_pn_out_masked_max = _ops.pointresnet_fused_pool(g, wstream, affine, M)
         else:
-            _, self.first_pn_out_masked_max = _ops.index_max_gather(self.first_pn_out, a.min_idx_i32, M, row_max)
+            g = _ops.som_group(xd, snd, a, want_decentered=not use_sn, want_augmented=use_sn)            # :140-172
+            sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes
+            self.som_node = sb.node
+            row_max = g["row_max"]
+            self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None,
+                              centers=None, x_decentered=None if use_sn else g["x_decentered"])
+            pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
+
+            self.first_pn_out = self.first_pointnet(pn_in, epoch)            # :175-178  B x 384 x kN
+
+            if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
+                gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
+                self.first_pn_out_masked_max = self.first_pn_out.gather(
+                    dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
+            else:
+                _, self.first_pn_out_masked_max = _ops.index_max_gather(self.first_pn_out, a.min_idx_i32, M, row_max)
 
         if opt.som_k >= 2:
             self.knn_center_1, self.knn_feature_1 = self.knnlayer(self.som_node, self.first_pn_out_masked_max,

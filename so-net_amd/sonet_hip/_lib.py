@@ -37,6 +37,9 @@ SIGNATURES = {
     "sonet_pointresnet_pack_size": [],
     "sonet_pointresnet_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sonet_pointresnet_fused_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "sonet_pointresnet_pool_ws_size": [_i, _i, _i],
+    "sonet_pointresnet_fused_pool_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_som_sort_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -47,6 +50,7 @@ _RESTYPES = {
     "sonet_pointmlp_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pack_size": ctypes.c_size_t,
+    "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
 }
 
 _lib = None

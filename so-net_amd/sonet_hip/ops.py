@@ -166,6 +166,28 @@ def som_group(x, sn, a, want_centers=False, want_decentered=False, want_augmente
     return out
 
 
+def som_sort_group(x, sn, a):
+    """Node-sorted grouping for the fused no-grad path -> dict(som_node, row_max, x_aug_sorted Bx6xkN, ids_sorted BxkN, pos0 B)."""
+    _chk(x, "x", torch.float32, 3)
+    _chk(sn, "sn", torch.float32, 3)
+    dev = _same_device(x, sn, a.min_idx_i32)
+    B, N, M, k = a.B, a.N, a.M, a.k
+    kN = k * N
+    out = dict(som_node=torch.empty((B, 3, M), dtype=torch.float32, device=dev),
+               row_max=torch.empty((B, M), dtype=torch.int32, device=dev),
+               x_aug_sorted=torch.empty((B, 6, kN), dtype=torch.float32, device=dev),
+               ids_sorted=torch.empty((B, kN), dtype=torch.int32, device=dev),
+               pos0=torch.empty((B,), dtype=torch.int32, device=dev),
+               node_off=torch.empty((B, M), dtype=torch.int32, device=dev), count=a.count)
+    cursor = torch.empty((B, M), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), _timed("som_sort_group"):
+        check(_lib.load().sonet_som_sort_group_f32(ptr(x), ptr(sn), ptr(a.min_idx_i32), ptr(a.count), ptr(a.sum_ws), B, N, M, k,
+                                                   ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
+                                                   ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(cursor), stream_ptr()),
+              "sonet_som_sort_group_f32")
+    return out
+
+
 def som_mask(min_idx_i32, M):
     _chk(min_idx_i32, "min_idx", torch.int32, 2)
     dev = _same_device(min_idx_i32)
@@ -217,6 +239,8 @@ POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "x3")
 
 # run the encoder's first PointNet (eval mode, "x3" arithmetic) as one fused kernel
 FUSE_POINTRESNET = _os.environ.get("SONET_FUSE_POINTRESNET", "1") != "0"
+# ... and pool it per node in the same kernel (no first_pn_out in HBM unless a caller reads the attribute)
+FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
 
 
 def x3_supported(C1, C2, Cout):
@@ -297,6 +321,24 @@ def pointresnet_fused(x, wstream, affine):
         check(_lib.load().sonet_pointresnet_fused_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
               "sonet_pointresnet_fused_f32")
     return y
+
+
+def pointresnet_fused_pool(sg, wstream, affine, M):
+    """First PointNet + per-node max-pool in one pass over node-sorted points (``sg`` = som_sort_group result)
+    -> B x 384 x M f32."""
+    x_sorted = sg["x_aug_sorted"]
+    _chk(x_sorted, "x_sorted", torch.float32, 3)
+    _chk(affine, "affine", torch.float32, 2)
+    dev = _same_device(x_sorted, wstream, affine, sg["ids_sorted"], sg["pos0"], sg["node_off"], sg["count"])
+    B, Cin0, L = x_sorted.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.sonet_pointresnet_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("pointresnet_fused_pool_L%d" % L):
+        check(lib.sonet_pointresnet_fused_pool_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
+                                                   ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
+              "sonet_pointresnet_fused_pool_f32")
+    return out
 
 
 def channel_stats(y):

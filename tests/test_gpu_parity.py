@@ -611,3 +611,63 @@ def test_backward_components_vs_float64():
     xk2 = xk.detach().clone().requires_grad_(True)
     torch.gather(xk2, 2, I.reshape(3, 1, 576).expand(3, 20, 576)).view(3, 20, 64, 9).backward(go)
     assert rel(xk.grad, xk2.grad) < 1e-6
+
+
+def test_sort_group_and_fused_pool():
+    """Node-sorted grouping + (first PointNet & per-node max-pool in one kernel) == layerwise path + index_max_gather."""
+    from models import layers as L
+    from sonet_hip import ops, synth
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    old = (ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET)
+    ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET = "x3", True
+    try:
+        for B, N, M, k, kind in [(3, 5000, 64, 3, "som"), (2, 333, 64, 3, "uniform"), (2, 40, 64, 1, "uniform"), (1, 1, 64, 3, "uniform")]:
+            inp = synth.make_inputs(B, N, M=M, som_k=9, seed=N + k, node_kind=kind)
+            x, sn = inp["pc"].to(DEV), inp["sn"].to(DEV)
+            a = ops.som_assign(x, inp["node"].to(DEV), k)
+            g = ops.som_group(x, sn, a, want_augmented=True)
+            s = ops.som_sort_group(x, sn, a)
+            # sorted grouping: same per-node means / occupancy, ids non-decreasing, same multiset of rows per node
+            assert torch.equal(s["som_node"], g["som_node"]) and torch.equal(s["row_max"], g["row_max"])
+            ids = s["ids_sorted"]
+            assert bool((ids[:, 1:] >= ids[:, :-1]).all())
+            assert torch.equal(torch.sort(a.min_idx_i32, dim=1)[0], ids)
+            xa, xs = g["x_augmented"].cpu(), s["x_aug_sorted"].cpu()
+            for b in range(B):
+                p0 = int(s["pos0"][b])
+                assert torch.equal(xs[b, :, p0], xa[b, :, 0])                          # original copy 0
+                order = torch.sort(a.min_idx_i32[b].cpu().long(), stable=True)[1]
+                ref_rows = xa[b][:, order].t()                                          # grouped by node, some order inside
+                got_rows = xs[b].t()
+                idsb = ids[b].cpu()
+                for m in torch.unique(idsb).tolist():
+                    sel = idsb == m
+                    assert torch.equal(torch.sort(ref_rows[sel], dim=0)[0], torch.sort(got_rows[sel], dim=0)[0])
+            with torch.no_grad():
+                first = pr(g["x_augmented"])                                            # fused, stores
+                _, ref = ops.index_max_gather(first, a.min_idx_i32, M, g["row_max"])
+                wstream, affine = pr._fused_state()
+                got = ops.pointresnet_fused_pool(s, wstream, affine, M)
+            assert tuple(got.shape) == (B, 384, M)
+            assert_close_rms(got.cpu().numpy(), ref.cpu().numpy(), 1e-6, "fused pool B=%d N=%d" % (B, N))
+    finally:
+        ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET = old
+
+
+def test_encoder_fast_path_lazily_materialises_first_pn_out():
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    g = golden("classifier_b2_n256")
+    opt = make_opt(g, 2, 256)
+    enc = NW.Encoder(opt)
+    synth.fill_state_dict_(enc.state_dict(), int(g["seed"]))
+    enc.to(DEV).eval()
+    args = (cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
+    with torch.no_grad(), ops.kernel_timing() as rec:
+        enc(*args)
+    names = [n for n, _, _ in rec.records]
+    assert any(n.startswith("pointresnet_fused_pool") for n in names) and not any(n.startswith("index_max") for n in names)
+    assert enc._first_pn_out is None
+    assert_close_rms(enc.first_pn_out[:, ::16, ::5].cpu().numpy(), g["first_pn_out_sub"], 1e-5, "lazy first_pn_out")

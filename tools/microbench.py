@@ -115,6 +115,19 @@ def bench_fused(B=64, L=15000):
             ms = timeit(lambda: pr(x))
             print("   fused ablation %-26s : %.3f ms  %.1f TF-eq" % (what, ms, flops / ms / 1e9), flush=True)
         os.environ.pop("SONET_FUSED_ABLATE", None)
+        # pooled variant on node-sorted input
+        from sonet_hip import synth as _s
+        inp = _s.make_inputs(B, L // 3, seed=1, device=DEV)
+        a = ops.som_assign(inp["pc"], inp["node"], 3)
+        sg = ops.som_sort_group(inp["pc"], inp["sn"], a)
+        wstream, affine = pr._fused_state()
+        for abl, what in ((0, "pool full"), (8, "pool: no flush"), (16, "pool: no wave reduce"), (32, "pool: no tail publish"), (56, "pool: affine only")):
+            os.environ["SONET_FUSED_ABLATE"] = str(abl)
+            ms = timeit(lambda: ops.pointresnet_fused_pool(sg, wstream, affine, 64))
+            print("   fused+pool %-26s : %.3f ms" % (what, ms), flush=True)
+        os.environ.pop("SONET_FUSED_ABLATE", None)
+        ms = timeit(lambda: ops.som_sort_group(inp["pc"], inp["sn"], a)); print("   som_sort_group %.3f ms" % ms)
+        ms = timeit(lambda: ops.som_group(inp["pc"], inp["sn"], a, want_augmented=True)); print("   som_group      %.3f ms" % ms)
     ops.FUSE_POINTRESNET = True
 
 
