@@ -49,10 +49,11 @@ constexpr int NSW = NSTG / PF_WAVES;                           // slices staged 
 static_assert(NSTG % PF_WAVES == 0, "");
 constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     h = cvt_pk_bf16(x0, x1);
@@ -83,6 +84,33 @@ template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v
         return b;
     } else {
         return split_chunk(v);
+    }
+}
+
+// The same split, one VALU instruction at a time, so that the fused kernel can place <= 3 of them behind each MFMA
+// (a clump of 11 dependent VALU between two MFMAs stalls the matrix pipe: tools/mfma_bf16_issue.hip).  Op I of 44:
+// two interleaved pairs per group of 22 (independent neighbours), stages h, hi-parts, residual, m, hi-parts, residual, l.
+struct SplitState { float x[8], r[8]; unsigned t[8], h[4], m[4], l[4]; };
+// (volatile asm: instruction selection floats pure VALU ops across sched_barrier and clumps 8-9 of them behind one MFMA)
+__device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
+__device__ __forceinline__ unsigned pin_shl16(unsigned a) { unsigned r; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ unsigned pin_hi16(unsigned a) { unsigned r; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float pin_sub(float a, unsigned b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
+    if constexpr (ABL & 2) {
+        if constexpr (I == 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) s.h[p] = s.m[p] = s.l[p] = __float_as_uint(s.x[0]);
+        }
+    } else if constexpr (I >= 0 && I < 44) {
+        constexpr int g = I / 22, k = I % 22;
+        if constexpr (k < 2) { constexpr int P = 2 * g + k; s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
+        else if constexpr (k < 6) { constexpr int P = 2 * g + (k - 2) / 2, hf = (k - 2) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.h[P]) : pin_hi16(s.h[P]); }
+        else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 6) / 2, hf = (k - 6) % 2; s.r[2 * P + hf] = pin_sub(s.x[2 * P + hf], s.t[2 * P + hf]); }
+        else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+        else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 12) / 2, hf = (k - 12) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.m[P]) : pin_hi16(s.m[P]); }
+        else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 16) / 2, hf = (k - 16) % 2; s.r[2 * P + hf] = pin_sub(s.r[2 * P + hf], s.t[2 * P + hf]); }
+        else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
     }
 }
 
@@ -179,6 +207,19 @@ __device__ __forceinline__ void dpp_halfwave_max4(float &a, float &b, float &c, 
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+#ifdef SONET_PROF
+// Profiling build only (make prof; tools/fused_phases.py): per-wave shader-clock cycles spent in each phase.
+constexpr int PROF_N = 8;
+__device__ long long g_prof[1024 * PROF_N];
+#define PROF_DECL long long prof_[PROF_N] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t_ = __builtin_readcyclecounter();
+#define PROF_MARK(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
+#define PROF_DUMP if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_DUMP
+#endif
+
 template <int ABL, bool SEGMAX>   // ABL: bench-only ablation: 1 = no stores, 2 = no bf16 split, 4 = no W streaming / barriers
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
@@ -196,27 +237,37 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const int j = lane & 31, h = lane >> 5;
     for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) aff[c] = affine_g[c];
 
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(Wst), 0, NSLICE * 1024, 0x00020000);
     const unsigned vow = (unsigned)lane * 16u;
     const unsigned rowB = (unsigned)L * 4u;
 
-    i32x4_t wreg[NSW];
-    auto stage_load = [&](int n) {                              // stream stage n (wraps: the stream restarts per tile)
+    // The W stream goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1 KiB slice per wave instruction,
+    // lane-linear, which is exactly the slice layout): no staging VGPRs and no ds_write pass.  hipcc does not see
+    // these loads; their completion is counted by hand (vmcnt(0) before the barrier that publishes the stage).
+    const unsigned wsm_lds = (unsigned)reinterpret_cast<size_t>(&wsm[0][0]);
+    const char *dma_g = nullptr;                                // this wave's NSW slices of the stage being streamed
+    unsigned dma_dst = 0;
+    auto dma_setup = [&](int n, int slot) {                     // stream stage n (wraps: the stream restarts per tile)
         const int sn = n % NSTAGE;
-#pragma unroll
-        for (int t = 0; t < NSW; ++t)
-            wreg[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(sn * NSTG + wave + t * PF_WAVES) * 1024u, 0);
+        dma_g = reinterpret_cast<const char *>(Wst) + (size_t)(sn * NSTG + wave * NSW) * 1024u;
+        dma_dst = wsm_lds + (unsigned)(slot * NSTG + wave * NSW) * 1024u;
     };
-    auto stage_write = [&](int slot) {
+    auto dma_one = [&](int t) {                                 // t is a literal at every call site
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vow), "s"(dma_g + t * 1024), "s"(dma_dst + (unsigned)t * 1024u) : "memory");
+    };
+    auto stage_dma = [&](int n, int slot) {
+        dma_setup(n, slot);
 #pragma unroll
-        for (int t = 0; t < NSW; ++t) wsm[slot * NSTG + wave + t * PF_WAVES][lane] = __builtin_bit_cast(uint4, wreg[t]);
+        for (int t = 0; t < NSW; ++t) dma_one(t);
     };
     // ring state (wave-uniform scalars)
     int n_cur = 0;                                              // stage being consumed
     int slot_cur = 0, slot_nxt = 1, slot_fill = 2;
-    stage_load(0); stage_write(0);
-    stage_load(1); stage_write(1);
-    stage_load(2);
+    stage_dma(0, 0);
+    stage_dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // stages 0 and 1 are published (stage 0 is read cold)
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
     const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
     bool first_boundary = true;
@@ -243,41 +294,102 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         }
     };
 
-    // boundary of the stage that the CURRENT step opens
-    auto boundary = [&](bool flush = false) {
+    // Boundary of the stage that the CURRENT step opens, in two halves so that the step can put its own `h` fragment
+    // reads between them (LDS executes a wave's operations in order: behind the nine ds_write_b128 they would
+    // return ~120 cycles later).
+    auto boundary_sync = [&]() {
         if constexpr (ABL & 4) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slices of the stage DMA'd one boundary ago have landed
         __syncthreads();
         if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
             const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t;
             n_cur += 1;
         }
         first_boundary = false;
-        stage_write(slot_fill);                                 // stage n_cur + 2
-        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
-        stage_load(n_cur + 3);
         lds_cur = &wsm[slot_cur * NSTG][lane];
         lds_nxt = &wsm[slot_nxt * NSTG][lane];
     };
-    // A fragments of the step at slice index sidx (compile-time); `ahead` = the step opens a new stage and is
-    // being prefetched from the stage before it
-#define PF_LOAD_A(af, NT, sidx, ahead)                                                               \
-    {                                                                                                \
-        const uint4 *base_ = (ahead) ? lds_nxt : lds_cur;                                            \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) {                                          \
-            af.h[u_] = __builtin_bit_cast(bf16x8, base_[(((sidx) % NSTG) + 3 * u_ + 0) * 64]);        \
-            af.m[u_] = __builtin_bit_cast(bf16x8, base_[(((sidx) % NSTG) + 3 * u_ + 1) * 64]);        \
-            af.l[u_] = __builtin_bit_cast(bf16x8, base_[(((sidx) % NSTG) + 3 * u_ + 2) * 64]);        \
-        }                                                                                            \
+    auto boundary_fill = [&](bool flush) {                      // the step itself issues the NSW slices (dma_one) between its MFMAs
+        if constexpr (ABL & 4) return;
+        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
+        dma_setup(n_cur + 2, slot_fill);                        // lands during this stage, published by the next barrier
+    };
+#define PF_LDA(base, slice) __builtin_bit_cast(bf16x8, (base)[(slice) * 64])
+#define PF_SB __builtin_amdgcn_sched_barrier(0);
+#define PF_MF(accarr, tbase, NT, fa, fb, u)                                                          \
+    if constexpr ((u) < (NT)) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0);
+    // VALU slot behind MFMA u of term TERM (0..5): two split ops.  At 6 tiles the four middle terms carry them
+    // (24 slots), at 4 tiles all six terms (24 slots): three ops per MFMA were measured NOT to hide (layer 3 ran at
+    // 62 % with them, 82 % without any split).
+#define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
+    if constexpr (HAVE && ((NT) < 6 || ((TERM) >= 1 && (TERM) <= 4))) {                              \
+        constexpr int f_ = 2 * (((NT) >= 6 ? (TERM) - 1 : (TERM)) * (NT) + (u));                     \
+        split_op<ABL, f_>(sp_); split_op<ABL, f_ + 1>(sp_);                                          \
     }
-    // six product terms, TERM-major across the NT tiles (consecutive MFMAs never share an accumulator)
-#define PF_MFMAS(accarr, tbase, NT, af, b)                                                           \
+#define PF_DMA_AFTER(NT, u)                                                                          \
+    if constexpr (so_ == 0 && !(ABL & 4)) {                                                          \
+        if constexpr ((0 * (NT)) / NSW == (u)) dma_one(0);                                           \
+        if constexpr ((1 * (NT)) / NSW == (u)) dma_one(1);                                           \
+        if constexpr ((2 * (NT)) / NSW == (u)) dma_one(2);                                           \
+        if constexpr ((3 * (NT)) / NSW == (u)) dma_one(3);                                           \
+        if constexpr ((4 * (NT)) / NSW == (u)) dma_one(4);                                           \
+        if constexpr ((5 * (NT)) / NSW == (u)) dma_one(5);                                           \
+        if constexpr ((6 * (NT)) / NSW == (u)) dma_one(6);                                           \
+        if constexpr ((7 * (NT)) / NSW == (u)) dma_one(7);                                           \
+        if constexpr ((8 * (NT)) / NSW == (u)) dma_one(8);                                           \
+    }
+#define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MF(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
+#define PF_TERM_A(accarr, tbase, NT, fa, fb, HAVE)                                                   \
+    PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 0) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 1) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 2)  \
+    PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 3) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 4) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 5)
+#define PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, u) if constexpr ((u) < (NT)) { PF_MF(accarr, tbase, NT, fa, fb, u) PF_SLOT(HAVE, NT, ti, u) PF_SB }
+#define PF_TERM_V(accarr, tbase, NT, fa, fb, HAVE, ti)                                               \
+    PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 0) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 1) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 2) \
+    PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 3) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 4) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 5)
+    // One step = one K chunk (16 channels) x NT cout tiles = 6 NT MFMAs, the six product terms TERM-major across the
+    // tiles (consecutive MFMAs never share an accumulator), in the order l.h m.m m.h h.l h.m h.h.  It is scheduled by
+    // hand (sched_barrier after every MFMA), because with one wave per SIMD nothing else hides a latency:
+    //  - on entry af.l / af.m already hold this step's fragments (read by the step before; COLD steps -- first of a
+    //    tile / of a layer-4 pass -- read them first thing, from the ring slot that is about to become current);
+    //  - a step that opens a stage waits for its own LDS-DMA slices, takes the barrier, and issues the NSW slices of
+    //    the stage after next between the MFMAs of the first term;
+    //  - `h` is read after the first term and not needed before the 4th; the freed `l` registers take the NEXT step's
+    //    `l` after the second term (from the next ring slot when that step opens a stage: published one barrier
+    //    earlier), `m` likewise after the fourth: no second fragment set, and never more than 12 LDS reads in
+    //    flight (with 18 hipcc falls back to lgkmcnt(0) and the h-terms wait for reads issued just before them);
+    //  - the next step's B chunk is split (fp32 -> 3 x bf16) 2-3 VALU instructions per MFMA behind terms 2..5
+    //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
+#define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, EXTRA)  \
     {                                                                                                \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.l[u_], b.h, accarr[(tbase) + u_], 0, 0, 0); \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h[u_], b.l, accarr[(tbase) + u_], 0, 0, 0); \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.m[u_], b.m, accarr[(tbase) + u_], 0, 0, 0); \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.m[u_], b.h, accarr[(tbase) + u_], 0, 0, 0); \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h[u_], b.m, accarr[(tbase) + u_], 0, 0, 0); \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) accarr[(tbase) + u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h[u_], b.h, accarr[(tbase) + u_], 0, 0, 0); \
+        constexpr int so_ = (sidx) % NSTG, son_ = (SIDXN) % NSTG;                                    \
+        SplitState sp_;                                                                              \
+        if (COLD) {                                                                                  \
+            const uint4 *cb_ = (so_ != 0 || first_boundary) ? lds_cur : lds_nxt;                     \
+            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.l[u_] = PF_LDA(cb_, so_ + 3 * u_ + 2); \
+            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.m[u_] = PF_LDA(cb_, so_ + 3 * u_ + 1); \
+        }                                                                                            \
+        if (so_ == 0) { boundary_sync(); boundary_fill(FLUSH); }                                     \
+        const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;                                            \
+        { CHUNKCODE }                                                                                \
+        PF_SB                                                                                        \
+        PF_TERM_A(accarr, tbase, NT, af.l, bcur.h, HAVE)                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(lds_cur, so_ + 3 * u_);  \
+        PF_SB                                                                                        \
+        PF_TERM_V(accarr, tbase, NT, af.m, bcur.m, HAVE, 1)                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + 3 * u_ + 2); \
+        PF_SB                                                                                        \
+        EXTRA                                                                                        \
+        PF_TERM_V(accarr, tbase, NT, af.m, bcur.h, HAVE, 2)                                          \
+        PF_TERM_V(accarr, tbase, NT, af.h, bcur.l, HAVE, 3)                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.m[u_] = PF_LDA(nb_, son_ + 3 * u_ + 1); \
+        PF_SB                                                                                        \
+        PF_TERM_V(accarr, tbase, NT, af.h, bcur.m, HAVE, 4)                                          \
+        PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 5)                                         \
+        if constexpr (HAVE) {                                                                        \
+            bnext.h = __builtin_bit_cast(bf16x8, make_uint4(sp_.h[0], sp_.h[1], sp_.h[2], sp_.h[3])); \
+            bnext.m = __builtin_bit_cast(bf16x8, make_uint4(sp_.m[0], sp_.m[1], sp_.m[2], sp_.m[3])); \
+            bnext.l = __builtin_bit_cast(bf16x8, make_uint4(sp_.l[0], sp_.l[1], sp_.l[2], sp_.l[3])); \
+        }                                                                                            \
     }
 #define PF_AFFINE_RELU(accv, chbase)                                                                 \
     {                                                                                                \
@@ -294,6 +406,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // slice index / tile group of middle step i (layer 2 first, then layer 3)
 #define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * 3 * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * 3 * GS)
 
+    AF af;
+    PROF_DECL
+    PROF_MARK(0)                                                // kernel prologue
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long b = tile / tpc;
         const int l0 = (int)(tile - b * tpc) * 128 + wave * 32;
@@ -354,13 +469,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) act3[t][r] = 0.f;
 
-        AF af[1];
         B3 bq[2];
-        // ---- layer 1 (slice 0 opens stage 0 of this tile): no prefetch into it, prefetches layer 2's first step ----
-        boundary();
-        PF_LOAD_A(af[0], T0, OFF1, false)
+        PROF_MARK(1)                                            // tile prologue (ids, x loads issued, accumulators zeroed)
+        // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
         bq[0] = split_chunk_abl<ABL>(xin);
-        PF_MFMAS(act1, 0, T0, af[0], bq[0])
+        PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, )
 #pragma unroll
         for (int t = 0; t < T0; ++t) PF_AFFINE_RELU(act1[t], 32 * t)
         {
@@ -368,45 +481,41 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             PF_CHUNK(v, act1, 0)
             bq[1] = split_chunk_abl<ABL>(v);
         }
+        PROF_MARK(6)                                            // layer 1
         // ---- layers 2 and 3: middle steps i = 0 .. NMID-1, set parity (i + 1) & 1 ----
+#define PF_MID_CHUNK if (last_of_l3) PF_CHUNK(sp_.x, act1, 0) else if (l2) PF_CHUNK(sp_.x, act1, (l2 ? kcn : 0)) else PF_CHUNK(sp_.x, act2, (l2 ? 0 : kcn))
 #define PF_MID(I_)                                                          \
         {                                                                   \
             constexpr int i = (I_);                                         \
-            const int sidx = MID_SIDX(i); \
-            const int cur = (i + 1) & 1, nxt = i & 1; \
-            const bool l2 = i < KC2 * (T1 / GS); \
-            const int kc = l2 ? i % KC2 : (i - KC2 * (T1 / GS)) % KC3; \
-            const int grp = l2 ? i / KC2 : (i - KC2 * (T1 / GS)) / KC3; \
-            if (sidx % NSTG == 0) boundary(); \
- \
-            PF_LOAD_A(af[0], GS, sidx, false) \
- \
-            const bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
-            if (!last_of_l2 && !last_of_l3) { \
-                float v[8]; \
-                const int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
-                if (l2) PF_CHUNK(v, act1, (l2 ? kcn : 0)) else PF_CHUNK(v, act2, (l2 ? 0 : kcn)) \
-                bq[nxt] = split_chunk_abl<ABL>(v); \
-            } \
-            if (l2) PF_MFMAS(act2, grp * GS, GS, af[0], bq[cur]) else PF_MFMAS(act3, grp * GS, GS, af[0], bq[cur]) \
+            constexpr int sidx = MID_SIDX(i); \
+            constexpr int cur = (i + 1) & 1, nxt = i & 1; \
+            constexpr bool l2 = i < KC2 * (T1 / GS); \
+            constexpr int grp = l2 ? i / KC2 : (i - KC2 * (T1 / GS)) / KC3; \
+            constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
+            constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
+            constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
+            /* the first group of layer 3 is finished after step 11: its affine rides along steps 12..15 */ \
+            constexpr int afft = i - (KC2 * (T1 / GS) + KC3);               \
+            if (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
+            else    { PF_STEP(act3, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], true, PF_MID_CHUNK, bq[nxt], false, false, \
+                              if (afft >= 0 && afft < GS) PF_AFFINE_RELU(act3[afft < 0 ? 0 : (afft < GS ? afft : 0)], 32 * (T0 + T1) + 32 * (afft < 0 ? 0 : afft))) } \
             if (last_of_l2) { \
 _Pragma("unroll") \
                 for (int t = 0; t < T1; ++t) PF_AFFINE_RELU(act2[t], 32 * T0 + 32 * t) \
-                float v[8]; \
-                PF_CHUNK(v, act2, 0) \
-                bq[nxt] = split_chunk_abl<ABL>(v); \
+                float v2[8]; \
+                PF_CHUNK(v2, act2, 0) \
+                bq[nxt] = split_chunk_abl<ABL>(v2); \
             } \
             if (last_of_l3) { \
 _Pragma("unroll") \
-                for (int t = 0; t < T2; ++t) PF_AFFINE_RELU(act3[t], 32 * (T0 + T1) + 32 * t) \
-                float v[8]; \
-                PF_CHUNK(v, act1, 0) \
-                bq[nxt] = split_chunk_abl<ABL>(v); \
+                for (int t = GS; t < T2; ++t) PF_AFFINE_RELU(act3[t], 32 * (T0 + T1) + 32 * t) \
             } \
         }
-        static_assert(NMID == 20, "expand PF_MID to NMID steps");
-        PF_MID(0) PF_MID(1) PF_MID(2) PF_MID(3) PF_MID(4) PF_MID(5) PF_MID(6) PF_MID(7) PF_MID(8) PF_MID(9) PF_MID(10) PF_MID(11) PF_MID(12) PF_MID(13) PF_MID(14) PF_MID(15) PF_MID(16) PF_MID(17) PF_MID(18) PF_MID(19)
+        static_assert(NMID == 20 && T2 == 2 * GS, "expand PF_MID to NMID steps; layer 3 = two groups");
+        PF_MID(0) PF_MID(1) PF_MID(2) PF_MID(3) PROF_MARK(7) PF_MID(4) PF_MID(5) PF_MID(6) PF_MID(7) PF_MID(8) PF_MID(9) PF_MID(10) PF_MID(11) PF_MID(12) PF_MID(13) PF_MID(14) PF_MID(15) PF_MID(16) PF_MID(17) PF_MID(18) PF_MID(19)
 #undef PF_MID
+#undef PF_MID_CHUNK
+        PROF_MARK(2)                                            // layers 1-3
         // ---- layer 4: NPASS passes x KC4 steps of MT4 tiles; set parity of step kc is (NMID + 1 + kc) & 1 ----
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc[MT4];
@@ -414,24 +523,20 @@ _Pragma("unroll") \
             for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#define PF_L4_CHUNK if (kn < KC2) PF_CHUNK(sp_.x, act1, (kn < KC2 ? kn : 0)) else PF_CHUNK(sp_.x, act3, (kn < KC2 ? 0 : kn - KC2))
 #define PF_L4(K_)                                                           \
             {                                                               \
                 constexpr int kc = (K_);                                    \
-                const int sidx = PRE + kc * MT4 * 3; \
-                const int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
-                if (sidx % NSTG == 0) boundary(kc == 0); \
-                const int kn = (kc + 1) % KC4; \
-                PF_LOAD_A(af[0], MT4, sidx, false) \
-                { \
-                    float v[8]; \
-                    if (kn < KC2) PF_CHUNK(v, act1, (kn < KC2 ? kn : 0)) else PF_CHUNK(v, act3, (kn < KC2 ? 0 : kn - KC2)) \
-                    bq[nxt] = split_chunk_abl<ABL>(v); \
-                } \
-                PF_MFMAS(acc, 0, MT4, af[0], bq[cur]) \
+                constexpr int sidx = PRE + kc * MT4 * 3; \
+                constexpr int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
+                constexpr int kn = (kc + 1) % KC4; \
+                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + 3 * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), ) \
             }
             static_assert(KC4 == 20, "expand PF_L4 to KC4 steps");
             PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
 #undef PF_L4
+#undef PF_L4_CHUNK
+            PROF_MARK(3)                                        // layer-4 pass (MFMA stream)
             if constexpr (SEGMAX) {
                 // ---- per-node max-pool of this pass's 192 channels (replaces index_max + masked gather,
                 //      models/networks.py:180-185, for the no-grad path: only the VALUES are needed) ----
@@ -465,7 +570,6 @@ _Pragma("unroll") \
                     const bool inseg = pv && nid == node;
                     const int slot = node - n0;
                     const bool to_lds = slot < SEG_SLOTS;
-                    unsigned *dst = to_lds ? &bins[slot][0] : pooled + ((long long)b * M + node) * (32 * T3) + pass * (32 * MT4);
 #pragma unroll
                     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
@@ -484,9 +588,18 @@ _Pragma("unroll") \
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         const float *st = reinterpret_cast<const float *>(&segst[wave][0]);
+                        // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
+                        // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
+                        if (to_lds) {
 #pragma unroll
-                        for (int i = 0; i < 32 * MT4 / 64; ++i)
-                            atomicMax(dst + lane + 64 * i, ord_f32(__float_as_uint(st[lane + 64 * i])));
+                            for (int i = 0; i < 32 * MT4 / 64; ++i)
+                                atomicMax(&bins[slot][lane + 64 * i], ord_f32(__float_as_uint(st[lane + 64 * i])));
+                        } else {
+                            unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * (32 * MT4);
+#pragma unroll
+                            for (int i = 0; i < 32 * MT4 / 64; ++i)
+                                atomicMax(gdst + lane + 64 * i, ord_f32(__float_as_uint(st[lane + 64 * i])));
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -511,14 +624,19 @@ _Pragma("unroll") \
                     }
                 }
             }
+            PROF_MARK(4)                                        // epilogue (pool or stores)
         }
     }
     if constexpr (SEGMAX && !(ABL & 8)) {
         __syncthreads();
         if (blockIdx.x < ntiles) flush_bins();
     }
-#undef PF_LOAD_A
-#undef PF_MFMAS
+    PROF_MARK(5)
+    PROF_DUMP
+#undef PF_STEP
+#undef PF_TERM
+#undef PF_LDA
+#undef PF_SPLIT_PAIR
 #undef PF_AFFINE_RELU
 #undef PF_CHUNK
 #undef MID_SIDX
@@ -637,10 +755,17 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
 #define PF_LAUNCH_POOL(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st, \
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr, \
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws)
-    switch (abl) { case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
+    switch (abl) { case 4: PF_LAUNCH_POOL(4); break; case 2: PF_LAUNCH_POOL(2); break; case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
                    case 56: PF_LAUNCH_POOL(56); break; default: PF_LAUNCH_POOL(0); }
 #undef PF_LAUNCH_POOL
     hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
                        ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);
     return sonet::launched(what);
 }
+
+#ifdef SONET_PROF
+extern "C" int sonet_prof_read(long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(long long) * (size_t)n, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif

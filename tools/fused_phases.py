@@ -1,0 +1,48 @@
+"""tools/fused_phases.py [pool|store] -- per-phase shader cycles of the fused first-PointNet kernel, from the
+profiling build (make -C so-net_amd/csrc prof).  Prints mean cycles per tile per wave next to the MFMA-only ideal."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "so-net_amd"))
+import torch  # noqa: E402
+from sonet_hip import _lib  # noqa: E402
+_lib.LIB_PATH = os.path.join(ROOT, "so-net_amd", "lib", "libsonet_hip_prof.so")
+from sonet_hip import ops, synth  # noqa: E402
+from models import layers as Lm  # noqa: E402
+import numpy as np  # noqa: E402
+
+DEV = torch.device("cuda:0")
+mode = sys.argv[1] if len(sys.argv) > 1 else "pool"
+B = 64
+pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+synth.fill_state_dict_(pr.state_dict(), seed=7)
+pr.to(DEV).eval()
+inp = synth.make_inputs(B, 5000, seed=1, device=DEV)
+a = ops.som_assign(inp["pc"], inp["node"], 3)
+wstream, affine = pr._fused_state()
+if mode == "pool":
+    sg = ops.som_sort_group(inp["pc"], inp["sn"], a)
+    run = lambda: ops.pointresnet_fused_pool(sg, wstream, affine, 64)
+else:
+    g = ops.som_group(inp["pc"], inp["sn"], a, want_augmented=True)
+    y = torch.empty(B, 384, 15000, device=DEV)
+    run = lambda: ops.pointresnet_fused(g["x_aug"], wstream, affine, out=y)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.sonet_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros(1024 * 8, dtype=np.int64)
+assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
+p = buf.reshape(1024, 8).astype(np.float64)
+tiles = B * ((15000 + 127) // 128) / 256.0
+names = ["kernel prologue", "tile prologue", "layer 3", "layer-4 MFMA passes", "epilogue", "tail", "layer 1", "layer 2"]
+ideal = [0, 0, 64 * 6 * 32, 2 * 720 * 32, 0, 0, 2 * 6 * 32, 16 * 6 * 32]
+tot = p.sum(1).mean()
+print("mode %s: %.0f cycles per wave (%.3f ms at 2.39 GHz), %.1f tiles per workgroup" % (mode, tot, tot / 2.39e6, tiles))
+for i, n in enumerate(names):
+    per_tile = p[:, i].mean() / tiles
+    print("  %-22s %9.0f cycles/tile  (%4.1f%%)%s" % (n, per_tile, 100 * p[:, i].mean() / tot,
+          "   MFMA-only ideal %d -> %.0f%%" % (ideal[i], 100 * ideal[i] / per_tile) if ideal[i] else ""))
