@@ -90,28 +90,50 @@ template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v
 // The same split, one VALU instruction at a time, so that the fused kernel can place <= 3 of them behind each MFMA
 // (a clump of 11 dependent VALU between two MFMAs stalls the matrix pipe: tools/mfma_bf16_issue.hip).  Op I of 44:
 // two interleaved pairs per group of 22 (independent neighbours), stages h, hi-parts, residual, m, hi-parts, residual, l.
-struct SplitState { float x[8], r[8]; unsigned t[8], h[4], m[4], l[4]; };
+struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned t[8], h[4], m[4], l[4]; };
 // (volatile asm: instruction selection floats pure VALU ops across sched_barrier and clumps 8-9 of them behind one MFMA)
 __device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
 __device__ __forceinline__ unsigned pin_shl16(unsigned a) { unsigned r; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ unsigned pin_hi16(unsigned a) { unsigned r; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ float pin_sub(float a, unsigned b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
+// relu as the layer-wise kernels do it (v < 0 ? 0 : v: a NaN stays a NaN, as in the reference)
+__device__ __forceinline__ float pin_relu(float a) { float r; asm volatile("v_cmp_gt_f32 vcc, 0, %1\n\tv_cndmask_b32 %0, %1, 0, vcc" : "=v"(r) : "v"(a) : "vcc"); return r; }
+// Op I of 60 (two groups of 30 = two value pairs each): the producing layer's BatchNorm affine + ReLU applied to the
+// raw accumulator values on the way (the activations stay raw in their registers; an in-place pass after each
+// layer cost ~4k cycles per tile in serialised LDS reads of the coefficients), then the 22 split ops.
+constexpr int SPLIT_OPS = 60;
 template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
     if constexpr (ABL & 2) {
         if constexpr (I == 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) s.h[p] = s.m[p] = s.l[p] = __float_as_uint(s.x[0]);
         }
-    } else if constexpr (I >= 0 && I < 44) {
-        constexpr int g = I / 22, k = I % 22;
-        if constexpr (k < 2) { constexpr int P = 2 * g + k; s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
-        else if constexpr (k < 6) { constexpr int P = 2 * g + (k - 2) / 2, hf = (k - 2) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.h[P]) : pin_hi16(s.h[P]); }
-        else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 6) / 2, hf = (k - 6) % 2; s.r[2 * P + hf] = pin_sub(s.x[2 * P + hf], s.t[2 * P + hf]); }
-        else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 12) / 2, hf = (k - 12) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.m[P]) : pin_hi16(s.m[P]); }
-        else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 16) / 2, hf = (k - 16) % 2; s.r[2 * P + hf] = pin_sub(s.r[2 * P + hf], s.t[2 * P + hf]); }
-        else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+    } else if constexpr (I >= 0 && I < SPLIT_OPS) {
+        constexpr int g = I / 30, k0 = I % 30;
+        if constexpr (k0 < 4) { constexpr int e = 4 * g + k0; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
+        else if constexpr (k0 < 8) { constexpr int e = 4 * g + k0 - 4; s.x[e] = pin_relu(s.x[e]); }
+        else {
+            constexpr int k = k0 - 8;
+            if constexpr (k < 2) { constexpr int P = 2 * g + k; s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
+            else if constexpr (k < 6) { constexpr int P = 2 * g + (k - 2) / 2, hf = (k - 2) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.h[P]) : pin_hi16(s.h[P]); }
+            else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 6) / 2, hf = (k - 6) % 2; s.r[2 * P + hf] = pin_sub(s.x[2 * P + hf], s.t[2 * P + hf]); }
+            else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+            else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 12) / 2, hf = (k - 12) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.m[P]) : pin_hi16(s.m[P]); }
+            else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 16) / 2, hf = (k - 16) % 2; s.r[2 * P + hf] = pin_sub(s.r[2 * P + hf], s.t[2 * P + hf]); }
+            else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+        }
     }
+}
+template <int ABL, int I> __device__ __forceinline__ void split_all(SplitState &s) {     // back to back (layer transitions)
+    if constexpr (I < SPLIT_OPS) { split_op<ABL, I>(s); split_all<ABL, I + 1>(s); }
+}
+__device__ __forceinline__ B3 split_result(const SplitState &s) {
+    B3 b;
+    b.h = __builtin_bit_cast(bf16x8, make_uint4(s.h[0], s.h[1], s.h[2], s.h[3]));
+    b.m = __builtin_bit_cast(bf16x8, make_uint4(s.m[0], s.m[1], s.m[2], s.m[3]));
+    b.l = __builtin_bit_cast(bf16x8, make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]));
+    return b;
 }
 
 // ---- weight stream packing -------------------------------------------------------------------------
@@ -162,18 +184,18 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------
-// LDS ring of NSLOT stages.  Before stage n is consumed, stages n and n+1 are resident and visible, the
-// registers hold stage n+2.  Boundary(n), run by every wave at the first step of stage n:
-//     barrier;  ds_write stage n+2 into the slot stage n-1 occupied;  load stage n+3 into the registers.
-// So while a wave computes the last step of stage n it may already read the A fragments of the first step
-// of stage n+1: every step prefetches the NEXT step's A fragments (LDS -> registers) and splits the next
-// step's B chunk before issuing its own MFMAs.  With one wave per SIMD nothing else hides those latencies.
+// LDS ring of NSLOT = 3 stages of W (36 KiB each), filled by LDS-DMA.  While stage n is consumed, stage n+1 is
+// resident and published (the last step of a stage reads the A fragments of the next stage's first step from it)
+// and stage n+2 is landing in the slot stage n-1 occupied.  Boundary(n), run by every wave at the first step of
+// stage n:   s_waitcnt vmcnt(0) (this wave's pieces of stage n+1 have landed);  barrier;  issue stage n+2.
+// (A 4-slot ring with vmcnt(9), two stages of slack, measured no faster.)
+// With one wave per SIMD nothing else hides those latencies.
 constexpr int NSLOT = 3;
 
 struct AF { bf16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
 
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
-constexpr int SEG_SLOTS = 16;                                 // nodes of a 128-point tile pre-reduced in LDS
+constexpr int SEG_SLOTS = 16;                                 // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
 constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
 
 __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
@@ -209,9 +231,9 @@ __device__ __forceinline__ void dpp_halfwave_max4(float &a, float &b, float &c, 
 
 #ifdef SONET_PROF
 // Profiling build only (make prof; tools/fused_phases.py): per-wave shader-clock cycles spent in each phase.
-constexpr int PROF_N = 8;
+constexpr int PROF_N = 32;
 __device__ long long g_prof[1024 * PROF_N];
-#define PROF_DECL long long prof_[PROF_N] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t_ = __builtin_readcyclecounter();
+#define PROF_DECL long long prof_[PROF_N] = {}; long long prof_t_ = __builtin_readcyclecounter();
 #define PROF_MARK(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
 #define PROF_DUMP if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
 #else
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
     __shared__ float4 segst[SEGMAX ? PF_WAVES : 1][SEGMAX ? 8 * MT4 : 1];   // per wave: one node's 192 reduced maxima
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 36 KiB
-    __shared__ float2 aff[CH_TOTAL];
+    __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,15 +273,24 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         dma_g = reinterpret_cast<const char *>(Wst) + (size_t)(sn * NSTG + wave * NSW) * 1024u;
         dma_dst = wsm_lds + (unsigned)(slot * NSTG + wave * NSW) * 1024u;
     };
-    auto dma_one = [&](int t) {                                 // t is a literal at every call site
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(vow), "s"(dma_g + t * 1024), "s"(dma_dst + (unsigned)t * 1024u) : "memory");
+    // pieces t and t+1 (t even) of the wave's NSW = 9: they share an M0 / base pair, the instruction offset moves both
+    // the global and the LDS address.  (M0 is written in the statement that uses it and not restored: nothing else
+    // in this kernel reads it.  Saving/restoring it and re-deriving the base per piece cost ~9 scalar instructions
+    // per piece, ~60 cycles in front of the next MFMA, 27 stage boundaries per tile.)
+    auto dma_pair = [&](int t, bool two) {                      // t, two: literals at every call site
+        const char *g = dma_g + (t / 4) * 4096;
+        const unsigned d = dma_dst + (unsigned)(t / 4) * 4096u;
+        const int o = (t % 4) * 1024;
+        if (two) {
+            if (o == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(vow), "s"(g), "s"(d) : "memory");
+            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(vow), "s"(g), "s"(d) : "memory");
+        } else {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vow), "s"(g), "s"(d) : "memory");
+        }
     };
     auto stage_dma = [&](int n, int slot) {
         dma_setup(n, slot);
-#pragma unroll
-        for (int t = 0; t < NSW; ++t) dma_one(t);
+        dma_pair(0, true); dma_pair(2, true); dma_pair(4, true); dma_pair(6, true); dma_pair(8, false);
     };
     // ring state (wave-uniform scalars)
     int n_cur = 0;                                              // stage being consumed
@@ -271,7 +302,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
     const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
     bool first_boundary = true;
-    int pend_n = 0;
     // SEGMAX: partial-maxima block whose LDS bins are still to be stored.  The very first flush is a dry run (all
     // INIT) into the block that the same lanes rewrite one pass later, which keeps the flush free of branches.
     unsigned *pend = partial + (blockIdx.x * (long long)NPASS * SEG_SLOTS) * (32 * MT4);
@@ -281,13 +311,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // put a memory round trip in front of the next ds_write (vmcnt(0)): measured 0.2 ms per launch.
     auto flush_bins = [&]() {                                   // branch-free on the common path (<= 4 nodes per tile)
 #pragma unroll
-        for (int i = 0; i < 4 * 32 * MT4 / PF_THREADS; ++i) {
+        for (int i = 0; i < SEG_SLOTS * 32 * MT4 / PF_THREADS; ++i) {
             const int e = i * PF_THREADS + threadIdx.x;
-            unsigned *bp = &bins[0][0] + e;
-            pend[e] = *bp;
-            *bp = SEG_INIT;
-        }
-        for (int e = 4 * 32 * MT4 + threadIdx.x; e < pend_n; e += PF_THREADS) {
             unsigned *bp = &bins[0][0] + e;
             pend[e] = *bp;
             *bp = SEG_INIT;
@@ -299,8 +324,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // return ~120 cycles later).
     auto boundary_sync = [&]() {
         if constexpr (ABL & 4) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slices of the stage DMA'd one boundary ago have landed
+        if constexpr (!(ABL & 128)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the stage issued one boundary ago have landed
         __syncthreads();
+        }
         if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
             const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t;
             n_cur += 1;
@@ -318,25 +345,32 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
 #define PF_MF(accarr, tbase, NT, fa, fb, u)                                                          \
     if constexpr ((u) < (NT)) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0);
-    // VALU slot behind MFMA u of term TERM (0..5): two split ops.  At 6 tiles the four middle terms carry them
-    // (24 slots), at 4 tiles all six terms (24 slots): three ops per MFMA were measured NOT to hide (layer 3 ran at
-    // 62 % with them, 82 % without any split).
+    // VALU slot behind MFMA u of term TERM: terms 1..5 carry the 60 affine+split ops of the next step's B chunk, two
+    // per MFMA at 6 tiles, three at 4 tiles (the first term leaves the coefficient reads time to land).
 #define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
-    if constexpr (HAVE && ((NT) < 6 || ((TERM) >= 1 && (TERM) <= 4))) {                              \
-        constexpr int f_ = 2 * (((NT) >= 6 ? (TERM) - 1 : (TERM)) * (NT) + (u));                     \
+    if constexpr (HAVE && (TERM) >= 1) {                                                             \
+        constexpr int ops_ = (NT) >= 6 ? 2 : 3, f_ = ops_ * (((TERM) - 1) * (NT) + (u));             \
         split_op<ABL, f_>(sp_); split_op<ABL, f_ + 1>(sp_);                                          \
+        if constexpr (ops_ == 3) split_op<ABL, f_ + 2>(sp_);                                         \
     }
 #define PF_DMA_AFTER(NT, u)                                                                          \
-    if constexpr (so_ == 0 && !(ABL & 4)) {                                                          \
-        if constexpr ((0 * (NT)) / NSW == (u)) dma_one(0);                                           \
-        if constexpr ((1 * (NT)) / NSW == (u)) dma_one(1);                                           \
-        if constexpr ((2 * (NT)) / NSW == (u)) dma_one(2);                                           \
-        if constexpr ((3 * (NT)) / NSW == (u)) dma_one(3);                                           \
-        if constexpr ((4 * (NT)) / NSW == (u)) dma_one(4);                                           \
-        if constexpr ((5 * (NT)) / NSW == (u)) dma_one(5);                                           \
-        if constexpr ((6 * (NT)) / NSW == (u)) dma_one(6);                                           \
-        if constexpr ((7 * (NT)) / NSW == (u)) dma_one(7);                                           \
-        if constexpr ((8 * (NT)) / NSW == (u)) dma_one(8);                                           \
+    if constexpr (so_ == 0 && !(ABL & 4) && !(ABL & 64)) {                                            \
+        static_assert(NSW == 9, "five statements: pieces 01 23 45 67 8");                           \
+        if constexpr ((NT) >= 5) {                                                                   \
+            if constexpr ((u) == 0) dma_pair(0, true);                                               \
+            if constexpr ((u) == 1) dma_pair(2, true);                                               \
+            if constexpr ((u) == 2) dma_pair(4, true);                                               \
+            if constexpr ((u) == 3) dma_pair(6, true);                                               \
+            if constexpr ((u) == 4) dma_pair(8, false);                                              \
+        } else if constexpr ((NT) == 4) {                                                            \
+            if constexpr ((u) == 0) dma_pair(0, true);                                               \
+            if constexpr ((u) == 1) dma_pair(2, true);                                               \
+            if constexpr ((u) == 2) dma_pair(4, true);                                               \
+            if constexpr ((u) == 3) { dma_pair(6, true); dma_pair(8, false); }                       \
+        } else {                                                                                     \
+            if constexpr ((u) == 0) { dma_pair(0, true); dma_pair(2, true); }                        \
+            if constexpr ((u) == 1) { dma_pair(4, true); dma_pair(6, true); dma_pair(8, false); }    \
+        }                                                                                            \
     }
 #define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MF(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
 #define PF_TERM_A(accarr, tbase, NT, fa, fb, HAVE)                                                   \
@@ -385,23 +419,20 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         PF_SB                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.m, HAVE, 4)                                          \
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 5)                                         \
-        if constexpr (HAVE) {                                                                        \
-            bnext.h = __builtin_bit_cast(bf16x8, make_uint4(sp_.h[0], sp_.h[1], sp_.h[2], sp_.h[3])); \
-            bnext.m = __builtin_bit_cast(bf16x8, make_uint4(sp_.m[0], sp_.m[1], sp_.m[2], sp_.m[3])); \
-            bnext.l = __builtin_bit_cast(bf16x8, make_uint4(sp_.l[0], sp_.l[1], sp_.l[2], sp_.l[3])); \
-        }                                                                                            \
+        if constexpr (HAVE) bnext = split_result(sp_);                                               \
     }
-#define PF_AFFINE_RELU(accv, chbase)                                                                 \
+    // raw values of K chunk kc of an activation array (registers 8q..8q+7 of tile kc>>1) + their 8 (scale, shift)
+    // pairs: element e is channel 32t + 16q + (e&3) + 8(e>>2) + 4h of the producing layer (base LB in `aff`)
+#define PF_CHUNK_AFF(sp, arr, kc, LB)                                                                \
     {                                                                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-            const float2 ss = aff[(chbase) + (r & 3) + 8 * (r >> 2) + 4 * h];                        \
-            const float v = __fmaf_rn(accv[r], ss.x, ss.y);                                          \
-            accv[r] = v < 0.f ? 0.f : v;                                                             \
-        }                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) sp.x[e] = arr[(kc) >> 1][8 * ((kc) & 1) + e];   \
+        const float4 *ap_ = reinterpret_cast<const float4 *>(&aff[(LB) + 32 * ((kc) >> 1) + 16 * ((kc) & 1) + 4 * h]); \
+        const float4 c0_ = ap_[0], c1_ = ap_[1], c2_ = ap_[4], c3_ = ap_[5];                          \
+        sp.sc[0] = make_float2(c0_.x, c0_.y); sp.sc[1] = make_float2(c0_.z, c0_.w);                  \
+        sp.sc[2] = make_float2(c1_.x, c1_.y); sp.sc[3] = make_float2(c1_.z, c1_.w);                  \
+        sp.sc[4] = make_float2(c2_.x, c2_.y); sp.sc[5] = make_float2(c2_.z, c2_.w);                  \
+        sp.sc[6] = make_float2(c3_.x, c3_.y); sp.sc[7] = make_float2(c3_.z, c3_.w);                  \
     }
-#define PF_CHUNK(dst, arr, kc)                                                                       \
-    { _Pragma("unroll") for (int e = 0; e < 8; ++e) dst[e] = arr[(kc) >> 1][8 * ((kc) & 1) + e]; }
-
     constexpr int NMID = KC2 * (T1 / GS) + KC3 * (T2 / GS);    // steps of layers 2 and 3 (4 + 16)
     // slice index / tile group of middle step i (layer 2 first, then layer 3)
 #define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * 3 * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * 3 * GS)
@@ -474,16 +505,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
         bq[0] = split_chunk_abl<ABL>(xin);
         PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, )
-#pragma unroll
-        for (int t = 0; t < T0; ++t) PF_AFFINE_RELU(act1[t], 32 * t)
-        {
-            float v[8];
-            PF_CHUNK(v, act1, 0)
-            bq[1] = split_chunk_abl<ABL>(v);
+        {                                                       // layer transition: nothing to overlap with
+            SplitState sp_;
+            PF_CHUNK_AFF(sp_, act1, 0, 0)
+            split_all<ABL, 0>(sp_);
+            bq[1] = split_result(sp_);
         }
         PROF_MARK(6)                                            // layer 1
         // ---- layers 2 and 3: middle steps i = 0 .. NMID-1, set parity (i + 1) & 1 ----
-#define PF_MID_CHUNK if (last_of_l3) PF_CHUNK(sp_.x, act1, 0) else if (l2) PF_CHUNK(sp_.x, act1, (l2 ? kcn : 0)) else PF_CHUNK(sp_.x, act2, (l2 ? 0 : kcn))
+#define PF_MID_CHUNK if (last_of_l3) PF_CHUNK_AFF(sp_, act1, 0, 0) else if (l2) PF_CHUNK_AFF(sp_, act1, (l2 ? kcn : 0), 0) else PF_CHUNK_AFF(sp_, act2, (l2 ? 0 : kcn), 32 * T0)
 #define PF_MID(I_)                                                          \
         {                                                                   \
             constexpr int i = (I_);                                         \
@@ -494,25 +524,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
             constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
             constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
-            /* the first group of layer 3 is finished after step 11: its affine rides along steps 12..15 */ \
-            constexpr int afft = i - (KC2 * (T1 / GS) + KC3);               \
             if (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
-            else    { PF_STEP(act3, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], true, PF_MID_CHUNK, bq[nxt], false, false, \
-                              if (afft >= 0 && afft < GS) PF_AFFINE_RELU(act3[afft < 0 ? 0 : (afft < GS ? afft : 0)], 32 * (T0 + T1) + 32 * (afft < 0 ? 0 : afft))) } \
-            if (last_of_l2) { \
-_Pragma("unroll") \
-                for (int t = 0; t < T1; ++t) PF_AFFINE_RELU(act2[t], 32 * T0 + 32 * t) \
-                float v2[8]; \
-                PF_CHUNK(v2, act2, 0) \
-                bq[nxt] = split_chunk_abl<ABL>(v2); \
-            } \
-            if (last_of_l3) { \
-_Pragma("unroll") \
-                for (int t = GS; t < T2; ++t) PF_AFFINE_RELU(act3[t], 32 * (T0 + T1) + 32 * t) \
+            else    { PF_STEP(act3, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], true, PF_MID_CHUNK, bq[nxt], false, false, ) } \
+            if (last_of_l2) {                                               /* layer transition */ \
+                SplitState sp2_; \
+                PF_CHUNK_AFF(sp2_, act2, 0, 32 * T0) \
+                split_all<ABL, 0>(sp2_); \
+                bq[nxt] = split_result(sp2_); \
             } \
         }
         static_assert(NMID == 20 && T2 == 2 * GS, "expand PF_MID to NMID steps; layer 3 = two groups");
-        PF_MID(0) PF_MID(1) PF_MID(2) PF_MID(3) PROF_MARK(7) PF_MID(4) PF_MID(5) PF_MID(6) PF_MID(7) PF_MID(8) PF_MID(9) PF_MID(10) PF_MID(11) PF_MID(12) PF_MID(13) PF_MID(14) PF_MID(15) PF_MID(16) PF_MID(17) PF_MID(18) PF_MID(19)
+        PF_MID(0) PROF_MARK(8) PF_MID(1) PROF_MARK(9) PF_MID(2) PROF_MARK(10) PF_MID(3) PROF_MARK(11) PF_MID(4) PROF_MARK(12) PF_MID(5) PROF_MARK(13) PF_MID(6) PROF_MARK(14) PF_MID(7) PROF_MARK(15) PF_MID(8) PROF_MARK(16) PF_MID(9) PROF_MARK(17) PF_MID(10) PROF_MARK(18) PF_MID(11) PROF_MARK(19) PF_MID(12) PROF_MARK(20) PF_MID(13) PROF_MARK(21) PF_MID(14) PROF_MARK(22) PF_MID(15) PROF_MARK(23) PF_MID(16) PROF_MARK(24) PF_MID(17) PROF_MARK(25) PF_MID(18) PROF_MARK(26) PF_MID(19) PROF_MARK(27)
 #undef PF_MID
 #undef PF_MID_CHUNK
         PROF_MARK(2)                                            // layers 1-3
@@ -523,7 +545,7 @@ _Pragma("unroll") \
             for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-#define PF_L4_CHUNK if (kn < KC2) PF_CHUNK(sp_.x, act1, (kn < KC2 ? kn : 0)) else PF_CHUNK(sp_.x, act3, (kn < KC2 ? 0 : kn - KC2))
+#define PF_L4_CHUNK if (kn < KC2) PF_CHUNK_AFF(sp_, act1, (kn < KC2 ? kn : 0), 0) else PF_CHUNK_AFF(sp_, act3, (kn < KC2 ? 0 : kn - KC2), 32 * (T0 + T1))
 #define PF_L4(K_)                                                           \
             {                                                               \
                 constexpr int kc = (K_);                                    \
@@ -605,7 +627,6 @@ _Pragma("unroll") \
                     }
                 }
                 }
-                if constexpr (!(ABL & 8)) pend_n = nslots * (32 * MT4);
                 if constexpr (!(ABL & 8))
                     pend = partial + ((tile * NPASS + pass) * SEG_SLOTS) * (long long)(32 * MT4);   // stored at the next boundary
             } else if (pv) {
@@ -637,8 +658,7 @@ _Pragma("unroll") \
 #undef PF_TERM
 #undef PF_LDA
 #undef PF_SPLIT_PAIR
-#undef PF_AFFINE_RELU
-#undef PF_CHUNK
+#undef PF_CHUNK_AFF
 #undef MID_SIDX
 }
 
@@ -755,7 +775,7 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
 #define PF_LAUNCH_POOL(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st, \
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr, \
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws)
-    switch (abl) { case 4: PF_LAUNCH_POOL(4); break; case 2: PF_LAUNCH_POOL(2); break; case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
+    switch (abl) { case 64: PF_LAUNCH_POOL(64); break; case 128: PF_LAUNCH_POOL(128); break; case 4: PF_LAUNCH_POOL(4); break; case 2: PF_LAUNCH_POOL(2); break; case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
                    case 56: PF_LAUNCH_POOL(56); break; default: PF_LAUNCH_POOL(0); }
 #undef PF_LAUNCH_POOL
     hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,

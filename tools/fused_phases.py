@@ -34,12 +34,13 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.sonet_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros(1024 * 8, dtype=np.int64)
+NP = 32
+buf = np.zeros(1024 * NP, dtype=np.int64)
 assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
-p = buf.reshape(1024, 8).astype(np.float64)
+p = buf.reshape(1024, NP).astype(np.float64)
 tiles = B * ((15000 + 127) // 128) / 256.0
-names = ["kernel prologue", "tile prologue", "layer 3", "layer-4 MFMA passes", "epilogue", "tail", "layer 1", "layer 2"]
-ideal = [0, 0, 64 * 6 * 32, 2 * 720 * 32, 0, 0, 2 * 6 * 32, 16 * 6 * 32]
+names = ["kernel prologue", "tile prologue", "(unused)", "layer-4 MFMA passes", "epilogue", "tail", "layer 1", "(unused)"] + ["mid step %d" % i for i in range(20)]
+ideal = [0, 0, 0, 2 * 720 * 32, 0, 0, 2 * 6 * 32, 0] + [24 * 32] * 20
 tot = p.sum(1).mean()
 print("mode %s: %.0f cycles per wave (%.3f ms at 2.39 GHz), %.1f tiles per workgroup" % (mode, tot, tot / 2.39e6, tiles))
 for i, n in enumerate(names):
