@@ -209,24 +209,20 @@ __device__ __forceinline__ unsigned dpp_max(unsigned v) {
     return umax_(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false));
 }
 
-// max over the 32 lanes of each half-wave, result in lanes 31 / 63, for four registers at once.  One v_max_f32 with a
-// DPP source per step (lanes without a source keep their value); the four independent chains are interleaved so a
-// dependent DPP read is always >= 2 instructions behind the write it needs (hipcc does not pad inline asm).
-__device__ __forceinline__ void dpp_halfwave_max4(float &a, float &b, float &c, float &d) {
+// max over the 32 lanes of each half-wave, result in lanes 31 / 63, for eight registers at once.  One v_max_f32 with a
+// DPP source per step (lanes without a source keep their value); the eight independent chains are interleaved so a
+// dependent DPP read is 8 instructions behind the write it needs (hipcc does not pad inline asm; with 4 chains the
+// dependent-DPP latency showed).
+__device__ __forceinline__ void dpp_halfwave_max8(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &hh) {
     asm volatile(
         "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
         "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(hh));
 }
 
 #ifdef SONET_PROF
@@ -440,52 +436,54 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     AF af;
     PROF_DECL
     PROF_MARK(0)                                                // kernel prologue
+    // inputs of a tile, read one tile ahead (in front of the previous tile's last epilogue): read at the top of the
+    // tile, the x / node-id loads put an HBM round trip (~3k cycles per tile) in front of layer 1
+    float xin_n[8];
+    int nid_n = -1, n0_n = 0, pos0_n = 0;
+    auto prefetch_tile = [&](long long t) {
+        if (t >= ntiles) return;
+        const long long bb = t / tpc;
+        const int t0 = (int)(t - bb * tpc) * 128;
+        const int ll0 = t0 + wave * 32;
+        const bool pvv = ll0 + j < L;
+        const int lcc = pvv ? ll0 + j : (ll0 < L ? ll0 : 0);
+        const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + bb * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowB), 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            xin_n[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
+        if constexpr (SEGMAX) {
+            const int32_t *idb = ids_sorted + bb * (long long)L;
+            nid_n = pvv ? idb[ll0 + j] : -1;
+            n0_n = idb[t0];                                                        // first node of the workgroup's tile
+            pos0_n = pos0[bb];
+        }
+    };
+    prefetch_tile(blockIdx.x);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long b = tile / tpc;
         const int l0 = (int)(tile - b * tpc) * 128 + wave * 32;
         const bool pv = l0 + j < L;
         const int lc = pv ? l0 + j : (l0 < L ? l0 : 0);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(x + b * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowB), 0x00020000);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
 
         // per-node max-pool bookkeeping of this wave's 32 (node-sorted) points
-        int nid = -1, n0 = 0, jpos0 = -1, nslots = 0;
-        bool seg_uniform = false, seg_tail = false, tail_lds = true, segf[5] = {false, false, false, false, false};
-        unsigned *bins_lane = nullptr, *pool_lane = nullptr;
+        int nid = -1, n0 = 0, jpos0 = -1;
         float *v0_lane = nullptr;
         const float2 *aff_l4 = aff + 32 * (T0 + T1 + T2) + 4 * h;
         if constexpr (SEGMAX) {
-            const int32_t *idb = ids_sorted + b * (long long)L;
-            nid = pv ? idb[l0 + j] : -1;
-            const int t0 = (int)(tile - b * tpc) * 128;
-            n0 = idb[t0];                                                          // first node of the workgroup's tile
-            const int nlast = idb[(t0 + 127 < L ? t0 + 127 : L - 1)];
-            nslots = nlast - n0 + 1 < SEG_SLOTS ? nlast - n0 + 1 : SEG_SLOTS;
-            const int nid_first = __builtin_amdgcn_readfirstlane(nid);
-            seg_uniform = __all(pv && nid == nid_first);
-            const int nxt = __shfl_down(nid, 1, 32);
-            seg_tail = pv && (j == 31 || nxt != nid);
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                const int up = __shfl_up(nid, 1 << d, 32);                         // every lane must execute the shuffle
-                segf[d] = pv && j >= (1 << d) && up == nid;
-            }
-            const int p0 = pos0[b] - l0;
+            nid = nid_n;
+            n0 = n0_n;
+            const int p0 = pos0_n - l0;
             jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
-            const int slot = nid - n0;
-            tail_lds = slot < SEG_SLOTS;
-            bins_lane = &bins[tail_lds && slot >= 0 ? slot : 0][4 * h];
-            pool_lane = pooled + ((long long)b * M + (nid >= 0 ? nid : 0)) * (32 * T3) + 4 * h;
             v0_lane = v0 + b * (32 * T3) + 4 * h;
             if (tile == blockIdx.x)                                               // first tile of this workgroup: clear the bins
                 for (int i = threadIdx.x; i < SEG_SLOTS * 32 * MT4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
         }
         float xin[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            xin[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (unsigned)(8 * h * L + lc) * 4u, (unsigned)e * rowB, 0));
+        for (int e = 0; e < 8; ++e) xin[e] = xin_n[e];
         f32x16 act1[T0], act2[T1], act3[T2];
 #pragma unroll
         for (int t = 0; t < T0; ++t)
@@ -558,6 +556,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
 #undef PF_L4
 #undef PF_L4_CHUNK
+            if (pass == NPASS - 1) prefetch_tile(tile + gridDim.x);
             PROF_MARK(3)                                        // layer-4 pass (MFMA stream)
             if constexpr (SEGMAX) {
                 // ---- per-node max-pool of this pass's 192 channels (replaces index_max + masked gather,
@@ -595,14 +594,18 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #pragma unroll
                     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 16; r += 4) {
-                            float v0_ = inseg ? acc[mt][r] : -__builtin_inff(), v1_ = inseg ? acc[mt][r + 1] : -__builtin_inff();
-                            float v2_ = inseg ? acc[mt][r + 2] : -__builtin_inff(), v3_ = inseg ? acc[mt][r + 3] : -__builtin_inff();
-                            dpp_halfwave_max4(v0_, v1_, v2_, v3_);
+                        for (int r = 0; r < 16; r += 8) {
+                            float w_[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) w_[q] = inseg ? acc[mt][r + q] : -__builtin_inff();
+                            dpp_halfwave_max8(w_[0], w_[1], w_[2], w_[3], w_[4], w_[5], w_[6], w_[7]);
                             if constexpr (!(ABL & 32)) {
-                                // rows r..r+3 of this register quad are 4 consecutive channels: lanes 31 / 63 park them in LDS
-                                if (j == 31) segst[wave][mt * 8 + 2 * (r >> 2) + h] = make_float4(v0_, v1_, v2_, v3_);
-                            } else { asm volatile("" ::"v"(v0_), "v"(v1_), "v"(v2_), "v"(v3_)); }
+                                // rows r..r+3 / r+4..r+7 are 4 consecutive channels each: lanes 31 / 63 park them in LDS
+                                if (j == 31) {
+                                    segst[wave][mt * 8 + 2 * (r >> 2) + h] = make_float4(w_[0], w_[1], w_[2], w_[3]);
+                                    segst[wave][mt * 8 + 2 * (r >> 2) + 2 + h] = make_float4(w_[4], w_[5], w_[6], w_[7]);
+                                }
+                            } else { asm volatile("" ::"v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3]), "v"(w_[4]), "v"(w_[5]), "v"(w_[6]), "v"(w_[7])); }
                         }
                     if constexpr (!(ABL & 32)) {
                         // ... and all 64 lanes publish them, 3 channels each (2 lanes x 96 LDS atomics cost 0.2 ms per launch)
