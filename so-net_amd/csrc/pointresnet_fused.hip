@@ -298,6 +298,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
     const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
     bool first_boundary = true;
+    int pend_n = 0;
     // SEGMAX: partial-maxima block whose LDS bins are still to be stored.  The very first flush is a dry run (all
     // INIT) into the block that the same lanes rewrite one pass later, which keeps the flush free of branches.
     unsigned *pend = partial + (blockIdx.x * (long long)NPASS * SEG_SLOTS) * (32 * MT4);
@@ -307,8 +308,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // put a memory round trip in front of the next ds_write (vmcnt(0)): measured 0.2 ms per launch.
     auto flush_bins = [&]() {                                   // branch-free on the common path (<= 4 nodes per tile)
 #pragma unroll
-        for (int i = 0; i < SEG_SLOTS * 32 * MT4 / PF_THREADS; ++i) {
+        for (int i = 0; i < 4 * 32 * MT4 / PF_THREADS; ++i) {          // branch-free on the common path (<= 4 nodes per tile)
             const int e = i * PF_THREADS + threadIdx.x;
+            unsigned *bp = &bins[0][0] + e;
+            pend[e] = *bp;
+            *bp = SEG_INIT;
+        }
+        for (int e = 4 * 32 * MT4 + threadIdx.x; e < pend_n; e += PF_THREADS) {   // only the slots this tile's nodes occupy
             unsigned *bp = &bins[0][0] + e;
             pend[e] = *bp;
             *bp = SEG_INIT;
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // inputs of a tile, read one tile ahead (in front of the previous tile's last epilogue): read at the top of the
     // tile, the x / node-id loads put an HBM round trip (~3k cycles per tile) in front of layer 1
     float xin_n[8];
-    int nid_n = -1, n0_n = 0, pos0_n = 0;
+    int nid_n = -1, n0_n = 0, nlast_n = 0, pos0_n = 0;
     auto prefetch_tile = [&](long long t) {
         if (t >= ntiles) return;
         const long long bb = t / tpc;
@@ -455,7 +461,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         if constexpr (SEGMAX) {
             const int32_t *idb = ids_sorted + bb * (long long)L;
             nid_n = pvv ? idb[ll0 + j] : -1;
-            n0_n = idb[t0];                                                        // first node of the workgroup's tile
+            n0_n = idb[t0];                                                        // first / last node of the workgroup's tile
+            nlast_n = idb[(t0 + 127 < L ? t0 + 127 : L - 1)];
             pos0_n = pos0[bb];
         }
     };
@@ -469,12 +476,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
 
         // per-node max-pool bookkeeping of this wave's 32 (node-sorted) points
-        int nid = -1, n0 = 0, jpos0 = -1;
+        int nid = -1, n0 = 0, jpos0 = -1, nslots = 0;
         float *v0_lane = nullptr;
         const float2 *aff_l4 = aff + 32 * (T0 + T1 + T2) + 4 * h;
         if constexpr (SEGMAX) {
             nid = nid_n;
             n0 = n0_n;
+            nslots = nlast_n - n0_n + 1 < SEG_SLOTS ? nlast_n - n0_n + 1 : SEG_SLOTS;
             const int p0 = pos0_n - l0;
             jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
             v0_lane = v0 + b * (32 * T3) + 4 * h;
@@ -630,6 +638,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     }
                 }
                 }
+                if constexpr (!(ABL & 8)) pend_n = nslots * (32 * MT4);
                 if constexpr (!(ABL & 8))
                     pend = partial + ((tile * NPASS + pass) * SEG_SLOTS) * (long long)(32 * MT4);   // stored at the next boundary
             } else if (pv) {

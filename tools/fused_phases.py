@@ -27,8 +27,7 @@ if mode == "pool":
     run = lambda: ops.pointresnet_fused_pool(sg, wstream, affine, 64)
 else:
     g = ops.som_group(inp["pc"], inp["sn"], a, want_augmented=True)
-    y = torch.empty(B, 384, 15000, device=DEV)
-    run = lambda: ops.pointresnet_fused(g["x_aug"], wstream, affine, out=y)
+    run = lambda: ops.pointresnet_fused(g["x_augmented"], wstream, affine)
 for _ in range(3):
     run()
 torch.cuda.synchronize()

@@ -13,8 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WIDE_READERS = ("index_max",)
-NAMES = [("pointresnet_fused_kernel", "pointresnet_fused_L15000"), ("index_max_kernel", "index_max_gather"),
-         ("som_assign_kernel", "som_assign"), ("som_group_kernel", "som_group")]
+NAMES = [("pointresnet_fused_kernel", "pointresnet_fused_pool_L15000"), ("index_max_kernel", "index_max_gather"),
+         ("som_assign_kernel", "som_assign"), ("som_sort_group_kernel", "som_sort_group"), ("som_group_kernel", "som_group")]
 
 
 def load(counter):
