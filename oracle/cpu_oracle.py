@@ -160,6 +160,21 @@ def chamfer_nn(q, db):
     return nn
 
 
+def chamfer_loss(predict, gt):
+    """ChamferLoss.forward restated (models/losses.py:237-290) on numpy float32: exact 1-NN both ways (chamfer_nn
+    above), gather, robust_norm = sqrt(sum_xyz(d^2) + 1e-8) (:17-22), means.  Returns (forward_loss, backward_loss,
+    loss_array B)."""
+    predict = _c(predict, np.float32)
+    gt = _c(gt, np.float32)
+    nn_gt = chamfer_nn(predict, gt)                    # predicted -> nearest gt point
+    nn_pr = chamfer_nn(gt, predict)                    # gt -> nearest predicted point
+    sel_gt = np.take_along_axis(gt, nn_gt[:, None, :].astype(np.int64).repeat(3, 1), axis=2)
+    sel_pr = np.take_along_axis(predict, nn_pr[:, None, :].astype(np.int64).repeat(3, 1), axis=2)
+    fwd = np.sqrt(((sel_gt - predict) ** 2).sum(1, dtype=np.float32) + np.float32(1e-8))      # B x M
+    bwd = np.sqrt(((sel_pr - gt) ** 2).sum(1, dtype=np.float32) + np.float32(1e-8))           # B x N
+    return float(fwd.mean(dtype=np.float64)), float(bwd.mean(dtype=np.float64)), fwd.mean(1) + bwd.mean(1)
+
+
 # ------------------------------------------------------------------ forward restatement (torch CPU)
 def _eq_layer(sd, prefix, x, bn, relu, eps=1e-5, conv2d=False):
     """EquivariantLayer / MyConv2d forward in eval mode (models/layers.py:282-296, :199-211)."""

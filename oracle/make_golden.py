@@ -290,8 +290,37 @@ def golden_segmenter(ref, tag, B, N, seed):
          segmenter_keys=np.array(sorted(model.segmenter.state_dict().keys())))
 
 
+def golden_autoencoder(ref, tag, B, N, seed):
+    """Reference autoencoder (models/autoencoder.py:62-125): encoder -> FC + conv decoder -> multi-resolution Chamfer
+    loss, eval forward plus the gradient of the loss w.r.t. the predicted clouds.  The nearest-neighbour search is the
+    harness's exact flat-L2 stand-in for faiss; everything else is the reference's own code."""
+    opt = ref_harness.make_opt(batch_size=B, input_pc_num=N, output_fc_pc_num=256, output_conv_pc_num=1024)
+    model = ref.autoencoder.Model(opt)
+    synth.fill_state_dict_(model.encoder.state_dict(), seed=seed)
+    synth.fill_state_dict_(model.decoder.state_dict(), seed=seed + 1)
+    inp = synth.make_inputs(B, N, M=opt.node_num, som_k=opt.som_k, seed=seed, node_kind="som")
+    model.set_input(inp["pc"], inp["sn"], inp["label"], inp["node"], inp["node_knn_I"])
+    with ref_harness.sorted_topk(), torch.no_grad():
+        model.test_model()
+    crit = model.chamfer_criteria
+    pred = model.predicted_pc.detach().clone().requires_grad_(True)
+    loss2 = crit(pred, model.pc)
+    loss2.backward()
+    save("autoencoder_" + tag, B=B, N=N, seed=seed, pc=inp["pc"], sn=inp["sn"], node=inp["node"], node_knn_I=inp["node_knn_I"],
+         feature=model.feature, predicted_pc=model.predicted_pc, conv_pc4=model.decoder.conv_pc4,
+         loss=model.loss, loss_chamfer=model.loss_chamfer, loss_chamfer_conv4=model.loss_chamfer_conv4,
+         forward_loss=crit.forward_loss, backward_loss=crit.backward_loss, loss_array=crit.loss_array,
+         grad_predicted=pred.grad, decoder_keys=np.array(sorted(model.decoder.state_dict().keys())))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "autoencoder":     # own process: needs the faiss stand-in at import time
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        ref = ref_harness.import_reference(with_faiss_shim=True)
+        golden_autoencoder(ref, "b2_n1024", B=2, N=1024, seed=401)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = ref_harness.import_reference()

@@ -12,7 +12,11 @@ What is shimmed -- nothing in the reference tree is edite
 * a module ``index_max`` whose ``forward_cuda`` is the reference's own compiled ``forward_cpu``
   (oracle/_ref/index_max.so, built from models/index_max_ext/index_max.cpp by build_ref.py),
   because models/networks.py:182 hard-codes ``forward_cuda``;
-* ``opt.gpu_id = 0`` (assert at util/som.py:187) with ``opt.device = cpu`` (fallback at :188).
+* ``opt.gpu_id = 0`` (assert at util/som.py:187) with ``opt.device = cpu`` (fallback at :188);
+* for the autoencoder only (``import_reference(with_faiss_shim=True)``): a ``faiss`` module whose ``IndexFlatL2`` is
+  the exact brute-force search of oracle/sonet_oracle.c (faiss is un-vendored and not installed: the reference's
+  ChamferLoss arithmetic -- gathers, robust_norm, means, models/losses.py:237-290 -- then runs unmodified, while
+  the search itself is the restated one; parity is unpinned at the faiss boundary).
 """
 import contextlib
 import os
@@ -28,11 +32,46 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "models"))
 
 
-def import_reference():
+def _faiss_shim():
+    """Exact flat-L2 search standing in for faiss (autoencoder fixtures only)."""
+    import numpy as np
+    m = types.ModuleType("faiss")
+
+    class StandardGpuResources(object):
+        def setTempMemoryFraction(self, f):
+            pass
+
+    class GpuIndexFlatConfig(object):
+        device = 0
+
+    class IndexFlatL2(object):
+        def __init__(self, d):
+            assert d == 3
+            self.db = None
+
+        def add(self, x):
+            self.db = np.ascontiguousarray(x, dtype=np.float32)
+
+        def search(self, q, k):
+            assert k == 1
+            from oracle import cpu_oracle as _o
+            q = np.ascontiguousarray(q, dtype=np.float32)
+            idx = _o.chamfer_nn(np.ascontiguousarray(q.T[None]), np.ascontiguousarray(self.db.T[None]))[0]
+            d = ((q - self.db[idx]) ** 2).sum(1, dtype=np.float32)
+            return d[:, None], idx[:, None].astype(np.int64)
+
+    m.StandardGpuResources, m.GpuIndexFlatConfig, m.IndexFlatL2 = StandardGpuResources, GpuIndexFlatConfig, IndexFlatL2
+    m.index_cpu_to_gpu = lambda res, dev, index: index
+    return m
+
+
+def import_reference(with_faiss_shim=False):
     """Import the reference packages; returns a namespace of its modules."""
     import torch  # noqa: F401
     if not available():
         raise RuntimeError("/root/reference is not mounted")
+    if with_faiss_shim:
+        sys.modules["faiss"] = _faiss_shim()
     for name in ("faiss", "torchvision", "h5py", "visdom"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
@@ -63,9 +102,11 @@ def import_reference():
     networks = importlib.import_module("models.networks")
     classifier = importlib.import_module("models.classifier")
     segmenter = importlib.import_module("models.segmenter")
+    autoencoder = importlib.import_module("models.autoencoder") if with_faiss_shim else None
+    losses = importlib.import_module("models.losses")
     assert som.__file__.startswith(REF_ROOT) and networks.__file__.startswith(REF_ROOT)
-    return Namespace(som=som, layers=layers, operations=operations, networks=networks,
-                     classifier=classifier, segmenter=segmenter, index_max=shim)
+    return Namespace(som=som, layers=layers, operations=operations, networks=networks, losses=losses,
+                     classifier=classifier, segmenter=segmenter, autoencoder=autoencoder, index_max=shim)
 
 
 def make_opt(**kw):

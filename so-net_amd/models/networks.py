@@ -289,3 +289,97 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
         g2 = _ops.node_gather(encoder.knn_feature_1.contiguous(), ids)
         g3 = _ops.node_gather(encoder.final_pn_out.contiguous(), ids)
     return segmenter(encoder.x_decentered, pc, encoder.centers, sn, label, encoder.first_pn_out, g1, g2, g3, feature)
+
+
+# ---------------------------------------------------------------------------------- autoencoder decoder
+class DecoderLinear(nn.Module):
+    """FC decoder feature -> 3 x output_fc_pc_num points (models/networks.py:347-369): widths P*2, P*3, P*4, then
+    P*3 outputs without norm/activation whose bias starts uniform in [-1, 1].  B x C only: plain PyTorch-ROCm."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.feature_num = opt.feature_num
+        self.output_point_number = P = opt.output_fc_pc_num
+        widths = [self.feature_num, 2 * P, 3 * P, 4 * P]
+        for i in range(3):
+            setattr(self, "linear%d" % (i + 1), MyLinear(widths[i], widths[i + 1], activation=opt.activation,
+                                                          normalization=opt.normalization))
+        self.linear_out = MyLinear(4 * P, 3 * P, activation=None, normalization=None)
+        self.linear_out.linear.bias.data.uniform_(-1, 1)
+
+    def forward(self, x):
+        for name in ("linear1", "linear2", "linear3", "linear_out"):
+            x = getattr(self, name)(x)
+        return x.view(-1, 3, self.output_point_number)
+
+
+class ConvToPC(nn.Module):
+    """Two 1x1 convs C -> C -> 3 turning a feature map into a point grid (models/networks.py:372-390)."""
+
+    def __init__(self, in_channels, opt):
+        super().__init__()
+        self.in_channels = in_channels
+        self.opt = opt
+        from .layers import MyConv2d
+        self.conv1 = MyConv2d(in_channels, int(in_channels), kernel_size=1, stride=1, padding=0, bias=True,
+                              activation=opt.activation, normalization=opt.normalization)
+        self.conv2 = MyConv2d(int(in_channels), 3, kernel_size=1, stride=1, padding=0, bias=True, activation=None,
+                              normalization=None)
+        self.conv2.conv.bias.data.uniform_(-1, 1)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class DecoderConv(nn.Module):
+    """Up-convolution pyramid 1x1 -> 64x64 with point heads at 16x16, 32x32 and 64x64 (models/networks.py:393-431)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        from .layers import UpConv
+        self.opt = opt
+        self.feature_num = F = opt.feature_num
+        self.output_point_num = opt.output_conv_pc_num
+        chans = [F, int(F), int(F / 2), int(F / 4), int(F / 8), int(F / 8), int(F / 8)]
+        for i in range(6):
+            setattr(self, "deconv%d" % (i + 1), UpConv(chans[i], chans[i + 1], activation=opt.activation,
+                                                         normalization=opt.normalization))
+            if i >= 3:
+                setattr(self, "conv2pc%d" % (i + 1), ConvToPC(chans[i + 1], opt))
+
+    def forward(self, x):
+        x = x.view(-1, self.feature_num, 1, 1)
+        for i in range(1, 7):
+            x = getattr(self, "deconv%d" % i)(x)
+            if i >= 4:
+                setattr(self, "pc%d" % i, getattr(self, "conv2pc%d" % i)(x))
+        return self.pc6
+
+
+class Decoder(nn.Module):
+    """FC points (if output_fc_pc_num > 0) concatenated with the conv pyramid's 1024- or 4096-point level
+    (models/networks.py:434-466); ``conv_pc4`` / ``conv_pc5`` / ``conv_pc6`` / ``linear_pc`` stay readable for the
+    multi-resolution Chamfer terms of models/autoencoder.py:89-104."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        if opt.output_fc_pc_num > 0:
+            self.fc_decoder = DecoderLinear(opt)
+        self.conv_decoder = DecoderConv(opt)
+
+    def forward(self, x):
+        opt = self.opt
+        if opt.output_fc_pc_num > 0:
+            self.linear_pc = self.fc_decoder(x)
+        if opt.output_conv_pc_num > 0:
+            self.conv_pc6 = self.conv_decoder(x).view(-1, 3, 4096)
+            self.conv_pc4 = self.conv_decoder.pc4.view(-1, 3, 256)
+            self.conv_pc5 = self.conv_decoder.pc5.view(-1, 3, 1024)
+        conv = {4096: "conv_pc6", 1024: "conv_pc5"}.get(opt.output_conv_pc_num)
+        if opt.output_fc_pc_num == 0:
+            return getattr(self, conv) if conv else None
+        if conv:
+            return torch.cat([self.linear_pc, getattr(self, conv)], 2)
+        return self.linear_pc

@@ -468,6 +468,68 @@ def test_segmenter_forward_golden(mode):
     assert_close_rms(score.cpu().numpy(), g["score_segmenter"], 1e-5, "score_segmenter")
 
 
+# ------------------------------------------------------------------------------------------ autoencoder (config 4)
+@pytest.mark.parametrize("mode", ["x3", "f32"])
+def test_autoencoder_forward_and_chamfer_golden(mode):
+    """Encoder -> FC + conv decoder -> multi-resolution Chamfer loss (models/autoencoder.py:62-125) vs the reference
+    run with an exact flat-L2 search in place of faiss; gradient of the loss w.r.t. the predicted cloud."""
+    from models import networks as NW, losses as LS
+    from sonet_hip import ops, synth
+    g = golden("autoencoder_b2_n1024")
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40,
+                    output_fc_pc_num=256, output_conv_pc_num=1024)
+    enc, dec, crit = NW.Encoder(opt), NW.Decoder(opt), LS.ChamferLoss(opt)
+    assert sorted(dec.state_dict().keys()) == [str(k) for k in g["decoder_keys"]]
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(dec.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    dec.to(DEV).eval()
+    old = ops.POINTMLP_PRECISION
+    ops.POINTMLP_PRECISION = mode
+    try:
+        with torch.no_grad():
+            feature = enc(cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]), False, None)
+            pred = dec(feature)
+            loss = crit(pred, cu(g["pc"])) + crit(dec.conv_pc4, cu(g["pc"]))      # autoencoder.py:118-122 at 1024 conv points
+    finally:
+        ops.POINTMLP_PRECISION = old
+    assert_close_rms(feature.cpu().numpy(), g["feature"], 1e-5, "feature")
+    assert_close_rms(pred.cpu().numpy(), g["predicted_pc"], 1e-5, "predicted_pc")
+    assert_close_rms(dec.conv_pc4.cpu().numpy(), g["conv_pc4"], 1e-5, "conv_pc4")
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    # the loss itself, on the reference's predicted cloud: values and gradient
+    p = cu(g["predicted_pc"]).requires_grad_(True)
+    l2 = crit(p, cu(g["pc"]))
+    l2.backward()
+    assert abs(float(crit.forward_loss) - float(g["forward_loss"])) <= 2e-6 * float(g["forward_loss"])
+    assert abs(float(crit.backward_loss) - float(g["backward_loss"])) <= 2e-6 * float(g["backward_loss"])
+    np.testing.assert_allclose(crit.loss_array.detach().cpu().numpy(), g["loss_array"], rtol=5e-6)
+    assert_close_rms(p.grad.cpu().numpy(), g["grad_predicted"], 1e-5, "d loss / d predicted_pc")
+
+
+def test_chamfer_loss_full_size_properties():
+    """Config 4 size (B=8, 1280 predicted vs 5000 gt points): size-independent properties of the loss."""
+    from models import losses as LS
+    gen = torch.Generator().manual_seed(5)
+    gt = (torch.rand(8, 3, 5000, generator=gen) * 2 - 1).to(DEV)
+    crit = LS.ChamferLoss(Namespace(gpu_id=0, device=torch.device(DEV)))
+    sub = gt[:, :, :1280].clone()
+    crit(sub, gt)                                                  # a subset: every predicted point has distance 0
+    assert abs(float(crit.forward_loss) - 1e-4) < 1e-7             # sqrt(0 + 1e-8)
+    perm = torch.randperm(5000, generator=gen).to(DEV)
+    a = float(crit(sub, gt))
+    b = float(crit(sub, gt[:, :, perm]))                            # permuting the database changes nothing
+    assert abs(a - b) <= 1e-6 * abs(a)
+    pred = (torch.rand(8, 3, 1280, generator=gen) * 2 - 1).to(DEV)
+    l1 = float(crit(pred, gt))
+    d = torch.cdist(pred.transpose(1, 2).double(), gt.transpose(1, 2).double())     # brute force, float64
+    ref = (d.min(2).values.pow(2) + 1e-8).sqrt().mean() + (d.min(1).values.pow(2) + 1e-8).sqrt().mean()
+    assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
+
+
 def test_node_gather_vs_torch():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(1)

@@ -101,3 +101,19 @@ def test_encoder_restatement_matches_reference_forward(case):
     assert_close_rms(r["feature"].numpy(), g["feature"], 1e-5, "feature")
     score = O.classifier_forward(cls_sd, r["feature"])
     assert_close_rms(score.numpy(), g["score"], 1e-5, "score")
+
+
+def test_chamfer_loss_restatement_matches_reference_arithmetic():
+    """models/losses.py:237-290 run live (exact flat-L2 stand-in for faiss, oracle/ref_harness.py) vs the numpy
+    restatement, on the reference decoder's own predicted cloud."""
+    g = golden("autoencoder_b2_n1024")
+    fwd, bwd, arr = O.chamfer_loss(g["predicted_pc"], g["pc"])
+    assert abs(fwd - float(g["forward_loss"])) <= 1e-6 * abs(float(g["forward_loss"]))
+    assert abs(bwd - float(g["backward_loss"])) <= 1e-6 * abs(float(g["backward_loss"]))
+    np.testing.assert_allclose(arr, g["loss_array"], rtol=2e-6)
+    assert abs(fwd + bwd - float(g["loss_chamfer"])) <= 2e-6 * float(g["loss_chamfer"])
+    # brute force in float64 picks the same neighbours except at exact float32 ties
+    p, q = g["predicted_pc"].astype(np.float64), g["pc"].astype(np.float64)
+    d = ((p[:, :, :, None] - q[:, :, None, :]) ** 2).sum(1)
+    nn = O.chamfer_nn(g["predicted_pc"], g["pc"])
+    assert (nn == d.argmin(2)).mean() > 0.999
