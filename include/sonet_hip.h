@@ -183,6 +183,20 @@ int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min
                              float *x_aug_sorted, int32_t *ids_sorted, int32_t *pos0, int32_t *node_off,
                              int32_t *cursor_ws, sonet_stream_t stream);
 
+/* Backward of act(BN(W x + b)) around the GEMMs (training-mode models/layers.py:282-296, :60-70), two passes:
+ *   stats: sums[c] = sum gy*mask, sums[C+c] = sum gy*mask*raw over (b, l), f64 (zeroed by the callee);
+ *   apply: g_raw = a[c]*(gy*mask) + b[c]*raw + c0[c];
+ * mask = (fma(raw, scale[c], shift[c]) > 0) if relu else 1 -- the forward's own affine, bit for bit.
+ * gy, raw, g_raw: [B][C][L] f32; scale, shift, a, b, c0: [C] f32; sums: [2C] f64. */
+int sonet_pointwise_bwd_stats_f32(const float *gy, const float *raw, const float *scale, const float *shift,
+                                  int relu, int B, int C, int L, double *sums, sonet_stream_t stream);
+int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float *scale, const float *shift, int relu,
+                                  const float *a, const float *b, const float *c0, float *g_raw,
+                                  int B, int C, int L, sonet_stream_t stream);
+/* y = act(x*scale[c] + shift[c]) out of place (training forward: raw stays for the backward). */
+int sonet_channel_affine_act_out_f32(const float *x, const float *scale, const float *shift, int relu, float *y,
+                                     int B, int C, int L, sonet_stream_t stream);
+
 /* Per-channel batch statistics of y [B][C][L] for training-mode BatchNorm (F.batch_norm with
  * training=True, models/layers.py:68): mean[c], biased var[c] over (B, L), f64 accumulation.
  * stat_ws: 2*C doubles of workspace, zeroed by the callee. */

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         }
         PROF_MARK(6)                                            // layer 1
         // ---- layers 2 and 3: middle steps i = 0 .. NMID-1, set parity (i + 1) & 1 ----
-#define PF_MID_CHUNK if (last_of_l3) PF_CHUNK_AFF(sp_, act1, 0, 0) else if (l2) PF_CHUNK_AFF(sp_, act1, (l2 ? kcn : 0), 0) else PF_CHUNK_AFF(sp_, act2, (l2 ? 0 : kcn), 32 * T0)
+#define PF_MID_CHUNK if constexpr (last_of_l3) PF_CHUNK_AFF(sp_, act1, 0, 0) else if constexpr (l2) PF_CHUNK_AFF(sp_, act1, (l2 ? kcn : 0), 0) else PF_CHUNK_AFF(sp_, act2, (l2 ? 0 : kcn), 32 * T0)
 #define PF_MID(I_)                                                          \
         {                                                                   \
             constexpr int i = (I_);                                         \
@@ -530,9 +530,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
             constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
             constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
-            if (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
+            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
             else    { PF_STEP(act3, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], true, PF_MID_CHUNK, bq[nxt], false, false, ) } \
-            if (last_of_l2) {                                               /* layer transition */ \
+            if constexpr (last_of_l2) {                                     /* layer transition */ \
                 SplitState sp2_; \
                 PF_CHUNK_AFF(sp2_, act2, 0, 32 * T0) \
                 split_all<ABL, 0>(sp2_); \
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-#define PF_L4_CHUNK if (kn < KC2) PF_CHUNK_AFF(sp_, act1, (kn < KC2 ? kn : 0), 0) else PF_CHUNK_AFF(sp_, act3, (kn < KC2 ? 0 : kn - KC2), 32 * (T0 + T1))
+#define PF_L4_CHUNK if constexpr (kn < KC2) PF_CHUNK_AFF(sp_, act1, (kn < KC2 ? kn : 0), 0) else PF_CHUNK_AFF(sp_, act3, (kn < KC2 ? 0 : kn - KC2), 32 * (T0 + T1))
 #define PF_L4(K_)                                                           \
             {                                                               \
                 constexpr int kc = (K_);                                    \

@@ -1,0 +1,142 @@
+// pointwise_bwd.hip -- backward of act(BN(W x + b)) around the GEMMs (training, configs 2 / 5).
+//
+// Replaces the autograd graph the reference builds for models/layers.py:282-296 (conv1d -> F.batch_norm ->
+// relu): two passes over (gy, raw) instead of ~20 element-wise aten launches over B x C x L tensors.
+//   pass 1  per channel:  s1 = sum gy*mask,  s2 = sum gy*mask*raw      (f64 accumulation, as channel_stats)
+//   pass 2  g_raw = a[c] * (gy*mask) + b[c] * raw + c0[c]
+// with mask = (fma(raw, scale[c], shift[c]) > 0) when the layer has a ReLU (bit-identical to the forward's
+// affine), else 1.  The host turns (s1, s2) into (a, b, c0) -- for training BatchNorm
+//   a = gamma*invstd,  b = -a*invstd*sg/n,  c0 = -a*s1/n - b*mean,  sg = invstd*(s2 - mean*s1)
+// (the usual  gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ), for a constant affine a = scale, b = c0 = 0.
+// The GEMMs themselves (dgrad = W^T g_raw on the pointmlp kernels, wgrad = g_raw x^T) are launched by the host.
+#include "common.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int BW_THREADS = 256;
+
+__global__ __launch_bounds__(BW_THREADS) void bwd_stats_kernel(const float *__restrict__ gy, const float *__restrict__ raw,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                int relu, int B, int C, int L, double *__restrict__ ws)
+{
+    const int c = blockIdx.y;
+    const long long per_c = (long long)B * L;
+    const long long chunk = (per_c + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * chunk, end = min(per_c, beg + chunk);
+    const float sc = scale[c], sh = shift[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (long long t = beg + threadIdx.x; t < end; t += BW_THREADS) {
+        const long long b = t / L;
+        const long long o = (b * C + c) * (long long)L + (t - b * L);
+        const float r = raw[o];
+        float g = gy[o];
+        if (relu && !(__fmaf_rn(r, sc, sh) > 0.f)) g = 0.f;
+        s1 += (double)g;
+        s2 += (double)g * (double)r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double red[2][BW_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, a2 = 0.0;
+        for (int w = 0; w < BW_THREADS / 64; ++w) { a += red[0][w]; a2 += red[1][w]; }
+        unsafeAtomicAdd(&ws[c], a);
+        unsafeAtomicAdd(&ws[C + c], a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bwd_ws_zero_kernel(double *ws, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ws[i] = 0.0;
+}
+
+// one workgroup row = one (b, c) row of L elements: coefficients are wave-uniform
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const float *__restrict__ gy, const float *__restrict__ raw,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                         const float *__restrict__ ca, const float *__restrict__ cb,
+                                                         const float *__restrict__ cc, float *__restrict__ out, int C, int L)
+{
+    const long long row = blockIdx.x;
+    const int c = (int)(row % C);
+    const float sc = scale[c], sh = shift[c], a = ca[c], b = cb[c], c0 = cc[c];
+    const float *g = gy + row * L, *r = raw + row * L;
+    float *o = out + row * L;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < L; t += gridDim.y * 256) {
+        const float rv = r[t];
+        float gv = g[t];
+        if (relu && !(__fmaf_rn(rv, sc, sh) > 0.f)) gv = 0.f;
+        o[t] = __fmaf_rn(a, gv, __fmaf_rn(b, rv, c0));
+    }
+}
+
+__global__ __launch_bounds__(256) void affine_act_out_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, int relu, float *__restrict__ y,
+                                                              int C, int L)
+{
+    const long long row = blockIdx.x;
+    const int c = (int)(row % C);
+    const float sc = scale[c], sh = shift[c];
+    const float *xi = x + row * L;
+    float *yo = y + row * L;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < L; t += gridDim.y * 256) {
+        float v = __fmaf_rn(xi[t], sc, sh);
+        if (relu) v = (v < 0.f) ? 0.f : v;
+        yo[t] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int sonet_pointwise_bwd_stats_f32(const float *gy, const float *raw, const float *scale, const float *shift,
+                                             int relu, int B, int C, int L, double *sums, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointwise_bwd_stats_f32";
+    SONET_REQUIRE(gy && raw && scale && shift && sums, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0 && C <= 65535, "%s: bad size B=%d C=%d L=%d", what, B, C, L);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(bwd_ws_zero_kernel, dim3(sonet::ceil_div(2 * C, 256)), dim3(256), 0, st, sums, 2 * C);
+    const long long per_c = (long long)B * L;
+    int chunks = (int)sonet::ceil_div64(per_c, 16384);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(bwd_stats_kernel, dim3(chunks, C), dim3(BW_THREADS), 0, st, gy, raw, scale, shift, relu, B, C, L, sums);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float *scale, const float *shift, int relu,
+                                             const float *a, const float *b, const float *c0, float *g_raw,
+                                             int B, int C, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointwise_bwd_apply_f32";
+    SONET_REQUIRE(gy && raw && scale && shift && a && b && c0 && g_raw, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0, "%s: bad size B=%d C=%d L=%d", what, B, C, L);
+    const long long rows = (long long)B * C;
+    SONET_REQUIRE(rows <= 2147483647LL, "%s: too many rows", what);
+    int gx = sonet::ceil_div(L, 256 * 8);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(bwd_apply_kernel, dim3((unsigned)rows, gx), dim3(256), 0, sonet::as_stream(stream),
+                       gy, raw, scale, shift, relu, a, b, c0, g_raw, C, L);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_channel_affine_act_out_f32(const float *x, const float *scale, const float *shift, int relu, float *y,
+                                                int B, int C, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_channel_affine_act_out_f32";
+    SONET_REQUIRE(x && scale && shift && y, "%s: NULL pointer", what);
+    const long long rows = (long long)B * C;
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0 && rows <= 2147483647LL, "%s: bad size B=%d C=%d L=%d", what, B, C, L);
+    int gx = sonet::ceil_div(L, 256 * 8);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(affine_act_out_kernel, dim3((unsigned)rows, gx), dim3(256), 0, sonet::as_stream(stream),
+                       x, scale, shift, relu, y, C, L);
+    return sonet::launched(what);
+}

@@ -82,8 +82,27 @@ class MyBatchNorm2d(_DecayingBatchNorm):
 # ---------------------------------------------------------------------------------------------------
 # fused conv1x1 + affine + relu
 # ---------------------------------------------------------------------------------------------------
+def _pack_transposed(weight2d, C1, C2):
+    """Packed W[:, :C1]^T (and W[:, C1:]^T) for the dgrad launches: g_x = W^T g_raw is the same fused 1x1-conv
+    kernel with the roles of the channel axes swapped."""
+    mode = _ops.POINTMLP_PRECISION
+    out = []
+    lo = 0
+    for Ci in (C1, C2):
+        if Ci == 0:
+            out.append(None)
+            continue
+        wt = weight2d[:, lo:lo + Ci].t().contiguous().float()                  # Ci x Cout
+        m = mode if (mode != "x3" or _ops.x3_supported(wt.shape[1], 0, wt.shape[0])) else "f32"
+        out.append((_ops.pointmlp_pack(wt, m), Ci))
+        lo += Ci
+    return out
+
+
 class _PointwiseFn(torch.autograd.Function):
-    """Differentiable fused layer.  forward: HIP kernels; backward: dgrad / wgrad as dense GEMMs.
+    """Differentiable fused layer.  forward: HIP kernels.  backward: two HIP passes turn gy into g_raw (ReLU mask,
+    BatchNorm backward: ``sonet_pointwise_bwd_stats/apply``), dgrad = W^T g_raw on the pointmlp kernel, wgrad one
+    batched GEMM (hipBLASLt through torch.bmm; K = L is the long axis).
 
     mode 'affine': y = act((W x) * scale + shift) with constant (scale, shift) (eval BN / no norm);
     mode 'batch' : training BatchNorm -- statistics over (B, L) of raw = W x + bias.
@@ -92,23 +111,23 @@ class _PointwiseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps):
         Cout = weight2d.shape[0]
+        dev = x1.device
+        ones = torch.ones(Cout, dtype=torch.float32, device=dev)
+        zeros = torch.zeros(Cout, dtype=torch.float32, device=dev)
         if mode == 'affine':
             y = _ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
-            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, scale, y if relu else x1.new_empty(0))
-            ctx.stats = None
+            # mask source: the output itself (y > 0 <=> pre-activation > 0)
+            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, scale, y if relu else x1.new_empty(0),
+                                  ones, zeros)
         else:
-            ones = torch.ones(Cout, dtype=torch.float32, device=x1.device)
             raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
             mean, var = _ops.channel_stats(raw)
             invstd = torch.rsqrt(var + eps)
-            sc = gamma * invstd
-            sh = beta - mean * sc
-            y = torch.empty_like(raw)
-            y.copy_(raw)
-            _ops.channel_affine_act_(y, sc.contiguous(), sh.contiguous(), relu)
-            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, y if relu else x1.new_empty(0),
-                                  raw, mean, invstd, gamma)
-            ctx.stats = (mean, var)
+            sc = (gamma * invstd).contiguous()
+            sh = (beta - mean * sc).contiguous()
+            y = _ops.channel_affine_act(raw, sc, sh, relu)
+            ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, sh, raw, mean, invstd, gamma,
+                                  zeros)
             ctx.mark_non_differentiable(mean, var)
         ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
         if mode == 'affine':
@@ -118,30 +137,49 @@ class _PointwiseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *unused):
         saved = ctx.saved_tensors
-        x1, x2, weight2d, sc, y = saved[:5]
-        if ctx.relu:
-            gy = gy * (y > 0).to(gy.dtype)
-        g_gamma = g_beta = None
+        x1, x2, weight2d = saved[:3]
+        gy = gy.contiguous()
+        g_gamma = g_beta = g_bias = None
         if ctx.mode == 'affine':
-            g_raw = gy * sc.view(1, -1, 1)
-            g_bias = g_raw.sum(dim=(0, 2)) if ctx.needs_input_grad[3] else None     # shift = bias*scale + ...
+            sc, y, ones, zeros = saved[3:7]
+            src = y if ctx.relu else gy                                   # relu=False: the mask input is unused
+            if ctx.needs_input_grad[3]:
+                s1, _ = _ops.pointwise_bwd_stats(gy, src, ones, zeros, ctx.relu)
+                g_bias = (sc.double() * s1).float()
+            g_raw = _ops.pointwise_bwd_apply(gy, src, ones, zeros, ctx.relu, sc.contiguous(), zeros, zeros)
         else:
-            raw, mean, invstd, gamma = saved[5:9]
-            n = raw.shape[0] * raw.shape[2]
-            xhat = (raw - mean.view(1, -1, 1)) * invstd.view(1, -1, 1)
-            g_beta = gy.sum(dim=(0, 2))
-            g_gamma = (gy * xhat).sum(dim=(0, 2))
-            g_raw = (gamma * invstd).view(1, -1, 1) * (gy - (g_beta / n).view(1, -1, 1) - xhat * (g_gamma / n).view(1, -1, 1))
-            g_bias = g_raw.sum(dim=(0, 2))
-        x = torch.cat((x1, x2), dim=1) if ctx.has_x2 else x1
-        g_w = torch.einsum('bol,bil->oi', g_raw, x) if ctx.needs_input_grad[2] else None
-        g_x1 = g_x2 = None
-        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
-            g_x = torch.matmul(weight2d.t().unsqueeze(0), g_raw)
+            sc, sh, raw, mean, invstd, gamma, zeros = saved[3:10]
+            n = float(raw.shape[0] * raw.shape[2])
+            s1, s2 = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu)
+            sg = invstd.double() * (s2 - mean.double() * s1)              # sum gy*mask*xhat
+            a = gamma.double() * invstd.double()
+            b = -a * invstd.double() * sg / n
+            c0 = -a * s1 / n - b * mean.double()
+            g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a.float().contiguous(), b.float().contiguous(),
+                                             c0.float().contiguous())
+            g_beta, g_gamma = s1.float(), sg.float()
+            g_bias = torch.zeros_like(zeros)                              # a bias in front of BatchNorm has no gradient
+        g_w = None
+        if ctx.needs_input_grad[2]:
+            parts = [torch.bmm(g_raw, x1.transpose(1, 2)).sum(0)]
             if ctx.has_x2:
-                g_x1, g_x2 = g_x[:, :x1.shape[1]].contiguous(), g_x[:, x1.shape[1]:].contiguous()
-            else:
-                g_x1 = g_x
+                parts.append(torch.bmm(g_raw, x2.transpose(1, 2)).sum(0))
+            g_w = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+        g_x1 = g_x2 = None
+        need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
+        if need1 or need2:
+            Cout = weight2d.shape[0]
+            ones_i = None
+            packs = _pack_transposed(weight2d.detach(), x1.shape[1], x2.shape[1] if ctx.has_x2 else 0)
+            outs = []
+            for need, pk in ((need1, packs[0]), (need2, packs[1])):
+                if not need or pk is None:
+                    outs.append(None)
+                    continue
+                wpt, Ci = pk
+                ones_i = torch.ones(Ci, dtype=torch.float32, device=gy.device)
+                outs.append(_ops.pointmlp(g_raw, wpt, ones_i, torch.zeros_like(ones_i), False, Ci))
+            g_x1, g_x2 = outs
         return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
 
 

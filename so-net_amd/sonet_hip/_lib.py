@@ -40,6 +40,9 @@ SIGNATURES = {
     "sonet_pointresnet_pool_ws_size": [_i, _i, _i],
     "sonet_pointresnet_fused_pool_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_som_sort_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sonet_pointwise_bwd_stats_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "sonet_pointwise_bwd_apply_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],

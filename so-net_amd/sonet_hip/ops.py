@@ -365,6 +365,44 @@ def channel_affine_act_(y, scale, shift, relu):
     return y
 
 
+def channel_affine_act(x, scale, shift, relu):
+    """y = act(x * scale[c] + shift[c]) out of place, x B x C x L."""
+    _chk(x, "x", torch.float32, 3)
+    dev = _same_device(x, scale, shift)
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev), _timed("channel_affine_act"):
+        check(_lib.load().sonet_channel_affine_act_out_f32(ptr(x), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, C, L, stream_ptr()),
+              "sonet_channel_affine_act_out_f32")
+    return y
+
+
+def pointwise_bwd_stats(gy, raw, scale, shift, relu):
+    """-> (s1, s2) float64 [C]: sum gy*mask, sum gy*mask*raw over (b, l); mask = (raw*scale+shift > 0) if relu."""
+    _chk(gy, "gy", torch.float32, 3)
+    _chk(raw, "raw", torch.float32, 3)
+    dev = _same_device(gy, raw, scale, shift)
+    B, C, L = gy.shape
+    sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev), _timed("pointwise_bwd_stats"):
+        check(_lib.load().sonet_pointwise_bwd_stats_f32(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), B, C, L,
+                                                        ptr(sums), stream_ptr()), "sonet_pointwise_bwd_stats_f32")
+    return sums[:C], sums[C:]
+
+
+def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
+    """g_raw = a[c] * (gy * mask) + b[c] * raw + c0[c]."""
+    _chk(gy, "gy", torch.float32, 3)
+    _chk(raw, "raw", torch.float32, 3)
+    dev = _same_device(gy, raw, scale, shift, a, b, c0)
+    B, C, L = gy.shape
+    out = torch.empty_like(gy)
+    with torch.cuda.device(dev), _timed("pointwise_bwd_apply"):
+        check(_lib.load().sonet_pointwise_bwd_apply_f32(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), ptr(a), ptr(b),
+                                                        ptr(c0), ptr(out), B, C, L, stream_ptr()), "sonet_pointwise_bwd_apply_f32")
+    return out
+
+
 def chamfer_nn(q, db):
     """q B x 3 x Nq, db B x 3 x Nd -> B x Nq i32 nearest database index."""
     _chk(q, "q", torch.float32, 3)
