@@ -193,6 +193,14 @@ int sonet_pointwise_bwd_stats_f32(const float *gy, const float *raw, const float
 int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float *scale, const float *shift, int relu,
                                   const float *a, const float *b, const float *c0, float *g_raw,
                                   int B, int C, int L, sonet_stream_t stream);
+/* Per-channel coefficients of training BatchNorm, forward (invstd = 1/sqrt(var+eps), scale = gamma*invstd,
+ * shift = beta - mean*scale) and backward (from the two sums of sonet_pointwise_bwd_stats_f32, n = B*L:
+ *   sg = invstd*(s2 - mean*s1);  a = gamma*invstd;  b = -a*invstd*sg/n;  c0 = -a*s1/n - b*mean;
+ *   g_gamma = sg;  g_beta = s1), all [C]. */
+int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, const float *gamma, const float *beta, float eps, int C,
+                            float *invstd, float *scale, float *shift, sonet_stream_t stream);
+int sonet_bn_bwd_coeffs_f32(const double *sums, const float *mean, const float *invstd, const float *gamma, double n, int C,
+                            float *a, float *b, float *c0, float *g_gamma, float *g_beta, sonet_stream_t stream);
 /* y = act(x*scale[c] + shift[c]) out of place (training forward: raw stays for the backward). */
 int sonet_channel_affine_act_out_f32(const float *x, const float *scale, const float *shift, int relu, float *y,
                                      int B, int C, int L, sonet_stream_t stream);

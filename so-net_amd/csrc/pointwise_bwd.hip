@@ -93,7 +93,63 @@ __global__ __launch_bounds__(256) void affine_act_out_kernel(const float *__rest
     }
 }
 
+// per-channel coefficient kernels (C threads): replace a dozen C-element aten launches per layer
+__global__ __launch_bounds__(256) void bn_fwd_coeffs_kernel(const float *__restrict__ mean, const float *__restrict__ var,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float eps, int C, float *__restrict__ invstd,
+                                                             float *__restrict__ sc, float *__restrict__ sh)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / __fsqrt_rn(var[c] + eps);          // torch.rsqrt(var + eps) to 1 ulp; only the product below is used
+    const float s = gamma[c] * is;
+    invstd[c] = is;
+    sc[c] = s;
+    sh[c] = beta[c] - mean[c] * s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double *__restrict__ sums, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                             double n, int C, float *__restrict__ a, float *__restrict__ b,
+                                                             float *__restrict__ c0, float *__restrict__ g_gamma,
+                                                             float *__restrict__ g_beta)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = sums[c], s2 = sums[C + c], m = (double)mean[c], is = (double)invstd[c];
+    const double sg = is * (s2 - m * s1);                       // sum gy*mask*xhat
+    const double av = (double)gamma[c] * is;
+    const double bv = -av * is * sg / n;
+    a[c] = (float)av;
+    b[c] = (float)bv;
+    c0[c] = (float)(-av * s1 / n - bv * m);
+    g_gamma[c] = (float)sg;
+    g_beta[c] = (float)s1;
+}
+
 }  // namespace
+
+extern "C" int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, const float *gamma, const float *beta, float eps, int C,
+                                       float *invstd, float *scale, float *shift, sonet_stream_t stream)
+{
+    const char *what = "sonet_bn_fwd_coeffs_f32";
+    SONET_REQUIRE(mean && var && gamma && beta && invstd && scale && shift, "%s: NULL pointer", what);
+    SONET_REQUIRE(C > 0, "%s: bad size C=%d", what, C);
+    hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       mean, var, gamma, beta, eps, C, invstd, scale, shift);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_bn_bwd_coeffs_f32(const double *sums, const float *mean, const float *invstd, const float *gamma, double n, int C,
+                                       float *a, float *b, float *c0, float *g_gamma, float *g_beta, sonet_stream_t stream)
+{
+    const char *what = "sonet_bn_bwd_coeffs_f32";
+    SONET_REQUIRE(sums && mean && invstd && gamma && a && b && c0 && g_gamma && g_beta, "%s: NULL pointer", what);
+    SONET_REQUIRE(C > 0 && n > 0, "%s: bad size C=%d", what, C);
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       sums, mean, invstd, gamma, n, C, a, b, c0, g_gamma, g_beta);
+    return sonet::launched(what);
+}
 
 extern "C" int sonet_pointwise_bwd_stats_f32(const float *gy, const float *raw, const float *scale, const float *shift,
                                              int relu, int B, int C, int L, double *sums, sonet_stream_t stream)

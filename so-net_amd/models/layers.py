@@ -112,8 +112,7 @@ class _PointwiseFn(torch.autograd.Function):
     def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps):
         Cout = weight2d.shape[0]
         dev = x1.device
-        ones = torch.ones(Cout, dtype=torch.float32, device=dev)
-        zeros = torch.zeros(Cout, dtype=torch.float32, device=dev)
+        ones, zeros = _ops.const_vec(Cout, 1.0, dev), _ops.const_vec(Cout, 0.0, dev)
         if mode == 'affine':
             y = _ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
             # mask source: the output itself (y > 0 <=> pre-activation > 0)
@@ -122,9 +121,7 @@ class _PointwiseFn(torch.autograd.Function):
         else:
             raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
             mean, var = _ops.channel_stats(raw)
-            invstd = torch.rsqrt(var + eps)
-            sc = (gamma * invstd).contiguous()
-            sh = (beta - mean * sc).contiguous()
+            invstd, sc, sh = _ops.bn_fwd_coeffs(mean, var, gamma, beta, eps)
             y = _ops.channel_affine_act(raw, sc, sh, relu)
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, sh, raw, mean, invstd, gamma,
                                   zeros)
@@ -150,15 +147,10 @@ class _PointwiseFn(torch.autograd.Function):
         else:
             sc, sh, raw, mean, invstd, gamma, zeros = saved[3:10]
             n = float(raw.shape[0] * raw.shape[2])
-            s1, s2 = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu)
-            sg = invstd.double() * (s2 - mean.double() * s1)              # sum gy*mask*xhat
-            a = gamma.double() * invstd.double()
-            b = -a * invstd.double() * sg / n
-            c0 = -a * s1 / n - b * mean.double()
-            g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a.float().contiguous(), b.float().contiguous(),
-                                             c0.float().contiguous())
-            g_beta, g_gamma = s1.float(), sg.float()
-            g_bias = torch.zeros_like(zeros)                              # a bias in front of BatchNorm has no gradient
+            sums = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu, want_sums=True)
+            a, b, c0, g_gamma, g_beta = _ops.bn_bwd_coeffs(sums, mean, invstd, gamma, n)
+            g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a, b, c0)
+            g_bias = zeros.clone()                                        # a bias in front of BatchNorm has no gradient
         g_w = None
         if ctx.needs_input_grad[2]:
             parts = [torch.bmm(g_raw, x1.transpose(1, 2)).sum(0)]
@@ -177,8 +169,7 @@ class _PointwiseFn(torch.autograd.Function):
                     outs.append(None)
                     continue
                 wpt, Ci = pk
-                ones_i = torch.ones(Ci, dtype=torch.float32, device=gy.device)
-                outs.append(_ops.pointmlp(g_raw, wpt, ones_i, torch.zeros_like(ones_i), False, Ci))
+                outs.append(_ops.pointmlp(g_raw, wpt, _ops.const_vec(Ci, 1.0, gy.device), _ops.const_vec(Ci, 0.0, gy.device), False, Ci))
             g_x1, g_x2 = outs
         return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
 

@@ -377,7 +377,43 @@ def channel_affine_act(x, scale, shift, relu):
     return y
 
 
-def pointwise_bwd_stats(gy, raw, scale, shift, relu):
+_CONST = {}
+
+
+def const_vec(C, value, device):
+    """Cached constant [C] f32 vector (ones / zeros for the kernels' scale / shift arguments)."""
+    key = (int(C), float(value), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.full((int(C),), float(value), dtype=torch.float32, device=device)
+        _CONST[key] = t
+    return t
+
+
+def bn_fwd_coeffs(mean, var, gamma, beta, eps):
+    """-> (invstd, scale, shift) of training BatchNorm, one launch."""
+    dev = _same_device(mean, var, gamma, beta)
+    C = mean.numel()
+    out = torch.empty((3, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_bn_fwd_coeffs_f32(ptr(mean), ptr(var), ptr(gamma.detach().contiguous()), ptr(beta.detach().contiguous()),
+                                                  float(eps), C, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "sonet_bn_fwd_coeffs_f32")
+    return out[0], out[1], out[2]
+
+
+def bn_bwd_coeffs(sums, mean, invstd, gamma, n):
+    """sums [2C] f64 of pointwise_bwd_stats -> (a, b, c0, g_gamma, g_beta), one launch."""
+    dev = _same_device(sums, mean, invstd, gamma)
+    C = mean.numel()
+    out = torch.empty((5, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_bn_bwd_coeffs_f32(ptr(sums), ptr(mean), ptr(invstd), ptr(gamma.detach().contiguous()), float(n), C,
+                                                  ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), stream_ptr()),
+              "sonet_bn_bwd_coeffs_f32")
+    return out[0], out[1], out[2], out[3], out[4]
+
+
+def pointwise_bwd_stats(gy, raw, scale, shift, relu, want_sums=False):
     """-> (s1, s2) float64 [C]: sum gy*mask, sum gy*mask*raw over (b, l); mask = (raw*scale+shift > 0) if relu."""
     _chk(gy, "gy", torch.float32, 3)
     _chk(raw, "raw", torch.float32, 3)
@@ -387,6 +423,8 @@ def pointwise_bwd_stats(gy, raw, scale, shift, relu):
     with torch.cuda.device(dev), _timed("pointwise_bwd_stats"):
         check(_lib.load().sonet_pointwise_bwd_stats_f32(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), B, C, L,
                                                         ptr(sums), stream_ptr()), "sonet_pointwise_bwd_stats_f32")
+    if want_sums:
+        return sums
     return sums[:C], sums[C:]
 
 
