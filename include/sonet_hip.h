@@ -193,6 +193,13 @@ int sonet_pointwise_bwd_stats_f32(const float *gy, const float *raw, const float
 int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float *scale, const float *shift, int relu,
                                   const float *a, const float *b, const float *c0, float *g_raw,
                                   int B, int C, int L, sonet_stream_t stream);
+/* t = act((t + z[b][c][min_idx[b][l]]) * scale[c] + shift[c]) in place.  t [B][C][L] (the per-point block of a layer's
+ * pre-activation), z [B][C][M] (its per-node block, computed once per node), min_idx [B][L] i32 node of every point
+ * copy.  Used for the first Segmenter layer, whose 3356 input channels are 393 per-point, 1923 per-node and 1040
+ * per-cloud ones (models/networks.py:296-326, models/segmenter.py:90-109). */
+int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
+                                  const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
+
 /* Per-channel coefficients of training BatchNorm, forward (invstd = 1/sqrt(var+eps), scale = gamma*invstd,
  * shift = beta - mean*scale) and backward (from the two sums of sonet_pointwise_bwd_stats_f32, n = B*L:
  *   sg = invstd*(s2 - mean*s1);  a = gamma*invstd;  b = -a*invstd*sg/n;  c0 = -a*s1/n - b*mean;

@@ -93,6 +93,31 @@ __global__ __launch_bounds__(256) void affine_act_out_kernel(const float *__rest
     }
 }
 
+// y = act((t + z[b][c][ids[b][l]]) * scale[c] + shift[c]) in place: the per-node block of a layer whose input concatenates
+// per-point and per-node (broadcast back) channels is computed once per node and added here (segmenter layer 1,
+// models/networks.py:296-326).  One workgroup per (b, c) row; the row's M node values sit in LDS.
+__global__ __launch_bounds__(256) void node_add_affine_act_kernel(float *__restrict__ t, const float *__restrict__ z,
+                                                                   const int32_t *__restrict__ ids, const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift, int relu, int C, int L, int M)
+{
+    extern __shared__ float zrow[];
+    const long long row = blockIdx.x;
+    const int c = (int)(row % C);
+    const long long b = row / C;
+    for (int m = threadIdx.x; m < M; m += 256) zrow[m] = z[row * M + m];
+    __syncthreads();
+    const float sc = scale[c], sh = shift[c];
+    float *tr = t + row * L;
+    const int32_t *id = ids + b * L;
+    for (int l = blockIdx.y * 256 + threadIdx.x; l < L; l += gridDim.y * 256) {
+        const int m = id[l];
+        float v = tr[l] + ((unsigned)m < (unsigned)M ? zrow[m] : 0.f);
+        v = __fmaf_rn(v, sc, sh);
+        if (relu) v = (v < 0.f) ? 0.f : v;
+        tr[l] = v;
+    }
+}
+
 // per-channel coefficient kernels (C threads): replace a dozen C-element aten launches per layer
 __global__ __launch_bounds__(256) void bn_fwd_coeffs_kernel(const float *__restrict__ mean, const float *__restrict__ var,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -194,5 +219,19 @@ extern "C" int sonet_channel_affine_act_out_f32(const float *x, const float *sca
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(affine_act_out_kernel, dim3((unsigned)rows, gx), dim3(256), 0, sonet::as_stream(stream),
                        x, scale, shift, relu, y, C, L);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
+                                             const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_node_add_affine_act_f32";
+    SONET_REQUIRE(t && z && min_idx_i32 && scale && shift, "%s: NULL pointer", what);
+    const long long rows = (long long)B * C;
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0 && M > 0 && M <= 8192 && rows <= 2147483647LL, "%s: bad size B=%d C=%d L=%d M=%d", what, B, C, L, M);
+    int gy = sonet::ceil_div(L, 256 * 8);
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(node_add_affine_act_kernel, dim3((unsigned)rows, gy), dim3(256), (size_t)M * sizeof(float),
+                       sonet::as_stream(stream), t, z, min_idx_i32, scale, shift, relu, C, L, M);
     return sonet::launched(what);
 }

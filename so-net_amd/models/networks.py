@@ -151,7 +151,9 @@ class Encoder(nn.Module):
         a = sb.assign(xd, opt.k)                                         # :127-128 (ids, counts, sums)
         use_sn = bool(opt.surface_normal)
         snd = sn.detach().float().contiguous() if use_sn else None
-        fused_pool = (use_sn and _ops.FUSE_POOL and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
+        # (a head that reads first_pn_out densely -- the segmenter -- sets want_first_pn_out: one store-variant pass then)
+        fused_pool = (use_sn and _ops.FUSE_POOL and not getattr(self, 'want_first_pn_out', False)
+                      and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
                       and a.k * a.N * 384 * 4 < 4e9)
         if fused_pool:
             # no-grad fast path: node-sorted grouping -> first PointNet + per-node max-pool in ONE kernel (:140-185)
@@ -270,13 +272,89 @@ class Segmenter(nn.Module):
         return self.layer5(h)
 
 
+    # ---- node-wise evaluation of layer 1 (no-grad / eval) ---------------------------------------------------------
+    # Of layer 1's 3356 input channels only 393 vary per point copy (x_decentered, x, sn, first_pn_out); 1923 are
+    # node features broadcast back to the copies (centers = the node's coordinates, and the three gathered maps) and
+    # 1040 are per-cloud (one-hot label, global feature).  W.[p | n | g] = W_p.x_p + (W_n.x_n + W_g.x_g)[node of the
+    # copy]: the node / cloud block is a 64-column GEMM per cloud instead of kN columns (8.5x fewer MACs overall,
+    # SURVEY.md section 8f-3).  Column blocks follow the concat order of forward().
+    def _layer1_blocks(self):
+        sn = 3 if self.opt.surface_normal else 0
+        knn = 512 if self.opt.som_k >= 2 else 0
+        o = {}
+        pos = 0
+        for name, width in (("x_dec", 3), ("x", 3), ("centers", 3), ("sn", sn), ("onehot", 16), ("first", 384), ("fm_first", 384),
+                            ("fm_knn", knn), ("fm_final", self.feature_num), ("feature", self.feature_num)):
+            o[name] = (pos, pos + width)
+            pos += width
+        return o
+
+    def _layer1_split(self):
+        lyr = self.layer1
+        w = lyr.conv.weight
+        key = (w._version, w.data_ptr(), w.device, _ops.POINTMLP_PRECISION)
+        if getattr(self, "_l1_key", None) != key:
+            with torch.no_grad():
+                W = w.detach().reshape(w.shape[0], w.shape[1]).float()
+                blk = self._layer1_blocks()
+                cols = lambda names: torch.cat([W[:, blk[n][0]:blk[n][1]] for n in names], dim=1).contiguous()
+                mode = _ops.POINTMLP_PRECISION
+                self._l1_wp_point = _ops.pointmlp_pack(cols(["first", "x_dec", "x", "sn"]), mode)      # x1 = first_pn_out (384), x2 = small
+                self._l1_wp_node = _ops.pointmlp_pack(cols(["centers", "fm_first", "fm_knn", "fm_final"]), mode)
+                self._l1_w_glob = cols(["onehot", "feature"])
+            self._l1_key = key
+        return self._l1_wp_point, self._l1_wp_node, self._l1_w_glob
+
+    def forward_nodewise(self, x_decentered, x, sn, label, first_pn_out, som_node, masked_max, knn_feature_1, final_pn_out, feature,
+                         min_idx_i32):
+        """Same result as forward() on the gathered tensors, for eval / no-grad: node-level inputs B x C x M + node ids."""
+        B, N, k = x.size()[0], x.size()[2], self.opt.k
+        lyr = self.layer1
+        wp_point, wp_node, w_glob = self._layer1_split()
+        scale, shift = lyr._eval_affine()
+        Cout = lyr.conv.out_channels
+        ones, zeros = _ops.const_vec(Cout, 1.0, x.device), _ops.const_vec(Cout, 0.0, x.device)
+        small = [x_decentered, torch.cat([x] * k, dim=2)] + ([torch.cat([sn] * k, dim=2)] if self.opt.surface_normal else [])
+        t = _ops.pointmlp(first_pn_out.contiguous(), wp_point, ones, zeros, False, Cout, x2=torch.cat(small, dim=1).contiguous())
+        node_in = [som_node, masked_max] + ([knn_feature_1] if self.opt.som_k >= 2 else []) + [final_pn_out]
+        onehot = torch.zeros(B, 16, dtype=torch.float32, device=x.device)
+        onehot.scatter_(1, label.unsqueeze(1), 1)
+        zg = torch.cat([onehot, feature], dim=1) @ w_glob.t()                       # B x Cout: per-cloud block
+        z = _ops.pointmlp(torch.cat(node_in, dim=1).contiguous(), wp_node, ones, zeros, False, Cout) + zg.unsqueeze(2)
+        h = _ops.node_add_affine_act_(t, z.contiguous(), min_idx_i32, scale, shift, lyr.activation == 'relu')
+        return self._tail(self.layer3(self.layer2(h)), k)
+
+    def _tail(self, h, k):
+        chunks = torch.split(h, self.opt.input_pc_num, dim=2)
+        assert len(chunks) == k
+        h = chunks[0]
+        for c in chunks[1:]:
+            h = h + c
+        if k > 1:
+            h = (1.0 / k) * h if k == 3 else 0.5 * h          # networks.py:331-336 (k in {2, 3})
+        h = self.layer4(h)
+        if self.opt.dropout > 0.1:
+            h = self.drop4(h)
+        return self.layer5(h)
+
+    def _nodewise_ok(self):
+        lyr = self.layer1
+        return (not torch.is_grad_enabled()) and not self.training and lyr.activation in ('relu', None) \
+            and lyr.normalization in (None, 'batch') and lyr._fusable()
+
+
 def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is_train=False, epoch=None):
     """Model.forward of the part-segmentation task (models/segmenter.py:79-109) on the level-2 encoder:
     the reference recovers the node of every point copy with argmax over the one-hot mask and gathers three
     node-level feature maps back to the kN copies; here the int32 ids are already there and one kernel does
     each gather (autograd falls back to torch.gather when gradients are needed)."""
+    encoder.want_first_pn_out = True                  # layer 1 consumes first_pn_out per point copy
     feature = encoder(pc, sn, node, node_knn_I, is_train, epoch)
     st = encoder._lazy
+    if segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True):
+        return segmenter.forward_nodewise(encoder.x_decentered, pc, sn, label, encoder.first_pn_out, encoder.som_node,
+                                          encoder.first_pn_out_masked_max.contiguous(), encoder.knn_feature_1.contiguous(),
+                                          encoder.final_pn_out.contiguous(), feature, st["a"].min_idx_i32)
     need_grad = torch.is_grad_enabled() and encoder.first_pn_out_masked_max.requires_grad
     if need_grad:
         idx = encoder.min_idx.unsqueeze(1)

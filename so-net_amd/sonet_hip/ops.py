@@ -212,6 +212,21 @@ def node_gather(feat, min_idx_i32):
     return out
 
 
+def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
+    """t B x C x L <- act((t + z[:, :, min_idx]) * scale + shift) in place; z B x C x M."""
+    _chk(t, "t", torch.float32, 3)
+    _chk(z, "z", torch.float32, 3)
+    _chk(min_idx_i32, "min_idx", torch.int32, 2)
+    dev = _same_device(t, z, min_idx_i32, scale, shift)
+    B, C, L = t.shape
+    if z.shape[0] != B or z.shape[1] != C or min_idx_i32.shape != (B, L):
+        raise SonetHipError("z must be B x C x M and min_idx B x L")
+    with torch.cuda.device(dev), _timed("node_add_affine_act"):
+        check(_lib.load().sonet_node_add_affine_act_f32(ptr(t), ptr(z), ptr(min_idx_i32), ptr(scale), ptr(shift), int(bool(relu)),
+                                                        B, C, L, z.shape[2], stream_ptr()), "sonet_node_add_affine_act_f32")
+    return t
+
+
 def knn_gather(x, knn_I):
     """x BxCxM f32, knn_I BxMxK i64 -> BxCxMxK (models/operations.py:38-54)."""
     _chk(x, "som_node", torch.float32, 3)

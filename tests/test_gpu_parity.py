@@ -458,10 +458,14 @@ def test_segmenter_forward_golden(mode):
     ops.POINTMLP_PRECISION = mode
     try:
         with torch.no_grad():
+            seg.nodewise = False                      # the reference's data flow: gather to the copies, dense 3356-channel layer
+            score_dense = NW.segmentation_forward(enc, seg, cu(g["pc"]), cu(g["sn"]), cu(g["label"]), cu(g["node"]), cu(g["node_knn_I"]))
+            seg.nodewise = True                       # per-node / per-cloud blocks of layer 1 computed once per node
             score = NW.segmentation_forward(enc, seg, cu(g["pc"]), cu(g["sn"]), cu(g["label"]), cu(g["node"]), cu(g["node_knn_I"]))
             bb = ops.node_gather(enc.first_pn_out_masked_max.contiguous(), enc._lazy["a"].min_idx_i32)
     finally:
         ops.POINTMLP_PRECISION = old
+    assert_close_rms(score_dense.cpu().numpy(), g["score_segmenter"], 1e-5, "score_segmenter (dense layer 1)")
     np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), g["min_idx"])
     assert_close_rms(bb[:, ::8].cpu().numpy(), g["feature_max_first_pn_out"], 1e-5, "back-broadcast")
     assert tuple(score.shape) == (B, 50, N)
@@ -528,6 +532,20 @@ def test_chamfer_loss_full_size_properties():
     d = torch.cdist(pred.transpose(1, 2).double(), gt.transpose(1, 2).double())     # brute force, float64
     ref = (d.min(2).values.pow(2) + 1e-8).sqrt().mean() + (d.min(1).values.pow(2) + 1e-8).sqrt().mean()
     assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
+
+
+def test_node_add_affine_act_vs_torch():
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(2)
+    for B, C, M, L, relu in [(2, 1024, 64, 3072, True), (3, 7, 5, 33, False), (1, 64, 64, 15000, True)]:
+        t = torch.randn(B, C, L, generator=gen)
+        z = torch.randn(B, C, M, generator=gen)
+        idx = torch.randint(0, M, (B, L), generator=gen, dtype=torch.int32)
+        sc, sh = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+        ref = (t + torch.gather(z, 2, idx.long().unsqueeze(1).expand(B, C, L))) * sc.view(1, -1, 1) + sh.view(1, -1, 1)
+        ref = torch.relu(ref) if relu else ref
+        out = ops.node_add_affine_act_(t.to(DEV), z.to(DEV), idx.to(DEV), sc.to(DEV), sh.to(DEV), relu)
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
 
 
 def test_node_gather_vs_torch():

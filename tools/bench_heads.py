@@ -1,0 +1,74 @@
+"""tools/bench_heads.py -- forward timings of the other heads on the same encoder (BASELINE configs 3 and 4):
+part-segmentation (B x 50 x N scores) and autoencoder (decoder + multi-resolution Chamfer loss).  Not the headline
+metric (bench.py); numbers for DESIGN.md."""
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "so-net_amd"))
+import torch  # noqa: E402
+from models import networks as NW, losses as LS  # noqa: E402
+from sonet_hip import ops, synth  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def opt_for(B, N, **kw):
+    d = dict(gpu_id=0, device=DEV, batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024, activation="relu",
+             normalization="batch", dropout=0.6, node_num=64, k=3, som_k=9, som_k_type="avg", bn_momentum=0.1,
+             bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=50, output_fc_pc_num=256, output_conv_pc_num=1024)
+    d.update(kw)
+    return Namespace(**d)
+
+
+def timeit(fn, steps=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    with ops.kernel_timing() as rec:
+        fn()
+    torch.cuda.synchronize()
+    top = sorted(rec.summary().items(), key=lambda kv: -kv[1]["total_ms"])[:6]
+    return dt * 1e3, top
+
+
+def main():
+    for B, N in ((8, 1024), (64, 1024), (16, 5000)):
+        opt = opt_for(B, N, som_k_type="center")
+        enc, seg = NW.Encoder(opt), NW.Segmenter(opt)
+        synth.fill_state_dict_(enc.state_dict(), 1)
+        synth.fill_state_dict_(seg.state_dict(), 2)
+        enc.to(DEV).eval(); seg.to(DEV).eval()
+        inp = synth.make_inputs(B, N, seed=3, device=DEV)
+        label = torch.randint(0, 16, (B,), device=DEV)
+        with torch.no_grad():
+            ms, top = timeit(lambda: NW.segmentation_forward(enc, seg, inp["pc"], inp["sn"], label, inp["node"], inp["node_knn_I"]))
+        print("segmenter  B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   top: %s" % (
+            B, N, ms, B / ms * 1e3, ", ".join("%s %.2f" % (k, v["total_ms"]) for k, v in top)))
+    for B, N in ((8, 5000), (64, 5000)):
+        opt = opt_for(B, N, classes=40)
+        enc, dec, crit = NW.Encoder(opt), NW.Decoder(opt), LS.ChamferLoss(opt)
+        synth.fill_state_dict_(enc.state_dict(), 1)
+        synth.fill_state_dict_(dec.state_dict(), 2)
+        enc.to(DEV).eval(); dec.to(DEV).eval()
+        inp = synth.make_inputs(B, N, seed=3, device=DEV)
+
+        def fwd():
+            f = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], False, None)
+            pred = dec(f)
+            return crit(pred, inp["pc"]) + crit(dec.conv_pc4, inp["pc"])
+        with torch.no_grad():
+            ms, top = timeit(fwd)
+        print("autoencoder B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   top: %s" % (
+            B, N, ms, B / ms * 1e3, ", ".join("%s %.2f" % (k, v["total_ms"]) for k, v in top)))
+
+
+if __name__ == "__main__":
+    main()
