@@ -36,6 +36,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 # the 3xbf16-split path issues 6 bf16 MFMAs per algorithmic f32 product: its ceiling in algorithmic flops
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# the fused first PointNet splits into fp16 pieces and issues 3 fp16 MFMAs (same 2.5 PF dense rate) per product
+PEAK_H3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
 
 def parse():
@@ -256,7 +258,8 @@ def main():
         if amount:
             if bound == "mfma":
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e12
-                peak = PEAK_X3_TFLOPS if name.startswith(("pointmlpx3", "pointresnet_fused")) else PEAK_F32_MFMA_TFLOPS
+                peak = (PEAK_H3_TFLOPS if name.startswith("pointresnet_fused") else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
+                        else PEAK_F32_MFMA_TFLOPS)
                 k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
             else:
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e9

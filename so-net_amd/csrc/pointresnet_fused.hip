@@ -6,19 +6,20 @@
 // intermediate activation in registers; HBM sees only the 6-channel input and the 384-channel output
 // (the unfused path writes and re-reads 64 + 128 + 256 channels per point: 3.6 KB / point).
 //
-// Arithmetic: the 3 x bf16 split scheme of pointmlp_x3.hip (6 bf16 MFMAs per product set, f32 accumulate).
+// Arithmetic: fp32 operands split into fp16 pieces, three v_mfma_f32_32x32x16_f16 per product set with fp32
+// accumulation (see "operand split" below; the layer-wise kernels of pointmlp_x3.hip use six bf16 terms).
 //
-// Register chaining.  v_mfma_f32_32x32x16_bf16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// Register chaining.  v_mfma_f32_32x32x16_f16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 // in register r of lane l and consumes B[k = 8*(l>>5) + e][col = l&31], e = 0..7.  Registers 8q .. 8q+7 of
 // an output tile therefore ARE the B operand of a 16-channel chunk of the next layer (after the affine +
-// ReLU and the bf16 split), provided the next layer's weights are packed with the matching channel order
+// ReLU and the split), provided the next layer's weights are packed with the matching channel order
 //     k = 8h + e   <->   channel 32*t + 16*q + (e&3) + 8*(e>>2) + 4*h          ("chained" packing)
 // No shuffle, no LDS round trip, no transposition between layers.
 //
 // Weights.  All four layers are packed (pointresnet_pack_kernel) into ONE linear stream of 1-KiB slices
-// (64 lanes x 8 bf16) in exactly the order the MFMAs consume them, so W staging is a linear copy:
-// the 4 waves of a workgroup load the next-next stage (NSTG slices) into registers, ds_write it after the
-// stage barrier, and read their A fragments back at (ring slot) + compile-time offsets.  One barrier per 72 MFMAs.
+// (64 lanes x 8 fp16) in exactly the order the MFMAs consume them, so W staging is a linear copy (LDS-DMA):
+// the 4 waves of a workgroup stream the stage after next (NSTG slices) into the LDS ring and read their A fragments
+// back at (ring slot) + compile-time offsets.  One barrier per 36 MFMAs.
 //   L1: 2 tiles x 1 chunk, L2: 4 x 4, L3: 8 x 8  (tile-major),  L4: 2 passes x 20 chunks x 6 tiles.
 // Workgroups are persistent (one per CU) and walk the 128-point tiles; the weight stream simply restarts.
 #include "common.hpp"
@@ -27,7 +28,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int PF_THREADS = 256, PF_WAVES = 4;
@@ -49,30 +51,45 @@ constexpr int NSW = NSTG / PF_WAVES;                           // slices staged 
 static_assert(NSTG % PF_WAVES == 0, "");
 constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
 
+// ---- fp32 -> 3 x fp16 operand split ------------------------------------------------------------------
+// x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; a product a*b is taken as
+//     ah*bh  +  (ah*2^-5) * fp16(32*bm)  +  fp16(32*am) * (bh*2^-5)
+// i.e. THREE fp16 MFMAs with fp32 accumulation (the dropped am*bm and the rounding of the scaled residuals are
+// <= 2^-22 relative).  The 2^5 / 2^-5 pair keeps the residual out of the fp16 subnormals (|x| > 4e-3 stays normal;
+// below that the absolute error is < 1e-9).  Measured on the reference fixtures: whole first PointNet within
+// 2.9e-6 * max(|ref|, rms) -- the same as the six-term 3 x bf16 split it replaces, at half the matrix work (any
+// five of the six bf16 terms: 3-4e-5, outside the 1e-5 bound).  Operand range: |x| <= 65504 (fp16); the split clamps.
+// Naming: term h = (ah, bh), m = (ah*2^-5, 32*bm), l = (32*am, bh*2^-5).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32 (round to nearest even)
+constexpr float F16_MAX = 65504.0f;
+constexpr unsigned F16_2_M5_PK = 0x28002800u;                  // packed fp16 (2^-5, 2^-5)
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {        // one v_cvt_pk_f16_f32 (round to nearest even)
     const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
+__device__ __forceinline__ float f16_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
+    const f16x2_t r = __builtin_bit_cast(f16x2_t, a) * __builtin_bit_cast(f16x2_t, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -F16_MAX), F16_MAX); }
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-    m = cvt_pk_bf16(r0, r1);
-    const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-    l = cvt_pk_bf16(q0, q1);
+    h = cvt_pk_f16(x0, x1);
+    m = cvt_pk_f16(32.f * (x0 - f16_lo(h)), 32.f * (x1 - f16_hi(h)));      // x - fp16(x) is exact
+    l = pk_mul_f16(h, F16_2_M5_PK);
 }
 
-struct B3 { bf16x8 h, m, l; };
+struct B3 { f16x8 h, m, l; };
 template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v)[8]);
-__device__ __forceinline__ B3 split_chunk(const float (&v)[8]) {
+__device__ __forceinline__ B3 split_chunk(const float (&v)[8]) {             // clamped, no affine (the network input)
     unsigned bh[4], bm[4], bl[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) split3_pair(v[2 * p], v[2 * p + 1], bh[p], bm[p], bl[p]);
+    for (int p = 0; p < 4; ++p) split3_pair(clamp_f16(v[2 * p]), clamp_f16(v[2 * p + 1]), bh[p], bm[p], bl[p]);
     B3 b;
-    b.h = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-    b.m = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
-    b.l = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+    b.h = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+    b.m = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+    b.l = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
     return b;
 }
 
@@ -80,29 +97,31 @@ template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v
     if constexpr (ABL & 2) {
         B3 b;
         const unsigned u = __float_as_uint(v[0]);
-        b.h = __builtin_bit_cast(bf16x8, make_uint4(u, u, u, u)); b.m = b.h; b.l = b.h;
+        b.h = __builtin_bit_cast(f16x8, make_uint4(u, u, u, u)); b.m = b.h; b.l = b.h;
         return b;
     } else {
         return split_chunk(v);
     }
 }
 
-// The same split, one VALU instruction at a time, so that the fused kernel can place <= 3 of them behind each MFMA
-// (a clump of 11 dependent VALU between two MFMAs stalls the matrix pipe: tools/mfma_bf16_issue.hip).  Op I of 44:
-// two interleaved pairs per group of 22 (independent neighbours), stages h, hi-parts, residual, m, hi-parts, residual, l.
-struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned t[8], h[4], m[4], l[4]; };
-// (volatile asm: instruction selection floats pure VALU ops across sched_barrier and clumps 8-9 of them behind one MFMA)
-__device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
-__device__ __forceinline__ unsigned pin_shl16(unsigned a) { unsigned r; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(a)); return r; }
-__device__ __forceinline__ unsigned pin_hi16(unsigned a) { unsigned r; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(a)); return r; }
-__device__ __forceinline__ float pin_sub(float a, unsigned b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// The same split fused with the producing layer's BatchNorm affine + ReLU, one VALU instruction at a time, so that
+// the fused kernel can place a few of them behind each MFMA (a clump of dependent VALU between two MFMAs stalls the
+// matrix pipe: tools/mfma_bf16_issue.hip).  (volatile asm: instruction selection floats pure VALU ops across
+// sched_barrier and clumps them.)  The activations stay raw in their registers; an in-place affine pass after each
+// layer cost ~4k cycles per tile in serialised LDS reads of the coefficients.
+struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned h[4], m[4], l[4]; };
 __device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
-// relu as the layer-wise kernels do it (v < 0 ? 0 : v: a NaN stays a NaN, as in the reference)
-__device__ __forceinline__ float pin_relu(float a) { float r; asm volatile("v_cmp_gt_f32 vcc, 0, %1\n\tv_cndmask_b32 %0, %1, 0, vcc" : "=v"(r) : "v"(a) : "vcc"); return r; }
-// Op I of 60 (two groups of 30 = two value pairs each): the producing layer's BatchNorm affine + ReLU applied to the
-// raw accumulator values on the way (the activations stay raw in their registers; an in-place pass after each
-// layer cost ~4k cycles per tile in serialised LDS reads of the coefficients), then the 22 split ops.
-constexpr int SPLIT_OPS = 60;
+// ReLU and the fp16 range clamp in one instruction (a NaN does not survive it; the exact-f32 mode keeps NaNs)
+__device__ __forceinline__ float pin_relu_clamp(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX)); return r; }
+__device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
+__device__ __forceinline__ float pin_mul32(float a) { float r; asm volatile("v_mul_f32 %0, 0x42000000, %1" : "=v"(r) : "v"(a)); return r; }
+// 32*x - 32*fp16 half of pk = 32 * (x - xh), exact
+__device__ __forceinline__ float pin_res_lo(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-32.0f), "v"(x32)); return r; }
+__device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-32.0f), "v"(x32)); return r; }
+__device__ __forceinline__ unsigned pin_scale_dn(unsigned pk) { unsigned r; asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(pk), "v"(F16_2_M5_PK)); return r; }
+// Op I of 44 = two groups of 22 (two value pairs each, neighbours independent): affine x4, relu+clamp x4, xh x2,
+// 32x x4, residual x4, xm x2, xh*2^-5 x2.
+constexpr int SPLIT_OPS = 44;
 template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
     if constexpr (ABL & 2) {
         if constexpr (I == 0) {
@@ -110,19 +129,14 @@ template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s
             for (int p = 0; p < 4; ++p) s.h[p] = s.m[p] = s.l[p] = __float_as_uint(s.x[0]);
         }
     } else if constexpr (I >= 0 && I < SPLIT_OPS) {
-        constexpr int g = I / 30, k0 = I % 30;
-        if constexpr (k0 < 4) { constexpr int e = 4 * g + k0; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
-        else if constexpr (k0 < 8) { constexpr int e = 4 * g + k0 - 4; s.x[e] = pin_relu(s.x[e]); }
-        else {
-            constexpr int k = k0 - 8;
-            if constexpr (k < 2) { constexpr int P = 2 * g + k; s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
-            else if constexpr (k < 6) { constexpr int P = 2 * g + (k - 2) / 2, hf = (k - 2) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.h[P]) : pin_hi16(s.h[P]); }
-            else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 6) / 2, hf = (k - 6) % 2; s.r[2 * P + hf] = pin_sub(s.x[2 * P + hf], s.t[2 * P + hf]); }
-            else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-            else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 12) / 2, hf = (k - 12) % 2; s.t[2 * P + hf] = hf == 0 ? pin_shl16(s.m[P]) : pin_hi16(s.m[P]); }
-            else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 16) / 2, hf = (k - 16) % 2; s.r[2 * P + hf] = pin_sub(s.r[2 * P + hf], s.t[2 * P + hf]); }
-            else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        }
+        constexpr int g = I / 22, k = I % 22;
+        if constexpr (k < 4) { constexpr int e = 4 * g + k; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
+        else if constexpr (k < 8) { constexpr int e = 4 * g + k - 4; s.x[e] = pin_relu_clamp(s.x[e]); }
+        else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 8); s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
+        else if constexpr (k < 14) { constexpr int e = 4 * g + (k - 10); s.r[e] = pin_mul32(s.x[e]); }
+        else if constexpr (k < 18) { constexpr int e = 4 * g + (k - 14); s.r[e] = (e & 1) ? pin_res_hi(s.h[e >> 1], s.r[e]) : pin_res_lo(s.h[e >> 1], s.r[e]); }
+        else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 18); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+        else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_scale_dn(s.h[P]); }
     }
 }
 template <int ABL, int I> __device__ __forceinline__ void split_all(SplitState &s) {     // back to back (layer transitions)
@@ -130,9 +144,9 @@ template <int ABL, int I> __device__ __forceinline__ void split_all(SplitState &
 }
 __device__ __forceinline__ B3 split_result(const SplitState &s) {
     B3 b;
-    b.h = __builtin_bit_cast(bf16x8, make_uint4(s.h[0], s.h[1], s.h[2], s.h[3]));
-    b.m = __builtin_bit_cast(bf16x8, make_uint4(s.m[0], s.m[1], s.m[2], s.m[3]));
-    b.l = __builtin_bit_cast(bf16x8, make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]));
+    b.h = __builtin_bit_cast(f16x8, make_uint4(s.h[0], s.h[1], s.h[2], s.h[3]));
+    b.m = __builtin_bit_cast(f16x8, make_uint4(s.m[0], s.m[1], s.m[2], s.m[3]));
+    b.l = __builtin_bit_cast(f16x8, make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]));
     return b;
 }
 
@@ -175,8 +189,10 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
                 const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
                 v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
             }
-            unsigned hh, mm, ll;
-            split3_pair(v[0], v[1], hh, mm, ll);
+            // A-side terms: h = fp16(w), m = h * 2^-5 (pairs with the scaled residual of x), l = fp16(32 * (w - h))
+            const unsigned hh = cvt_pk_f16(v[0], v[1]);
+            const unsigned mm = pk_mul_f16(hh, F16_2_M5_PK);
+            const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
             w[p] = term == 0 ? hh : term == 1 ? mm : ll;
         }
     }
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
 // With one wave per SIMD nothing else hides those latencies.
 constexpr int NSLOT = 3;
 
-struct AF { bf16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
+struct AF { f16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
 
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
 constexpr int SEG_SLOTS = 16;                                 // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
@@ -238,7 +254,7 @@ __device__ long long g_prof[1024 * PROF_N];
 #define PROF_DUMP
 #endif
 
-template <int ABL, bool SEGMAX>   // ABL: bench-only ablation: 1 = no stores, 2 = no bf16 split, 4 = no W streaming / barriers
+template <int ABL, bool SEGMAX>   // ABL: bench-only ablation: 1 = no stores, 2 = no operand split, 4 = no W streaming / barriers
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
     float *__restrict__ y, int L, int tpc /*128-point tiles per cloud*/, long long ntiles,
@@ -343,17 +359,21 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
         dma_setup(n_cur + 2, slot_fill);                        // lands during this stage, published by the next barrier
     };
-#define PF_LDA(base, slice) __builtin_bit_cast(bf16x8, (base)[(slice) * 64])
+#define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
 #define PF_MF(accarr, tbase, NT, fa, fb, u)                                                          \
-    if constexpr ((u) < (NT)) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0);
-    // VALU slot behind MFMA u of term TERM: terms 1..5 carry the 60 affine+split ops of the next step's B chunk, two
-    // per MFMA at 6 tiles, three at 4 tiles (the first term leaves the coefficient reads time to land).
+    if constexpr ((u) < (NT)) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0);
+    // VALU slot behind MFMA number q = TERM * NT + u of the step: the 44 affine+split ops of the next step's B chunk
+    // start after the first PF_SKIP MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles, 5 at 4.
 #define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
-    if constexpr (HAVE && (TERM) >= 1) {                                                             \
-        constexpr int ops_ = (NT) >= 6 ? 2 : 3, f_ = ops_ * (((TERM) - 1) * (NT) + (u));             \
-        split_op<ABL, f_>(sp_); split_op<ABL, f_ + 1>(sp_);                                          \
-        if constexpr (ops_ == 3) split_op<ABL, f_ + 2>(sp_);                                         \
+    if constexpr (HAVE) {                                                                            \
+        constexpr int skip_ = (NT) >= 6 ? 3 : 2, q_ = (TERM) * (NT) + (u) - skip_;                   \
+        constexpr int ops_ = (SPLIT_OPS + 3 * (NT) - skip_ - 1) / (3 * (NT) - skip_);                \
+        if constexpr (q_ >= 0) {                                                                     \
+            split_op<ABL, ops_ * q_>(sp_); split_op<ABL, ops_ * q_ + 1>(sp_); split_op<ABL, ops_ * q_ + 2>(sp_); \
+            if constexpr (ops_ > 3) { split_op<ABL, ops_ * q_ + 3>(sp_); split_op<ABL, ops_ * q_ + 4>(sp_); } \
+            static_assert(ops_ <= 5, "slot width");                                                  \
+        }                                                                                            \
     }
 #define PF_DMA_AFTER(NT, u)                                                                          \
     if constexpr (so_ == 0 && !(ABL & 4) && !(ABL & 64)) {                                            \
@@ -382,18 +402,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #define PF_TERM_V(accarr, tbase, NT, fa, fb, HAVE, ti)                                               \
     PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 0) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 1) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 2) \
     PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 3) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 4) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 5)
-    // One step = one K chunk (16 channels) x NT cout tiles = 6 NT MFMAs, the six product terms TERM-major across the
-    // tiles (consecutive MFMAs never share an accumulator), in the order l.h m.m m.h h.l h.m h.h.  It is scheduled by
-    // hand (sched_barrier after every MFMA), because with one wave per SIMD nothing else hides a latency:
+    // One step = one K chunk (16 channels) x NT cout tiles = 3 NT MFMAs: the three product terms l, m, h TERM-major
+    // across the tiles (consecutive MFMAs never share an accumulator).  It is scheduled by hand (sched_barrier after
+    // every MFMA), because with one wave per SIMD nothing else hides a latency:
     //  - on entry af.l / af.m already hold this step's fragments (read by the step before; COLD steps -- first of a
     //    tile / of a layer-4 pass -- read them first thing, from the ring slot that is about to become current);
     //  - a step that opens a stage waits for its own LDS-DMA slices, takes the barrier, and issues the NSW slices of
     //    the stage after next between the MFMAs of the first term;
-    //  - `h` is read after the first term and not needed before the 4th; the freed `l` registers take the NEXT step's
-    //    `l` after the second term (from the next ring slot when that step opens a stage: published one barrier
-    //    earlier), `m` likewise after the fourth: no second fragment set, and never more than 12 LDS reads in
-    //    flight (with 18 hipcc falls back to lgkmcnt(0) and the h-terms wait for reads issued just before them);
-    //  - the next step's B chunk is split (fp32 -> 3 x bf16) 2-3 VALU instructions per MFMA behind terms 2..5
+    //  - `h` is read after the first term (used two terms later); the freed `l` registers take the NEXT step's `l`
+    //    after the second term (from the next ring slot when that step opens a stage: published one barrier
+    //    earlier), `m` likewise after the third: no second fragment set, <= 12 LDS reads in flight;
+    //  - the next step's B chunk gets its affine + ReLU + split a few VALU instructions behind each MFMA
     //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
 #define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, EXTRA)  \
     {                                                                                                \
@@ -408,19 +427,16 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;                                            \
         { CHUNKCODE }                                                                                \
         PF_SB                                                                                        \
-        PF_TERM_A(accarr, tbase, NT, af.l, bcur.h, HAVE)                                                 \
+        PF_TERM_A(accarr, tbase, NT, af.l, bcur.l, HAVE)                                             \
         _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(lds_cur, so_ + 3 * u_);  \
         PF_SB                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.m, bcur.m, HAVE, 1)                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + 3 * u_ + 2); \
         PF_SB                                                                                        \
         EXTRA                                                                                        \
-        PF_TERM_V(accarr, tbase, NT, af.m, bcur.h, HAVE, 2)                                          \
-        PF_TERM_V(accarr, tbase, NT, af.h, bcur.l, HAVE, 3)                                          \
+        PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.m[u_] = PF_LDA(nb_, son_ + 3 * u_ + 1); \
         PF_SB                                                                                        \
-        PF_TERM_V(accarr, tbase, NT, af.h, bcur.m, HAVE, 4)                                          \
-        PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 5)                                         \
         if constexpr (HAVE) bnext = split_result(sp_);                                               \
     }
     // raw values of K chunk kc of an activation array (registers 8q..8q+7 of tile kc>>1) + their 8 (scale, shift)
