@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (BASELINE configs[4]: 512 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["x3", "f32"], default=None,
+    ap.add_argument("--precision", choices=["h3", "x3", "f32"], default=None,
                     help="point-wise layer arithmetic: x3 = 3xbf16 split on bf16 MFMA (default), f32 = exact f32 MFMA")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the BASELINE metric (default); train = forward+backward+gradient all-reduce+Adam "
@@ -247,7 +247,8 @@ def main():
 
     if rank != 0:
         return
-    dtype = ("f32 (3xbf16-split operands on bf16 MFMA, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "x3"
+    dtype = ("f32 (operands split into fp16 pieces, 3 fp16 MFMAs per product, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "h3"
+             else "f32 (3xbf16-split operands on bf16 MFMA, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "x3"
              else "f32 (exact f32 MFMA)")
     summ = rec.summary()
     kernels = []
@@ -258,7 +259,7 @@ def main():
         if amount:
             if bound == "mfma":
                 ach = amount / (s["mean_ms"] * 1e-3) / 1e12
-                peak = (PEAK_H3_TFLOPS if name.startswith("pointresnet_fused") else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
+                peak = (PEAK_H3_TFLOPS if name.startswith("pointresnet_fused") else PEAK_H3_TFLOPS if name.startswith("pointmlph3") else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
                         else PEAK_F32_MFMA_TFLOPS)
                 k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
             else:

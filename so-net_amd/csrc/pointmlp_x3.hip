@@ -17,6 +17,13 @@
 //                              D as in pointmlp.hip (rows = output channels, columns = points).
 // Split cost: 11 VALU per value pair (v_cvt_pk_bf16_f32, unpack, exact f32 subtract) = 44 per chunk per lane,
 // on the VALU pipe, while the 6*MT MFMAs of the chunk run on the matrix pipe.
+//
+// F16 variant (sonet_pointmlp_h3_*): the same kernel on v_mfma_f32_32x32x16_f16 with a THREE-term split,
+//      x = xh + xm,  xh = fp16(x):   W.x ~= Wh.xh + (Wh*2^-5).fp16(32 xm) + fp16(32 Wm).(xh*2^-5)
+// (dropped terms and the rounding of the scaled residuals <= 2^-22 relative; the 2^5 / 2^-5 pair keeps the residuals out
+// of the fp16 subnormals).  Same 3e-6 accuracy on the fixtures at half the MFMAs, but an fp16 operand RANGE: inputs are
+// clamped to +-65504 and magnitudes below ~1e-4 lose relative precision -- fine for coordinates and normalised
+// activations (forward), not for gradients: the dgrad launches of the backward keep the bf16 split.
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -24,6 +31,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int X3_THREADS = 256;
@@ -44,7 +54,23 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, uns
     l = cvt_pk_bf16(q0, q1);
 }
 
-// Wp3[ct][kc][term][lane] (uint4 = 8 bf16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
+// fp16 flavour: (x0, x1) -> xh, fp16(32 * (x - xh)), xh * 2^-5 (packed pairs); x - fp16(x) is exact in f32
+constexpr unsigned F16_2_M5_PK = 0x28002800u;
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ void split16_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    x0 = __builtin_fminf(__builtin_fmaxf(x0, -65504.f), 65504.f);
+    x1 = __builtin_fminf(__builtin_fmaxf(x1, -65504.f), 65504.f);
+    h = cvt_pk_f16(x0, x1);
+    const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+    m = cvt_pk_f16(32.f * (x0 - (float)hv[0]), 32.f * (x1 - (float)hv[1]));
+    l = __builtin_bit_cast(unsigned, hv * __builtin_bit_cast(f16x2_t, F16_2_M5_PK));
+}
+
+// Wp3[ct][kc][term][lane] (uint4 = 8 bf16 / fp16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
+template <bool F16>
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
                                                        int Cin, int Cout, int KC, long long total)
 {
@@ -61,7 +87,14 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
         const int c = c0 + 2 * p;
         const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
         const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
-        split3_pair(w0, w1, h[p], m[p], l[p]);
+        if constexpr (F16) {
+            // A side: h = fp16(w); "m" = h * 2^-5 (meets the x residual scaled by 32); "l" = fp16(32 * (w - h)) (meets xh * 2^-5)
+            unsigned hh, res, hs;
+            split16_pair(w0, w1, hh, res, hs);
+            h[p] = hh; m[p] = hs; l[p] = res;
+        } else {
+            split3_pair(w0, w1, h[p], m[p], l[p]);
+        }
     }
     uint4 *dst = Wp3 + (r * 3) * 64 + lane;
     dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -69,7 +102,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
     dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int MT, int S>
+template <int MT, int S, bool F16>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
@@ -157,6 +190,22 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 unsigned bh[4], bm[4], bl[4];
+                if constexpr (F16) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) split16_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
+                    const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const f16x8 Bm = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));     // 32 * residual
+                    const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh * 2^-5
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 2][lane]), Bl, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 1][lane]), Bm, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 0][lane]), Bh, acc[mt], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) split3_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
                 const bf16x8 Bh = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
@@ -174,6 +223,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[mt], 0, 0, 0);
+                }
                 }
             }
         };
@@ -227,23 +277,33 @@ extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
     return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 3 * 64 * 16;     // bytes
 }
 
-extern "C" int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
+static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
 {
-    const char *what = "sonet_pointmlp_x3_pack";
     SONET_REQUIRE(W && Wp3, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
     const int KC = sonet::ceil_div(Cin, 16);
     const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
-    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                       W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
+    if (f16) hipLaunchKernelGGL(x3_pack_kernel<true>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
+    else     hipLaunchKernelGGL(x3_pack_kernel<false>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
     return sonet::launched(what);
 }
 
-extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
-                                     const float *scale, const float *shift, int relu, float *y,
-                                     int B, int Cout, int L, sonet_stream_t stream)
+extern "C" int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
 {
-    const char *what = "sonet_pointmlp_x3_f32";
+    return x3_pack_impl("sonet_pointmlp_x3_pack", false, W, Wp3, Cin, Cout, stream);
+}
+
+extern "C" int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
+{
+    return x3_pack_impl("sonet_pointmlp_h3_pack", true, W, Wp3, Cin, Cout, stream);
+}
+
+static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, const float *x2, int C2, const void *Wp3,
+                       const float *scale, const float *shift, int relu, float *y,
+                       int B, int Cout, int L, sonet_stream_t stream)
+{
     SONET_REQUIRE(x1 && Wp3 && scale && shift && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
@@ -279,8 +339,10 @@ extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, i
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
 #define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y
-#define X3_LAUNCH(MM) do { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2>), X3_ARGS); \
-                           else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1>), X3_ARGS); } while (0)
+#define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
+                                      else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
+                           else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
+                                      else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, false>), X3_ARGS); } } while (0)
     switch (MT) {
         case 6: X3_LAUNCH(6); break;
         case 4: X3_LAUNCH(4); break;
@@ -290,4 +352,18 @@ extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, i
 #undef X3_LAUNCH
 #undef X3_ARGS
     return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
+                                     const float *scale, const float *shift, int relu, float *y,
+                                     int B, int Cout, int L, sonet_stream_t stream)
+{
+    return x3_run_impl("sonet_pointmlp_x3_f32", false, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream);
+}
+
+extern "C" int sonet_pointmlp_h3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
+                                     const float *scale, const float *shift, int relu, float *y,
+                                     int B, int Cout, int L, sonet_stream_t stream)
+{
+    return x3_run_impl("sonet_pointmlp_h3_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream);
 }

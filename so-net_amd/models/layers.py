@@ -86,6 +86,8 @@ def _pack_transposed(weight2d, C1, C2):
     """Packed W[:, :C1]^T (and W[:, C1:]^T) for the dgrad launches: g_x = W^T g_raw is the same fused 1x1-conv
     kernel with the roles of the channel axes swapped."""
     mode = _ops.POINTMLP_PRECISION
+    if mode == "h3":
+        mode = "x3"                                   # gradients span the f32 exponent range: bf16 pieces, not fp16
     out = []
     lo = 0
     for Ci in (C1, C2):
@@ -93,7 +95,7 @@ def _pack_transposed(weight2d, C1, C2):
             out.append(None)
             continue
         wt = weight2d[:, lo:lo + Ci].t().contiguous().float()                  # Ci x Cout
-        m = mode if (mode != "x3" or _ops.x3_supported(wt.shape[1], 0, wt.shape[0])) else "f32"
+        m = mode if (mode == "f32" or _ops.x3_supported(wt.shape[1], 0, wt.shape[0])) else "f32"
         out.append((_ops.pointmlp_pack(wt, m), Ci))
         lo += Ci
     return out
@@ -191,7 +193,7 @@ class _FusedPointwise(nn.Module):
         """Packed weight for the current arithmetic mode (``sonet_hip.ops.POINTMLP_PRECISION``)."""
         w = self.conv.weight
         mode = _ops.POINTMLP_PRECISION
-        if mode == "x3" and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
+        if mode in ("x3", "h3") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
             mode = "f32"
         key = (w._version, w.data_ptr(), w.device, mode)
         if getattr(self, '_wp_key', None) != key:
@@ -504,7 +506,7 @@ class PointResNet(nn.Module):
         """One-kernel path: standard first-PointNet shape, eval BatchNorm + ReLU, no autograd, x3 arithmetic."""
         if self.training or torch.is_grad_enabled():             # training BN / autograd: layer-by-layer path
             return False
-        if _ops.POINTMLP_PRECISION != "x3" or not _ops.FUSE_POINTRESNET or not x.is_cuda:
+        if _ops.POINTMLP_PRECISION not in ("x3", "h3") or not _ops.FUSE_POINTRESNET or not x.is_cuda:
             return False
         if list(self.out_channels_list) != [64, 128, 256, 384] or x.shape[1] > 16:
             return False

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_h3_pack": [_vp, _vp, _i, _i, _vp],
+    "sonet_pointmlp_h3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointresnet_pack_size": [],
     "sonet_pointresnet_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sonet_pointresnet_fused_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],

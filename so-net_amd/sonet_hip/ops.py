@@ -247,9 +247,12 @@ import os as _os
 
 # arithmetic of the fused point-wise layer:
 #   "f32": exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an f32 fma chain
-#   "x3" : bf16 MFMA on a 3-way bf16 split of both operands, f32 accumulate (DEFAULT: f32-class accuracy --
-#          the reference fixtures are met at the same 1e-5 tolerance -- and 1.4-1.7x faster)
-POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "x3")
+#   "x3" : bf16 MFMA on a 3-way bf16 split of both operands (six terms), f32 accumulate: f32-class accuracy (the
+#          reference fixtures are met at the same 1e-5 tolerance), f32 operand range, 1.4-1.7x faster than "f32"
+#   "h3" : fp16 MFMA on a two-piece fp16 split with scaled residuals (three terms): the same accuracy at half the
+#          matrix work, fp16 operand RANGE (|x| <= 65504 clamped, relative precision fades below ~1e-4) -- DEFAULT for
+#          the forward layers (coordinates, normalised activations); gradients (dgrad) always use "x3"
+POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "h3")
 
 
 # run the encoder's first PointNet (eval mode, "x3" arithmetic) as one fused kernel
@@ -272,6 +275,9 @@ def pointmlp_pack(weight2d, mode="f32"):
         if mode == "x3":
             wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin, Cout),), dtype=torch.uint8, device=dev)
             check(lib.sonet_pointmlp_x3_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_x3_pack")
+        elif mode == "h3":                                   # same size; int8 marks the fp16 flavour
+            wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin, Cout),), dtype=torch.int8, device=dev)
+            check(lib.sonet_pointmlp_h3_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_h3_pack")
         else:
             wp = torch.empty((lib.sonet_pointmlp_pack_size(Cin, Cout),), dtype=torch.float32, device=dev)
             check(lib.sonet_pointmlp_pack_f32(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_pack_f32")
@@ -292,15 +298,16 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
     _chk(shift, "shift", torch.float32, 1)
     dev = _same_device(x1, x2, wp, scale, shift)
     lib = _lib.load()
-    x3 = wp.dtype == torch.uint8
+    h3 = wp.dtype == torch.int8
+    x3 = wp.dtype == torch.uint8 or h3
     want = lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout) if x3 else lib.sonet_pointmlp_pack_size(C1 + C2, Cout)
     if wp.numel() != want:
         raise SonetHipError("packed weight has %d elements, expected %d for Cin=%d Cout=%d" % (wp.numel(), want, C1 + C2, Cout))
     y = out if out is not None else torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
     if y.numel() == 0:
         return y
-    fn = lib.sonet_pointmlp_x3_f32 if x3 else lib.sonet_pointmlp_f32
-    with torch.cuda.device(dev), _timed("pointmlp%s_%dx%d_L%d" % ("x3" if x3 else "", C1 + C2, Cout, L)):
+    fn = lib.sonet_pointmlp_h3_f32 if h3 else lib.sonet_pointmlp_x3_f32 if x3 else lib.sonet_pointmlp_f32
+    with torch.cuda.device(dev), _timed("pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)):
         check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
                  B, Cout, L, stream_ptr()), "sonet_pointmlp")
     return y

@@ -349,8 +349,9 @@ def x3_mode():
     (2, 6, 0, 64, 300, True, True), (2, 64, 0, 128, 768, True, True), (1, 64, 256, 384, 1000, False, False),
     (3, 387, 0, 512, 576, True, True), (4, 515, 0, 768, 64, True, True), (2, 768, 0, 1024, 64, False, False),
     (2, 100, 0, 96, 77, False, True), (1, 3, 0, 32, 1, True, True), (2, 16, 16, 64, 40, False, False)])
-def test_pointmlp_x3_vs_oracle(B, C1, C2, Cout, L, bn, relu):
-    """bf16x3 split MFMA path: f32-class accuracy (same 1e-5 tolerance as the exact-f32 path)."""
+@pytest.mark.parametrize("split", ["x3", "h3"])
+def test_pointmlp_x3_vs_oracle(B, C1, C2, Cout, L, bn, relu, split):
+    """Split-operand MFMA paths (six bf16 terms / three fp16 terms): f32-class accuracy, the exact-f32 path's 1e-5 tolerance."""
     from oracle import cpu_oracle as O
     from sonet_hip import ops
     g = torch.Generator().manual_seed(C1 + Cout + L)
@@ -368,12 +369,12 @@ def test_pointmlp_x3_vs_oracle(B, C1, C2, Cout, L, bn, relu):
     else:
         scale, shift = torch.ones(Cout), bias
         ref = O.pointwise_layer(x.numpy(), W.numpy(), bias.numpy(), bn=None, relu=relu)
-    wp = ops.pointmlp_pack(W.to(DEV), "x3")
-    assert wp.dtype == torch.uint8
+    wp = ops.pointmlp_pack(W.to(DEV), split)
+    assert wp.dtype == (torch.uint8 if split == "x3" else torch.int8)
     x1 = x[:, :C1].contiguous().to(DEV)
     x2 = x[:, C1:].contiguous().to(DEV) if C2 else None
     y = ops.pointmlp(x1, wp, scale.to(DEV), shift.to(DEV), relu, Cout, x2=x2)
-    assert_close_rms(y.cpu().numpy(), ref, 1e-5, "pointmlp x3")
+    assert_close_rms(y.cpu().numpy(), ref, 1e-5, "pointmlp " + split)
 
 
 @pytest.fixture
@@ -438,7 +439,7 @@ def test_pointresnet_fused_vs_layerwise_and_golden():
 
 
 # ------------------------------------------------------------------------------------------ segmenter (config 3)
-@pytest.mark.parametrize("mode", ["x3", "f32"])
+@pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
 def test_segmenter_forward_golden(mode):
     """Part-segmentation forward (level-2 encoder + back-broadcast gathers + Segmenter head) vs the reference."""
     from models import networks as NW
@@ -473,7 +474,7 @@ def test_segmenter_forward_golden(mode):
 
 
 # ------------------------------------------------------------------------------------------ autoencoder (config 4)
-@pytest.mark.parametrize("mode", ["x3", "f32"])
+@pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
 def test_autoencoder_forward_and_chamfer_golden(mode):
     """Encoder -> FC + conv decoder -> multi-resolution Chamfer loss (models/autoencoder.py:62-125) vs the reference
     run with an exact flat-L2 search in place of faiss; gradient of the loss w.r.t. the predicted cloud."""
@@ -560,7 +561,7 @@ def test_node_gather_vs_torch():
 
 
 # ------------------------------------------------------------------------------------------ training step (configs 2 / 5)
-@pytest.mark.parametrize("mode", ["x3", "f32"])
+@pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
 def test_classifier_training_step_golden(mode):
     """One training step (train-mode BN, backward, two Adam steps) vs the reference's Model.optimize."""
     from models import networks as NW
@@ -645,7 +646,7 @@ def test_backward_components_vs_float64():
             r = F.batch_norm(r, None, None, l.norm.weight.detach().double(), l.norm.bias.detach().double(), True, 0.1, 1e-5)
         return F.relu(r) if l.activation == "relu" else r
 
-    for mode in ("x3", "f32"):
+    for mode in ("h3", "x3", "f32"):
         old = ops.POINTMLP_PRECISION
         ops.POINTMLP_PRECISION = mode
         try:
