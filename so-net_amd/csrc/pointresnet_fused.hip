@@ -219,28 +219,6 @@ __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -
     const unsigned o = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
     return (bits & 0x7FFFFFFFu) > 0x7F800000u ? 0u : o;
 }
-__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned dpp_max(unsigned v) {
-    return umax_(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false));
-}
-
-// max over the 32 lanes of each half-wave, result in lanes 31 / 63, for eight registers at once.  One v_max_f32 with a
-// DPP source per step (lanes without a source keep their value); the eight independent chains are interleaved so a
-// dependent DPP read is 8 instructions behind the write it needs (hipcc does not pad inline asm; with 4 chains the
-// dependent-DPP latency showed).
-__device__ __forceinline__ void dpp_halfwave_max8(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &hh) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(hh));
-}
-
 #ifdef SONET_PROF
 // Profiling build only (make prof; tools/fused_phases.py): per-wave shader-clock cycles spent in each phase.
 constexpr int PROF_N = 32;
@@ -262,7 +240,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/)
 {
     __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
-    __shared__ float4 segst[SEGMAX ? PF_WAVES : 1][SEGMAX ? 8 * MT4 : 1];   // per wave: one node's 192 reduced maxima
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 36 KiB
     __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
 
@@ -361,8 +338,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     };
 #define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
+    // PF_SWAP (layer 4 of the pool variant): X as the A operand, W as B -> the accumulator tile comes out transposed
+    // (rows = points, columns = channels); the per-lane register contents of both operands are the same either way.
 #define PF_MF(accarr, tbase, NT, fa, fb, u)                                                          \
-    if constexpr ((u) < (NT)) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0);
+    if constexpr ((u) < (NT)) {                                                                      \
+        if constexpr (PF_SWAP) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa[u], accarr[(tbase) + (u)], 0, 0, 0); \
+        else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0); \
+    }
     // VALU slot behind MFMA number q = TERM * NT + u of the step: the 44 affine+split ops of the next step's B chunk
     // start after the first PF_SKIP MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles, 5 at 4.
 #define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
@@ -416,6 +398,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
 #define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, EXTRA)  \
     {                                                                                                \
+        constexpr bool PF_SWAP = SEGMAX && ((sidx) >= PRE);                                          \
         constexpr int so_ = (sidx) % NSTG, son_ = (SIDXN) % NSTG;                                    \
         SplitState sp_;                                                                              \
         if (COLD) {                                                                                  \
@@ -493,15 +476,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 
         // per-node max-pool bookkeeping of this wave's 32 (node-sorted) points
         int nid = -1, n0 = 0, jpos0 = -1, nslots = 0;
-        float *v0_lane = nullptr;
-        const float2 *aff_l4 = aff + 32 * (T0 + T1 + T2) + 4 * h;
         if constexpr (SEGMAX) {
             nid = nid_n;
             n0 = n0_n;
             nslots = nlast_n - n0_n + 1 < SEG_SLOTS ? nlast_n - n0_n + 1 : SEG_SLOTS;
             const int p0 = pos0_n - l0;
             jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
-            v0_lane = v0 + b * (32 * T3) + 4 * h;
             if (tile == blockIdx.x)                                               // first tile of this workgroup: clear the bins
                 for (int i = threadIdx.x; i < SEG_SLOTS * 32 * MT4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
         }
@@ -585,72 +565,79 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             if constexpr (SEGMAX) {
                 // ---- per-node max-pool of this pass's 192 channels (replaces index_max + masked gather,
                 //      models/networks.py:180-185, for the no-grad path: only the VALUES are needed) ----
-                // 1) affine in place, features of original copy 0 (wave-uniform branch: one wave per cloud)
+                // Layer 4 of this variant runs with the MFMA operands swapped (PF_MF ... SWAP): the accumulators are
+                // TRANSPOSED, acc[mt][r] = Y[point prow(r)][channel 32 mt + j] with prow(r) = (r&3) + 8 (r>>2) + 4 h, so the
+                // maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a 5-step
+                // cross-lane reduction of every register (80 DPP ops per tile); the two half-waves (16 points each)
+                // meet in the LDS atomic.
+                // 1) affine in place (one coefficient pair per lane and tile); features of original copy 0
 #pragma unroll
-                for (int mt = 0; mt < MT4; ++mt)
+                for (int mt = 0; mt < MT4; ++mt) {
+                    const float2 ss = aff[32 * (T0 + T1 + T2) + (pass * MT4 + mt) * 32 + j];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float2 ss = aff_l4[(pass * MT4 + mt) * 32 + (r & 3) + 8 * (r >> 2)];
-                        acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                    }
-                if (jpos0 >= 0) {
-                    if (j == jpos0) {
-#pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) v0_lane[(pass * MT4 + mt) * 32 + (r & 3) + 8 * (r >> 2)] = acc[mt][r];
-                    }
+                    for (int r = 0; r < 16; ++r) acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
                 }
-                // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted): mask the other
-                //    points to -inf, DPP-reduce the 32 lanes of each half-wave to lanes 31 / 63 (v_max_f32 ignores a NaN
-                //    operand, as the reference's '>' does), and let those two lanes publish -- to the LDS bins of the
-                //    workgroup's first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
-                if constexpr (!(ABL & 16)) {
-                unsigned long long remaining = __ballot(pv);
-                while (remaining != 0ull) {
-                    const int lead = __builtin_ctzll(remaining);
-                    const int node = __builtin_amdgcn_readlane(nid, lead);
-                    const unsigned long long segmask = __ballot(pv && nid == node);
-                    remaining &= ~segmask;
-                    const bool inseg = pv && nid == node;
-                    const int slot = node - n0;
-                    const bool to_lds = slot < SEG_SLOTS;
+                if (jpos0 >= 0) {                                                 // wave-uniform: one wave per cloud
 #pragma unroll
-                    for (int mt = 0; mt < MT4; ++mt)
+                    for (int r = 0; r < 16; ++r)
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0) {
 #pragma unroll
-                        for (int r = 0; r < 16; r += 8) {
-                            float w_[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) w_[q] = inseg ? acc[mt][r + q] : -__builtin_inff();
-                            dpp_halfwave_max8(w_[0], w_[1], w_[2], w_[3], w_[4], w_[5], w_[6], w_[7]);
-                            if constexpr (!(ABL & 32)) {
-                                // rows r..r+3 / r+4..r+7 are 4 consecutive channels each: lanes 31 / 63 park them in LDS
-                                if (j == 31) {
-                                    segst[wave][mt * 8 + 2 * (r >> 2) + h] = make_float4(w_[0], w_[1], w_[2], w_[3]);
-                                    segst[wave][mt * 8 + 2 * (r >> 2) + 2 + h] = make_float4(w_[4], w_[5], w_[6], w_[7]);
-                                }
-                            } else { asm volatile("" ::"v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3]), "v"(w_[4]), "v"(w_[5]), "v"(w_[6]), "v"(w_[7])); }
+                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = acc[mt][r];
                         }
+                }
+                // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted, so a node's points
+                //    are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's '>'
+                //    does), published by integer atomicMax on orderable keys -- to the LDS bins of the workgroup's
+                //    first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
+                if constexpr (!(ABL & 16)) {
+                unsigned remaining = (unsigned)__ballot(pv);                      // lanes 0..31 <-> the wave's 32 points
+                const int nvalid = __builtin_popcount(remaining);
+                while (remaining != 0u) {
+                    const int s0 = __builtin_ctz(remaining);
+                    const int node = __builtin_amdgcn_readlane(nid, s0);
+                    const unsigned segmask = (unsigned)__ballot(pv && nid == node);
+                    remaining &= ~segmask;
+                    const int e0 = s0 + __builtin_popcount(segmask);
+                    const bool whole = (s0 == 0 && e0 == 32);
+                    const int slot = node - n0;
+                    float mx[MT4];
+                    if (whole) {
+#pragma unroll
+                        for (int mt = 0; mt < MT4; ++mt) {
+                            float m = acc[mt][0];
+#pragma unroll
+                            for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][r]));
+                            mx[mt] = m;
+                        }
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = -__builtin_inff();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const bool in = prow >= s0 && prow < e0;
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) {
+                                const float v = in ? acc[mt][r] : -__builtin_inff();
+                                asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));
+                            }
+                        }
+                    }
+                    (void)nvalid;
                     if constexpr (!(ABL & 32)) {
-                        // ... and all 64 lanes publish them, 3 channels each (2 lanes x 96 LDS atomics cost 0.2 ms per launch)
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const float *st = reinterpret_cast<const float *>(&segst[wave][0]);
                         // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
                         // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
-                        if (to_lds) {
+                        if (slot < SEG_SLOTS) {
 #pragma unroll
-                            for (int i = 0; i < 32 * MT4 / 64; ++i)
-                                atomicMax(&bins[slot][lane + 64 * i], ord_f32(__float_as_uint(st[lane + 64 * i])));
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(&bins[slot][32 * mt + j], ord_f32(__float_as_uint(mx[mt])));
                         } else {
                             unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * (32 * MT4);
 #pragma unroll
-                            for (int i = 0; i < 32 * MT4 / 64; ++i)
-                                atomicMax(gdst + lane + 64 * i, ord_f32(__float_as_uint(st[lane + 64 * i])));
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < MT4; ++mt) asm volatile("" ::"v"(mx[mt]));
                     }
                 }
                 }

@@ -39,7 +39,7 @@ assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
 p = buf.reshape(1024, NP).astype(np.float64)
 tiles = B * ((15000 + 127) // 128) / 256.0
 names = ["kernel prologue", "tile prologue", "(unused)", "layer-4 MFMA passes", "epilogue", "tail", "layer 1", "(unused)"] + ["mid step %d" % i for i in range(20)]
-ideal = [0, 0, 0, 2 * 720 * 32, 0, 0, 2 * 6 * 32, 0] + [24 * 32] * 20
+ideal = [0, 0, 0, 2 * 360 * 32, 0, 0, 2 * 3 * 32, 0] + [12 * 32] * 20
 tot = p.sum(1).mean()
 print("mode %s: %.0f cycles per wave (%.3f ms at 2.39 GHz), %.1f tiles per workgroup" % (mode, tot, tot / 2.39e6, tiles))
 for i, n in enumerate(names):
