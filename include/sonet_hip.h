@@ -120,6 +120,14 @@ int sonet_node_gather_f32(const float *feat, const int32_t *min_idx_i32, float *
 int sonet_knn_gather_f32(const float *x, const int64_t *knn_I, float *out,
                          int B, int C, int M, int K, sonet_stream_t stream);
 
+/* KNNModule input in one pass (models/layers.py:313-350): out [B][3+C][M][K] = cat(coord[:, I] - center, feat[:, I]),
+ * center [B][3][M] = mean of the K neighbour coordinates (center_avg != 0) or the node itself.  knn_I [B][M][K] i64. */
+int sonet_knn_group_f32(const float *coord, const float *feat, const int64_t *knn_I, int B, int C, int M, int K,
+                        int center_avg, float *center, float *out, sonet_stream_t stream);
+/* out[row] = max over the K contiguous values of each of `rows` rows (NaN propagates, as torch.amax):
+ * the neighbourhood max of KNNModule (models/layers.py:365) and the max over nodes (models/networks.py:197). */
+int sonet_lastdim_max_f32(const float *x, float *out, long long rows, int K, sonet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * pointmlp  -- fused point-wise layer: Conv1d/Conv2d(kernel 1) + per-channel affine + ReLU
  *   reference: models/layers.py:282-296 (EquivariantLayer.forward), :199-211 (MyConv2d.forward),

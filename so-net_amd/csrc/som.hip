@@ -184,6 +184,59 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict
     out[t] = ((unsigned long long)id < (unsigned long long)M) ? x[bc * M + id] : 0.f;
 }
 
+// KNNModule input in one pass (models/layers.py:313-350): out[b][0:3][m][k] = coord[b][:, I[b][m][k]] - center[b][:, m],
+// out[b][3:3+C][m][k] = feat[b][:, I[b][m][k]]; center = mean over the K neighbours ("avg", sequential f32 sum / K) or
+// the node itself ("center").  Replaces two gathers, a mean, a subtraction and a 387-channel concat.
+__global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict__ coord, const float *__restrict__ feat,
+                                                         const int64_t *__restrict__ I, int C, int M, int K, int avg,
+                                                         float *__restrict__ center, float *__restrict__ out, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // over [B][3 + C][M*K]
+    if (t >= total) return;
+    const int MK = M * K, CC = 3 + C;
+    const long long bc = t / MK;
+    const int mk = (int)(t - bc * MK);
+    const long long b = bc / CC;
+    const int c = (int)(bc - b * CC);
+    const int64_t *Ib = I + b * MK;
+    const long long id = Ib[mk];
+    const bool ok = (unsigned long long)id < (unsigned long long)M;
+    if (c >= 3) {
+        out[t] = ok ? feat[(b * C + (c - 3)) * M + id] : 0.f;
+        return;
+    }
+    const float *cr = coord + (b * 3 + c) * M;
+    const int m = mk / K;
+    float ctr;
+    if (avg) {
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const long long ik = Ib[m * K + k];
+            sum += ((unsigned long long)ik < (unsigned long long)M) ? cr[ik] : 0.f;
+        }
+        ctr = sum / (float)K;
+    } else {
+        ctr = cr[m];
+    }
+    if (mk - m * K == 0) center[(b * 3 + c) * M + m] = ctr;
+    out[t] = (ok ? cr[id] : 0.f) - ctr;
+}
+
+// out[row] = max over the K contiguous values of the row (NaN wins, as torch.amax): the neighbourhood max of
+// KNNModule (K = 9) and the global max over the nodes (K = M = 64), models/layers.py:365, models/networks.py:197.
+__global__ __launch_bounds__(256) void lastdim_max_kernel(const float *__restrict__ x, float *__restrict__ out, int K, long long rows)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = x + r * K;
+    float m = p[0];
+    for (int k = 1; k < K; ++k) {
+        const float v = p[k];
+        m = (v > m || v != v) ? v : m;
+    }
+    out[r] = m;
+}
+
 // out[b][c][j] = feat[b][c][ idx[b][j] ]   (models/segmenter.py:90-98: node features broadcast back to the
 // kN point copies).  One thread per 4 consecutive j of one (b, c) row: coalesced 16-byte stores, the 256-byte
 // feature row and the id row stay in L1/L2.
@@ -386,5 +439,30 @@ extern "C" int sonet_knn_gather_f32(const float *x, const int64_t *knn_I, float 
     if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
     hipLaunchKernelGGL(knn_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
                        x, knn_I, out, C, M, K, total);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_knn_group_f32(const float *coord, const float *feat, const int64_t *knn_I, int B, int C, int M, int K,
+                                   int center_avg, float *center, float *out, sonet_stream_t stream)
+{
+    const char *what = "sonet_knn_group_f32";
+    SONET_REQUIRE(coord && feat && knn_I && center && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && K > 0, "%s: non-positive size", what);
+    const long long total = (long long)B * (3 + C) * M * K;
+    const long long blocks = sonet::ceil_div64(total, 256);
+    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
+                       coord, feat, knn_I, C, M, K, center_avg, center, out, total);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_lastdim_max_f32(const float *x, float *out, long long rows, int K, sonet_stream_t stream)
+{
+    const char *what = "sonet_lastdim_max_f32";
+    SONET_REQUIRE(x && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(rows > 0 && K > 0, "%s: non-positive size", what);
+    const long long blocks = sonet::ceil_div64(rows, 256);
+    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(lastdim_max_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream), x, out, K, rows);
     return sonet::launched(what);
 }

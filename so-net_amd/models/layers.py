@@ -441,6 +441,14 @@ class KNNModule(nn.Module):
         else:                                                              # fallback M x M kNN (layers.py:333-337)
             d = ((coord.unsqueeze(3) - coord.unsqueeze(2)) ** 2).sum(dim=1)
             _, knn_I = torch.topk(d, k=K, dim=2, largest=False, sorted=True)
+        if center_type not in ('avg', 'center'):
+            raise ValueError(center_type)
+        if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
+            # no-grad path: gathers, centre, de-centring and the concat in one kernel; max over K in one kernel
+            center, h = _ops.knn_group(coord.contiguous(), x.contiguous(), knn_I, center_type == 'avg')
+            for layer in self.layers:
+                h = layer(h, epoch)
+            return center, _ops.lastdim_max(h.contiguous())
         neighbors = operations.knn_gather_wrapper(coord, knn_I)            # B x 3 x M x K
         if center_type == 'avg':
             center = neighbors.mean(dim=3, keepdim=True)

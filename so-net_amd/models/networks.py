@@ -191,7 +191,7 @@ class Encoder(nn.Module):
         if torch.is_grad_enabled() and self.final_pn_out.requires_grad:
             self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)     # :197; amax would split the gradient over ties
         else:
-            self.feature = torch.amax(self.final_pn_out, dim=2)
+            self.feature = _ops.lastdim_max(self.final_pn_out.contiguous())
         return self.feature
 
 

@@ -227,6 +227,36 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     return t
 
 
+def knn_group(coord, feat, knn_I, center_avg):
+    """coord B x 3 x M, feat B x C x M, knn_I B x M x K i64 -> (center B x 3 x M, out B x (3+C) x M x K)."""
+    _chk(coord, "coord", torch.float32, 3)
+    _chk(feat, "feat", torch.float32, 3)
+    _chk(knn_I, "knn_I", torch.int64, 3)
+    dev = _same_device(coord, feat, knn_I)
+    B, C, M = feat.shape
+    K = knn_I.shape[2]
+    center = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
+    out = torch.empty((B, 3 + C, M, K), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("knn_group"):
+        check(_lib.load().sonet_knn_group_f32(ptr(coord), ptr(feat), ptr(knn_I), B, C, M, K, int(bool(center_avg)), ptr(center), ptr(out),
+                                              stream_ptr()), "sonet_knn_group_f32")
+    return center, out
+
+
+def lastdim_max(x):
+    """max over the last (contiguous) axis, values only; NaN propagates like torch.amax."""
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise SonetHipError("lastdim_max needs a contiguous float32 tensor")
+    dev = _same_device(x)
+    K = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(dev), _timed("lastdim_max"):
+        check(_lib.load().sonet_lastdim_max_f32(ptr(x), ptr(out), out.numel(), K, stream_ptr()), "sonet_lastdim_max_f32")
+    return out
+
+
 def knn_gather(x, knn_I):
     """x BxCxM f32, knn_I BxMxK i64 -> BxCxMxK (models/operations.py:38-54)."""
     _chk(x, "som_node", torch.float32, 3)

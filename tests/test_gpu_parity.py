@@ -535,6 +535,29 @@ def test_chamfer_loss_full_size_properties():
     assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
 
 
+def test_knn_group_and_lastdim_max_vs_torch():
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(4)
+    for B, C, M, K, avg in [(3, 384, 64, 9, True), (2, 5, 16, 4, False), (1, 1, 7, 7, True)]:
+        coord, feat = torch.randn(B, 3, M, generator=gen), torch.randn(B, C, M, generator=gen)
+        I = torch.stack([torch.stack([torch.randperm(M, generator=gen)[:K] for _ in range(M)]) for _ in range(B)])
+        idx = I.reshape(B, 1, M * K)
+        nb = torch.gather(coord, 2, idx.expand(B, 3, M * K)).reshape(B, 3, M, K)
+        center = nb.mean(dim=3, keepdim=True) if avg else coord.unsqueeze(3)
+        ref = torch.cat((nb - center, torch.gather(feat, 2, idx.expand(B, C, M * K)).reshape(B, C, M, K)), dim=1)
+        c, out = ops.knn_group(coord.to(DEV), feat.to(DEV), I.to(DEV), avg)
+        assert torch.allclose(c.cpu(), center.squeeze(3), rtol=1e-6, atol=1e-6)
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+        assert torch.equal(out[:, 3:].cpu(), ref[:, 3:])
+    x = torch.randn(5, 17, 64, 9, generator=gen)
+    x[0, 0, 0, 3] = float("nan")
+    got = ops.lastdim_max(x.to(DEV)).cpu()
+    ref = torch.amax(x, dim=3)
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(got[~torch.isnan(ref)], ref[~torch.isnan(ref)])
+    y = torch.randn(4, 1024, 64, generator=gen)
+    assert torch.equal(ops.lastdim_max(y.to(DEV)).cpu(), torch.amax(y, dim=2))
+
+
 def test_node_add_affine_act_vs_torch():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(2)
