@@ -189,23 +189,21 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict
 // the node itself ("center").  Replaces two gathers, a mean, a subtraction and a 387-channel concat.
 __global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict__ coord, const float *__restrict__ feat,
                                                          const int64_t *__restrict__ I, int C, int M, int K, int avg,
-                                                         float *__restrict__ center, float *__restrict__ out, long long total)
+                                                         float *__restrict__ center, float *__restrict__ out)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // over [B][3 + C][M*K]
-    if (t >= total) return;
     const int MK = M * K, CC = 3 + C;
-    const long long bc = t / MK;
-    const int mk = (int)(t - bc * MK);
-    const long long b = bc / CC;
-    const int c = (int)(bc - b * CC);
-    const int64_t *Ib = I + b * MK;
+    const int mk = blockIdx.x * 256 + threadIdx.x;                       // position inside the (b, c) row
+    if (mk >= MK) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t *Ib = I + (size_t)b * MK;
     const long long id = Ib[mk];
     const bool ok = (unsigned long long)id < (unsigned long long)M;
+    float *o = out + ((size_t)b * CC + c) * MK;
     if (c >= 3) {
-        out[t] = ok ? feat[(b * C + (c - 3)) * M + id] : 0.f;
+        o[mk] = ok ? feat[((size_t)b * C + (c - 3)) * M + id] : 0.f;
         return;
     }
-    const float *cr = coord + (b * 3 + c) * M;
+    const float *cr = coord + ((size_t)b * 3 + c) * M;
     const int m = mk / K;
     float ctr;
     if (avg) {
@@ -218,23 +216,31 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict_
     } else {
         ctr = cr[m];
     }
-    if (mk - m * K == 0) center[(b * 3 + c) * M + m] = ctr;
-    out[t] = (ok ? cr[id] : 0.f) - ctr;
+    if (mk - m * K == 0) center[((size_t)b * 3 + c) * M + m] = ctr;
+    o[mk] = (ok ? cr[id] : 0.f) - ctr;
 }
 
 // out[row] = max over the K contiguous values of the row (NaN wins, as torch.amax): the neighbourhood max of
 // KNNModule (K = 9) and the global max over the nodes (K = M = 64), models/layers.py:365, models/networks.py:197.
+template <int TPR>   // threads per row (power of two <= 64): each reads a strided share of the row, then a shuffle tree
 __global__ __launch_bounds__(256) void lastdim_max_kernel(const float *__restrict__ x, float *__restrict__ out, int K, long long rows)
 {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float *p = x + r * K;
-    float m = p[0];
-    for (int k = 1; k < K; ++k) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / TPR;
+    const int q = (int)(t % TPR);
+    const bool live = r < rows;
+    const float *p = x + (live ? r : 0) * K;
+    float m = p[q < K ? q : 0];
+    for (int k = q + TPR; k < K; k += TPR) {
         const float v = p[k];
         m = (v > m || v != v) ? v : m;
     }
-    out[r] = m;
+#pragma unroll
+    for (int off = TPR >> 1; off > 0; off >>= 1) {
+        const float v = __shfl_xor(m, off, 64);
+        m = (v > m || v != v) ? v : m;
+    }
+    if (live && q == 0) out[r] = m;
 }
 
 // out[b][c][j] = feat[b][c][ idx[b][j] ]   (models/segmenter.py:90-98: node features broadcast back to the
@@ -319,23 +325,52 @@ __global__ __launch_bounds__(SG_THREADS) void som_sort_group_kernel(
     __syncthreads();
     for (int m = tid; m < M; m += SG_THREADS) base[m] = hist[m] ? atomicAdd(&cursor[(size_t)b * M + m], hist[m]) : 0;
     __syncthreads();
-    const float *xb = x + (size_t)b * 3 * N;
-    const float *snb = sn + (size_t)b * 3 * N;
+    // Phase A ends here: only the source copy index (parked, as raw bits, in channel plane 5 of x_aug_sorted, where
+    // the same thread of phase B overwrites it with the value) and the node id go to their sorted position.  Writing the
+    // six channels from here scattered 4-byte stores over six planes: 80 MB of HBM writes for 27 MB of payload.
+    int32_t *src_plane = reinterpret_cast<int32_t *>(x_aug_sorted + ((size_t)b * 6 + 5) * kN);
 #pragma unroll
     for (int i = 0; i < SG_PER_THREAD; ++i) {
         const size_t j = j0 + (size_t)i * SG_THREADS;
         if (id[i] < 0) continue;
         const int m = id[i];
         const size_t pos = (size_t)(offs[m] + base[m] + rk[i]);
-        const int n = (int)(j % (size_t)N);
         ids_sorted[(size_t)b * kN + pos] = m;
+        src_plane[pos] = (int32_t)j;
         if (j == 0) pos0[b] = (int)pos;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            x_aug_sorted[((size_t)b * 6 + c) * kN + pos] = __fsub_rn(xb[(size_t)c * N + n], mean[c * M + m]);
-            x_aug_sorted[((size_t)b * 6 + 3 + c) * kN + pos] = snb[(size_t)c * N + n];
-        }
     }
+}
+
+// Phase B: one thread per sorted position: coalesced stores of the six channels; the gathers hit the cloud's 120 KB of
+// x / sn in L2.
+__global__ __launch_bounds__(256) void som_sort_fill_kernel(
+    const float *__restrict__ x, const float *__restrict__ sn, const int32_t *__restrict__ count,
+    const double *__restrict__ sum_ws, const int32_t *__restrict__ ids_sorted, int N, int M, int k, float *__restrict__ x_aug_sorted)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];          // mean[3][M]
+    float *mean = smem_f;
+    const int b = blockIdx.y;
+    const double *ws = sum_ws + (size_t)b * 3 * M;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const float denom = __fadd_rn((float)count[(size_t)b * M + m], 1e-5f);
+        mean[m] = __fdiv_rn((float)ws[m], denom);
+        mean[M + m] = __fdiv_rn((float)ws[M + m], denom);
+        mean[2 * M + m] = __fdiv_rn((float)ws[2 * M + m], denom);
+    }
+    __syncthreads();
+    const size_t kN = (size_t)k * N;
+    const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= kN) return;
+    float *ob = x_aug_sorted + (size_t)b * 6 * kN;
+    const int j = reinterpret_cast<const int32_t *>(ob + 5 * kN)[pos];
+    const int m = ids_sorted[(size_t)b * kN + pos];
+    const int n = j % N;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *snb = sn + (size_t)b * 3 * N;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ob[(size_t)c * kN + pos] = __fsub_rn(xb[(size_t)c * N + n], mean[c * M + m]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ob[(size_t)(3 + c) * kN + pos] = snb[(size_t)c * N + n];
 }
 
 }  // namespace
@@ -357,6 +392,8 @@ extern "C" int sonet_som_sort_group_f32(const float *x, const float *sn, const i
     dim3 grid((unsigned)sonet::ceil_div64(kN, SG_THREADS * SG_PER_THREAD), B), block(SG_THREADS);
     hipLaunchKernelGGL(som_sort_group_kernel, grid, block, (size_t)M * (3 * sizeof(float) + 3 * sizeof(int)), st,
                        x, sn, min_idx_i32, count, sum_ws, N, M, k, som_node, row_max, x_aug_sorted, ids_sorted, pos0, cursor_ws, node_off);
+    hipLaunchKernelGGL(som_sort_fill_kernel, dim3((unsigned)sonet::ceil_div64(kN, 256), B), dim3(256), (size_t)M * 3 * sizeof(float), st,
+                       x, sn, count, sum_ws, ids_sorted, N, M, k, x_aug_sorted);
     return sonet::launched(what);
 }
 
@@ -448,11 +485,9 @@ extern "C" int sonet_knn_group_f32(const float *coord, const float *feat, const 
     const char *what = "sonet_knn_group_f32";
     SONET_REQUIRE(coord && feat && knn_I && center && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && K > 0, "%s: non-positive size", what);
-    const long long total = (long long)B * (3 + C) * M * K;
-    const long long blocks = sonet::ceil_div64(total, 256);
-    if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
-    hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream),
-                       coord, feat, knn_I, C, M, K, center_avg, center, out, total);
+    if (B > 65535 || 3 + C > 65535 || (long long)M * K > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)sonet::ceil_div(M * K, 256), (unsigned)(3 + C), (unsigned)B), dim3(256), 0,
+                       sonet::as_stream(stream), coord, feat, knn_I, C, M, K, center_avg, center, out);
     return sonet::launched(what);
 }
 
@@ -461,8 +496,12 @@ extern "C" int sonet_lastdim_max_f32(const float *x, float *out, long long rows,
     const char *what = "sonet_lastdim_max_f32";
     SONET_REQUIRE(x && out, "%s: NULL pointer", what);
     SONET_REQUIRE(rows > 0 && K > 0, "%s: non-positive size", what);
-    const long long blocks = sonet::ceil_div64(rows, 256);
+    const int tpr = K >= 48 ? 16 : K >= 6 ? 4 : 1;            // K = 64: 16 lanes x float loads (coalesced 256 B); K = 9: 4 lanes
+    const long long blocks = sonet::ceil_div64(rows * tpr, 256);
     if (blocks > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
-    hipLaunchKernelGGL(lastdim_max_kernel, dim3((unsigned)blocks), dim3(256), 0, sonet::as_stream(stream), x, out, K, rows);
+    hipStream_t st = sonet::as_stream(stream);
+    if (tpr == 16) hipLaunchKernelGGL(lastdim_max_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
+    else if (tpr == 4) hipLaunchKernelGGL(lastdim_max_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
+    else hipLaunchKernelGGL(lastdim_max_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
     return sonet::launched(what);
 }
