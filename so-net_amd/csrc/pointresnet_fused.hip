@@ -206,12 +206,15 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
 // stage n:   s_waitcnt vmcnt(0) (this wave's pieces of stage n+1 have landed);  barrier;  issue stage n+2.
 // (A 4-slot ring with vmcnt(9), two stages of slack, measured no faster.)
 // With one wave per SIMD nothing else hides those latencies.
-constexpr int NSLOT = 3;
+#ifndef SONET_NSLOT
+#define SONET_NSLOT 3
+#endif
+constexpr int NSLOT = SONET_NSLOT;                            // 4 (experimental): two stages of landing time, SEG_SLOTS 8
 
 struct AF { f16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
 
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
-constexpr int SEG_SLOTS = 16;                                 // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
+constexpr int SEG_SLOTS = NSLOT == 4 ? 8 : 16;                               // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
 constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
 
 __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
@@ -283,9 +286,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     };
     // ring state (wave-uniform scalars)
     int n_cur = 0;                                              // stage being consumed
-    int slot_cur = 0, slot_nxt = 1, slot_fill = 2;
+    int slot_cur = 0, slot_nxt = 1, slot_nx2 = 2, slot_fill = NSLOT - 1;
     stage_dma(0, 0);
     stage_dma(1, 1);
+    if constexpr (NSLOT == 4) stage_dma(2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                            // stages 0 and 1 are published (stage 0 is read cold)
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
@@ -320,11 +324,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     auto boundary_sync = [&]() {
         if constexpr (ABL & 4) return;
         if constexpr (!(ABL & 128)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the stage issued one boundary ago have landed
+        if constexpr (NSLOT == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the pieces issued TWO boundaries ago have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage issued one boundary ago have landed
         __syncthreads();
         }
         if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
-            const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t;
+            const int t = slot_cur; slot_cur = slot_nxt;
+            if constexpr (NSLOT == 4) { slot_nxt = slot_nx2; slot_nx2 = slot_fill; } else { slot_nxt = slot_fill; }
+            slot_fill = t;
             n_cur += 1;
         }
         first_boundary = false;
@@ -334,7 +341,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     auto boundary_fill = [&](bool flush) {                      // the step itself issues the NSW slices (dma_one) between its MFMAs
         if constexpr (ABL & 4) return;
         if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
-        dma_setup(n_cur + 2, slot_fill);                        // lands during this stage, published by the next barrier
+        dma_setup(n_cur + NSLOT - 1, slot_fill);                // lands during this stage (two stages with 4 slots), published by a later barrier
+        (void)slot_nx2;
     };
 #define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             for (int r = 0; r < 16; ++r) act3[t][r] = 0.f;
 
         B3 bq[2];
+        B3 bsave[KC3];                                          // layer 3: the split chunks of act2, made once for both tile groups
         PROF_MARK(1)                                            // tile prologue (ids, x loads issued, accumulators zeroed)
         // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
         bq[0] = split_chunk_abl<ABL>(xin);
@@ -527,7 +536,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
             constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
             if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
-            else    { PF_STEP(act3, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], true, PF_MID_CHUNK, bq[nxt], false, false, ) } \
+            else if constexpr (grp == 0) {                                  /* layer 3, tiles 0-3: keep each split chunk */ \
+                constexpr int kc3 = i - KC2 * (T1 / GS);                    \
+                bsave[kc3] = bq[cur];                                       \
+                PF_STEP(act3, 0, GS, sidx, ntn, sidx + 3 * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, ) \
+            } else {                                                        /* tiles 4-7 reuse them: no split work at all */ \
+                constexpr int kc3 = i - KC2 * (T1 / GS) - KC3;              \
+                PF_STEP(act3, GS, GS, sidx, ntn, sidx + 3 * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, ) \
+            } \
             if constexpr (last_of_l2) {                                     /* layer transition */ \
                 SplitState sp2_; \
                 PF_CHUNK_AFF(sp2_, act2, 0, 32 * T0) \
