@@ -249,7 +249,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) aff[c] = affine_g[c];
+    bool l4_unit_lane = true;                                   // layer 4 has no BatchNorm in the reference: scale == 1
+    for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) {
+        const float2 v = affine_g[c];
+        aff[c] = v;
+        if (c >= 32 * (T0 + T1 + T2) && v.x != 1.0f) l4_unit_lane = false;
+    }
+    const bool l4_unit = __syncthreads_and(l4_unit_lane) != 0;   // then max(x + b) = max(x) + b exactly: bias after the pool
 
     const unsigned vow = (unsigned)lane * 16u;
     const unsigned rowB = (unsigned)L * 4u;
@@ -353,6 +359,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         if constexpr (PF_SWAP) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa[u], accarr[(tbase) + (u)], 0, 0, 0); \
         else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0); \
     }
+    // first term of an accumulator's first K chunk: C = 0 as an inline constant (no v_mov zero-fill of 416 registers per tile)
+#define PF_MFZ(accarr, tbase, NT, fa, fb, u)                                                         \
+    if constexpr ((u) < (NT)) {                                                                      \
+        const f32x16 cz_ = PF_ZERO ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : accarr[(tbase) + (u)]; \
+        if constexpr (PF_SWAP) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa[u], cz_, 0, 0, 0); \
+        else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, cz_, 0, 0, 0); \
+    }
     // VALU slot behind MFMA number q = TERM * NT + u of the step: the 44 affine+split ops of the next step's B chunk
     // start after the first PF_SKIP MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles, 5 at 4.
 #define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             if constexpr ((u) == 1) { dma_pair(4, true); dma_pair(6, true); dma_pair(8, false); }    \
         }                                                                                            \
     }
-#define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MF(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
+#define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MFZ(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
 #define PF_TERM_A(accarr, tbase, NT, fa, fb, HAVE)                                                   \
     PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 0) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 1) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 2)  \
     PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 3) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 4) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 5)
@@ -404,9 +417,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     //    earlier), `m` likewise after the third: no second fragment set, <= 12 LDS reads in flight;
     //  - the next step's B chunk gets its affine + ReLU + split a few VALU instructions behind each MFMA
     //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
-#define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, EXTRA)  \
+#define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, ZERO)   \
     {                                                                                                \
         constexpr bool PF_SWAP = SEGMAX && ((sidx) >= PRE);                                          \
+        constexpr bool PF_ZERO = (ZERO);                                                             \
         constexpr int so_ = (sidx) % NSTG, son_ = (SIDXN) % NSTG;                                    \
         SplitState sp_;                                                                              \
         if (COLD) {                                                                                  \
@@ -424,7 +438,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         PF_TERM_V(accarr, tbase, NT, af.m, bcur.m, HAVE, 1)                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + 3 * u_ + 2); \
         PF_SB                                                                                        \
-        EXTRA                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.m[u_] = PF_LDA(nb_, son_ + 3 * u_ + 1); \
         PF_SB                                                                                        \
@@ -496,26 +509,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         float xin[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) xin[e] = xin_n[e];
-        f32x16 act1[T0], act2[T1], act3[T2];
-#pragma unroll
-        for (int t = 0; t < T0; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) act1[t][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) act2[t][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < T2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) act3[t][r] = 0.f;
-
+        f32x16 act1[T0], act2[T1], act3[T2];                   // written by the first MFMA of their first K chunk (C = 0)
         B3 bq[2];
         B3 bsave[KC3];                                          // layer 3: the split chunks of act2, made once for both tile groups
         PROF_MARK(1)                                            // tile prologue (ids, x loads issued, accumulators zeroed)
         // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
         bq[0] = split_chunk_abl<ABL>(xin);
-        PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, )
+        PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, true)
         {                                                       // layer transition: nothing to overlap with
             SplitState sp_;
             PF_CHUNK_AFF(sp_, act1, 0, 0)
@@ -535,14 +535,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
             constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
             constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
-            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, ) } \
+            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, (i % KC2 == 0)) } \
             else if constexpr (grp == 0) {                                  /* layer 3, tiles 0-3: keep each split chunk */ \
                 constexpr int kc3 = i - KC2 * (T1 / GS);                    \
                 bsave[kc3] = bq[cur];                                       \
-                PF_STEP(act3, 0, GS, sidx, ntn, sidx + 3 * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, ) \
+                PF_STEP(act3, 0, GS, sidx, ntn, sidx + 3 * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
             } else {                                                        /* tiles 4-7 reuse them: no split work at all */ \
                 constexpr int kc3 = i - KC2 * (T1 / GS) - KC3;              \
-                PF_STEP(act3, GS, GS, sidx, ntn, sidx + 3 * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, ) \
+                PF_STEP(act3, GS, GS, sidx, ntn, sidx + 3 * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
             } \
             if constexpr (last_of_l2) {                                     /* layer transition */ \
                 SplitState sp2_; \
@@ -559,10 +559,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         // ---- layer 4: NPASS passes x KC4 steps of MT4 tiles; set parity of step kc is (NMID + 1 + kc) & 1 ----
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc[MT4];
-#pragma unroll
-            for (int mt = 0; mt < MT4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 #define PF_L4_CHUNK if constexpr (kn < KC2) PF_CHUNK_AFF(sp_, act1, (kn < KC2 ? kn : 0), 0) else PF_CHUNK_AFF(sp_, act3, (kn < KC2 ? 0 : kn - KC2), 32 * (T0 + T1))
 #define PF_L4(K_)                                                           \
             {                                                               \
@@ -570,7 +566,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 constexpr int sidx = PRE + kc * MT4 * 3; \
                 constexpr int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
                 constexpr int kn = (kc + 1) % KC4; \
-                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + 3 * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), ) \
+                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + 3 * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), (kc == 0)) \
             }
             static_assert(KC4 == 20, "expand PF_L4 to KC4 steps");
             PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
@@ -587,18 +583,22 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 // cross-lane reduction of every register (80 DPP ops per tile); the two half-waves (16 points each)
                 // meet in the LDS atomic.
                 // 1) affine in place (one coefficient pair per lane and tile); features of original copy 0
+                float bias4[MT4];
 #pragma unroll
                 for (int mt = 0; mt < MT4; ++mt) {
                     const float2 ss = aff[32 * (T0 + T1 + T2) + (pass * MT4 + mt) * 32 + j];
+                    bias4[mt] = ss.y;
+                    if (!l4_unit) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                        for (int r = 0; r < 16; ++r) acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    }
                 }
                 if (jpos0 >= 0) {                                                 // wave-uniform: one wave per cloud
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0) {
 #pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = acc[mt][r];
+                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = l4_unit ? __fadd_rn(acc[mt][r], bias4[mt]) : acc[mt][r];
                         }
                 }
                 // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted, so a node's points
@@ -640,6 +640,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                         }
                     }
                     (void)nvalid;
+                    if (l4_unit) {                                                // fl(x + b) is monotone in x: add after the max
+#pragma unroll
+                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fadd_rn(mx[mt], bias4[mt]);
+                    }
                     if constexpr (!(ABL & 32)) {
                         // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
                         // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
