@@ -241,6 +241,19 @@ def main():
                 step()
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t1) * 1e3 / args.steps
+        rec_store = None
+        if ops.FUSE_POOL:
+            ops.FUSE_POOL = False
+            try:
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                with ops.kernel_timing() as rec_store:
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+            finally:
+                ops.FUSE_POOL = True
     elapsed = dp.all_reduce_max(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
@@ -250,22 +263,31 @@ def main():
     dtype = ("f32 (operands split into fp16 pieces, 3 fp16 MFMAs per product, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "h3"
              else "f32 (3xbf16-split operands on bf16 MFMA, f32 accumulate; parity 1e-5)" if ops.POINTMLP_PRECISION == "x3"
              else "f32 (exact f32 MFMA)")
-    summ = rec.summary()
-    kernels = []
-    for name, s in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
-        bound, amount = algorithmic(name, B, N)
-        k = {"name": name, "launches_per_step": s["count"] // args.steps, "mean_ms": round(s["mean_ms"], 5),
-             "ms_per_step": round(s["total_ms"] / args.steps, 5), "bound": bound}
-        if amount:
-            if bound == "mfma":
-                ach = amount / (s["mean_ms"] * 1e-3) / 1e12
-                peak = (PEAK_H3_TFLOPS if name.startswith("pointresnet_fused") else PEAK_H3_TFLOPS if name.startswith("pointmlph3") else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
-                        else PEAK_F32_MFMA_TFLOPS)
-                k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
-            else:
-                ach = amount / (s["mean_ms"] * 1e-3) / 1e9
-                k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
-        kernels.append(k)
+    def kernel_entries(summary, steps, suffix=""):
+        out = []
+        for name, s_ in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
+            bound, amount = algorithmic(name, B, N)
+            k = {"name": name + suffix, "launches_per_step": s_["count"] // steps, "mean_ms": round(s_["mean_ms"], 5),
+                 "ms_per_step": round(s_["total_ms"] / steps, 5), "bound": bound}
+            if amount:
+                if bound == "mfma":
+                    ach = amount / (s_["mean_ms"] * 1e-3) / 1e12
+                    peak = (PEAK_H3_TFLOPS if name.startswith(("pointresnet_fused", "pointmlph3")) else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
+                            else PEAK_F32_MFMA_TFLOPS)
+                    k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
+                else:
+                    ach = amount / (s_["mean_ms"] * 1e-3) / 1e9
+                    k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+            out.append(k)
+        return out
+
+    kernels = kernel_entries(rec.summary(), args.steps)
+    # The training / segmenter data path keeps first_pn_out (store variant of the fused kernel + index_max_gather + som_group):
+    # same inputs, a few instrumented steps, so that the segmented arg-max pool has its roofline line here as well.
+    store_path = []
+    if rec_store is not None:
+        store_path = [k for k in kernel_entries(rec_store.summary(), 3, " [store path]")
+                      if k["name"].startswith(("index_max", "pointresnet_fused_L", "som_group"))]
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tpath):
@@ -295,6 +317,7 @@ def main():
         "roofline": roofline,
         "kernel_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 4),
         "kernels": kernels,
+        "kernels_store_path": store_path,
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
