@@ -120,6 +120,11 @@ int sonet_node_gather_f32(const float *feat, const int32_t *min_idx_i32, float *
 int sonet_knn_gather_f32(const float *x, const int64_t *knn_I, float *out,
                          int B, int C, int M, int K, sonet_stream_t stream);
 
+/* Self k-NN of the SOM nodes: knn_I [B][M][K] i64 = the K nearest nodes of every node (itself first), ascending
+ * (distance, index), distance (dx*dx + dy*dy) + dz*dz.  Replaces the host-side faiss IndexFlatL2 search of the loaders
+ * (data/modelnet_shrec_loader.py:116-150,257-259) and KNNModule's dense fallback (models/layers.py:333-337).  K <= 16. */
+int sonet_knn_self_f32(const float *node, int64_t *knn_I, int B, int M, int K, sonet_stream_t stream);
+
 /* KNNModule input in one pass (models/layers.py:313-350): out [B][3+C][M][K] = cat(coord[:, I] - center, feat[:, I]),
  * center [B][3][M] = mean of the K neighbour coordinates (center_avg != 0) or the node itself.  knn_I [B][M][K] i64. */
 int sonet_knn_group_f32(const float *coord, const float *feat, const int64_t *knn_I, int B, int C, int M, int K,

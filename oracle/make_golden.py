@@ -313,8 +313,29 @@ def golden_autoencoder(ref, tag, B, N, seed):
          grad_predicted=pred.grad, decoder_keys=np.array(sorted(model.decoder.state_dict().keys())))
 
 
+def golden_som_update(ref):
+    """BatchSOM.batch_update (util/som.py:295-350): batched SOM training iterations from given nodes (the potential-field
+    initialiser is bypassed: nodes start from a seeded uniform layout)."""
+    B, N = 2, 3000
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3, N, generator=g) * 2 - 1
+    node0 = torch.rand(B, 3, 64, generator=g) * 1.6 - 0.8
+    s = ref.som.BatchSOM(8, 8, 3, 0, B)
+    s.node.copy_(node0)
+    s.batch_update(x, s.learning_rate, s.sigma)
+    node1 = s.node.clone()
+    for it in range(5):
+        decay = 1 + 2 * it / 5
+        s.batch_update(x, s.learning_rate / decay, s.sigma / decay)
+    save("som_update_b2_n3000", x=x, node0=node0, node1=node1, node6=s.node, weighting=s.get_weighting_matrix(0.3))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "som_update":
+        torch.manual_seed(0)
+        golden_som_update(ref_harness.import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "autoencoder":     # own process: needs the faiss stand-in at import time
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -333,6 +354,7 @@ def main():
     golden_classifier(ref, "b2_n5000", B=2, N=5000, seed=103, node_kind="som")          # configs[1] shape
     golden_train_step(ref, "b16_n512", B=16, N=512, seed=201)   # B=16: BN over 4 samples is too ill-conditioned to compare gradients
     golden_segmenter(ref, "b2_n256", B=2, N=256, seed=301)
+    golden_som_update(ref)
     golden_classifier(ref, "b2_n300_k1_center", B=2, N=300, seed=104, node_kind="uniform", k=1,
                       som_k=5, som_k_type="center")
 

@@ -220,6 +220,43 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict_
     o[mk] = (ok ? cr[id] : 0.f) - ctr;
 }
 
+// Self k-NN of the SOM nodes (the node_knn_I table the reference builds with faiss on the host,
+// data/modelnet_shrec_loader.py:116-150,257-259, and KNNModule's fallback, models/layers.py:333-337): for every node the
+// K nearest nodes (itself first), ascending (distance, index), distance (dx*dx + dy*dy) + dz*dz.  One thread per
+// (cloud, node); the K best live in registers (static compare-exchange chain, K <= 16).
+constexpr int KS_MAX = 16;
+__global__ __launch_bounds__(256) void knn_self_kernel(const float *__restrict__ node, int64_t *__restrict__ knn_I,
+                                                        int M, int K, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // b * M + m
+    if (t >= total) return;
+    const long long b = t / M;
+    const int m = (int)(t - b * M);
+    const float *nb = node + b * 3 * M;
+    const float qx = nb[m], qy = nb[M + m], qz = nb[2 * M + m];
+    float bd[KS_MAX];
+    int bi[KS_MAX];
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j) { bd[j] = __builtin_inff(); bi[j] = 0x7FFFFFFF; }
+    for (int i = 0; i < M; ++i) {
+        const float dx = __fsub_rn(qx, nb[i]), dy = __fsub_rn(qy, nb[M + i]), dz = __fsub_rn(qz, nb[2 * M + i]);
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        int id = i;
+#pragma unroll
+        for (int j = 0; j < KS_MAX; ++j) {                               // insert, pushing the larger one down the chain
+            const bool lt = d < bd[j] || (d == bd[j] && id < bi[j]);
+            const float td = lt ? bd[j] : d;
+            const int ti = lt ? bi[j] : id;
+            bd[j] = lt ? d : bd[j];
+            bi[j] = lt ? id : bi[j];
+            d = td; id = ti;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KS_MAX; ++j)
+        if (j < K) knn_I[t * K + j] = bi[j];
+}
+
 // out[row] = max over the K contiguous values of the row (NaN wins, as torch.amax): the neighbourhood max of
 // KNNModule (K = 9) and the global max over the nodes (K = M = 64), models/layers.py:365, models/networks.py:197.
 template <int TPR>   // threads per row (power of two <= 64): each reads a strided share of the row, then a shuffle tree
@@ -503,5 +540,17 @@ extern "C" int sonet_lastdim_max_f32(const float *x, float *out, long long rows,
     if (tpr == 16) hipLaunchKernelGGL(lastdim_max_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
     else if (tpr == 4) hipLaunchKernelGGL(lastdim_max_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
     else hipLaunchKernelGGL(lastdim_max_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, out, K, rows);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_knn_self_f32(const float *node, int64_t *knn_I, int B, int M, int K, sonet_stream_t stream)
+{
+    const char *what = "sonet_knn_self_f32";
+    SONET_REQUIRE(node && knn_I, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && M > 0 && K > 0 && K <= M, "%s: bad size B=%d M=%d K=%d", what, B, M, K);
+    if (K > KS_MAX) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: K=%d > %d", what, K, KS_MAX);
+    const long long total = (long long)B * M;
+    hipLaunchKernelGGL(knn_self_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       node, knn_I, M, K, total);
     return sonet::launched(what);
 }

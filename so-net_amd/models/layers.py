@@ -439,8 +439,7 @@ class KNNModule(nn.Module):
             assert precomputed_knn_I.size()[2] >= K
             knn_I = precomputed_knn_I[:, :, 0:K].contiguous()
         else:                                                              # fallback M x M kNN (layers.py:333-337)
-            d = ((coord.unsqueeze(3) - coord.unsqueeze(2)) ** 2).sum(dim=1)
-            _, knn_I = torch.topk(d, k=K, dim=2, largest=False, sorted=True)
+            knn_I = _ops.knn_self(coord.float().contiguous(), K)
         if center_type not in ('avg', 'center'):
             raise ValueError(center_type)
         if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_mask_i32": [_vp, _vp, _i, _i, _i, _vp],
     "sonet_node_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_knn_self_f32": [_vp, _vp, _i, _i, _i, _vp],
     "sonet_knn_group_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "sonet_lastdim_max_f32": [_vp, _vp, ctypes.c_longlong, _i, _vp],
     "sonet_knn_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

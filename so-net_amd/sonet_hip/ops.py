@@ -227,6 +227,17 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     return t
 
 
+def knn_self(node, K):
+    """node B x 3 x M f32 -> B x M x K i64: the K nearest nodes of every node (itself first)."""
+    _chk(node, "node", torch.float32, 3)
+    dev = _same_device(node)
+    B, _, M = node.shape
+    out = torch.empty((B, M, int(K)), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev), _timed("knn_self"):
+        check(_lib.load().sonet_knn_self_f32(ptr(node), ptr(out), B, M, int(K), stream_ptr()), "sonet_knn_self_f32")
+    return out
+
+
 def knn_group(coord, feat, knn_I, center_avg):
     """coord B x 3 x M, feat B x C x M, knn_I B x M x K i64 -> (center B x 3 x M, out B x (3+C) x M x K)."""
     _chk(coord, "coord", torch.float32, 3)

@@ -535,6 +535,36 @@ def test_chamfer_loss_full_size_properties():
     assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
 
 
+def test_knn_self_vs_topk():
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(9)
+    for B, M, K in [(4, 64, 9), (2, 100, 16), (3, 5, 5)]:
+        node = torch.rand(B, 3, M, generator=gen) * 2 - 1
+        d = ((node.unsqueeze(3) - node.unsqueeze(2)) ** 2).sum(dim=1)        # (dx^2 + dy^2) + dz^2, as layers.py:333-337
+        ref = torch.topk(d, k=K, dim=2, largest=False, sorted=True)[1]
+        got = ops.knn_self(node.to(DEV), K).cpu()
+        assert torch.equal(got[:, :, 0], torch.arange(M).expand(B, M))       # itself first
+        assert torch.equal(got, ref)
+    dup = torch.zeros(1, 3, 8)                                                # all nodes coincide: ties -> ascending index
+    assert torch.equal(ops.knn_self(dup.to(DEV), 4).cpu()[0, 5], torch.tensor([0, 1, 2, 3]))
+
+
+def test_batch_som_update_golden():
+    """BatchSOM.batch_update (SOM training iterations, util/som.py:295-366) on the assignment / grouping kernels."""
+    from util import som
+    g = golden("som_update_b2_n3000")
+    x = cu(g["x"])
+    s = som.BatchSOM(8, 8, 3, 0, x.shape[0])
+    np.testing.assert_allclose(s.get_weighting_matrix(0.3).cpu().numpy(), g["weighting"], rtol=1e-6, atol=1e-12)
+    s.node = cu(g["node0"]).clone()
+    s.batch_update(x, s.learning_rate, s.sigma)
+    assert_close_rms(s.node.cpu().numpy(), g["node1"], 1e-5, "nodes after one update")
+    for it in range(5):
+        decay = 1 + 2 * it / 5
+        s.batch_update(x, s.learning_rate / decay, s.sigma / decay)
+    assert_close_rms(s.node.cpu().numpy(), g["node6"], 1e-4, "nodes after six updates")
+
+
 def test_knn_group_and_lastdim_max_vs_torch():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(4)
