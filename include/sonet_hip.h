@@ -221,6 +221,16 @@ int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float
 int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
                                   const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
 
+/* Sparse dgrad of the pooled last layer of the first PointNet (training, classifier / autoencoder): the gradient of
+ * first_pn_out = W . [x1; x2] + b arrives only through the per-node max-pool (models/networks.py:180-185), i.e. as
+ * g_pooled [B][C][M] at the arg-max positions pos [B][C][M] (i32 in [0, L); out-of-range entries are ignored).
+ *   gx1 [B][C1][L], gx2 [B][C2][L]  <-  sum over entries (c, m) with pos == l of g_pooled[b][c][m] * W[c][:]
+ * W [C][C1+C2] row-major f32.  Dense outputs (zero where nothing hits), C*M*(C1+C2) MACs per cloud instead of
+ * C*L*(C1+C2).  ws: sonet_pooled_dgrad_ws_size bytes.  Deterministic (entries sorted per 64-column tile). */
+size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L);
+int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                           int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
+
 /* Per-channel coefficients of training BatchNorm, forward (invstd = 1/sqrt(var+eps), scale = gamma*invstd,
  * shift = beta - mean*scale) and backward (from the two sums of sonet_pointwise_bwd_stats_f32, n = B*L:
  *   sg = invstd*(s2 - mean*s1);  a = gamma*invstd;  b = -a*invstd*sg/n;  c0 = -a*s1/n - b*mean;

@@ -235,3 +235,170 @@ extern "C" int sonet_node_add_affine_act_f32(float *t, const float *z, const int
                        sonet::as_stream(stream), t, z, min_idx_i32, scale, shift, relu, C, L, M);
     return sonet::launched(what);
 }
+
+// ---- sparse dgrad of the pooled last layer ---------------------------------------------------
+// In the classifier / autoencoder the only consumer of first_pn_out = W4 . [x1; x2] + b is the per-node max-pool
+// (models/networks.py:180-185), so d loss / d first_pn_out has exactly M non-zeros per (b, c) row -- at the arg-max
+// positions.  Instead of scattering them into a dense B x 384 x kN tensor and running a dense W4^T GEMM over it
+// (234x more MACs than needed at N = 5000), the entries are bucketed by 64-column tile and every tile accumulates
+//     g_x[b][:, l] += g[b][c][m] * W4[c][:]      for its entries (c, m) -> l
+// in LDS, then writes its 320 x 64 block with coalesced stores (the [C][L] layout makes a direct scatter of the 320-vectors
+// uncoalesced in both directions).  Entries of a tile are sorted by (column, channel) before they are applied, so the
+// result does not depend on the order the bucket atomics happened to take.
+namespace {
+
+constexpr int PD_TL = 32;                      // columns per tile (41 KB of LDS at 320 channels: 3 workgroups per CU)
+constexpr int PD_SORT = 1024;                  // entries per tile sorted in LDS (more: chunks in arrival order)
+
+__global__ __launch_bounds__(256) void pooled_bucket_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g,
+                                                            int E, int L, int ntile, int32_t *__restrict__ tile_off,
+                                                            uint32_t *__restrict__ ent_key, float *__restrict__ ent_val)
+{
+    extern __shared__ int sm_i[];                // cnt[ntile] | off[ntile + 1]
+    int *cnt = sm_i, *off = sm_i + ntile;
+    const int b = blockIdx.x;
+    const int32_t *pb = pos + (size_t)b * E;
+    for (int t = threadIdx.x; t < ntile; t += 256) cnt[t] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const int l = pb[e];
+        if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_TL], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int t = 0; t < ntile; ++t) { off[t] = acc; acc += cnt[t]; cnt[t] = 0; }
+        off[ntile] = acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t <= ntile; t += 256) tile_off[(size_t)b * (ntile + 1) + t] = off[t];
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const int l = pb[e];
+        if ((unsigned)l >= (unsigned)L) continue;
+        const int t = l / PD_TL;
+        const int p = off[t] + atomicAdd(&cnt[t], 1);
+        // sort key (column, entry id); entry id = c * M + m, the consumer recovers the channel as id / M
+        ent_key[(size_t)b * E + p] = ((uint32_t)(l - t * PD_TL) << 20) | (uint32_t)e;
+        ent_val[(size_t)b * E + p] = g[(size_t)b * E + e];
+    }
+}
+
+__global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
+                                                           const float *__restrict__ ent_val, const float *__restrict__ W,
+                                                           int E, int M, int Cin, int C1, int L, int ntile,
+                                                           float *__restrict__ gx1, float *__restrict__ gx2)
+{
+    extern __shared__ float sm_f[];              // acc[PD_TL][Cin + 1] | keys[PD_SORT] | vals[PD_SORT]
+    const int ld = Cin + 1;
+    float *acc = sm_f;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld);
+    float *vals = reinterpret_cast<float *>(keys + PD_SORT);
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < PD_TL * ld; i += nth) acc[i] = 0.f;
+    const int beg = tile_off[(size_t)b * (ntile + 1) + tile], end = tile_off[(size_t)b * (ntile + 1) + tile + 1];
+    const uint32_t *kb = ent_key + (size_t)b * E;
+    const float *vb = ent_val + (size_t)b * E;
+    for (int base = beg; base < end; base += PD_SORT) {
+        const int n = min(PD_SORT, end - base);
+        __syncthreads();
+        if (n <= 256) {
+            // the usual case (~50 entries per tile): rank sort, one barrier -- each entry counts the smaller keys (keys are distinct)
+            uint32_t mykey = 0xFFFFFFFFu;
+            float myval = 0.f;
+            if (tid < n) { mykey = kb[base + tid]; myval = vb[base + tid]; keys[PD_SORT / 2 + tid] = mykey; }
+            __syncthreads();
+            if (tid < n) {
+                int rank = 0;
+                for (int q = 0; q < n; ++q) rank += keys[PD_SORT / 2 + q] < mykey;
+                keys[rank] = mykey;
+                vals[rank] = myval;
+            }
+            __syncthreads();
+        } else {
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        for (int i = tid; i < n2; i += nth) {
+            keys[i] = i < n ? kb[base + i] : 0xFFFFFFFFu;
+            vals[i] = i < n ? vb[base + i] : 0.f;
+        }
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)                      // bitonic sort by (column, entry id)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += nth) {
+                    const int p = i ^ j;
+                    if (p > i) {
+                        const bool up = (i & k) == 0;
+                        const uint32_t a = keys[i], c = keys[p];
+                        if ((a > c) == up) { keys[i] = c; keys[p] = a; const float t = vals[i]; vals[i] = vals[p]; vals[p] = t; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // one wave per column (no two waves touch the same accumulators, entries of a column in sorted order: deterministic);
+        // its lanes cover the input channels, two entries in flight to overlap the W-row loads (L2 latency)
+        const int wv = tid >> 6, ln = tid & 63, nwv = nth >> 6;
+        for (int col = wv; col < PD_TL; col += nwv) {
+            int lo = 0, hi = n;                                  // first entry with column >= col / > col
+            for (int a = 0, z = n; a < z;) { const int mid = (a + z) >> 1; if ((int)(keys[mid] >> 20) < col) a = mid + 1; else z = mid; lo = a; }
+            for (int a = lo, z = n; a < z;) { const int mid = (a + z) >> 1; if ((int)(keys[mid] >> 20) <= col) a = mid + 1; else z = mid; hi = a; }
+            if (lo >= n || (int)(keys[lo] >> 20) != col) continue;
+            if (hi < lo) hi = lo;
+            float *ac = acc + col * ld;
+            int e = lo;
+            for (; e + 2 <= hi; e += 2) {
+                const float g0 = vals[e], g1 = vals[e + 1];
+                const float *w0 = W + (size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin, *w1 = W + (size_t)((int)(keys[e + 1] & 0xFFFFFu) / M) * Cin;
+                for (int i = ln; i < Cin; i += 64) {
+                    const float a0 = w0[i], a1 = w1[i];
+                    ac[i] = __fmaf_rn(g1, a1, __fmaf_rn(g0, a0, ac[i]));
+                }
+            }
+            if (e < hi) {
+                const float g0 = vals[e];
+                const float *w0 = W + (size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin;
+                for (int i = ln; i < Cin; i += 64) ac[i] = __fmaf_rn(g0, w0[i], ac[i]);
+            }
+        }
+    }
+    __syncthreads();
+    const int l0 = tile * PD_TL;
+    for (int idx = tid; idx < Cin * PD_TL; idx += nth) {        // coalesced: consecutive threads along the columns of one channel
+        const int i = idx / PD_TL, col = idx - i * PD_TL;
+        if (l0 + col >= L) continue;
+        const float v = acc[col * ld + i];
+        if (i < C1) gx1[((size_t)b * C1 + i) * L + l0 + col] = v;
+        else gx2[((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
+{
+    if (B <= 0 || C <= 0 || M <= 0 || L <= 0) return 0;
+    const size_t E = (size_t)C * M, ntile = (size_t)sonet::ceil_div(L, PD_TL);
+    return (size_t)B * (E * 8 + (ntile + 1) * 4);
+}
+
+extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                      int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream)
+{
+    const char *what = "sonet_pooled_dgrad_f32";
+    SONET_REQUIRE(g_pooled && pos && W && ws && gx1, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
+    const int Cin = C1 + C2, E = C * M, ntile = sonet::ceil_div(L, PD_TL);
+    if ((long long)C * M >= (1 << 20) || B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C*M=%d entries per cloud (max 2^20)", what, E);
+    const size_t lds2 = ((size_t)PD_TL * (Cin + 1) + 2 * PD_SORT) * 4;
+    if (lds2 > 160 * 1024 || (size_t)(2 * ntile + 1) * 4 > 64 * 1024)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d or L=%d too large for the LDS tile", what, Cin, L);
+    uint32_t *ent_key = reinterpret_cast<uint32_t *>(ws);
+    float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
+    int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(256), (size_t)(2 * ntile + 1) * 4, st, pos, g_pooled, E, L, ntile, tile_off, ent_key, ent_val);
+    hipLaunchKernelGGL(pooled_dgrad_kernel, dim3(ntile, B), dim3(320), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1, L, ntile, gx1,
+                       gx2 ? gx2 : gx1);
+    return sonet::launched(what);
+}

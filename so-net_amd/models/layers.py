@@ -145,7 +145,10 @@ class _PointwiseFn(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 s1, _ = _ops.pointwise_bwd_stats(gy, src, ones, zeros, ctx.relu)
                 g_bias = (sc.double() * s1).float()
-            g_raw = _ops.pointwise_bwd_apply(gy, src, ones, zeros, ctx.relu, sc.contiguous(), zeros, zeros)
+            if not ctx.relu and sc.data_ptr() == ones.data_ptr():
+                g_raw = gy                                                # no activation, unit scale (layers without a norm): identity
+            else:
+                g_raw = _ops.pointwise_bwd_apply(gy, src, ones, zeros, ctx.relu, sc.contiguous(), zeros, zeros)
         else:
             sc, sh, raw, mean, invstd, gamma, zeros = saved[3:10]
             n = float(raw.shape[0] * raw.shape[2])
@@ -174,6 +177,65 @@ class _PointwiseFn(torch.autograd.Function):
                 outs.append(_ops.pointmlp(g_raw, wpt, _ops.const_vec(Ci, 1.0, gy.device), _ops.const_vec(Ci, 0.0, gy.device), False, Ci))
             g_x1, g_x2 = outs
         return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
+
+
+class _PooledLastLayerFn(torch.autograd.Function):
+    """Last (norm-free, activation-free) layer of the first PointNet + per-node arg-max pool as ONE autograd node
+    (models/layers.py:431 + models/networks.py:180-185).  Outputs (first_pn_out, first_pn_out_masked_max).  When only
+    the pooled output is used downstream (classifier, autoencoder) the incoming gradient of first_pn_out is None and the
+    backward runs the sparse dgrad (``sonet_pooled_dgrad_f32``: C*M 320-vectors per cloud instead of a dense W^T GEMM
+    over kN columns); if first_pn_out itself is consumed (segmenter) the dense path runs and the pooled gradient is
+    scatter-added into it -- exactly what the reference's gather backward does."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M):
+        Cout = weight2d.shape[0]
+        ones = _ops.const_vec(Cout, 1.0, x1.device)
+        y = _ops.pointmlp(x1, wp, ones, bias.detach().float().contiguous(), False, Cout, x2=x2)
+        idx, val = _ops.index_max_gather(y, min_idx_i32, M, row_max)
+        gi = idx * row_max.unsqueeze(1)                                   # networks.py:185: empty nodes gather position 0
+        ctx.save_for_backward(x1, x2, weight2d, gi, row_max)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(gi)
+        return y, val, gi
+
+    @staticmethod
+    def backward(ctx, g_y, g_mm, _g_gi):
+        x1, x2, weight2d, gi, row_max = ctx.saved_tensors
+        B, C1, L = x1.shape
+        C2 = x2.shape[1]
+        if g_y is None and g_mm is None:
+            return (None,) * 8
+        sparse = g_y is None
+        if sparse:
+            G = torch.zeros((B, weight2d.shape[0], L), dtype=torch.float32, device=x1.device)
+        else:
+            G = g_y.contiguous().clone() if g_mm is not None else g_y.contiguous()
+        if g_mm is not None:
+            g_mm = g_mm.contiguous()
+            G.scatter_add_(2, gi.long(), g_mm)                            # the gather's backward (duplicates accumulate)
+        g_bias = G.sum(dim=(0, 2)) if ctx.needs_input_grad[3] else None
+        g_w = None
+        if ctx.needs_input_grad[2]:
+            g_w = torch.cat((torch.bmm(G, x1.transpose(1, 2)).sum(0), torch.bmm(G, x2.transpose(1, 2)).sum(0)), dim=1)
+        g_x1 = g_x2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if sparse:
+                # every channel of an EMPTY node gathers position 0: those C entries per node are one dense mat-vec into
+                # column 0 (left in the sparse kernel they would pile thousands of entries onto a single tile)
+                w = weight2d.detach().float().contiguous()
+                occ = row_max.unsqueeze(1) > 0
+                g_x1, g_x2 = _ops.pooled_dgrad(g_mm, torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L)
+                col0 = torch.matmul((g_mm * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
+                g_x1[:, :, 0] += col0[:, :C1]
+                g_x2[:, :, 0] += col0[:, C1:]
+            else:
+                packs = _pack_transposed(weight2d.detach(), C1, C2)
+                outs = []
+                for wpt, Ci in packs:
+                    outs.append(_ops.pointmlp(G, wpt, _ops.const_vec(Ci, 1.0, G.device), _ops.const_vec(Ci, 0.0, G.device), False, Ci))
+                g_x1, g_x2 = outs
+        return g_x1, g_x2, g_w, g_bias, None, None, None, None
 
 
 class _FusedPointwise(nn.Module):
@@ -216,7 +278,7 @@ class _FusedPointwise(nn.Module):
             with torch.no_grad():
                 b = self._bias().detach().float()
                 if bn is None:
-                    scale, shift = torch.ones_like(b), b.clone()
+                    scale, shift = _ops.const_vec(b.numel(), 1.0, b.device), b.clone()      # the shared ones vector marks a unit scale
                 else:
                     scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
                     shift = (b - bn.running_mean) * scale + bn.bias.detach()
@@ -534,6 +596,22 @@ class PointResNet(nn.Module):
             self._fused_aff = torch.stack((torch.cat([a[0] for a in aff]), torch.cat([a[1] for a in aff])), dim=1).contiguous()
             self._fused_akey = akey
         return self._fused_w, self._fused_aff
+
+    def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None):
+        """Training path of the encoder: hidden layers as usual, then the last layer and the per-node arg-max pool as one
+        autograd node -> (first_pn_out, first_pn_out_masked_max, gather_index) or None when the layout does not allow it."""
+        n = len(self.out_channels_list)
+        last = self.layers[n - 1]
+        if n < 3 or last.normalization is not None or last.activation is not None or not last._fusable():
+            return None
+        skip = self.layers[0](x, epoch)
+        t = skip
+        for l in range(1, n - 1):
+            t = self.layers[l](t, epoch)
+        if skip.shape[1] % 16 != 0:
+            return None
+        wp = last._packed(skip.shape[1], t.shape[1])
+        return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M)
 
     def forward(self, x, epoch=None):
         if self._fusable_eval(x):

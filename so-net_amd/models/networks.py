@@ -173,14 +173,20 @@ class Encoder(nn.Module):
                               centers=None, x_decentered=None if use_sn else g["x_decentered"])
             pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
 
-            self.first_pn_out = self.first_pointnet(pn_in, epoch)            # :175-178  B x 384 x kN
-
-            if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
-                gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
-                self.first_pn_out_masked_max = self.first_pn_out.gather(
-                    dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
+            pooled = None
+            if torch.is_grad_enabled() and isinstance(self.first_pointnet, PointResNet) and getattr(self, "pooled_backward", True):
+                # training: last layer + arg-max pool as one autograd node (sparse dgrad when only the pooled output is consumed)
+                pooled = self.first_pointnet.forward_pooled(pn_in, a.min_idx_i32, row_max, M, epoch)
+            if pooled is not None:
+                self.first_pn_out, self.first_pn_out_masked_max, _ = pooled
             else:
-                _, self.first_pn_out_masked_max = _ops.index_max_gather(self.first_pn_out, a.min_idx_i32, M, row_max)
+                self.first_pn_out = self.first_pointnet(pn_in, epoch)        # :175-178  B x 384 x kN
+                if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
+                    gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
+                    self.first_pn_out_masked_max = self.first_pn_out.gather(
+                        dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
+                else:
+                    _, self.first_pn_out_masked_max = _ops.index_max_gather(self.first_pn_out, a.min_idx_i32, M, row_max)
 
         if opt.som_k >= 2:
             self.knn_center_1, self.knn_feature_1 = self.knnlayer(self.som_node, self.first_pn_out_masked_max,

@@ -48,6 +48,8 @@ SIGNATURES = {
     "sonet_pointwise_bwd_stats_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "sonet_pointwise_bwd_apply_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_node_add_affine_act_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sonet_pooled_dgrad_ws_size": [_i, _i, _i, _i],
+    "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -62,6 +64,7 @@ _RESTYPES = {
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
+    "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
 }
 
 _lib = None

@@ -504,6 +504,23 @@ def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     return out
 
 
+def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L):
+    """Sparse W^T . g for a gradient that exists only at the pooled positions: g_pooled, pos B x C x M -> (gx1 B x C1 x L, gx2 B x C2 x L)."""
+    _chk(g_pooled, "g_pooled", torch.float32, 3)
+    _chk(pos_i32, "pos", torch.int32, 3)
+    _chk(weight2d, "weight", torch.float32, 2)
+    dev = _same_device(g_pooled, pos_i32, weight2d)
+    B, C, M = g_pooled.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.sonet_pooled_dgrad_ws_size(B, C, M, int(L)),), dtype=torch.uint8, device=dev)
+    gx1 = torch.empty((B, C1, int(L)), dtype=torch.float32, device=dev)
+    gx2 = torch.empty((B, C2, int(L)), dtype=torch.float32, device=dev) if C2 else None
+    with torch.cuda.device(dev), _timed("pooled_dgrad"):
+        check(lib.sonet_pooled_dgrad_f32(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2),
+                                         stream_ptr()), "sonet_pooled_dgrad_f32")
+    return gx1, gx2
+
+
 def chamfer_nn(q, db):
     """q B x 3 x Nq, db B x 3 x Nd -> B x Nq i32 nearest database index."""
     _chk(q, "q", torch.float32, 3)

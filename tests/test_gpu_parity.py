@@ -535,6 +535,26 @@ def test_chamfer_loss_full_size_properties():
     assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
 
 
+def test_pooled_dgrad_vs_dense():
+    """Sparse W^T.g of the pooled last layer vs scatter_add + dense matmul (float64), incl. duplicate and empty-node positions."""
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(11)
+    for B, C, M, C1, C2, L in [(2, 384, 64, 64, 256, 3072), (1, 32, 5, 16, 0, 100), (3, 96, 8, 16, 48, 130)]:
+        g = torch.randn(B, C, M, generator=gen)
+        pos = torch.randint(0, L, (B, C, M), generator=gen, dtype=torch.int32)
+        pos[:, : C // 4, 0] = 0
+        pos[:, : C // 8, 1] = 0                                            # duplicates on one column
+        pos[:, 0, 2] = -1                                                  # ignored entry
+        W = torch.randn(C, C1 + C2, generator=gen) * 0.1
+        G = torch.zeros(B, C, L + 1, dtype=torch.float64).scatter_add_(2, torch.where(pos < 0, L, pos).long(), g.double())[:, :, :L]
+        ref = torch.matmul(W.double().t().unsqueeze(0), G)
+        gx1, gx2 = ops.pooled_dgrad(g.to(DEV), pos.to(DEV), W.to(DEV), C1, C2, L)
+        got = torch.cat([gx1.cpu()] + ([gx2.cpu()] if C2 else []), dim=1).double()
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        gx1b, _ = ops.pooled_dgrad(g.to(DEV), pos.to(DEV), W.to(DEV), C1, C2, L)
+        assert torch.equal(gx1b, gx1)                                      # deterministic
+
+
 def test_knn_self_vs_topk():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(9)
