@@ -95,10 +95,23 @@ def _pack_transposed(weight2d, C1, C2):
             out.append(None)
             continue
         wt = weight2d[:, lo:lo + Ci].t().contiguous().float()                  # Ci x Cout
-        m = mode if (mode == "f32" or _ops.x3_supported(wt.shape[1], 0, wt.shape[0])) else "f32"
-        out.append((_ops.pointmlp_pack(wt, m), Ci))
+        Cp = Ci
+        if mode != "f32" and Ci % 32 != 0 and Ci > 32:
+            # the split-operand kernels want 32-row output tiles: pad with zero rows and drop them afterwards (387 and 515
+            # input channels in the KNN module / final PointNet would otherwise fall back to the exact-f32 kernel: 10x slower)
+            Cp = (Ci + 31) // 32 * 32
+            wt = torch.cat((wt, wt.new_zeros(Cp - Ci, wt.shape[1])), dim=0)
+        m = mode if (mode == "f32" or _ops.x3_supported(wt.shape[1], 0, Cp)) else "f32"
+        out.append((_ops.pointmlp_pack(wt, m), Ci, Cp))
         lo += Ci
     return out
+
+
+def _dgrad(g_raw, pack):
+    """W^T . g_raw through the fused 1x1-conv kernel (pack from _pack_transposed)."""
+    wpt, Ci, Cp = pack
+    y = _ops.pointmlp(g_raw, wpt, _ops.const_vec(Cp, 1.0, g_raw.device), _ops.const_vec(Cp, 0.0, g_raw.device), False, Cp)
+    return y if Cp == Ci else y[:, :Ci]
 
 
 class _PointwiseFn(torch.autograd.Function):
@@ -173,8 +186,7 @@ class _PointwiseFn(torch.autograd.Function):
                 if not need or pk is None:
                     outs.append(None)
                     continue
-                wpt, Ci = pk
-                outs.append(_ops.pointmlp(g_raw, wpt, _ops.const_vec(Ci, 1.0, gy.device), _ops.const_vec(Ci, 0.0, gy.device), False, Ci))
+                outs.append(_dgrad(g_raw, pk))
             g_x1, g_x2 = outs
         return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
 
@@ -232,8 +244,8 @@ class _PooledLastLayerFn(torch.autograd.Function):
             else:
                 packs = _pack_transposed(weight2d.detach(), C1, C2)
                 outs = []
-                for wpt, Ci in packs:
-                    outs.append(_ops.pointmlp(G, wpt, _ops.const_vec(Ci, 1.0, G.device), _ops.const_vec(Ci, 0.0, G.device), False, Ci))
+                for pk in packs:
+                    outs.append(_dgrad(G, pk))
                 g_x1, g_x2 = outs
         return g_x1, g_x2, g_w, g_bias, None, None, None, None
 
