@@ -535,6 +535,41 @@ def test_chamfer_loss_full_size_properties():
     assert abs(l1 - float(ref)) <= 1e-5 * float(ref)
 
 
+def test_pooled_last_layer_node_dense_and_sparse_branches():
+    """The joint (last layer + arg-max pool) autograd node vs the plain data flow (layer, index_max, torch gather):
+    gradients when only the pooled output is used (sparse dgrad) and when first_pn_out is used too (dense branch with the
+    pooled gradient scatter-added, as the segmenter needs)."""
+    from models import networks as NW
+    from sonet_hip import synth
+    B, N = 4, 600
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+    inp = synth.make_inputs(B, N, seed=21, device=DEV)
+    w_dense = torch.randn(B, 384, 3 * N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    grads = {}
+    for use_dense in (False, True):
+        for joint in (True, False):
+            enc = NW.Encoder(opt)
+            synth.fill_state_dict_(enc.state_dict(), 5)
+            enc.to(DEV).train()
+            enc.pooled_backward = joint
+            feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], True, 0)
+            loss = feat.square().mean()
+            if use_dense:
+                loss = loss + 1e-3 * (enc.first_pn_out * w_dense).mean()
+            loss.backward()
+            grads[(use_dense, joint)] = {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}
+    for use_dense in (False, True):
+        a, b = grads[(use_dense, True)], grads[(use_dense, False)]
+        assert a.keys() == b.keys()
+        for k in a:
+            # (conv biases sit in front of a training-mode BatchNorm -- directly or through the pool -- so their true gradient
+            #  is zero and both sides hold rounding noise of ~1e-8)
+            if k.startswith("first_pointnet") and not k.endswith("conv.bias"):
+                assert_close_rms(a[k].cpu().numpy(), b[k].cpu().numpy(), 2e-5, "%s (dense=%s)" % (k, use_dense))
+
+
 def test_pooled_dgrad_vs_dense():
     """Sparse W^T.g of the pooled last layer vs scatter_add + dense matmul (float64), incl. duplicate and empty-node positions."""
     from sonet_hip import ops
