@@ -191,33 +191,44 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict_
                                                          const int64_t *__restrict__ I, int C, int M, int K, int avg,
                                                          float *__restrict__ center, float *__restrict__ out)
 {
+    // one thread = 4 consecutive (m, k) positions of one (b, c) row: 32-byte index loads, 16-byte stores
     const int MK = M * K, CC = 3 + C;
-    const int mk = blockIdx.x * 256 + threadIdx.x;                       // position inside the (b, c) row
-    if (mk >= MK) return;
+    const int mk0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (mk0 >= MK) return;
     const int c = blockIdx.y, b = blockIdx.z;
     const int64_t *Ib = I + (size_t)b * MK;
-    const long long id = Ib[mk];
-    const bool ok = (unsigned long long)id < (unsigned long long)M;
     float *o = out + ((size_t)b * CC + c) * MK;
-    if (c >= 3) {
-        o[mk] = ok ? feat[((size_t)b * C + (c - 3)) * M + id] : 0.f;
-        return;
-    }
-    const float *cr = coord + ((size_t)b * 3 + c) * M;
-    const int m = mk / K;
-    float ctr;
-    if (avg) {
-        float sum = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const long long ik = Ib[m * K + k];
-            sum += ((unsigned long long)ik < (unsigned long long)M) ? cr[ik] : 0.f;
+    const float *src = c >= 3 ? feat + ((size_t)b * C + (c - 3)) * M : coord + ((size_t)b * 3 + c) * M;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mk = mk0 + q;
+        float val = 0.f;
+        if (mk < MK) {
+            const long long id = Ib[mk];
+            val = ((unsigned long long)id < (unsigned long long)M) ? src[id] : 0.f;
+            if (c < 3) {
+                const int m = mk / K;
+                float ctr;
+                if (avg) {
+                    float sum = 0.f;
+                    for (int k = 0; k < K; ++k) {
+                        const long long ik = Ib[m * K + k];
+                        sum += ((unsigned long long)ik < (unsigned long long)M) ? src[ik] : 0.f;
+                    }
+                    ctr = sum / (float)K;
+                } else {
+                    ctr = src[m];
+                }
+                if (mk - m * K == 0) center[((size_t)b * 3 + c) * M + m] = ctr;
+                val -= ctr;
+            }
         }
-        ctr = sum / (float)K;
-    } else {
-        ctr = cr[m];
+        v[q] = val;
     }
-    if (mk - m * K == 0) center[((size_t)b * 3 + c) * M + m] = ctr;
-    o[mk] = (ok ? cr[id] : 0.f) - ctr;
+    if (mk0 + 3 < MK && (MK & 3) == 0) *reinterpret_cast<float4 *>(o + mk0) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+        for (int q = 0; q < 4 && mk0 + q < MK; ++q) o[mk0 + q] = v[q];
 }
 
 // Self k-NN of the SOM nodes (the node_knn_I table the reference builds with faiss on the host,
@@ -523,7 +534,7 @@ extern "C" int sonet_knn_group_f32(const float *coord, const float *feat, const 
     SONET_REQUIRE(coord && feat && knn_I && center && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && K > 0, "%s: non-positive size", what);
     if (B > 65535 || 3 + C > 65535 || (long long)M * K > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
-    hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)sonet::ceil_div(M * K, 256), (unsigned)(3 + C), (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)sonet::ceil_div(M * K, 1024), (unsigned)(3 + C), (unsigned)B), dim3(256), 0,
                        sonet::as_stream(stream), coord, feat, knn_I, C, M, K, center_avg, center, out);
     return sonet::launched(what);
 }
