@@ -221,6 +221,12 @@ int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float
 int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
                                   const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
 
+/* Small-batch fully connected layer: y[b][o] = act((sum_k x[b][k] W[o][k]) * scale[o] + shift[o]); x [B][Cin], W [Cout][Cin]
+ * (nn.Linear layout), exact f32 fma chain.  MyLinear = Linear + BatchNorm1d(eval) + ReLU (models/layers.py:123-166) with the
+ * bias and the running statistics folded into (scale, shift): the classifier head of models/networks.py:202-227. */
+int sonet_linear_act_f32(const float *x, const float *W, const float *scale, const float *shift, int relu, float *y,
+                         int B, int Cin, int Cout, sonet_stream_t stream);
+
 /* Sparse dgrad of the pooled last layer of the first PointNet (training, classifier / autoencoder): the gradient of
  * first_pn_out = W . [x1; x2] + b arrives only through the per-node max-pool (models/networks.py:180-185), i.e. as
  * g_pooled [B][C][M] at the arg-max positions pos [B][C][M] (i32 in [0, L); out-of-range entries are ignored).

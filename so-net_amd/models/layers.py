@@ -411,7 +411,30 @@ class MyLinear(nn.Module):
             self.norm.weight.data.fill_(1)
             self.norm.bias.data.zero_()
 
+    def _eval_affine(self):
+        """(scale, shift) folding the bias and the eval-mode BatchNorm1d into the matrix product."""
+        bn = self.norm if self.normalization == 'batch' else None
+        ts = [self.linear.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        key = tuple((t._version, t.data_ptr()) if t is not None else None for t in ts)
+        if getattr(self, '_affine_key', None) != key:
+            with torch.no_grad():
+                b = self.linear.bias.detach().float() if self.linear.bias is not None else torch.zeros(self.linear.out_features, device=self.linear.weight.device)
+                if bn is None:
+                    scale, shift = torch.ones_like(b), b.clone()
+                else:
+                    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+                    shift = (b - bn.running_mean) * scale + bn.bias.detach()
+                self._affine = (scale.contiguous(), shift.contiguous())
+            self._affine_key = key
+        return self._affine
+
     def forward(self, x, epoch=None):
+        fast = (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+                and self.normalization in (None, 'batch') and self.activation in (None, 'relu')
+                and not (self.normalization == 'batch' and self.norm.training))
+        if fast:                                         # eval / no-grad: Linear + BN + ReLU as one kernel
+            scale, shift = self._eval_affine()
+            return _ops.linear_act(x.contiguous(), self.linear.weight.detach().contiguous(), scale, shift, self.activation == 'relu')
         x = self.linear(x)
         if self.normalization == 'batch':
             x = self.norm(x, epoch)

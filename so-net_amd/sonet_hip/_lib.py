@@ -48,6 +48,7 @@ SIGNATURES = {
     "sonet_pointwise_bwd_stats_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "sonet_pointwise_bwd_apply_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_node_add_affine_act_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sonet_linear_act_f32": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pooled_dgrad_ws_size": [_i, _i, _i, _i],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],

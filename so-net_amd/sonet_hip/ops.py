@@ -521,6 +521,20 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L):
     return gx1, gx2
 
 
+def linear_act(x, weight, scale, shift, relu):
+    """x B x Cin, weight Cout x Cin -> act((x @ weight^T) * scale + shift), B x Cout (exact f32)."""
+    _chk(x, "x", torch.float32, 2)
+    _chk(weight, "weight", torch.float32, 2)
+    dev = _same_device(x, weight, scale, shift)
+    B, Cin = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("linear_act_%dx%d" % (Cin, Cout)):
+        check(_lib.load().sonet_linear_act_f32(ptr(x), ptr(weight), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cin, Cout, stream_ptr()),
+              "sonet_linear_act_f32")
+    return y
+
+
 def chamfer_nn(q, db):
     """q B x 3 x Nq, db B x 3 x Nd -> B x Nq i32 nearest database index."""
     _chk(q, "q", torch.float32, 3)

@@ -590,6 +590,18 @@ def test_pooled_dgrad_vs_dense():
         assert torch.equal(gx1b, gx1)                                      # deterministic
 
 
+def test_linear_act_vs_torch():
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(13)
+    for B, Cin, Cout, relu in [(64, 1024, 512, True), (8, 512, 256, True), (3, 256, 40, False), (70, 33, 5, True)]:
+        x, W = torch.randn(B, Cin, generator=gen), torch.randn(Cout, Cin, generator=gen) * 0.05
+        sc, sh = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+        ref = (x.double() @ W.double().t()) * sc.double() + sh.double()
+        ref = torch.relu(ref) if relu else ref
+        got = ops.linear_act(x.to(DEV), W.to(DEV), sc.to(DEV), sh.to(DEV), relu).cpu().double()
+        assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 def test_knn_self_vs_topk():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(9)

@@ -14,7 +14,7 @@ B = int(os.environ.get("B", "64"))
 if name == "pointmlp":
     C1, C2, Cout, L = 64, 256, 384, 15000
     x1, x2 = torch.randn(B, C1, L, device=DEV), torch.randn(B, C2, L, device=DEV)
-    wp = ops.pointmlp_pack(torch.randn(Cout, C1 + C2, device=DEV) * 0.08)
+    wp = ops.pointmlp_pack(torch.randn(Cout, C1 + C2, device=DEV) * 0.08, os.environ.get("MODE", "h3"))
     sc, sh = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
     y = torch.empty(B, Cout, L, device=DEV)
     for _ in range(iters):
