@@ -509,8 +509,8 @@ def test_autoencoder_forward_and_chamfer_golden(mode):
     p = cu(g["predicted_pc"]).requires_grad_(True)
     l2 = crit(p, cu(g["pc"]))
     l2.backward()
-    assert abs(float(crit.forward_loss) - float(g["forward_loss"])) <= 2e-6 * float(g["forward_loss"])
-    assert abs(float(crit.backward_loss) - float(g["backward_loss"])) <= 2e-6 * float(g["backward_loss"])
+    assert abs(float(crit.forward_loss.detach()) - float(g["forward_loss"])) <= 2e-6 * float(g["forward_loss"])
+    assert abs(float(crit.backward_loss.detach()) - float(g["backward_loss"])) <= 2e-6 * float(g["backward_loss"])
     np.testing.assert_allclose(crit.loss_array.detach().cpu().numpy(), g["loss_array"], rtol=5e-6)
     assert_close_rms(p.grad.cpu().numpy(), g["grad_predicted"], 1e-5, "d loss / d predicted_pc")
 
@@ -588,6 +588,36 @@ def test_pooled_dgrad_vs_dense():
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
         gx1b, _ = ops.pooled_dgrad(g.to(DEV), pos.to(DEV), W.to(DEV), C1, C2, L)
         assert torch.equal(gx1b, gx1)                                      # deterministic
+
+
+@pytest.mark.parametrize("node_num,sn,k,N", [(16, True, 3, 700), (64, False, 3, 900), (36, True, 2, 333), (16, False, 1, 257)])
+def test_encoder_other_configs_fast_path_vs_exact_path(node_num, sn, k, N):
+    """Configurations the reference fixtures do not cover (other SOM sizes, no surface normals, other k): the default
+    path (fused kernel / fp16-split arithmetic / pooled epilogue) against the exact-f32 layer-wise path of the same
+    encoder -- two independent implementations of the same forward."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B = 3
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=sn, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.7, node_num=node_num, k=k, som_k=5, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+    enc = NW.Encoder(opt)
+    synth.fill_state_dict_(enc.state_dict(), 31)
+    enc.to(DEV).eval()
+    inp = synth.make_inputs(B, N, M=node_num, som_k=5, seed=32, device=DEV)
+    old = (ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL)
+    out = {}
+    try:
+        for name, cfg in (("fast", ("h3", True, True)), ("exact", ("f32", False, False))):
+            ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL = cfg
+            with torch.no_grad():
+                f = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], False, None)
+                out[name] = (f.cpu().numpy(), enc.first_pn_out_masked_max.cpu().numpy(), enc.som_node.cpu().numpy())
+    finally:
+        ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL = old
+    np.testing.assert_array_equal(out["fast"][2], out["exact"][2])
+    assert_close_rms(out["fast"][1], out["exact"][1], 1e-5, "first_pn_out_masked_max")
+    assert_close_rms(out["fast"][0], out["exact"][0], 1e-5, "feature")
 
 
 def test_linear_act_vs_torch():
