@@ -45,6 +45,12 @@ const char *sonet_build_arch(void);
 const char *sonet_last_error(void);
 /* SONET_OK iff the current HIP device reports gcnArchName gfx950*. */
 int sonet_check_device(void);
+/* Measuring stick (bench.py's roofline line; no reference counterpart): the rate a pure
+ * v_mfma_f32_32x32x16_f16 loop -- one wave per SIMD on every CU, six independent accumulators, 48 * iters MFMAs per
+ * wave -- sustains on the current device, in TFLOP/s, and the shader clock it ran at, in GHz.  random_operands != 0
+ * fills the operands with random fp16 mantissas: on the whole chip that rate is power-limited well below the
+ * nominal 2.4 GHz figure (finding 8).  Synchronous: returns after the timed launch has finished. */
+int sonet_diag_mfma_f16_rate(int random_operands, int iters, double *tflops_out, double *ghz_out, sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * index_max  -- replaces index_max.forward_cuda / forward_cuda_shared_mem

@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int PF_THREADS = 256, PF_WAVES = 4;
 constexpr int T0 = 2, T1 = 4, T2 = 8, T3 = 12;               // output tiles (x32 channels) of the four layers
@@ -204,17 +205,31 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
 // resident and published (the last step of a stage reads the A fragments of the next stage's first step from it)
 // and stage n+2 is landing in the slot stage n-1 occupied.  Boundary(n), run by every wave at the first step of
 // stage n:   s_waitcnt vmcnt(0) (this wave's pieces of stage n+1 have landed);  barrier;  issue stage n+2.
-// (A 4-slot ring with vmcnt(9), two stages of slack, measured no faster.)
+// (A 4-slot ring with vmcnt(9), two stages of landing time, measured no faster.)
 // With one wave per SIMD nothing else hides those latencies.
+//
+// SONET_NSLOT = 4: the same ring with one more slot and NO per-stage barrier.  Each wave publishes a progress counter
+// in LDS at its boundary(n) (prog[wave] = n + 1: "my pieces of the stages <= n + 1 have landed and I have finished
+// reading the stages <= n - 1") and, in the LAST step of stage n, waits until every counter is >= n + 1 before it
+// touches stage n + 1 (its first fragments are read there) -- which is also what boundary(n + 1) needs to refill the
+// slot of stage n - 1 with stage n + 3.  A wave may therefore run up to (a stage minus a step) ahead of the slowest
+// one instead of meeting it 27 times per tile; the real barrier stays only where the pool bins are flushed.
 #ifndef SONET_NSLOT
 #define SONET_NSLOT 3
 #endif
-constexpr int NSLOT = SONET_NSLOT;                            // 4 (experimental): two stages of landing time, SEG_SLOTS 8
+constexpr int NSLOT = SONET_NSLOT;
+#ifndef SONET_RING_BARRIER
+constexpr bool FLAGS = NSLOT == 4;
+constexpr bool DEEP = false;
+#else
+constexpr bool FLAGS = false;                                  // experiment: 4 slots, per-stage barrier, stage n + 3 issued at
+constexpr bool DEEP = NSLOT == 4;                              // boundary(n) and waited for with vmcnt(9): two stages to land
+#endif
 
 struct AF { f16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
 
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
-constexpr int SEG_SLOTS = NSLOT == 4 ? 8 : 16;                               // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
+constexpr int SEG_SLOTS = NSLOT == 4 ? 12 : 16;                              // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
 constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
 
 __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
@@ -226,12 +241,16 @@ __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -
 // Profiling build only (make prof; tools/fused_phases.py): per-wave shader-clock cycles spent in each phase.
 constexpr int PROF_N = 32;
 __device__ long long g_prof[1024 * PROF_N];
-#define PROF_DECL long long prof_[PROF_N] = {}; long long prof_t_ = __builtin_readcyclecounter();
+#define PROF_DECL long long prof_[PROF_N] = {}; const long long prof_rt0_ = (long long)__builtin_amdgcn_s_memrealtime(); long long prof_t_ = __builtin_readcyclecounter();
 #define PROF_MARK(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
-#define PROF_DUMP if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
+#define PROF_T0 long long pt_ = __builtin_readcyclecounter();
+#define PROF_T1(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - pt_; pt_ = n_; }
+#define PROF_DUMP prof_[31] = (long long)__builtin_amdgcn_s_memrealtime() - prof_rt0_; /* 100 MHz constant clock */ if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
+#define PROF_T0
+#define PROF_T1(i)
 #define PROF_DUMP
 #endif
 
@@ -245,6 +264,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 36 KiB
     __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
+    __shared__ __attribute__((aligned(16))) unsigned prog[PF_WAVES];   // FLAGS: per-wave progress counters
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         if (c >= 32 * (T0 + T1 + T2) && v.x != 1.0f) l4_unit_lane = false;
     }
     const bool l4_unit = __syncthreads_and(l4_unit_lane) != 0;   // then max(x + b) = max(x) + b exactly: bias after the pool
+    PROF_DECL
 
     const unsigned vow = (unsigned)lane * 16u;
     const unsigned rowB = (unsigned)L * 4u;
@@ -292,10 +313,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     };
     // ring state (wave-uniform scalars)
     int n_cur = 0;                                              // stage being consumed
-    int slot_cur = 0, slot_nxt = 1, slot_nx2 = 2, slot_fill = NSLOT - 1;
+    int slot_cur = 0, slot_nxt = 1, slot_fill = DEEP ? 3 : 2;
     stage_dma(0, 0);
     stage_dma(1, 1);
-    if constexpr (NSLOT == 4) stage_dma(2, 2);
+    if constexpr (DEEP) stage_dma(2, 2);
+    if (FLAGS && threadIdx.x < PF_WAVES) prog[threadIdx.x] = 1u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                            // stages 0 and 1 are published (stage 0 is read cold)
     const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
@@ -327,18 +349,36 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // Boundary of the stage that the CURRENT step opens, in two halves so that the step can put its own `h` fragment
     // reads between them (LDS executes a wave's operations in order: behind the nine ds_write_b128 they would
     // return ~120 cycles later).
-    auto boundary_sync = [&]() {
+    auto boundary_sync = [&](bool flush) {                      // `flush` is a literal at every call site
         if constexpr (ABL & 4) return;
-        if constexpr (!(ABL & 128)) {
-        if constexpr (NSLOT == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the pieces issued TWO boundaries ago have landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage issued one boundary ago have landed
-        __syncthreads();
-        }
-        if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
-            const int t = slot_cur; slot_cur = slot_nxt;
-            if constexpr (NSLOT == 4) { slot_nxt = slot_nx2; slot_nx2 = slot_fill; } else { slot_nxt = slot_fill; }
-            slot_fill = t;
-            n_cur += 1;
+        if constexpr (FLAGS) {
+            PROF_T0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage n + 1 have landed
+            PROF_T1(28)
+            if (!first_boundary) n_cur += 1;
+            if (lane == 0) *(volatile __attribute__((address_space(3))) unsigned *)(&prog[wave]) = (unsigned)n_cur + 1u;
+            if constexpr (SEGMAX && !(ABL & 8)) { if (flush) __syncthreads(); }   // every wave's bin atomics of the pass are in
+            slot_cur = n_cur & 3; slot_nxt = (n_cur + 1) & 3; slot_fill = (n_cur + 2) & 3;
+        } else {
+            if constexpr (!(ABL & 128)) {
+                PROF_T0
+                if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the pieces issued TWO boundaries ago
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage issued one boundary ago have landed
+                PROF_T1(28)
+#ifdef SONET_LITE_BARRIER
+                // experiment: no lgkmcnt(0) in front of the barrier.  The only LDS operations in flight here are the
+                // fragment reads of the step that opens the stage (slots nobody refills now); the bins need the full fence.
+                if (flush) __syncthreads(); else asm volatile("s_barrier" ::: "memory");
+#else
+                __syncthreads();
+#endif
+                PROF_T1(29)
+            }
+            if (!first_boundary) {                              // rotate: the stage just finished becomes the fill slot
+                n_cur += 1;
+                if constexpr (DEEP) { slot_cur = n_cur & 3; slot_nxt = (n_cur + 1) & 3; slot_fill = (n_cur + 3) & 3; }
+                else { const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t; }
+            }
         }
         first_boundary = false;
         lds_cur = &wsm[slot_cur * NSTG][lane];
@@ -346,9 +386,31 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     };
     auto boundary_fill = [&](bool flush) {                      // the step itself issues the NSW slices (dma_one) between its MFMAs
         if constexpr (ABL & 4) return;
-        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }   // `flush` is a literal at every call site
-        dma_setup(n_cur + NSLOT - 1, slot_fill);                // lands during this stage (two stages with 4 slots), published by a later barrier
-        (void)slot_nx2;
+        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }
+        dma_setup(n_cur + (DEEP ? 3 : 2), slot_fill);           // lands during this stage, published at the next boundary
+    };
+    // FLAGS: last step of stage n -- nobody is more than (a stage minus this step) behind.  `pg` was read at the top of
+    // the step, so the common case costs a min and a scalar compare.
+    // explicit LDS address space: through a generic pointer the re-read becomes a FLAT load, and one FLAT operation
+    // in the loop turns every counted lgkmcnt wait of the MFMA steps into lgkmcnt(0)
+    typedef volatile __attribute__((address_space(3))) u32x4_t *prog_vec_p;
+    auto prog_wait = [&](u32x4_t pg) {
+        const unsigned need = (unsigned)n_cur + 1u;
+        PROF_T0
+#ifdef SONET_SPIN_LIMIT
+        int spins = 0;                                          // experiments only: abort instead of hanging the GPU
+#endif
+        for (;;) {
+            const unsigned a = pg.x < pg.y ? pg.x : pg.y, c = pg.z < pg.w ? pg.z : pg.w;
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)(a < c ? a : c)) >= need) break;
+#ifdef SONET_SPIN_LIMIT
+            if (++spins > SONET_SPIN_LIMIT) __builtin_trap();
+#endif
+            __builtin_amdgcn_s_sleep(1);
+            pg = *(prog_vec_p)(&prog[0]);
+        }
+        PROF_T1(30)
+        asm volatile("" ::: "memory");                          // the stage's fragment reads stay behind the check
     };
 #define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
@@ -428,14 +490,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.l[u_] = PF_LDA(cb_, so_ + 3 * u_ + 2); \
             _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.m[u_] = PF_LDA(cb_, so_ + 3 * u_ + 1); \
         }                                                                                            \
-        if (so_ == 0) { boundary_sync(); boundary_fill(FLUSH); }                                     \
+        if (so_ == 0) { boundary_sync(FLUSH); boundary_fill(FLUSH); }                                \
         const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;                                            \
+        u32x4_t pg_ = {0u, 0u, 0u, 0u};                                                                \
+        if constexpr (FLAGS && son_ == 0 && !(ABL & 4)) pg_ = *(prog_vec_p)(&prog[0]); \
         { CHUNKCODE }                                                                                \
         PF_SB                                                                                        \
         PF_TERM_A(accarr, tbase, NT, af.l, bcur.l, HAVE)                                             \
         _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(lds_cur, so_ + 3 * u_);  \
         PF_SB                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.m, bcur.m, HAVE, 1)                                          \
+        if constexpr (FLAGS && son_ == 0 && !(ABL & 4)) prog_wait(pg_);                              \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + 3 * u_ + 2); \
         PF_SB                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
@@ -460,7 +525,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * 3 * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * 3 * GS)
 
     AF af;
-    PROF_DECL
     PROF_MARK(0)                                                // kernel prologue
     // inputs of a tile, read one tile ahead (in front of the previous tile's last epilogue): read at the top of the
     // tile, the x / node-id loads put an HBM round trip (~3k cycles per tile) in front of layer 1
@@ -504,7 +568,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             const int p0 = pos0_n - l0;
             jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
             if (tile == blockIdx.x)                                               // first tile of this workgroup: clear the bins
+            {
                 for (int i = threadIdx.x; i < SEG_SLOTS * 32 * MT4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
+                if constexpr (FLAGS) __syncthreads();                             // (the 3-slot ring meets at its first boundary)
+            }
         }
         float xin[8];
 #pragma unroll
@@ -766,6 +833,7 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
+    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // bench-only (tools/fused_variants.py)
     const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
     int abl = 0;
     if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
@@ -804,6 +872,7 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
+    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // bench-only
     const long long grid = ntiles < cus ? ntiles : cus;
     int abl = 0;
     if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)

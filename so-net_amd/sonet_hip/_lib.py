@@ -20,6 +20,7 @@ SIGNATURES = {
     "sonet_build_arch": [],
     "sonet_last_error": [],
     "sonet_check_device": [],
+    "sonet_diag_mfma_f16_rate": [_i, _i, _vp, _vp, _vp],
     "sonet_index_max_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_index_max_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_index_max_gather_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

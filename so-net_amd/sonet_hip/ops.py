@@ -546,3 +546,16 @@ def chamfer_nn(q, db):
     with torch.cuda.device(dev), _timed("chamfer_nn"):
         check(_lib.load().sonet_chamfer_nn_f32(ptr(q), ptr(db), ptr(nn), B, Nq, Nd, stream_ptr()), "sonet_chamfer_nn_f32")
     return nn
+
+
+def mfma_f16_sustained_rate(random_operands=True, iters=4000, device=None):
+    """(TFLOP/s, shader GHz) a pure fp16 MFMA loop holds on the whole chip -- the measuring stick beside the nominal
+    matrix peak (``sonet_diag_mfma_f16_rate``; with random operands the rate is power-limited, DESIGN.md finding 8)."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    with torch.cuda.device(dev):
+        _lib.require_device(dev)
+        check(_lib.load().sonet_diag_mfma_f16_rate(1 if random_operands else 0, int(iters), ctypes.byref(tf), ctypes.byref(ghz), stream_ptr()),
+              "sonet_diag_mfma_f16_rate")
+    return tf.value, ghz.value

@@ -896,9 +896,26 @@ def test_encoder_fast_path_lazily_materialises_first_pn_out():
     synth.fill_state_dict_(enc.state_dict(), int(g["seed"]))
     enc.to(DEV).eval()
     args = (cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
-    with torch.no_grad(), ops.kernel_timing() as rec:
-        enc(*args)
-    names = [n for n, _, _ in rec.records]
-    assert any(n.startswith("pointresnet_fused_pool") for n in names) and not any(n.startswith("index_max") for n in names)
-    assert enc._first_pn_out is None
-    assert_close_rms(enc.first_pn_out[:, ::16, ::5].cpu().numpy(), g["first_pn_out_sub"], 1e-5, "lazy first_pn_out")
+    # the fast path is what this test is about: pin the switches that select it, whatever the
+    # environment defaults (SONET_POINTMLP_PRECISION / SONET_FUSE_*) say
+    old = ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL
+    ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL = "h3", True, True
+    try:
+        with torch.no_grad(), ops.kernel_timing() as rec:
+            enc(*args)
+        names = [n for n, _, _ in rec.records]
+        assert any(n.startswith("pointresnet_fused_pool") for n in names) and not any(n.startswith("index_max") for n in names)
+        assert enc._first_pn_out is None
+        assert_close_rms(enc.first_pn_out[:, ::16, ::5].cpu().numpy(), g["first_pn_out_sub"], 1e-5, "lazy first_pn_out")
+    finally:
+        ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET, ops.FUSE_POOL = old
+
+
+def test_mfma_sustained_rate_probe():
+    """The roofline measuring stick (sonet_diag_mfma_f16_rate): constant operands run near the nominal matrix rate,
+    random mantissas cannot be faster, and both report a plausible shader clock."""
+    from sonet_hip import ops
+    tf_c, ghz_c = ops.mfma_f16_sustained_rate(random_operands=False, iters=2000)
+    tf_r, ghz_r = ops.mfma_f16_sustained_rate(random_operands=True, iters=2000)
+    assert 500.0 < tf_r <= tf_c * 1.05 and tf_c < 2700.0, (tf_c, tf_r)
+    assert 0.8 < ghz_r < 2.6 and 0.8 < ghz_c < 2.6, (ghz_c, ghz_r)
