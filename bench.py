@@ -32,6 +32,7 @@ for p in (os.path.join(ROOT, "so-net_amd"), ROOT):
 import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PEAK_VALU_TLANEOPS = 39.3    # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz: vector instructions x lanes per second, in 1e12
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 # the 3xbf16-split path issues 6 bf16 MFMAs per algorithmic f32 product: its ceiling in algorithmic flops
@@ -278,6 +279,12 @@ def main():
                 else:
                     ach = amount / (s_["mean_ms"] * 1e-3) / 1e9
                     k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+                    if name.startswith("som_assign"):
+                        # 64 nodes per 12-byte point: ~21 VALU operations per node-point pair (exact, un-contracted distance
+                        # + 3-deep selection) put this kernel on the vector-issue roof long before the HBM one
+                        lane_ops = 21.0 * B * N * 64
+                        k["valu"] = {"achieved": round(lane_ops / (s_["mean_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_VALU_TLANEOPS,
+                                     "unit": "T lane-ops/s", "frac": round(lane_ops / (s_["mean_ms"] * 1e-3) / 1e12 / PEAK_VALU_TLANEOPS, 4)}
             out.append(k)
         return out
 
