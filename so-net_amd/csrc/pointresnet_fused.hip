@@ -19,8 +19,8 @@
 // Weights.  All four layers are packed (pointresnet_pack_kernel) into ONE linear stream of 1-KiB slices
 // (64 lanes x 8 fp16) in exactly the order the MFMAs consume them, so W staging is a linear copy (LDS-DMA):
 // the 4 waves of a workgroup stream the stage after next (NSTG slices) into the LDS ring and read their A fragments
-// back at (ring slot) + compile-time offsets.  One barrier per 36 MFMAs.
-//   L1: 2 tiles x 1 chunk, L2: 4 x 4, L3: 8 x 8  (tile-major),  L4: 2 passes x 20 chunks x 6 tiles.
+// back at (ring slot) + compile-time offsets.  One barrier per 36 MFMAs (24 slices).
+//   L1: 2 tiles x 1 chunk, L2: 4 x 4, L3: 8 x 8  (tile-major),  L4: 2 passes x 20 chunks x 6 tiles; two slices each.
 // Workgroups are persistent (one per CU) and walk the 128-point tiles; the weight stream simply restarts.
 #include "common.hpp"
 #include <stdlib.h>
@@ -37,14 +37,15 @@ constexpr int PF_THREADS = 256, PF_WAVES = 4;
 constexpr int T0 = 2, T1 = 4, T2 = 8, T3 = 12;               // output tiles (x32 channels) of the four layers
 constexpr int KC1 = 1, KC2 = 2 * T0, KC3 = 2 * T1, KC4 = 2 * T0 + 2 * T2;   // 16-channel K chunks per layer
 constexpr int MT4 = 6, NPASS = T3 / MT4;                      // layer-4 cout tiles per accumulator pass
-constexpr int NSTG = 36;                                       // slices per LDS stage
+constexpr int NSTG = 24;                                       // slices per LDS stage (2 slices feed 3 MFMAs)
+constexpr int NTERM = 2;                                       // W slices per (cout tile, K chunk): h and l (see the operand split)
 constexpr int GS = 4;                                          // cout tiles processed together in layers 2 and 3
-constexpr int SL1 = 12 /* 6 used + 6 pad: keeps every step aligned */, SL2 = T1 * KC2 * 3, SL3 = T2 * KC3 * 3;
+constexpr int SL1 = 8 /* 4 used + 4 pad: keeps every step aligned */, SL2 = T1 * KC2 * NTERM, SL3 = T2 * KC3 * NTERM;
 constexpr int OFF1 = 0, OFF2 = SL1, OFF3 = SL1 + SL2;
 constexpr int PRE = ((SL1 + SL2 + SL3 + NSTG - 1) / NSTG) * NSTG;                 // layer 4 starts on a stage boundary
-static_assert(OFF2 % (3 * GS) == 0 && OFF3 % (3 * GS) == 0 && NSTG % (3 * GS) == 0 && NSTG % (3 * MT4) == 0 && T1 % GS == 0 && T2 % GS == 0,
+static_assert(OFF2 % (NTERM * GS) == 0 && OFF3 % (NTERM * GS) == 0 && NSTG % (NTERM * GS) == 0 && NSTG % (NTERM * MT4) == 0 && T1 % GS == 0 && T2 % GS == 0,
               "a step (one K chunk x a group of tiles) must never straddle a stage boundary");
-constexpr int SL4 = KC4 * MT4 * 3;                             // slices per layer-4 pass
+constexpr int SL4 = KC4 * MT4 * NTERM;                         // slices per layer-4 pass
 constexpr int NSLICE = PRE + NPASS * SL4;
 constexpr int NSTAGE = NSLICE / NSTG;
 static_assert(SL4 % NSTG == 0 && NSLICE % NSTG == 0 && PRE == SL1 + SL2 + SL3, "whole stages, no padding stage");
@@ -53,16 +54,21 @@ static_assert(NSTG % PF_WAVES == 0, "");
 constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
 
 // ---- fp32 -> 3 x fp16 operand split ------------------------------------------------------------------
-// x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; a product a*b is taken as
-//     ah*bh  +  (ah*2^-5) * fp16(32*bm)  +  fp16(32*am) * (bh*2^-5)
+// x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; 32 * (a*b) is taken as
+//     ah * (32 bh)  +  ah * fp16(32 bm)  +  fp16(32 am) * bh
 // i.e. THREE fp16 MFMAs with fp32 accumulation (the dropped am*bm and the rounding of the scaled residuals are
-// <= 2^-22 relative).  The 2^5 / 2^-5 pair keeps the residual out of the fp16 subnormals (|x| > 4e-3 stays normal;
-// below that the absolute error is < 1e-9).  Measured on the reference fixtures: whole first PointNet within
-// 2.9e-6 * max(|ref|, rms) -- the same as the six-term 3 x bf16 split it replaces, at half the matrix work (any
-// five of the six bf16 terms: 3-4e-5, outside the 1e-5 bound).  Operand range: |x| <= 65504 (fp16); the split clamps.
-// Naming: term h = (ah, bh), m = (ah*2^-5, 32*bm), l = (32*am, bh*2^-5).
+// <= 2^-22 relative).  The factor 32 keeps the residuals out of the fp16 subnormals (|x| > 4e-3 stays normal; below
+// that the absolute error is < 1e-9); it is carried by the ACCUMULATOR (every power-of-two scaling is exact) and
+// taken out again by the layer's affine (scale / 32), so the first two terms share ONE weight operand: the stream
+// holds two slices per (cout tile, K chunk), ah and fp16(32 am), for three MFMAs -- a third less LDS-DMA, LDS read
+// and L2 traffic than one slice per MFMA, for bit-identical results.  Measured on the reference fixtures: whole first
+// PointNet within 2.9e-6 * max(|ref|, rms) -- the same as the six-term 3 x bf16 split it replaces, at half the
+// matrix work (any five of the six bf16 terms: 3-4e-5, outside the 1e-5 bound).  Operand range: |x| <= 2047
+// (32 x must fit fp16); the split clamps.
+// Naming: term h = (ah, 32 bh), m = (ah, 32 bm), l = (32 am, bh); the B side keeps them as b.h, b.m, b.l.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-constexpr float F16_MAX = 65504.0f;
+constexpr float F16_MAX = 2047.0f;                             // 32 * 2047 = 65504, the largest fp16
+constexpr float ACC_UNSCALE = 0.03125f;                        // accumulators hold 32 * (W . x)
 constexpr unsigned F16_2_M5_PK = 0x28002800u;                  // packed fp16 (2^-5, 2^-5)
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {        // one v_cvt_pk_f16_f32 (round to nearest even)
     const f32x2_t v = {lo, hi};
@@ -76,9 +82,9 @@ __device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
 }
 __device__ __forceinline__ float clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -F16_MAX), F16_MAX); }
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    h = cvt_pk_f16(x0, x1);
-    m = cvt_pk_f16(32.f * (x0 - f16_lo(h)), 32.f * (x1 - f16_hi(h)));      // x - fp16(x) is exact
-    l = pk_mul_f16(h, F16_2_M5_PK);
+    h = cvt_pk_f16(32.f * x0, 32.f * x1);                                  // 32 xh
+    m = cvt_pk_f16(32.f * x0 - f16_lo(h), 32.f * x1 - f16_hi(h));          // 32 (x - xh), exact before the rounding
+    l = pk_mul_f16(h, F16_2_M5_PK);                                        // xh
 }
 
 struct B3 { f16x8 h, m, l; };
@@ -116,12 +122,12 @@ __device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; a
 __device__ __forceinline__ float pin_relu_clamp(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX)); return r; }
 __device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
 __device__ __forceinline__ float pin_mul32(float a) { float r; asm volatile("v_mul_f32 %0, 0x42000000, %1" : "=v"(r) : "v"(a)); return r; }
-// 32*x - 32*fp16 half of pk = 32 * (x - xh), exact
-__device__ __forceinline__ float pin_res_lo(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-32.0f), "v"(x32)); return r; }
-__device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-32.0f), "v"(x32)); return r; }
+// 32*x - (fp16 half of pk = 32 xh) = 32 * (x - xh), exact
+__device__ __forceinline__ float pin_res_lo(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
+__device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
 __device__ __forceinline__ unsigned pin_scale_dn(unsigned pk) { unsigned r; asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(pk), "v"(F16_2_M5_PK)); return r; }
-// Op I of 44 = two groups of 22 (two value pairs each, neighbours independent): affine x4, relu+clamp x4, xh x2,
-// 32x x4, residual x4, xm x2, xh*2^-5 x2.
+// Op I of 44 = two groups of 22 (two value pairs each, neighbours independent): affine x4, relu+clamp x4, 32x x4,
+// 32xh x2, residual x4, 32xm x2, xh = 32xh * 2^-5 x2.
 constexpr int SPLIT_OPS = 44;
 template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
     if constexpr (ABL & 2) {
@@ -133,8 +139,8 @@ template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s
         constexpr int g = I / 22, k = I % 22;
         if constexpr (k < 4) { constexpr int e = 4 * g + k; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
         else if constexpr (k < 8) { constexpr int e = 4 * g + k - 4; s.x[e] = pin_relu_clamp(s.x[e]); }
-        else if constexpr (k < 10) { constexpr int P = 2 * g + (k - 8); s.h[P] = pin_cvt(s.x[2 * P], s.x[2 * P + 1]); }
-        else if constexpr (k < 14) { constexpr int e = 4 * g + (k - 10); s.r[e] = pin_mul32(s.x[e]); }
+        else if constexpr (k < 12) { constexpr int e = 4 * g + (k - 8); s.r[e] = pin_mul32(s.x[e]); }
+        else if constexpr (k < 14) { constexpr int P = 2 * g + (k - 12); s.h[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
         else if constexpr (k < 18) { constexpr int e = 4 * g + (k - 14); s.r[e] = (e & 1) ? pin_res_hi(s.h[e >> 1], s.r[e]) : pin_res_lo(s.h[e >> 1], s.r[e]); }
         else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 18); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
         else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_scale_dn(s.h[P]); }
@@ -166,18 +172,18 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
     bool chained = true, valid = true;
     // consumption order: per layer, tile-group major, then K chunk, then tile within the group, then split term
     if (s < OFF2) {                       // L1: 2 tiles x 1 chunk, standard channel order (input comes from memory)
-        const int u = s - OFF1; term = u % 3; kc = 0; ct = u / 3; W = W1; Cin = Cin0; chained = false; valid = u < T0 * 3;
+        const int u = s - OFF1; term = u % NTERM; kc = 0; ct = u / NTERM; W = W1; Cin = Cin0; chained = false; valid = u < T0 * NTERM;
     } else if (s < OFF3) {
-        const int u = s - OFF2; term = u % 3; const int mt = (u / 3) % GS; kc = (u / (3 * GS)) % KC2;
-        ct = (u / (3 * GS * KC2)) * GS + mt; W = W2; Cin = 32 * T0;
+        const int u = s - OFF2; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC2;
+        ct = (u / (NTERM * GS * KC2)) * GS + mt; W = W2; Cin = 32 * T0;
     } else if (s < OFF3 + SL3) {
-        const int u = s - OFF3; term = u % 3; const int mt = (u / 3) % GS; kc = (u / (3 * GS)) % KC3;
-        ct = (u / (3 * GS * KC3)) * GS + mt; W = W3; Cin = 32 * T1;
+        const int u = s - OFF3; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC3;
+        ct = (u / (NTERM * GS * KC3)) * GS + mt; W = W3; Cin = 32 * T1;
     } else if (s < PRE) {
         valid = false;                    // padding up to an even number of stages
     } else {                              // L4: pass-major, then chunk-major, MT4 tiles per chunk
         const int u = (s - PRE) % SL4, pass = (s - PRE) / SL4;
-        term = u % 3; ct = pass * MT4 + (u / 3) % MT4; kc = u / (3 * MT4); W = W4; Cin = 32 * (T0 + T2);
+        term = u % NTERM; ct = pass * MT4 + (u / NTERM) % MT4; kc = u / (NTERM * MT4); W = W4; Cin = 32 * (T0 + T2);
     }
     unsigned w[4] = {0, 0, 0, 0};
     if (valid) {
@@ -190,11 +196,10 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
                 const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
                 v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
             }
-            // A-side terms: h = fp16(w), m = h * 2^-5 (pairs with the scaled residual of x), l = fp16(32 * (w - h))
+            // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
             const unsigned hh = cvt_pk_f16(v[0], v[1]);
-            const unsigned mm = pk_mul_f16(hh, F16_2_M5_PK);
             const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
-            w[p] = term == 0 ? hh : term == 1 ? mm : ll;
+            w[p] = term == 0 ? hh : ll;
         }
     }
     out[(long long)s * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -226,7 +231,7 @@ constexpr bool FLAGS = false;                                  // experiment: 4 
 constexpr bool DEEP = NSLOT == 4;                              // boundary(n) and waited for with vmcnt(9): two stages to land
 #endif
 
-struct AF { f16x8 h[MT4], m[MT4], l[MT4]; };                  // A fragments of one step (up to MT4 tiles x 3 terms)
+struct AF { f16x8 h[MT4], l[MT4]; };                          // A fragments of one step (up to MT4 tiles x 2 slices)
 
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
 constexpr int SEG_SLOTS = NSLOT == 4 ? 12 : 16;                              // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/)
 {
     __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
-    __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 36 KiB
+    __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 24 KiB
     __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
     __shared__ __attribute__((aligned(16))) unsigned prog[PF_WAVES];   // FLAGS: per-wave progress counters
 
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     bool l4_unit_lane = true;                                   // layer 4 has no BatchNorm in the reference: scale == 1
     for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) {
         const float2 v = affine_g[c];
-        aff[c] = v;
+        aff[c] = make_float2(v.x * ACC_UNSCALE, v.y);          // the accumulators carry a factor 32 (exact either way)
         if (c >= 32 * (T0 + T1 + T2) && v.x != 1.0f) l4_unit_lane = false;
     }
     const bool l4_unit = __syncthreads_and(l4_unit_lane) != 0;   // then max(x + b) = max(x) + b exactly: bias after the pool
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         dma_g = reinterpret_cast<const char *>(Wst) + (size_t)(sn * NSTG + wave * NSW) * 1024u;
         dma_dst = wsm_lds + (unsigned)(slot * NSTG + wave * NSW) * 1024u;
     };
-    // pieces t and t+1 (t even) of the wave's NSW = 9: they share an M0 / base pair, the instruction offset moves both
+    // pieces t and t+1 (t even) of the wave's NSW = 6: they share an M0 / base pair, the instruction offset moves both
     // the global and the LDS address.  (M0 is written in the statement that uses it and not restored: nothing else
     // in this kernel reads it.  Saving/restoring it and re-deriving the base per piece cost ~9 scalar instructions
     // per piece, ~60 cycles in front of the next MFMA, 27 stage boundaries per tile.)
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     };
     auto stage_dma = [&](int n, int slot) {
         dma_setup(n, slot);
-        dma_pair(0, true); dma_pair(2, true); dma_pair(4, true); dma_pair(6, true); dma_pair(8, false);
+        dma_pair(0, true); dma_pair(2, true); dma_pair(4, true);
     };
     // ring state (wave-uniform scalars)
     int n_cur = 0;                                              // stage being consumed
@@ -442,21 +447,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     }
 #define PF_DMA_AFTER(NT, u)                                                                          \
     if constexpr (so_ == 0 && !(ABL & 4) && !(ABL & 64)) {                                            \
-        static_assert(NSW == 9, "five statements: pieces 01 23 45 67 8");                           \
-        if constexpr ((NT) >= 5) {                                                                   \
+        static_assert(NSW == 6, "three statements: pieces 01 23 45");                               \
+        if constexpr ((NT) >= 3) {                                                                   \
             if constexpr ((u) == 0) dma_pair(0, true);                                               \
             if constexpr ((u) == 1) dma_pair(2, true);                                               \
             if constexpr ((u) == 2) dma_pair(4, true);                                               \
-            if constexpr ((u) == 3) dma_pair(6, true);                                               \
-            if constexpr ((u) == 4) dma_pair(8, false);                                              \
-        } else if constexpr ((NT) == 4) {                                                            \
-            if constexpr ((u) == 0) dma_pair(0, true);                                               \
-            if constexpr ((u) == 1) dma_pair(2, true);                                               \
-            if constexpr ((u) == 2) dma_pair(4, true);                                               \
-            if constexpr ((u) == 3) { dma_pair(6, true); dma_pair(8, false); }                       \
         } else {                                                                                     \
             if constexpr ((u) == 0) { dma_pair(0, true); dma_pair(2, true); }                        \
-            if constexpr ((u) == 1) { dma_pair(4, true); dma_pair(6, true); dma_pair(8, false); }    \
+            if constexpr ((u) == 1) dma_pair(4, true);                                               \
         }                                                                                            \
     }
 #define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MFZ(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
@@ -470,13 +468,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // One step = one K chunk (16 channels) x NT cout tiles = 3 NT MFMAs: the three product terms l, m, h TERM-major
     // across the tiles (consecutive MFMAs never share an accumulator).  It is scheduled by hand (sched_barrier after
     // every MFMA), because with one wave per SIMD nothing else hides a latency:
-    //  - on entry af.l / af.m already hold this step's fragments (read by the step before; COLD steps -- first of a
+    //  - on entry af.l / af.h already hold this step's fragments (read by the step before; COLD steps -- first of a
     //    tile / of a layer-4 pass -- read them first thing, from the ring slot that is about to become current);
     //  - a step that opens a stage waits for its own LDS-DMA slices, takes the barrier, and issues the NSW slices of
     //    the stage after next between the MFMAs of the first term;
-    //  - `h` is read after the first term (used two terms later); the freed `l` registers take the NEXT step's `l`
-    //    after the second term (from the next ring slot when that step opens a stage: published one barrier
-    //    earlier), `m` likewise after the third: no second fragment set, <= 12 LDS reads in flight;
+    //  - `h` feeds the second and third term; the freed `l` registers take the NEXT step's `l` after the second term
+    //    (from the next ring slot when that step opens a stage: published one barrier earlier), `h` likewise after
+    //    the third (it lands under the next step's first term): no second fragment set, <= 12 LDS reads in flight;
     //  - the next step's B chunk gets its affine + ReLU + split a few VALU instructions behind each MFMA
     //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
 #define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, ZERO)   \
@@ -487,8 +485,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         SplitState sp_;                                                                              \
         if (COLD) {                                                                                  \
             const uint4 *cb_ = (so_ != 0 || first_boundary) ? lds_cur : lds_nxt;                     \
-            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.l[u_] = PF_LDA(cb_, so_ + 3 * u_ + 2); \
-            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.m[u_] = PF_LDA(cb_, so_ + 3 * u_ + 1); \
+            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.l[u_] = PF_LDA(cb_, so_ + NTERM * u_ + 1); \
+            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(cb_, so_ + NTERM * u_);     \
         }                                                                                            \
         if (so_ == 0) { boundary_sync(FLUSH); boundary_fill(FLUSH); }                                \
         const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;                                            \
@@ -497,14 +495,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         { CHUNKCODE }                                                                                \
         PF_SB                                                                                        \
         PF_TERM_A(accarr, tbase, NT, af.l, bcur.l, HAVE)                                             \
-        _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(lds_cur, so_ + 3 * u_);  \
         PF_SB                                                                                        \
-        PF_TERM_V(accarr, tbase, NT, af.m, bcur.m, HAVE, 1)                                          \
+        PF_TERM_V(accarr, tbase, NT, af.h, bcur.m, HAVE, 1)                                          \
         if constexpr (FLAGS && son_ == 0 && !(ABL & 4)) prog_wait(pg_);                              \
-        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + 3 * u_ + 2); \
+        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + NTERM * u_ + 1); \
         PF_SB                                                                                        \
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
-        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.m[u_] = PF_LDA(nb_, son_ + 3 * u_ + 1); \
+        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.h[u_] = PF_LDA(nb_, son_ + NTERM * u_); \
         PF_SB                                                                                        \
         if constexpr (HAVE) bnext = split_result(sp_);                                               \
     }
@@ -522,7 +519,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     }
     constexpr int NMID = KC2 * (T1 / GS) + KC3 * (T2 / GS);    // steps of layers 2 and 3 (4 + 16)
     // slice index / tile group of middle step i (layer 2 first, then layer 3)
-#define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * 3 * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * 3 * GS)
+#define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * NTERM * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * NTERM * GS)
 
     AF af;
     PROF_MARK(0)                                                // kernel prologue
@@ -602,14 +599,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
             constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
             constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
-            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + 3 * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, (i % KC2 == 0)) } \
+            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + NTERM * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, (i % KC2 == 0)) } \
             else if constexpr (grp == 0) {                                  /* layer 3, tiles 0-3: keep each split chunk */ \
                 constexpr int kc3 = i - KC2 * (T1 / GS);                    \
                 bsave[kc3] = bq[cur];                                       \
-                PF_STEP(act3, 0, GS, sidx, ntn, sidx + 3 * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
+                PF_STEP(act3, 0, GS, sidx, ntn, sidx + NTERM * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
             } else {                                                        /* tiles 4-7 reuse them: no split work at all */ \
                 constexpr int kc3 = i - KC2 * (T1 / GS) - KC3;              \
-                PF_STEP(act3, GS, GS, sidx, ntn, sidx + 3 * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
+                PF_STEP(act3, GS, GS, sidx, ntn, sidx + NTERM * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
             } \
             if constexpr (last_of_l2) {                                     /* layer transition */ \
                 SplitState sp2_; \
@@ -630,10 +627,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #define PF_L4(K_)                                                           \
             {                                                               \
                 constexpr int kc = (K_);                                    \
-                constexpr int sidx = PRE + kc * MT4 * 3; \
+                constexpr int sidx = PRE + kc * MT4 * NTERM; \
                 constexpr int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
                 constexpr int kn = (kc + 1) % KC4; \
-                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + 3 * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), (kc == 0)) \
+                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + NTERM * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), (kc == 0)) \
             }
             static_assert(KC4 == 20, "expand PF_L4 to KC4 steps");
             PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
@@ -665,7 +662,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     for (int r = 0; r < 16; ++r)
                         if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0) {
 #pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = l4_unit ? __fadd_rn(acc[mt][r], bias4[mt]) : acc[mt][r];
+                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = l4_unit ? __fmaf_rn(acc[mt][r], ACC_UNSCALE, bias4[mt]) : acc[mt][r];
                         }
                 }
                 // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted, so a node's points
@@ -707,9 +704,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                         }
                     }
                     (void)nvalid;
-                    if (l4_unit) {                                                // fl(x + b) is monotone in x: add after the max
+                    if (l4_unit) {                                                // fl(x / 32 + b) is monotone in x: after the max
 #pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fadd_rn(mx[mt], bias4[mt]);
+                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
                     }
                     if constexpr (!(ABL & 32)) {
                         // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
