@@ -168,7 +168,7 @@ int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, cons
                           int B, int Cout, int L, sonet_stream_t stream);
 
 /* The same layer on a THREE-term fp16 split (v_mfma_f32_32x32x16_f16): half the matrix work at the same 3e-6 accuracy,
- * but an fp16 operand range (|x| <= 65504, clamped; magnitudes below ~1e-4 lose relative precision): forward
+ * but an fp16 operand range (|x| <= 2047, clamped; magnitudes below ~1e-4 lose relative precision): forward
  * activations and coordinates, not gradients.  Packed size = sonet_pointmlp_x3_pack_size. */
 int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream);
 int sonet_pointmlp_h3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,

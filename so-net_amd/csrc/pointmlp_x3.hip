@@ -19,11 +19,13 @@
 // on the VALU pipe, while the 6*MT MFMAs of the chunk run on the matrix pipe.
 //
 // F16 variant (sonet_pointmlp_h3_*): the same kernel on v_mfma_f32_32x32x16_f16 with a THREE-term split,
-//      x = xh + xm,  xh = fp16(x):   W.x ~= Wh.xh + (Wh*2^-5).fp16(32 xm) + fp16(32 Wm).(xh*2^-5)
-// (dropped terms and the rounding of the scaled residuals <= 2^-22 relative; the 2^5 / 2^-5 pair keeps the residuals out
-// of the fp16 subnormals).  Same 3e-6 accuracy on the fixtures at half the MFMAs, but an fp16 operand RANGE: inputs are
-// clamped to +-65504 and magnitudes below ~1e-4 lose relative precision -- fine for coordinates and normalised
-// activations (forward), not for gradients: the dgrad launches of the backward keep the bf16 split.
+//      x = xh + xm,  xh = fp16(x):   32 W.x ~= Wh.(32 xh) + Wh.fp16(32 xm) + fp16(32 Wm).xh
+// (dropped terms and the rounding of the scaled residuals <= 2^-22 relative; the factor 32 keeps the residuals out of the
+// fp16 subnormals, rides in the accumulator -- power-of-two scalings are exact -- and leaves through scale / 32).  The
+// first two terms share the weight operand Wh: two W slices per chunk and tile go through LDS for three MFMAs.  Same
+// 3e-6 accuracy on the fixtures at half the MFMAs, but an fp16 operand RANGE: inputs are clamped to +-2047 (32 x must
+// fit) and magnitudes below ~1e-4 lose relative precision -- fine for coordinates and normalised activations (forward),
+// not for gradients: the dgrad launches of the backward keep the bf16 split.
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -54,19 +56,27 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, uns
     l = cvt_pk_bf16(q0, q1);
 }
 
-// fp16 flavour: (x0, x1) -> xh, fp16(32 * (x - xh)), xh * 2^-5 (packed pairs); x - fp16(x) is exact in f32
+// fp16 flavour, B side: (x0, x1) -> 32 xh = fp16(32 x), fp16(32 x - 32 xh), xh = 32 xh * 2^-5 (packed pairs; exact residual)
 constexpr unsigned F16_2_M5_PK = 0x28002800u;
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
 __device__ __forceinline__ void split16_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    x0 = __builtin_fminf(__builtin_fmaxf(x0, -65504.f), 65504.f);
-    x1 = __builtin_fminf(__builtin_fmaxf(x1, -65504.f), 65504.f);
+    x0 = 32.f * __builtin_fminf(__builtin_fmaxf(x0, -2047.f), 2047.f);
+    x1 = 32.f * __builtin_fminf(__builtin_fmaxf(x1, -2047.f), 2047.f);
     h = cvt_pk_f16(x0, x1);
     const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
-    m = cvt_pk_f16(32.f * (x0 - (float)hv[0]), 32.f * (x1 - (float)hv[1]));
+    m = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
     l = __builtin_bit_cast(unsigned, hv * __builtin_bit_cast(f16x2_t, F16_2_M5_PK));
+}
+// A side: (w0, w1) -> fp16(w), fp16(32 * (w - fp16(w)))
+__device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsigned &res) {
+    w0 = __builtin_fminf(__builtin_fmaxf(w0, -65504.f), 65504.f);
+    w1 = __builtin_fminf(__builtin_fmaxf(w1, -65504.f), 65504.f);
+    h = cvt_pk_f16(w0, w1);
+    const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+    res = cvt_pk_f16(32.f * (w0 - (float)hv[0]), 32.f * (w1 - (float)hv[1]));
 }
 
 // Wp3[ct][kc][term][lane] (uint4 = 8 bf16 / fp16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
@@ -88,10 +98,11 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
         const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
         const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
         if constexpr (F16) {
-            // A side: h = fp16(w); "m" = h * 2^-5 (meets the x residual scaled by 32); "l" = fp16(32 * (w - h)) (meets xh * 2^-5)
-            unsigned hh, res, hs;
-            split16_pair(w0, w1, hh, res, hs);
-            h[p] = hh; m[p] = hs; l[p] = res;
+            // A side: slice 0 = fp16(w) (meets 32 xh and the scaled x residual), slice 2 = fp16(32 * (w - h)) (meets xh);
+            // slice 1 is unused by the fp16 kernel (the packed size is shared with the bf16 flavour)
+            unsigned hh, res;
+            split16_w(w0, w1, hh, res);
+            h[p] = hh; m[p] = 0u; l[p] = res;
         } else {
             split3_pair(w0, w1, h[p], m[p], l[p]);
         }
@@ -108,7 +119,8 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y)
 {
-    constexpr int NSL = S * MT * 3;                           // 1 KiB W slices per stage (3 split terms)
+    constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
+    constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
     constexpr int NS = (NSL + X3_WAVES - 1) / X3_WAVES;
     __shared__ uint4 wsm[2][NS * X3_WAVES][64];
     __shared__ float2 affine[1024];
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const int ct_begin = blockIdx.y * ct_per_y;
     const int ct_end = min(CT, ct_begin + ct_per_y);
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
-        affine[o - ct_begin * 32] = make_float2(scale[o], shift[o]);
+        affine[o - ct_begin * 32] = make_float2(F16 ? scale[o] * 0.03125f : scale[o], shift[o]);   // fp16: accumulators hold 32 W.x
 
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
         f32x16 acc[MT];
@@ -168,14 +180,14 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-        // slice sl of a stage: chunk i = sl / (3*MT), cout tile mt = (sl / 3) % MT, term = sl % 3
+        // slice sl of a stage: chunk i = sl / (NTW*MT), cout tile mt = (sl / NTW) % MT, term = sl % NTW (fp16: packed slices 0 and 2)
         auto stage_load = [&](i32x4_t (&w)[NS], int st) {
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 int sl = wave + t * X3_WAVES;
                 sl = sl < NSL ? sl : NSL - 1;
-                const int i = sl / (3 * MT), rem = sl - i * (3 * MT);
-                const int mt = rem / 3, term = rem - mt * 3;
+                const int i = sl / (NTW * MT), rem = sl - i * (NTW * MT);
+                const int mt = rem / NTW, term = (rem - mt * NTW) * (F16 ? 2 : 1);
                 int kc = st * S + i;
                 kc = kc < KC ? kc : KC - 1;
                 w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(((ct0 + mt) * KC + kc) * 3 + term) * 1024u, 0);
@@ -193,18 +205,20 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 if constexpr (F16) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p) split16_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
-                    const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));     // 32 xh
                     const f16x8 Bm = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));     // 32 * residual
-                    const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh * 2^-5
+                    const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh
+                    f16x8 Ah[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 2][lane]), Bl, acc[mt], 0, 0, 0);
+                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 2 + 1][lane]), Bl, acc[mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 1][lane]), Bm, acc[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        Ah[mt] = __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 2 + 0][lane]);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bm, acc[mt], 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 3 + 0][lane]), Bh, acc[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bh, acc[mt], 0, 0, 0);
                 } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) split3_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);

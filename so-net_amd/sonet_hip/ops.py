@@ -291,7 +291,7 @@ import os as _os
 #   "x3" : bf16 MFMA on a 3-way bf16 split of both operands (six terms), f32 accumulate: f32-class accuracy (the
 #          reference fixtures are met at the same 1e-5 tolerance), f32 operand range, 1.4-1.7x faster than "f32"
 #   "h3" : fp16 MFMA on a two-piece fp16 split with scaled residuals (three terms): the same accuracy at half the
-#          matrix work, fp16 operand RANGE (|x| <= 65504 clamped, relative precision fades below ~1e-4) -- DEFAULT for
+#          matrix work, fp16 operand RANGE (|x| <= 2047 clamped, relative precision fades below ~1e-4) -- DEFAULT for
 #          the forward layers (coordinates, normalised activations); gradients (dgrad) always use "x3"
 POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "h3")
 
