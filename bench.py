@@ -87,7 +87,7 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
     if name.startswith("pointmlp"):
         dims, L = name.split("_", 1)[1].split("_L")
         cin, cout = dims.split("x")
-        return "mfma", 2.0 * int(cin) * int(cout) * B * int(L)
+        return "mfma", 2.0 * int(cin) * int(cout) * B * int(L.split("_")[0])     # ("_kmax9": the max over k is in the epilogue)
     return "hbm", None
 
 
@@ -273,7 +273,7 @@ def main():
             if amount:
                 if bound == "mfma":
                     ach = amount / (s_["mean_ms"] * 1e-3) / 1e12
-                    peak = (PEAK_H3_TFLOPS if name.startswith(("pointresnet_fused", "pointmlph3")) else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
+                    peak = (PEAK_H3_TFLOPS if name.startswith(("pointresnet_fused", "pointmlph3", "pointmlpws")) else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
                             else PEAK_F32_MFMA_TFLOPS)
                     k.update(achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
                 else:

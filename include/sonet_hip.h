@@ -135,6 +135,21 @@ int sonet_knn_self_f32(const float *node, int64_t *knn_I, int B, int M, int K, s
  * center [B][3][M] = mean of the K neighbour coordinates (center_avg != 0) or the node itself.  knn_I [B][M][K] i64. */
 int sonet_knn_group_f32(const float *coord, const float *feat, const int64_t *knn_I, int B, int C, int M, int K,
                         int center_avg, float *center, float *out, sonet_stream_t stream);
+/* KNNModule without the gathered tensor (models/layers.py:313-364, no-grad path).  sonet_knn_prepare_f32 writes the
+ * neighbourhood centre [B][3][M] ("avg": sequential f32 mean of the K neighbours, else the node), the de-centred neighbour
+ * coordinates K-MAJOR [B][3][K*M] (column k*M + m) and the int32 gather index of every column [B][K*M] (-1 where
+ * knn_I is out of range: such a column reads as zeros, as in sonet_knn_group_f32).
+ * sonet_pointmlp_h3_gather_f32 is sonet_pointmlp_h3_f32 with x1 = [B][C1][L1] read through that index: column l takes
+ * x1[b][:, gidx[b][l]] -- the neighbour gather happens in the operand load; x2 [B][C2][L] and y [B][Cout][L] as usual.
+ * sonet_planes_max_f32: out[row][m] = max_k x[row][k*M + m] (torch.max over the neighbourhood, layers.py:361-364, on the
+ * k-major layout; NaN-propagating). */
+int sonet_knn_prepare_f32(const float *coord, const int64_t *knn_I, int B, int M, int K, int center_avg,
+                          float *center, float *dec, int32_t *gidx, sonet_stream_t stream);
+int sonet_pointmlp_h3_gather_f32(const float *x1, int C1, int L1, const int32_t *gidx, const float *x2, int C2, const void *Wp3,
+                                 const float *scale, const float *shift, int relu, float *y,
+                                 int B, int Cout, int L, sonet_stream_t stream);
+int sonet_planes_max_f32(const float *x, float *out, long long rows, int K, int M, sonet_stream_t stream);
+
 /* out[row] = max over the K contiguous values of each of `rows` rows (NaN propagates, as torch.amax):
  * the neighbourhood max of KNNModule (models/layers.py:365) and the max over nodes (models/networks.py:197). */
 int sonet_lastdim_max_f32(const float *x, float *out, long long rows, int K, sonet_stream_t stream);

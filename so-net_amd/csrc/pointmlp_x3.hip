@@ -117,7 +117,8 @@ template <int MT, int S, bool F16>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
-    int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y)
+    int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
+    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/)
 {
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const bool pv = wave_valid && (l0 + j < L);
     const int lc = (l0 + j < L) ? l0 + j : l0;
 
-    const unsigned rowB = (unsigned)L * 4u;
+    const unsigned rowB = (unsigned)L * 4u, rowB1 = (unsigned)L1 * 4u;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(x1 + b * (long long)C1 * L), 0, (int)((unsigned)C1 * rowB), 0x00020000);
+        const_cast<float *>(x1 + b * (long long)C1 * L1), 0, (int)((unsigned)C1 * rowB1), 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
@@ -147,6 +148,13 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(Wp3), 0, (int)((unsigned)CT * (unsigned)KC * 3072u), 0x00020000);
     const unsigned vox = (unsigned)(8 * h * L + lc) * 4u;      // lane byte offset inside a 16-channel chunk
+    // x1 through a gather index (the neighbour gather of KNNModule, models/layers.py:313-350, done by the operand load):
+    // an index outside [0, L1) reads zeros (lane offset past the panel: the descriptor's bounds check)
+    unsigned vox1 = vox;
+    if (gidx) {
+        const int src = gidx[b * L + lc];
+        vox1 = (unsigned)src < (unsigned)L1 ? (unsigned)(8 * h * L1 + src) * 4u : 0x7FFFFF00u;
+    }
     const unsigned voy = (unsigned)(4 * h * L + lc) * 4u;
     const unsigned vow = (unsigned)lane * 16u;
 
@@ -158,12 +166,13 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         for (int i = 0; i < S; ++i) {
             const int kc = st * S + i;
             const bool second = kc >= KC1;
-            const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rowB;
+            const unsigned rb = second ? rowB : rowB1;
+            const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rb;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const unsigned so = row0 + (unsigned)t * rowB;
+                const unsigned so = row0 + (unsigned)t * rb;
                 raw[i][t] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
-                                                              : __builtin_amdgcn_raw_buffer_load_b32(r1, vox, so, 0));
+                                                              : __builtin_amdgcn_raw_buffer_load_b32(r1, vox1, so, 0));
             }
         }
     };
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     }
 }
 
+
 }  // namespace
 
 extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
@@ -316,8 +326,10 @@ extern "C" int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Co
 
 static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, const float *x2, int C2, const void *Wp3,
                        const float *scale, const float *shift, int relu, float *y,
-                       int B, int Cout, int L, sonet_stream_t stream)
+                       int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0)
 {
+    if (!gidx) L1 = L;
+    SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
     SONET_REQUIRE(x1 && Wp3 && scale && shift && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
@@ -327,7 +339,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int CT = Cout / 32, KC = sonet::ceil_div(Cin, 16);
     const int gpc = sonet::ceil_div(L, 32);
     const long long ngroups = (long long)B * gpc;
-    if ((double)(C1 > C2 ? C1 : C2) * L * 4.0 >= 4.0e9 || (double)Cout * L * 4.0 >= 4.0e9 || (double)CT * KC * 3072.0 >= 4.0e9)
+    if ((double)C1 * L1 * 4.0 >= 2.0e9 || (double)(C1 > C2 ? C1 : C2) * L * 4.0 >= 4.0e9 || (double)Cout * L * 4.0 >= 4.0e9 || (double)CT * KC * 3072.0 >= 4.0e9)
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
     const long long nwg_x = sonet::ceil_div64(ngroups, (long long)X3_WAVES);
     if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
@@ -352,7 +364,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
@@ -380,4 +392,16 @@ extern "C" int sonet_pointmlp_h3_f32(const float *x1, int C1, const float *x2, i
                                      int B, int Cout, int L, sonet_stream_t stream)
 {
     return x3_run_impl("sonet_pointmlp_h3_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream);
+}
+
+
+// The same layer with x1 read through a per-column gather index: x1 is [B][C1][L1], column l of cloud b takes
+// x1[b][:, gidx[b][l]] (zeros when the index is outside [0, L1)); x2 [B][C2][L] and y [B][Cout][L] as usual.
+extern "C" int sonet_pointmlp_h3_gather_f32(const float *x1, int C1, int L1, const int32_t *gidx, const float *x2, int C2, const void *Wp3,
+                                            const float *scale, const float *shift, int relu, float *y,
+                                            int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_h3_gather_f32";
+    SONET_REQUIRE(gidx, "%s: NULL pointer", what);
+    return x3_run_impl(what, true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, gidx, L1);
 }

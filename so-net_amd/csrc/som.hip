@@ -231,6 +231,59 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float *__restrict_
         for (int q = 0; q < 4 && mk0 + q < MK; ++q) o[mk0 + q] = v[q];
 }
 
+// out[row][m] = max over k of x[row][k * M + m] (k-major neighbourhood planes), NaN-propagating like torch.max
+__global__ __launch_bounds__(256) void planes_max_kernel(const float *__restrict__ x, float *__restrict__ out, int K, int M, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // row * M + m
+    if (t >= total) return;
+    const long long row = t / M;
+    const int m = (int)(t - row * M);
+    const float *p = x + row * (long long)K * M + m;
+    float best = p[0];
+    for (int k = 1; k < K; ++k) {
+        const float v = p[(long long)k * M];
+        best = (v > best || v != v) ? v : best;
+    }
+    out[t] = best;
+}
+
+// KNNModule input for the gathering layer (sonet_pointmlp_h3_gather_f32): nothing but the 3 de-centred coordinate rows is
+// materialised, K-MAJOR (column k * M + m), together with the int32 gather index of every column (-1: index out of range,
+// reads as 0 like knn_group) -- the 384 feature rows are gathered by the layer's operand loads.
+__global__ __launch_bounds__(256) void knn_prepare_kernel(const float *__restrict__ coord, const int64_t *__restrict__ I, int M, int K, int avg,
+                                                           float *__restrict__ center, float *__restrict__ dec, int32_t *__restrict__ gidx,
+                                                           long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (b * K + k) * M + m
+    if (t >= total) return;
+    const int m = (int)(t % M);
+    const long long bk = t / M;
+    const int k = (int)(bk % K);
+    const long long b = bk / K;
+    const int64_t *Ib = I + (b * M + m) * K;
+    const float *cb = coord + b * 3 * M;
+    const long long id = Ib[k];
+    const bool ok = (unsigned long long)id < (unsigned long long)M;
+    gidx[t] = ok ? (int32_t)id : -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *src = cb + c * M;
+        float ctr;
+        if (avg) {
+            float sum = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                const long long ik = Ib[kk];
+                sum += ((unsigned long long)ik < (unsigned long long)M) ? src[ik] : 0.f;
+            }
+            ctr = sum / (float)K;
+        } else {
+            ctr = src[m];
+        }
+        if (k == 0) center[(b * 3 + c) * M + m] = ctr;
+        dec[(b * 3 + c) * (long long)K * M + (long long)k * M + m] = (ok ? src[id] : 0.f) - ctr;
+    }
+}
+
 // Self k-NN of the SOM nodes (the node_knn_I table the reference builds with faiss on the host,
 // data/modelnet_shrec_loader.py:116-150,257-259, and KNNModule's fallback, models/layers.py:333-337): for every node the
 // K nearest nodes (itself first), ascending (distance, index), distance (dx*dx + dy*dy) + dz*dz.  One thread per
@@ -536,6 +589,30 @@ extern "C" int sonet_knn_group_f32(const float *coord, const float *feat, const 
     if (B > 65535 || 3 + C > 65535 || (long long)M * K > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
     hipLaunchKernelGGL(knn_group_kernel, dim3((unsigned)sonet::ceil_div(M * K, 1024), (unsigned)(3 + C), (unsigned)B), dim3(256), 0,
                        sonet::as_stream(stream), coord, feat, knn_I, C, M, K, center_avg, center, out);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_planes_max_f32(const float *x, float *out, long long rows, int K, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_planes_max_f32";
+    SONET_REQUIRE(x && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(rows > 0 && K > 0 && M > 0, "%s: non-positive size", what);
+    const long long total = rows * M;
+    if (sonet::ceil_div64(total, 256) > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(planes_max_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream), x, out, K, M, total);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_knn_prepare_f32(const float *coord, const int64_t *knn_I, int B, int M, int K, int center_avg,
+                                     float *center, float *dec, int32_t *gidx, sonet_stream_t stream)
+{
+    const char *what = "sonet_knn_prepare_f32";
+    SONET_REQUIRE(coord && knn_I && center && dec && gidx, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && M > 0 && K > 0, "%s: non-positive size", what);
+    const long long total = (long long)B * K * M;
+    if (sonet::ceil_div64(total, 256) > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipLaunchKernelGGL(knn_prepare_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       coord, knn_I, M, K, center_avg, center, dec, gidx, total);
     return sonet::launched(what);
 }
 

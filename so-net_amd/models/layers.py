@@ -276,6 +276,25 @@ class _FusedPointwise(nn.Module):
             self._wp_key = key
         return self._wp
 
+    def _packed_rotated(self, lead):
+        """h3 pack of the weight with its first ``lead`` input channels moved behind the others: a caller that feeds
+        cat(a, b) with a narrow ``a`` (3 coordinate rows) passes (b, a) as (x1, x2) instead, so that x1 is 16-aligned."""
+        w = self.conv.weight
+        key = (w._version, w.data_ptr(), w.device, lead)
+        if getattr(self, '_wpr_key', None) != key:
+            with torch.no_grad():
+                w2 = self._weight2d().detach().float()
+                self._wpr = _ops.pointmlp_pack(torch.cat((w2[:, lead:], w2[:, :lead]), dim=1).contiguous(), "h3")
+            self._wpr_key = key
+        return self._wpr
+
+    def _direct_ok(self, x):
+        """Eval-mode, no-grad, h3: the caller may launch the kernel itself with this layer's pack and folded affine."""
+        return (_ops.GATHER_NODE_STAGE and _ops.POINTMLP_PRECISION == "h3" and not torch.is_grad_enabled() and x.is_cuda
+                and x.dtype == torch.float32 and self._fusable() and self.conv.out_channels % 32 == 0
+                and self.normalization in (None, 'batch') and not (self.normalization == 'batch' and self.norm.training)
+                and self.activation in (None, 'relu'))
+
     def _bias(self):
         if self.conv.bias is not None:
             return self.conv.bias
@@ -539,6 +558,19 @@ class KNNModule(nn.Module):
             knn_I = _ops.knn_self(coord.float().contiguous(), K)
         if center_type not in ('avg', 'center'):
             raise ValueError(center_type)
+        if (len(self.layers) == 2 and x.shape[1] % 16 == 0 and all(l._direct_ok(x) for l in self.layers)
+                and self.layers[0].conv.in_channels == 3 + x.shape[1]):
+            # no-grad h3 path: only the 3 de-centred coordinate rows are materialised (k-major); the features are gathered by
+            # the first layer's operand loads; the max over the K neighbours reads k-major planes (coalesced)
+            center, dec, gidx = _ops.knn_prepare(coord.contiguous(), knn_I, center_type == 'avg')
+            l1, l2 = self.layers
+            s1, t1 = l1._eval_affine()
+            h = _ops.pointmlp(x.contiguous(), l1._packed_rotated(3), s1, t1, l1.activation == 'relu', l1.conv.out_channels,
+                              x2=dec, gidx=gidx)                          # B x C1 x (K*M), k-major columns
+            s2, t2 = l2._eval_affine()
+            h = _ops.pointmlp(h, l2._packed(h.shape[1], 0), s2, t2, l2.activation == 'relu', l2.conv.out_channels)
+            feature = _ops.planes_max(h, K)                               # B x C2 x M
+            return center, feature
         if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
             # no-grad path: gathers, centre, de-centring and the concat in one kernel; max over K in one kernel
             center, h = _ops.knn_group(coord.contiguous(), x.contiguous(), knn_I, center_type == 'avg')
@@ -585,6 +617,19 @@ class PointNet(nn.Module):
         for layer in self.layers:
             x = layer(x, epoch)
         return x
+
+    def forward_cat(self, lead, x, epoch=None):
+        """forward(cat(lead, x)) for a narrow ``lead`` (the 3 centre rows of models/networks.py:191-194).  No-grad h3: the
+        concat is replaced by a rotated weight pack (x first, lead as the second panel); otherwise the plain path."""
+        if x.shape[1] % 16 == 0 and all(l._direct_ok(x) for l in self.layers):
+            first = self.layers[0]
+            s, t = first._eval_affine()
+            h = _ops.pointmlp(x.contiguous(), first._packed_rotated(lead.shape[1]), s, t, first.activation == 'relu',
+                              first.conv.out_channels, x2=lead.contiguous())
+            for layer in self.layers[1:]:
+                h = layer(h, epoch)
+            return h
+        return self.forward(torch.cat((lead, x), dim=1), epoch)
 
 
 class PointResNet(nn.Module):

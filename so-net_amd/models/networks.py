@@ -191,9 +191,12 @@ class Encoder(nn.Module):
         if opt.som_k >= 2:
             self.knn_center_1, self.knn_feature_1 = self.knnlayer(self.som_node, self.first_pn_out_masked_max,
                                                                   node_knn_I, opt.som_k, opt.som_k_type, epoch)
-            self.final_pn_out = self.final_pointnet(torch.cat((self.knn_center_1, self.knn_feature_1), dim=1), epoch)
+            lead, feat = self.knn_center_1, self.knn_feature_1
         else:
-            self.final_pn_out = self.final_pointnet(torch.cat((self.som_node, self.first_pn_out_masked_max), dim=1), epoch)
+            lead, feat = self.som_node, self.first_pn_out_masked_max
+        forward_cat = getattr(self.final_pointnet, 'forward_cat', None)   # PointNet: concat-free (rotated weight pack)
+        self.final_pn_out = (forward_cat(lead, feat, epoch) if forward_cat is not None
+                             else self.final_pointnet(torch.cat((lead, feat), dim=1), epoch))
         if torch.is_grad_enabled() and self.final_pn_out.requires_grad:
             self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)     # :197; amax would split the gradient over ties
         else:

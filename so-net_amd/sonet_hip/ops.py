@@ -300,6 +300,9 @@ POINTMLP_PRECISION = _os.environ.get("SONET_POINTMLP_PRECISION", "h3")
 FUSE_POINTRESNET = _os.environ.get("SONET_FUSE_POINTRESNET", "1") != "0"
 # ... and pool it per node in the same kernel (no first_pn_out in HBM unless a caller reads the attribute)
 FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
+# no-grad node-level stage (KNNModule + final PointNet) without the gathered tensor and without concats: the neighbour
+# gather happens in the first layer's operand loads, narrow leading panels go last through a rotated weight pack (h3 only)
+GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
 
 
 def x3_supported(C1, C2, Cout):
@@ -325,10 +328,18 @@ def pointmlp_pack(weight2d, mode="f32"):
     return wp
 
 
-def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
-    """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``."""
+def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
+    """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``.
+    ``gidx`` (B x L i32, h3 packs only): column l of x1 (B x C1 x L1) is taken from x1[:, :, gidx[b, l]] -- zeros when the
+    index is out of range -- i.e. the layer runs on the gathered tensor without materialising it."""
     _chk(x1, "x", torch.float32, 3)
     B, C1, L = x1.shape
+    L1 = L
+    if gidx is not None:
+        _chk(gidx, "gidx", torch.int32, 2)
+        if wp.dtype != torch.int8 or gidx.shape[0] != B:
+            raise SonetHipError("pointmlp: a gather index needs an h3 pack and B rows")
+        L = gidx.shape[1]
     C2 = 0
     if x2 is not None:
         _chk(x2, "x2", torch.float32, 3)
@@ -337,7 +348,7 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
         C2 = x2.shape[1]
     _chk(scale, "scale", torch.float32, 1)
     _chk(shift, "shift", torch.float32, 1)
-    dev = _same_device(x1, x2, wp, scale, shift)
+    dev = _same_device(x1, x2, wp, scale, shift, gidx)
     lib = _lib.load()
     h3 = wp.dtype == torch.int8
     x3 = wp.dtype == torch.uint8 or h3
@@ -349,8 +360,12 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None):
         return y
     fn = lib.sonet_pointmlp_h3_f32 if h3 else lib.sonet_pointmlp_x3_f32 if x3 else lib.sonet_pointmlp_f32
     with torch.cuda.device(dev), _timed("pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)):
-        check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
-                 B, Cout, L, stream_ptr()), "sonet_pointmlp")
+        if gidx is not None:
+            check(lib.sonet_pointmlp_h3_gather_f32(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
+                                                   ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_h3_gather_f32")
+        else:
+            check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
+                     B, Cout, L, stream_ptr()), "sonet_pointmlp")
     return y
 
 
@@ -559,3 +574,38 @@ def mfma_f16_sustained_rate(random_operands=True, iters=4000, device=None):
         check(_lib.load().sonet_diag_mfma_f16_rate(1 if random_operands else 0, int(iters), ctypes.byref(tf), ctypes.byref(ghz), stream_ptr()),
               "sonet_diag_mfma_f16_rate")
     return tf.value, ghz.value
+
+
+def knn_prepare(coord, knn_I, center_avg):
+    """coord B x 3 x M, knn_I B x M x K i64 -> (center B x 3 x M, de-centred neighbour coordinates B x 3 x (K*M) K-MAJOR,
+    gather index B x (K*M) i32) -- what the gathering KNNModule layer needs beside the features (models/layers.py:313-350)."""
+    _chk(coord, "coord", torch.float32, 3)
+    _chk(knn_I, "knn_I", torch.int64, 3)
+    dev = _same_device(coord, knn_I)
+    B, _, M = coord.shape
+    K = knn_I.shape[2]
+    if coord.shape[1] != 3 or knn_I.shape[0] != B or knn_I.shape[1] != M:
+        raise SonetHipError("knn_prepare: coord must be B x 3 x M and knn_I B x M x K")
+    center = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
+    dec = torch.empty((B, 3, K * M), dtype=torch.float32, device=dev)
+    gidx = torch.empty((B, K * M), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), _timed("knn_prepare"):
+        check(_lib.load().sonet_knn_prepare_f32(ptr(coord), ptr(knn_I), B, M, K, int(bool(center_avg)), ptr(center), ptr(dec), ptr(gidx),
+                                                stream_ptr()), "sonet_knn_prepare_f32")
+    return center, dec, gidx
+
+
+
+def planes_max(x, K):
+    """x B x C x (K*M) with k-major columns -> B x C x M, max over the K planes (values only, NaN-propagating)."""
+    _chk(x, "x", torch.float32, 3)
+    B, C, L = x.shape
+    if K <= 0 or L % K:
+        raise SonetHipError("planes_max: L=%d is not %d planes" % (L, K))
+    dev = _same_device(x)
+    out = torch.empty((B, C, L // K), dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(dev), _timed("planes_max"):
+        check(_lib.load().sonet_planes_max_f32(ptr(x), ptr(out), B * C, K, L // K, stream_ptr()), "sonet_planes_max_f32")
+    return out

@@ -919,3 +919,61 @@ def test_mfma_sustained_rate_probe():
     tf_r, ghz_r = ops.mfma_f16_sustained_rate(random_operands=True, iters=2000)
     assert 500.0 < tf_r <= tf_c * 1.05 and tf_c < 2700.0, (tf_c, tf_r)
     assert 0.8 < ghz_r < 2.6 and 0.8 < ghz_c < 2.6, (ghz_c, ghz_r)
+
+
+@pytest.mark.parametrize("M,K,C", [(64, 9, 384), (36, 5, 48), (100, 3, 16)])
+def test_pointmlp_gather_and_planes_max(M, K, C):
+    """knn_prepare + a gather index in the layer's operand load + planes_max reproduce knn_group -> layer -> max over K
+    bit for bit (same MFMA sequence; only the gathered tensor is never written)."""
+    from sonet_hip import ops
+    B, Cout = 3, 64
+    g = torch.Generator(device="cpu").manual_seed(M * 10 + K)
+    feat = torch.randn(B, C, M, generator=g).to(DEV)
+    coord = torch.randn(B, 3, M, generator=g).to(DEV)
+    knn_I = torch.randint(0, M, (B, M, K), generator=g).to(DEV)
+    knn_I[0, 1, 0] = M + 5                                           # out of range: reads as zeros
+    center, dec, gidx = ops.knn_prepare(coord, knn_I, True)
+    c_ref, grouped = ops.knn_group(coord, feat, knn_I, True)         # B x (3 + C) x M x K
+    assert torch.equal(center, c_ref)
+    kmaj = grouped.permute(0, 1, 3, 2).reshape(B, 3 + C, K * M).contiguous()      # k-major columns
+    assert torch.equal(dec, kmaj[:, :3].contiguous())
+    W = (torch.randn(Cout, 3 + C, generator=g) * 0.1).to(DEV)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    w_rot = ops.pointmlp_pack(torch.cat((W[:, 3:], W[:, :3]), dim=1).contiguous(), "h3")
+    x_rot = torch.cat((kmaj[:, 3:], kmaj[:, :3]), dim=1).contiguous()
+    ref = ops.pointmlp(x_rot, w_rot, sc, sh, True, Cout)             # B x Cout x (K*M)
+    got = ops.pointmlp(feat, w_rot, sc, sh, True, Cout, x2=dec, gidx=gidx)
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.planes_max(got, K), ref.reshape(B, Cout, K, M).amax(dim=2))
+    bad = got.clone()
+    bad[1, 5, 2 * M + 3] = float("nan")                              # plane 2, node 3
+    out = ops.planes_max(bad, K)
+    assert bool(torch.isnan(out[1, 5, 3])) and int(torch.isnan(out).sum()) == 1
+
+
+def test_encoder_node_stage_gather_matches_materialised_path():
+    """SONET_GATHER_NODE_STAGE on/off: same features within the split arithmetic's own noise (the 3 coordinate channels
+    move to the end of the summation order, nothing else changes)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    g = golden("classifier_b2_n256")
+    opt = make_opt(g, 2, 256)
+    enc = NW.Encoder(opt)
+    synth.fill_state_dict_(enc.state_dict(), int(g["seed"]))
+    enc.to(DEV).eval()
+    args = (cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
+    old = ops.GATHER_NODE_STAGE, ops.POINTMLP_PRECISION
+    try:
+        ops.POINTMLP_PRECISION = "h3"
+        outs = {}
+        for flag in (True, False):
+            ops.GATHER_NODE_STAGE = flag
+            with torch.no_grad(), ops.kernel_timing() as rec:
+                f = enc(*args).clone()
+            names = [n for n, _, _ in rec.records]
+            assert ("knn_prepare" in names) == flag and ("knn_group" in names) == (not flag)
+            outs[flag] = (f, enc.knn_feature_1.clone(), enc.final_pn_out.clone(), enc.knn_center_1.clone())
+        for a, b in zip(outs[True], outs[False]):
+            assert_close_rms(a.cpu().numpy(), b.cpu().numpy(), 5e-6, "gathering node stage vs materialised")   # the split itself: ~3e-6
+    finally:
+        ops.GATHER_NODE_STAGE, ops.POINTMLP_PRECISION = old
