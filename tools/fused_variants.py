@@ -42,7 +42,7 @@ def child(name, out_path):
             e0.record(); out = run(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         ts.sort()
-        res[mode] = out[:, :, ::7].contiguous().cpu().numpy() if mode == "store" else out.cpu().numpy()
+        res[mode] = out[:, :, ::97].contiguous().cpu().numpy() if mode == "store" else out.cpu().numpy()
         print("%-14s %-5s median %.4f ms  min %.4f ms (incl. init/decode launches for pool)" % (name, mode, ts[len(ts) // 2], ts[0]), flush=True)
     np.savez(out_path, **res)
 
@@ -52,7 +52,7 @@ if __name__ == "__main__":
         child(sys.argv[2], sys.argv[3])
         sys.exit(0)
     import numpy as np
-    outdir = os.path.join(ROOT, "gpurun_out", "variants")
+    outdir = "/tmp/sonet_variants"                               # (scratch: the store-path outputs are large)
     os.makedirs(outdir, exist_ok=True)
     first = None
     for name in sys.argv[1:]:
