@@ -143,8 +143,8 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
     def step():
         feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
         score = cls(feat, 0)
-        enc.zero_grad(set_to_none=False)
-        cls.zero_grad(set_to_none=False)
+        enc.zero_grad(set_to_none=True)      # (no fill launch per parameter; backward assigns instead of accumulating)
+        cls.zero_grad(set_to_none=True)
         loss = torch.nn.functional.cross_entropy(score, label)
         loss.backward()
         nbytes = reducer.reduce()

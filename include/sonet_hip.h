@@ -264,6 +264,10 @@ int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const floa
  *   g_gamma = sg;  g_beta = s1), all [C]. */
 int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, const float *gamma, const float *beta, float eps, int C,
                             float *invstd, float *scale, float *shift, sonet_stream_t stream);
+/* Running-statistics update of training BatchNorm (F.batch_norm semantics, models/layers.py:60-70):
+ * running = running*(1 - momentum) + momentum*stat, the variance entering as var*unbias (unbias = n/(n-1)); in place, [C]. */
+int sonet_bn_running_update_f32(float *running_mean, float *running_var, const float *mean, const float *var,
+                                float momentum, float unbias, int C, sonet_stream_t stream);
 int sonet_bn_bwd_coeffs_f32(const double *sums, const float *mean, const float *invstd, const float *gamma, double n, int C,
                             float *a, float *b, float *c0, float *g_gamma, float *g_beta, sonet_stream_t stream);
 /* y = act(x*scale[c] + shift[c]) out of place (training forward: raw stays for the backward). */

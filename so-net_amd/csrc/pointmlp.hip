@@ -35,7 +35,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PM_THREADS = 256;
 constexpr int PM_WAVES = PM_THREADS / 64;
-constexpr int PM_S = 4;             // K-groups (of 8 input channels) per LDS stage of the W-through-LDS kernel
 
 __global__ __launch_bounds__(256) void pointmlp_pack_kernel(const float *__restrict__ W, float *__restrict__ Wp,
                                                              int Cin, int Cout, int G, long long total)

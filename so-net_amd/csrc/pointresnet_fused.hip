@@ -35,7 +35,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int PF_THREADS = 256, PF_WAVES = 4;
 constexpr int T0 = 2, T1 = 4, T2 = 8, T3 = 12;               // output tiles (x32 channels) of the four layers
-constexpr int KC1 = 1, KC2 = 2 * T0, KC3 = 2 * T1, KC4 = 2 * T0 + 2 * T2;   // 16-channel K chunks per layer
+constexpr int KC2 = 2 * T0, KC3 = 2 * T1, KC4 = 2 * T0 + 2 * T2;   // 16-channel K chunks per layer
 constexpr int MT4 = 6, NPASS = T3 / MT4;                      // layer-4 cout tiles per accumulator pass
 constexpr int NSTG = 24;                                       // slices per LDS stage (2 slices feed 3 MFMAs)
 constexpr int NTERM = 2;                                       // W slices per (cout tile, K chunk): h and l (see the operand split)

@@ -133,6 +133,18 @@ __global__ __launch_bounds__(256) void bn_fwd_coeffs_kernel(const float *__restr
     sh[c] = beta[c] - mean[c] * s;
 }
 
+// F.batch_norm's running-statistics update (models/layers.py:60-70 via MyBatchNorm*): r = r*(1-m) + m*stat, the variance
+// entering unbiased (var * n/(n-1)).  One launch instead of four C-element aten launches per BatchNorm layer and step.
+__global__ __launch_bounds__(256) void bn_running_update_kernel(float *__restrict__ rmean, float *__restrict__ rvar,
+                                                                 const float *__restrict__ mean, const float *__restrict__ var,
+                                                                 float m, float unbias, int C)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    rmean[c] = __fmaf_rn(mean[c], m, __fmul_rn(rmean[c], 1.0f - m));
+    rvar[c] = __fmaf_rn(__fmul_rn(var[c], unbias), m, __fmul_rn(rvar[c], 1.0f - m));
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double *__restrict__ sums, const float *__restrict__ mean,
                                                              const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                              double n, int C, float *__restrict__ a, float *__restrict__ b,
@@ -162,6 +174,17 @@ extern "C" int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, cons
     SONET_REQUIRE(C > 0, "%s: bad size C=%d", what, C);
     hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, sonet::as_stream(stream),
                        mean, var, gamma, beta, eps, C, invstd, scale, shift);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_bn_running_update_f32(float *running_mean, float *running_var, const float *mean, const float *var,
+                                          float momentum, float unbias, int C, sonet_stream_t stream)
+{
+    const char *what = "sonet_bn_running_update_f32";
+    SONET_REQUIRE(running_mean && running_var && mean && var, "%s: NULL pointer", what);
+    SONET_REQUIRE(C > 0, "%s: bad size C=%d", what, C);
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       running_mean, running_var, mean, var, momentum, unbias, C);
     return sonet::launched(what);
 }
 

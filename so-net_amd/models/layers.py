@@ -335,8 +335,11 @@ class _FusedPointwise(nn.Module):
             with torch.no_grad():                                       # F.batch_norm running-stat update
                 n = y.shape[0] * y.shape[2]
                 m = bn.momentum
-                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                if bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() and bn.running_mean.dtype == torch.float32:
+                    _ops.bn_running_update_(bn.running_mean, bn.running_var, mean.contiguous(), var.contiguous(), m, n / max(n - 1, 1))
+                else:
+                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
                 # (F.batch_norm does not touch num_batches_tracked; the reference never increments it)
         else:
             if norm in (None, 'batch'):

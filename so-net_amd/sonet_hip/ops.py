@@ -609,3 +609,13 @@ def planes_max(x, K):
     with torch.cuda.device(dev), _timed("planes_max"):
         check(_lib.load().sonet_planes_max_f32(ptr(x), ptr(out), B * C, K, L // K, stream_ptr()), "sonet_planes_max_f32")
     return out
+
+
+def bn_running_update_(running_mean, running_var, mean, var, momentum, unbias):
+    """running = running*(1-momentum) + momentum*stat in place (variance entering as var*unbias): F.batch_norm's update."""
+    for t, n in ((running_mean, "running_mean"), (running_var, "running_var"), (mean, "mean"), (var, "var")):
+        _chk(t, n, torch.float32, 1)
+    dev = _same_device(running_mean, running_var, mean, var)
+    with torch.cuda.device(dev):
+        check(_lib.load().sonet_bn_running_update_f32(ptr(running_mean), ptr(running_var), ptr(mean), ptr(var), float(momentum), float(unbias),
+                                                      running_mean.numel(), stream_ptr()), "sonet_bn_running_update_f32")
