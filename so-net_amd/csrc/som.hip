@@ -523,8 +523,10 @@ extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, in
     if (M > 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 1024 nodes", what, M);
     if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
     hipStream_t st = sonet::as_stream(stream);
-    if (hipMemsetAsync(count, 0, (size_t)B * M * sizeof(int32_t), st) != hipSuccess ||
-        hipMemsetAsync(sum_ws, 0, (size_t)B * 3 * M * sizeof(double), st) != hipSuccess)
+    const size_t sum_bytes = (size_t)B * 3 * M * sizeof(double), cnt_bytes = (size_t)B * M * sizeof(int32_t);
+    const bool adjacent = reinterpret_cast<char *>(sum_ws) + sum_bytes == reinterpret_cast<char *>(count);   // one clear launch then
+    if (adjacent ? hipMemsetAsync(sum_ws, 0, sum_bytes + cnt_bytes, st) != hipSuccess
+                 : (hipMemsetAsync(count, 0, cnt_bytes, st) != hipSuccess || hipMemsetAsync(sum_ws, 0, sum_bytes, st) != hipSuccess))
         return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
     dim3 grid(sonet::ceil_div(N, SA_THREADS), B), block(SA_THREADS);
     const size_t lds = (size_t)M * (sizeof(float4) + 3 * sizeof(double) + sizeof(unsigned));

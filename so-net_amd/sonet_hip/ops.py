@@ -135,8 +135,10 @@ def som_assign(x, node, k, want_i64=False):
     r.B, r.N, r.M, r.k = B, N, M, int(k)
     r.min_idx_i32 = torch.empty((B, r.k * N), dtype=torch.int32, device=dev)
     r.min_idx_i64 = torch.empty((B, r.k * N), dtype=torch.int64, device=dev) if want_i64 else None
-    r.count = torch.empty((B, M), dtype=torch.int32, device=dev)
-    r.sum_ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev)
+    # one allocation, sums first (8-byte aligned), counts right behind: the library clears both with a single memset
+    ws = torch.empty((B * 3 * M * 8 + B * M * 4,), dtype=torch.uint8, device=dev)
+    r.sum_ws = ws[:B * 3 * M * 8].view(torch.float64).view(B, 3, M)
+    r.count = ws[B * 3 * M * 8:].view(torch.int32).view(B, M)
     with torch.cuda.device(dev), _timed("som_assign"):
         check(_lib.load().sonet_som_assign_f32(ptr(x), ptr(node), B, N, M, r.k, ptr(r.min_idx_i32), ptr(r.min_idx_i64),
                                                ptr(r.count), ptr(r.sum_ws), stream_ptr()), "sonet_som_assign_f32")
