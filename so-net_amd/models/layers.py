@@ -100,6 +100,9 @@ def _pack_transposed(weight2d, C1, C2):
             # the split-operand kernels want 32-row output tiles: pad with zero rows and drop them afterwards (387 and 515
             # input channels in the KNN module / final PointNet would otherwise fall back to the exact-f32 kernel: 10x slower)
             Cp = (Ci + 31) // 32 * 32
+            if (Cp // 32) % 2 == 1 and Cp >= 256:
+                # an odd tile count runs one 32-row tile per wave (MT = 1: 2x slower per tile than MT = 4): 13 -> 16, 17 -> 20
+                Cp = (Ci + 127) // 128 * 128
             wt = torch.cat((wt, wt.new_zeros(Cp - Ci, wt.shape[1])), dim=0)
         m = mode if (mode == "f32" or _ops.x3_supported(wt.shape[1], 0, Cp)) else "f32"
         out.append((_ops.pointmlp_pack(wt, m), Ci, Cp))
