@@ -255,6 +255,12 @@ int sonet_linear_act_f32(const float *x, const float *W, const float *scale, con
  * W [C][C1+C2] row-major f32.  Dense outputs (zero where nothing hits), C*M*(C1+C2) MACs per cloud instead of
  * C*L*(C1+C2).  ws: sonet_pooled_dgrad_ws_size bytes.  Deterministic (entries sorted per 64-column tile). */
 size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L);
+/* The matching wgrad, with g_pooled and pos TRANSPOSED to [B][M][C] (coalesced entry walks):
+ * gw_partial[b][c][ci] = sum_m g_pooled[b][m][c] * x[b][ci][pos[b][m][c]] (x [B][Ci][L]; positions
+ * outside [0, L) are ignored); the caller sums the per-cloud partials over b.  Replaces scatter-into-zeros + a dense
+ * [C x L] x [L x Ci] GEMM over a gradient that is zero everywhere except at the C*M gathered positions of a cloud. */
+int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
+                           float *gw_partial, sonet_stream_t stream);
 int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                            int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
 

@@ -404,6 +404,79 @@ extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
     return (size_t)B * (E * 8 + (ntile + 1) * 4);
 }
 
+// Sparse wgrad of the pooled last layer: the gradient of first_pn_out exists only at the C*M gathered positions of a
+// cloud, so  g_W[c][ci] = sum over (b, m) of g[b][c][m] * x[b][ci][pos[b][c][m]]  -- 24,576 x Ci MACs per cloud instead of
+// a dense [C x L] x [L x Ci] GEMM over a tensor that is 99.6 % zeros (and that then need not be built at all).
+// One workgroup per (cloud, PW_R input-channel rows): the rows sit in LDS (coalesced load; the column gathers of x that
+// make a direct scatter formulation uncoalesced become LDS reads), thread <-> output channel c keeps its M entries in
+// registers (g and pos come TRANSPOSED, [B][M][C], so that loading them is coalesced) and applies them to PW_G row pairs.
+// Per-cloud partials out[b][c][ci]; the caller sums over b (fixed order: deterministic).
+constexpr int PW_R = 2;                                      // x rows resident in LDS at a time
+constexpr int PW_G = 8;                                      // row pairs per workgroup (the entries are loaded once for all of them)
+constexpr int PW_M = 64;                                     // entries per output channel kept in registers (M <= PW_M)
+__global__ __launch_bounds__(384) void pooled_wgrad_kernel(const float *__restrict__ g, const int32_t *__restrict__ pos,
+                                                            const float *__restrict__ x, int C, int M, int Ci, int L,
+                                                            float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float rows[];           // [PW_R][L]
+    const int b = blockIdx.y;
+    const int c = threadIdx.x;                                            // C <= blockDim.x (checked by the launcher)
+    // this thread's M entries: L2 latency was the whole cost when they were re-read for every row pair
+    float gv[PW_M];
+    int pv[PW_M];
+#pragma unroll
+    for (int m = 0; m < PW_M; ++m) {
+        const bool ok = m < M && c < C;
+        gv[m] = ok ? g[((size_t)b * M + m) * C + c] : 0.f;
+        const int p = ok ? pos[((size_t)b * M + m) * C + c] : -1;
+        pv[m] = (unsigned)p < (unsigned)L ? p : -1;
+    }
+    for (int gi = 0; gi < PW_G; ++gi) {
+        const int ci0 = (blockIdx.x * PW_G + gi) * PW_R;
+        if (ci0 >= Ci) break;
+        const int nr = min(PW_R, Ci - ci0);
+        const float *xb = x + ((size_t)b * Ci + ci0) * L;
+        __syncthreads();                                                  // the previous pair has been consumed
+        if ((L & 3) == 0 && ((size_t)xb & 15) == 0) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(xb);
+            float4 *r4 = reinterpret_cast<float4 *>(rows);
+            for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) r4[i] = x4[i];
+        } else {
+            for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = xb[i];
+        }
+        __syncthreads();
+        if (c < C) {
+            float acc[PW_R];
+#pragma unroll
+            for (int r = 0; r < PW_R; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < PW_M; ++m) {
+                if (pv[m] >= 0) {
+                    acc[0] = __fmaf_rn(gv[m], rows[pv[m]], acc[0]);
+                    if (nr > 1) acc[1] = __fmaf_rn(gv[m], rows[L + pv[m]], acc[1]);
+                }
+            }
+            for (int r = 0; r < nr; ++r) out[((size_t)b * C + c) * Ci + ci0 + r] = acc[r];
+        }
+    }
+}
+
+extern "C" int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
+                                      float *gw_partial, sonet_stream_t stream)
+{
+    const char *what = "sonet_pooled_wgrad_f32";
+    SONET_REQUIRE(g_pooled && pos && x && gw_partial, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && Ci > 0 && L > 0 && B <= 65535, "%s: bad size B=%d C=%d M=%d Ci=%d L=%d", what, B, C, M, Ci, L);
+    if (C > 384 || M > PW_M) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d > 384 or M=%d > %d", what, C, M, PW_M);
+    const size_t lds = (size_t)PW_R * L * sizeof(float);
+    if (lds > 152 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d rows do not fit LDS", what, L);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
+    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(384), lds, sonet::as_stream(stream),
+                       g_pooled, pos, x, C, M, Ci, L, gw_partial);
+    return sonet::launched(what);
+}
+
 extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                                       int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream)
 {

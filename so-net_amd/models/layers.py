@@ -222,17 +222,28 @@ class _PooledLastLayerFn(torch.autograd.Function):
         if g_y is None and g_mm is None:
             return (None,) * 8
         sparse = g_y is None
-        if sparse:
-            G = torch.zeros((B, weight2d.shape[0], L), dtype=torch.float32, device=x1.device)
-        else:
-            G = g_y.contiguous().clone() if g_mm is not None else g_y.contiguous()
+        G = None
         if g_mm is not None:
             g_mm = g_mm.contiguous()
-            G.scatter_add_(2, gi.long(), g_mm)                            # the gather's backward (duplicates accumulate)
-        g_bias = G.sum(dim=(0, 2)) if ctx.needs_input_grad[3] else None
+        if not sparse:
+            G = g_y.contiguous().clone() if g_mm is not None else g_y.contiguous()
+            if g_mm is not None:
+                G.scatter_add_(2, gi.long(), g_mm)                        # the gather's backward (duplicates accumulate)
+        g_bias = None
+        if ctx.needs_input_grad[3]:
+            # sparse: the gradient of first_pn_out is the scatter of g_mm and nothing else (never built): its sum is the sum of g_mm
+            g_bias = g_mm.sum(dim=(0, 2)) if sparse else G.sum(dim=(0, 2))
         g_w = None
         if ctx.needs_input_grad[2]:
-            g_w = torch.cat((torch.bmm(G, x1.transpose(1, 2)).sum(0), torch.bmm(G, x2.transpose(1, 2)).sum(0)), dim=1)
+            if sparse and g_mm.shape[1] <= 384 and g_mm.shape[2] <= 64 and L * 8 <= 152 * 1024:
+                # 24,576 entries per cloud instead of a dense GEMM over kN columns (the kernel's limits: C, M, two rows in LDS)
+                g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()     # B x M x C: coalesced entry loads
+                g_w = torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1), _ops.pooled_wgrad(g_t, gi_t, x2)), dim=1)
+            else:
+                if G is None:
+                    G = torch.zeros((B, weight2d.shape[0], L), dtype=torch.float32, device=x1.device)
+                    G.scatter_add_(2, gi.long(), g_mm)
+                g_w = torch.cat((torch.bmm(G, x1.transpose(1, 2)).sum(0), torch.bmm(G, x2.transpose(1, 2)).sum(0)), dim=1)
         g_x1 = g_x2 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if sparse:

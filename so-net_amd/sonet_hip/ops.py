@@ -538,6 +538,23 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L):
     return gx1, gx2
 
 
+def pooled_wgrad(g_pooled_t, pos_i32_t, x):
+    """Sparse wgrad of the pooled last layer: g_pooled_t, pos_t B x M x C (TRANSPOSED entries), x B x Ci x L -> g_W C x Ci
+    (= sum over clouds and entries of g * x[:, pos]; per-cloud partials summed in a fixed order)."""
+    _chk(g_pooled_t, "g_pooled_t", torch.float32, 3)
+    _chk(pos_i32_t, "pos_t", torch.int32, 3)
+    _chk(x, "x", torch.float32, 3)
+    dev = _same_device(g_pooled_t, pos_i32_t, x)
+    B, M, C = g_pooled_t.shape
+    g_pooled, pos_i32 = g_pooled_t, pos_i32_t
+    Ci, L = x.shape[1], x.shape[2]
+    part = torch.empty((B, C, Ci), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("pooled_wgrad"):
+        check(_lib.load().sonet_pooled_wgrad_f32(ptr(g_pooled), ptr(pos_i32), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()),
+              "sonet_pooled_wgrad_f32")
+    return part.sum(0)
+
+
 def linear_act(x, weight, scale, shift, relu):
     """x B x Cin, weight Cout x Cin -> act((x @ weight^T) * scale + shift), B x Cout (exact f32)."""
     _chk(x, "x", torch.float32, 2)

@@ -977,3 +977,23 @@ def test_encoder_node_stage_gather_matches_materialised_path():
             assert_close_rms(a.cpu().numpy(), b.cpu().numpy(), 5e-6, "gathering node stage vs materialised")   # the split itself: ~3e-6
     finally:
         ops.GATHER_NODE_STAGE, ops.POINTMLP_PRECISION = old
+
+
+def test_pooled_wgrad_matches_dense_scatter_gemm():
+    """sonet_pooled_wgrad_f32 == (scatter g into zeros at pos) @ x^T summed over the batch (float64 reference), including
+    duplicate positions, position 0 pile-ups (empty nodes) and out-of-range entries."""
+    from sonet_hip import ops
+    B, C, M, Ci, L = 3, 40, 16, 10, 500
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gp = torch.randn(B, C, M, generator=g).to(DEV)
+    pos = torch.randint(0, L, (B, C, M), generator=g, dtype=torch.int32).to(DEV)
+    pos[:, :, 3] = 0                                                  # an "empty node": every channel gathers position 0
+    pos[1, 5, 7] = pos[1, 5, 8]                                       # duplicate
+    pos[2, 0, 0] = -1                                                 # ignored
+    x = torch.randn(B, Ci, L, generator=g).to(DEV)
+    got = ops.pooled_wgrad(gp.transpose(1, 2).contiguous(), pos.transpose(1, 2).contiguous(), x)
+    G = torch.zeros(B, C, L, dtype=torch.float64, device=DEV)
+    ok = pos >= 0
+    G.scatter_add_(2, pos.clamp_min(0).long(), (gp.double() * ok))
+    ref = torch.bmm(G, x.double().transpose(1, 2)).sum(0)
+    assert_close_rms(got.cpu().numpy(), ref.cpu().numpy(), 1e-5, "pooled wgrad")
