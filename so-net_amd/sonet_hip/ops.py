@@ -546,11 +546,10 @@ def pooled_wgrad(g_pooled_t, pos_i32_t, x):
     _chk(x, "x", torch.float32, 3)
     dev = _same_device(g_pooled_t, pos_i32_t, x)
     B, M, C = g_pooled_t.shape
-    g_pooled, pos_i32 = g_pooled_t, pos_i32_t
     Ci, L = x.shape[1], x.shape[2]
     part = torch.empty((B, C, Ci), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("pooled_wgrad"):
-        check(_lib.load().sonet_pooled_wgrad_f32(ptr(g_pooled), ptr(pos_i32), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()),
+        check(_lib.load().sonet_pooled_wgrad_f32(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()),
               "sonet_pooled_wgrad_f32")
     return part.sum(0)
 
