@@ -504,10 +504,10 @@ extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos,
 // fma chain in k order.  MyLinear (models/layers.py:123-166) on a B x C feature: three of these (1024 -> 512 -> 256 -> 40)
 // replace ~12 aten launches (GEMM + bias, batch-norm transform, clamp) that cost 110 us of a 1.4 ms step.
 namespace {
-constexpr int FC_OC = 4;
-// One workgroup = FC_OC output channels x 64 rows; thread (r, kq) owns row r and a quarter of the k range: its x values are
+// One workgroup = FC_OC output channels (4, 2 or 1: the launcher keeps >= ~256 workgroups in flight) x 64 rows; thread (r, kq) owns row r and a quarter of the k range: its x values are
 // one contiguous segment read with independent 16-byte loads (all in flight at once: the layer is latency-, not
 // bandwidth-bound), the FC_OC weight rows sit in LDS (broadcast reads); the four quarters meet in LDS in a fixed order.
+template <int FC_OC>
 __global__ __launch_bounds__(256) void linear_act_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                           const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                                                           float *__restrict__ y, int B, int Cin, int Cout)
@@ -572,9 +572,15 @@ extern "C" int sonet_linear_act_f32(const float *x, const float *W, const float 
     SONET_REQUIRE(x && W && scale && shift && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0, "%s: non-positive size", what);
     if (sonet::ceil_div(B, 64) > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d too large", what, B);
-    const size_t lds = ((size_t)FC_OC * Cin + 4 * 64 * FC_OC) * sizeof(float);
+    const int rows = sonet::ceil_div(B, 64);
+    int oc = 4;                                                   // fewer channels per workgroup while the grid would not fill the chip
+    while (oc > 1 && (long long)sonet::ceil_div(Cout, oc) * rows < 256) oc >>= 1;
+    const size_t lds = ((size_t)oc * Cin + 4 * 64 * oc) * sizeof(float);
     if (lds > 64 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d too large (max 3840)", what, Cin);
-    hipLaunchKernelGGL(linear_act_kernel, dim3(sonet::ceil_div(Cout, FC_OC), sonet::ceil_div(B, 64)), dim3(256), lds, sonet::as_stream(stream),
-                       x, W, scale, shift, relu, y, B, Cin, Cout);
+    dim3 grid(sonet::ceil_div(Cout, oc), rows), block(256);
+    hipStream_t st = sonet::as_stream(stream);
+    if (oc == 4)      hipLaunchKernelGGL(linear_act_kernel<4>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
+    else if (oc == 2) hipLaunchKernelGGL(linear_act_kernel<2>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
+    else              hipLaunchKernelGGL(linear_act_kernel<1>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
     return sonet::launched(what);
 }
