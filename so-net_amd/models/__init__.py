@@ -1,5 +1,6 @@
 """Overlay package: ``models.layers``, ``models.operations`` and ``models.networks`` (the hot path)
-live here; ``models.classifier`` / ``segmenter`` / ``autoencoder`` / ``losses`` are resolved from a
+live here together with the loss classes of the heads (``models.losses``: ChamferLoss without faiss, the rest
+delegated to the reference file); ``models.classifier`` / ``segmenter`` / ``autoencoder`` are resolved from a
 reference checkout found later on sys.path and run unchanged on top."""
 import os as _os
 import sys as _sys
