@@ -17,56 +17,18 @@ file (``compute_iou`` -- called by part-seg/train.py:95 --, ``compute_iou_np_arr
 host-side numpy metrics / visdom plotting, off the hot path) is served lazily from the reference checkout's
 own file through the module ``__getattr__`` below; nothing of it is restated here.
 """
-import importlib.util as _ilu
-import os as _os
-import sys as _sys
-import types as _types
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from sonet_hip import ops as _ops
+from sonet_hip import overlay as _overlay
 
-
-_reference_module = None
+__getattr__ = _overlay.delegate(__package__, "losses.py", __file__, optional_imports=("faiss",))
 
 
 def _reference_losses():
-    """The reference checkout's own models/losses.py (next ``models`` directory on the package path), loaded once
-    under a private name.  Its only third-party import besides torch / numpy is faiss (models/losses.py:9), used by
-    nothing but the ChamferLoss this file replaces: when faiss is not installed the file is loaded with an empty
-    stand-in module for that one import."""
-    global _reference_module
-    if _reference_module is not None:
-        return _reference_module
-    here = _os.path.dirname(_os.path.abspath(__file__))
-    for d in list(_sys.modules[__package__].__path__):
-        path = _os.path.join(d, "losses.py")
-        if _os.path.abspath(d) == here or not _os.path.isfile(path):
-            continue
-        spec = _ilu.spec_from_file_location(__package__ + "._reference_losses", path)
-        mod = _ilu.module_from_spec(spec)
-        stub = None
-        if "faiss" not in _sys.modules and _ilu.find_spec("faiss") is None:
-            stub = _sys.modules["faiss"] = _types.ModuleType("faiss")
-        try:
-            spec.loader.exec_module(mod)
-        finally:
-            if stub is not None and _sys.modules.get("faiss") is stub:
-                del _sys.modules["faiss"]
-        _reference_module = mod
-        return mod
-    raise ImportError("models.losses: no reference checkout (SO-Net/models/losses.py) behind the overlay on sys.path")
-
-
-def __getattr__(name):
-    if name.startswith("__"):
-        raise AttributeError(name)
-    try:
-        return getattr(_reference_losses(), name)
-    except ImportError as e:
-        raise AttributeError("models.losses.%s is not part of the MI355X hot path and %s" % (name, e)) from None
+    return _overlay.reference_module(__package__, "losses.py", __file__, optional_imports=("faiss",))
 
 
 def robust_norm(var):

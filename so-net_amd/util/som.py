@@ -23,6 +23,11 @@ import numpy as np
 import torch
 
 from sonet_hip import ops as _ops
+from sonet_hip import overlay as _overlay
+
+# the single-cloud ``SOM`` class (util/som.py:17-172; used by no model, its twin under data/build_som builds the
+# node files offline) is served from the reference checkout's own file
+__getattr__ = _overlay.delegate(__package__, "som.py", __file__, optional_imports=("torchvision", "faiss"))
 
 
 class BatchSOM():

@@ -90,6 +90,9 @@ def test_losses_names_off_the_hot_path_resolve_to_the_reference_file():
         import numpy as np
         out = {n: getattr(losses, n).__module__ for n in ("compute_iou", "compute_iou_np_array", "visualize_pc_seg",
                                                              "ChamferLoss", "CrossEntropyLossSeg", "robust_norm")}
+        from util import som
+        out["SOM"] = som.SOM.__module__
+        out["BatchSOM"] = som.BatchSOM.__module__
         out["faiss_leaked"] = "faiss" in sys.modules
         try:
             losses.no_such_name
@@ -109,6 +112,7 @@ def test_losses_names_off_the_hot_path_resolve_to_the_reference_file():
         assert r[n] == "models._reference_losses"
     for n in ("ChamferLoss", "CrossEntropyLossSeg", "robust_norm"):
         assert r[n] == "models.losses"
+    assert r["SOM"] == "util._reference_som" and r["BatchSOM"] == "util.som"
     assert r["missing"] == "AttributeError" and not r["faiss_leaked"]
     assert r["nll_equal"] and r["robust_norm_equal"]
 
