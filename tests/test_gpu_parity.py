@@ -76,6 +76,22 @@ def test_index_max_vs_oracle_random(shape):
     np.testing.assert_array_equal(val.cpu().numpy(), exp.numpy())
 
 
+@pytest.mark.parametrize("flavour", ["plain", "ties", "special", "empty", "low"])
+def test_index_max_random_edge_cases_vs_compiled_reference(flavour):
+    """The seeded cases of tests/test_oracle_differential.py (ties, NaN / +-inf / <= -1000 / signed zeros, empty nodes,
+    nothing above -1000; odd and tiny sizes) through the HIP kernel, against the reference's own compiled
+    index_max.cpp (oracle/_ref) where it was built, else against the C restatement pinned to it."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    from test_oracle_differential import SHAPES, _index_max_case
+    for shape in SHAPES:
+        B, C, N, K = shape
+        data, index = _index_max_case(1000 * SHAPES.index(shape) + len(flavour), B, C, N, K, flavour)
+        ref = O.ref_index_max(data, index, K) if O.ref_module() is not None else O.index_max(data, index, K)
+        out = ops.index_max(cu(data), cu(index), K)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg="%s %s" % (shape, flavour))
+
+
 def test_index_max_bf16_ties():
     """bf16 features make exact ties common: the tie rule (smallest n) is load-bearing."""
     from oracle import cpu_oracle as O
