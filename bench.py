@@ -343,4 +343,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        from sonet_hip import dp as _dp
+        _dp.shutdown()

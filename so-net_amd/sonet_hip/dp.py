@@ -146,4 +146,15 @@ def all_reduce_max(value, device):
 
 def barrier():
     if world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            # name the device: without it the first barrier guesses one from the rank ("devices used by this process
+            # are currently unknown"), which is wrong whenever the visible-device list is remapped
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+def shutdown():
+    """Leave the process group (no-op for a single process); ranks call it right before they return."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
