@@ -130,7 +130,7 @@ def cpu_baseline(args, enc_sd, cls_sd):
 
 
 def train_bench(args, enc, cls, inp, world, rank, dev):
-    """Data-parallel training step (models/classifier.py:78-99 + one flat RCCL gradient all-reduce)."""
+    """Data-parallel training step (models/classifier.py:78-99 + the bucketed RCCL gradient all-reduce of sonet_hip/dp.py)."""
     from sonet_hip import dp
     enc.train()
     cls.train()
@@ -173,7 +173,8 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (%s forward; backward GEMMs on PyTorch-ROCm)" % ops.POINTMLP_PRECISION, "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
-                   "global_batch": B * world, "parallelism": "dp%d: batch shards + one flat %d-byte gradient all-reduce per step" % (world, nbytes)}}))
+                   "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
+                                  % (world, nbytes, max(1, len(reducer.buckets)))}}))
 
 
 def main():

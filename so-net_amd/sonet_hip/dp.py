@@ -7,9 +7,11 @@ all-reduce between ``loss.backward()`` and the optimizer steps of the task ``Mod
 (models/classifier.py:95-99).  The reference has no distributed code at all; this is new.
 
 Design for MI355X / xGMI: the whole gradient payload (Encoder 1,999,041 + Classifier 667,944
-parameters = 10.7 MB fp32) is ONE flat bucket -> one RCCL all-reduce per step.  xGMI is
-point-to-point (7 links x ~153 GB/s per GPU), so a 10 MB message is latency/algorithm-bound, and
-splitting it into per-parameter calls would only multiply that latency.  Parameters whose ``.grad``
+parameters = 10.7 MB fp32) lives in ONE flat buffer cut into at most three ~4 MB buckets, each one
+RCCL all-reduce started from a gradient hook as soon as backward has filled it.  xGMI is
+point-to-point (7 links x ~153 GB/s per GPU), so messages of this size are latency/algorithm-bound:
+per-parameter calls would only multiply that latency, a few large buckets keep it while the
+transfer of the heads' gradients hides behind the first PointNet's backward.  Parameters whose ``.grad``
 is None (the never-called ``transformer.*``, models/networks.py:78) are skipped, which is why plain
 DistributedDataParallel (which expects every registered parameter to take part) is not used.
 BatchNorm statistics stay per rank, as in the reference (no SyncBN).
@@ -83,17 +85,32 @@ def broadcast_parameters(modules, src=0):
 
 
 class GradientAllReducer:
-    """Flat-bucket gradient averaging for a set of modules (two optimizers, dead parameters OK).
+    """Bucketed gradient averaging for a set of modules (two optimizers, dead parameters OK), overlapped with backward.
 
-    ``reduce()`` is called between ``loss.backward()`` and ``optimizer.step()``.  The set of
-    parameters that take part is decided on the first call (those with ``grad is not None``) and
-    checked to be identical on every rank; the flat buffer is reused afterwards.
+    ``reduce()`` is called between ``loss.backward()`` and ``optimizer.step()``.  The set of parameters that take part
+    is decided on the first call (those with ``grad is not None``) and checked to be identical on every rank; that
+    first step is one flat all-reduce.  From the second step on, the live parameters sit in ``len(buckets)`` slices of
+    one flat buffer, cut in REVERSE registration order (the order backward produces gradients in: heads first, the
+    first PointNet last) at ``bucket_bytes``; a post-accumulate hook copies each gradient into its slice and, when a
+    bucket is complete, starts its all-reduce asynchronously -- the heads' and node-level layers' gradients (about 9 of
+    the 10.7 MB) travel over xGMI while the first PointNet's backward, the bulk of the step, is still running.
+    ``reduce()`` then only waits, scales and scatters back.  Few large buckets on purpose: xGMI is point-to-point and a
+    message of a few MB is latency-bound (module docstring).  ``overlap=False`` keeps the single flat call.
     """
 
-    def __init__(self, modules):
+    def __init__(self, modules, bucket_bytes=4 << 20, overlap=True):
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
-        self._live = None
+        self.bucket_bytes = int(bucket_bytes)
+        self.overlap = bool(overlap)
+        self._live = None            # indices into self.params, flat-buffer order
         self._flat = None
+        self._slices = {}            # param index -> (offset, numel)
+        self.buckets = []            # [(offset, numel, [param indices])]
+        self._bucket_of = {}
+        self._pending = []           # per bucket: gradients still missing this step
+        self._work = []              # per bucket: async handle (or None)
+        self._hooks = []
+        self._armed = False
 
     def _setup(self):
         live = [i for i, p in enumerate(self.params) if p.grad is not None]
@@ -104,34 +121,83 @@ class GradientAllReducer:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
                 raise RuntimeError("ranks disagree on which parameters received gradients")
+        live = live[::-1]                                            # backward order: last registered first
         self._live = live
-        n = sum(self.params[i].numel() for i in live)
         ref = self.params[live[0]] if live else self.params[0]
-        self._flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off, start, members = 0, 0, []
+        for i in live:
+            n = self.params[i].numel()
+            self._slices[i] = (off, n)
+            members.append(i)
+            off += n
+            if (off - start) * ref.element_size() >= self.bucket_bytes:
+                self.buckets.append((start, off - start, members))
+                start, members = off, []
+        if members:
+            self.buckets.append((start, off - start, members))
+        for b, (_, _, members) in enumerate(self.buckets):
+            for i in members:
+                self._bucket_of[i] = b
+        self._flat = torch.zeros(off, dtype=ref.dtype, device=ref.device)
+        if self.overlap and world_size() > 1:
+            for i in live:
+                self._hooks.append(self.params[i].register_post_accumulate_grad_hook(self._make_hook(i)))
+            self._arm()
+
+    def _arm(self):
+        self._pending = [len(members) for _, _, members in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._armed = True
+
+    def _make_hook(self, i):
+        def hook(p):
+            if not self._armed or p.grad is None:
+                return
+            off, n = self._slices[i]
+            self._flat[off:off + n].copy_(p.grad.reshape(-1))
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                bo, bn, _ = self.buckets[b]
+                self._work[b] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
+        return hook
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._armed = [], False
 
     @torch.no_grad()
     def reduce(self):
-        if self._live is None:
+        first = self._live is None
+        if first:
             self._setup()
         w = world_size()
         if w == 1 or not self._live:
             return 0
-        off = 0
-        for i in self._live:
-            g = self.params[i].grad
-            if g is None:
-                raise RuntimeError("parameter %d had a gradient on the first step but has none now" % i)
-            n = g.numel()
-            self._flat[off:off + n].copy_(g.reshape(-1))
-            off += n
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        overlapped = self._armed and not first
+        if overlapped:
+            for b, (bo, bn, members) in enumerate(self.buckets):
+                if self._pending[b] != 0:
+                    missing = [i for i in members if self.params[i].grad is None]
+                    raise RuntimeError("bucket %d: %d gradient(s) did not arrive during backward (parameters %s had one on "
+                                       "the first step)" % (b, self._pending[b], missing[:4]))
+                self._work[b].wait()
+        else:
+            for i in self._live:
+                g = self.params[i].grad
+                if g is None:
+                    raise RuntimeError("parameter %d had a gradient on the first step but has none now" % i)
+                off, n = self._slices[i]
+                self._flat[off:off + n].copy_(g.reshape(-1))
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         self._flat.div_(w)
-        off = 0
         for i in self._live:
             g = self.params[i].grad
-            n = g.numel()
+            off, n = self._slices[i]
             g.copy_(self._flat[off:off + n].view_as(g))
-            off += n
+        if self._armed:
+            self._arm()                                               # next backward
         return self._flat.numel() * self._flat.element_size()
 
 

@@ -56,10 +56,38 @@ def _worker(rank, world, port, q):
     assert torch.allclose(live[0].weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(live[0].bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-6)
     assert all(p.grad is None for p in dead.parameters())
-    # second step reuses the bucket
-    live.zero_grad()
-    live[0](xs).sum().backward()
+    # second step: gradients travel from the hooks, bucket by bucket, during backward
+    assert red.buckets and red._armed
+    live.zero_grad(set_to_none=True)
+    live[0](xs).pow(2).sum().backward()
+    assert all(wk is not None for wk in red._work)                            # every bucket was started by a hook
     red.reduce()
+    assert torch.allclose(live[0].weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(live[0].bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-6)
+    # several buckets (tiny cap), reverse registration order, same numbers as the flat call; a gradient that stops
+    # arriving is an error, not a silent stale slice
+    torch.manual_seed(7)
+    net = nn.Sequential(nn.Linear(4, 6), nn.ReLU(), nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 2))
+    dp.broadcast_parameters([net])
+    net_flat = nn.Sequential(nn.Linear(4, 6), nn.ReLU(), nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 2))
+    net_flat.load_state_dict(net.state_dict())
+    r_b, r_f = dp.GradientAllReducer([net], bucket_bytes=64), dp.GradientAllReducer([net_flat], overlap=False)
+    for step in range(3):
+        for m, r in ((net, r_b), (net_flat, r_f)):
+            m.zero_grad(set_to_none=True)
+            m(xs * (step + 1)).pow(2).sum().backward()
+            r.reduce()
+        for pa, pb in zip(net.parameters(), net_flat.parameters()):
+            assert torch.equal(pa.grad, pb.grad), step
+    assert len(r_b.buckets) >= 3 and r_b.buckets[0][2][0] == len(r_b.params) - 1 and len(r_f.buckets) == 1
+    net.zero_grad(set_to_none=True)
+    net[0](xs).sum().backward()                                               # the last two layers get no gradient
+    try:
+        r_b.reduce()
+        raise AssertionError("a missing gradient went unnoticed")
+    except RuntimeError as e:
+        assert "did not arrive" in str(e)
+    r_b.remove_hooks()
     assert dp.all_reduce_max(float(rank), torch.device("cpu")) == float(world - 1)
     dp.barrier()
     dist.destroy_process_group()
