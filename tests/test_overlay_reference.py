@@ -134,3 +134,92 @@ def test_overlay_forward_refuses_to_run_without_the_gpu():
     """)
     if not r["cuda"]:
         assert r["res"] == "RuntimeError"
+
+
+def test_layer_constructors_match_the_reference_for_every_option():
+    """Every activation / normalisation option the reference's layer classes accept (models/layers.py:130-141,
+    :176-187, :254-266) builds here with the same parameter / buffer names and shapes, the same sub-module names and
+    the same activation module type; an option the reference does not know yields no norm / act there and here."""
+    r = run("""
+        import importlib.util, itertools
+        from models import layers as ours
+        from sonet_hip import overlay
+        ref = overlay.reference_module("models", "layers.py", ours.__file__)
+        def sig(m):
+            return {"state": {k: list(v.shape) for k, v in m.state_dict().items()},
+                    "children": {n: type(c).__name__ for n, c in m.named_children()}}
+        out, bad = 0, []
+        acts, norms = [None, "relu", "elu", "swish", "leakyrelu", "selu"], [None, "batch", "instance"]
+        for act, norm in itertools.product(acts, norms):
+            cases = {
+                "EquivariantLayer": lambda L: L.EquivariantLayer(6, 16, activation=act, normalization=norm, momentum=0.2,
+                                                                 bn_momentum_decay_step=3, bn_momentum_decay=0.5),
+                "MyLinear": lambda L: L.MyLinear(8, 4, activation=act, normalization=norm, momentum=0.2,
+                                                 bn_momentum_decay_step=3, bn_momentum_decay=0.5),
+                "MyConv2d": lambda L: L.MyConv2d(3, 5, 1, activation=act, normalization=norm, momentum=0.2,
+                                                 bn_momentum_decay_step=3, bn_momentum_decay=0.5),
+                "UpConv": lambda L: L.UpConv(4, 2, activation=act, normalization=norm),
+            }
+            if act is not None:
+                cases["PointNet"] = lambda L: L.PointNet(3, (8, 16), activation=act, normalization=norm)
+                cases["PointResNet"] = lambda L: L.PointResNet(6, [8, 16, 32, 48], activation=act, normalization=norm)
+                cases["KNNModule"] = lambda L: L.KNNModule(7, (8, 8), activation=act, normalization=norm)
+            for name, make in cases.items():
+                try:
+                    a = sig(make(ref))
+                except Exception as e:
+                    a = "raises " + type(e).__name__
+                try:
+                    b = sig(make(ours))
+                except Exception as e:
+                    b = "raises " + type(e).__name__
+                out += 1
+                if a != b:
+                    bad.append([name, act, norm, a, b])
+        print(json.dumps({"n": out, "bad": bad[:5], "nbad": len(bad)}))
+    """)
+    assert r["n"] >= 100 and r["nbad"] == 0, r["bad"]
+
+
+def test_network_constructors_match_the_reference_for_every_configuration():
+    """Encoder / Classifier / Segmenter / Decoder variants (models/networks.py:71-109, :202-216, :230-257, :347-448):
+    same state_dict keys and shapes as the reference's classes over the option combinations the task scripts use."""
+    r = run("""
+        import copy, itertools
+        from models import networks as ours
+        from sonet_hip import overlay
+        import sys, types
+        sys.modules.setdefault("faiss", types.ModuleType("faiss"))           # the reference's util/som.py imports it
+        ref = overlay.reference_module("models", "networks.py", ours.__file__)
+        sys.modules.pop("faiss", None)
+        def keys(m):
+            return {k: list(v.shape) for k, v in m.state_dict().items()}
+        bad, n = [], 0
+        for sn, som_k, node_num, fn, act, norm in itertools.product([True, False], [1, 9], [16, 64], [512, 1024],
+                                                                      ["relu", "leakyrelu"], ["batch", "instance"]):
+            o = copy.copy(opt)
+            o.surface_normal, o.som_k, o.node_num, o.feature_num, o.activation, o.normalization = sn, som_k, node_num, fn, act, norm
+            for name in ("Encoder", "Classifier", "Segmenter"):
+                a, b = keys(getattr(ref, name)(o)), keys(getattr(ours, name)(o))
+                n += 1
+                if a != b:
+                    bad.append([name, sn, som_k, node_num, fn, act, norm, sorted(set(a) ^ set(b))[:6]])
+        for out_fc, conv_pc, conv_size, fn in itertools.product([256, 512], [1024, 4096], [32, 64], [512, 1024]):
+            o = copy.copy(opt)
+            o.output_fc_pc_num, o.output_conv_pc_num, o.output_conv_size, o.feature_num = out_fc, conv_pc, conv_size, fn
+            o.output_pc_num = out_fc + conv_pc
+            for name in ("DecoderLinear", "DecoderConv", "Decoder"):
+                try:
+                    a = keys(getattr(ref, name)(o))
+                except Exception as e:
+                    a = "raises " + type(e).__name__
+                try:
+                    b = keys(getattr(ours, name)(o))
+                except Exception as e:
+                    b = "raises " + type(e).__name__
+                n += 1
+                if a != b:
+                    bad.append([name, out_fc, conv_pc, conv_size, fn, a if isinstance(a, str) else "keys", b if isinstance(b, str) else "keys"])
+        print(json.dumps({"n": n, "nbad": len(bad), "bad": bad[:6]}))
+    """)
+    assert r["n"] >= 200 and r["nbad"] == 0, r["bad"]
