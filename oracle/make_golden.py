@@ -16,7 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("SONET_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (tests regenerate into a scratch dir)
 sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != HERE]
 sys.path.insert(0, ROOT)
 

@@ -223,3 +223,28 @@ def test_network_constructors_match_the_reference_for_every_configuration():
         print(json.dumps({"n": n, "nbad": len(bad), "bad": bad[:6]}))
     """)
     assert r["n"] >= 200 and r["nbad"] == 0, r["bad"]
+
+
+@pytest.mark.timeout(900)
+def test_committed_golden_fixtures_regenerate_bit_identically_from_the_live_reference(tmp_path):
+    """oracle/make_golden.py, run against the mounted reference into a scratch directory, reproduces every committed
+    tests/golden/*.npz array for array (inputs, integer outputs and float outputs alike): the fixtures the GPU box
+    checks the HIP path against ARE outputs of the unmodified reference at this commit, not hand-kept numbers."""
+    import glob
+    import numpy as np
+    env = dict(os.environ, SONET_GOLDEN_OUT=str(tmp_path))
+    for extra in ([], ["autoencoder"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden.py")] + extra, env=env,
+                           capture_output=True, text=True, timeout=800)
+        assert p.returncode == 0, p.stderr[-3000:]
+    made = sorted(os.path.basename(f) for f in glob.glob(os.path.join(str(tmp_path), "*.npz")))
+    kept = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+    assert made == kept, set(made) ^ set(kept)
+    for name in kept:
+        a, b = np.load(os.path.join(str(tmp_path), name)), np.load(os.path.join(ROOT, "tests", "golden", name))
+        assert sorted(a.files) == sorted(b.files), name
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (name, k)
+            assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind in "fc"), (name, k)
+    assert json.load(open(os.path.join(str(tmp_path), "state_dict_keys.json"))) == \
+        json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
