@@ -341,6 +341,7 @@ def main():
         torch.set_num_threads(8)
         ref = ref_harness.import_reference(with_faiss_shim=True)
         golden_autoencoder(ref, "b2_n1024", B=2, N=1024, seed=401)
+        golden_autoencoder(ref, "b2_n5000", B=2, N=5000, seed=402)            # BASELINE configs[3] size: 5000 gt vs 1280 predicted points
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -354,6 +355,7 @@ def main():
     golden_classifier(ref, "b2_n5000", B=2, N=5000, seed=103, node_kind="som")          # configs[1] shape
     golden_train_step(ref, "b16_n512", B=16, N=512, seed=201)   # B=16: BN over 4 samples is too ill-conditioned to compare gradients
     golden_segmenter(ref, "b2_n256", B=2, N=256, seed=301)
+    golden_segmenter(ref, "b2_n1024", B=2, N=1024, seed=302)                  # BASELINE configs[2] size
     golden_som_update(ref)
     golden_classifier(ref, "b2_n300_k1_center", B=2, N=300, seed=104, node_kind="uniform", k=1,
                       som_k=5, som_k_type="center")

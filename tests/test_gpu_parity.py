@@ -455,12 +455,13 @@ def test_pointresnet_fused_vs_layerwise_and_golden():
 
 
 # ------------------------------------------------------------------------------------------ segmenter (config 3)
+@pytest.mark.parametrize("case", ["segmenter_b2_n256", "segmenter_b2_n1024"])        # n1024: BASELINE configs[2] size
 @pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
-def test_segmenter_forward_golden(mode):
+def test_segmenter_forward_golden(mode, case):
     """Part-segmentation forward (level-2 encoder + back-broadcast gathers + Segmenter head) vs the reference."""
     from models import networks as NW
     from sonet_hip import ops, synth
-    g = golden("segmenter_b2_n256")
+    g = golden(case)
     B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
     opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
                     activation="relu", normalization="batch", dropout=0.6, node_num=64, k=3, som_k=9, som_k_type="center",
@@ -490,13 +491,14 @@ def test_segmenter_forward_golden(mode):
 
 
 # ------------------------------------------------------------------------------------------ autoencoder (config 4)
+@pytest.mark.parametrize("case", ["autoencoder_b2_n1024", "autoencoder_b2_n5000"])  # n5000: BASELINE configs[3] size
 @pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
-def test_autoencoder_forward_and_chamfer_golden(mode):
+def test_autoencoder_forward_and_chamfer_golden(mode, case):
     """Encoder -> FC + conv decoder -> multi-resolution Chamfer loss (models/autoencoder.py:62-125) vs the reference
     run with an exact flat-L2 search in place of faiss; gradient of the loss w.r.t. the predicted cloud."""
     from models import networks as NW, losses as LS
     from sonet_hip import ops, synth
-    g = golden("autoencoder_b2_n1024")
+    g = golden(case)
     B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
     opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
                     activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9, som_k_type="avg",

@@ -103,10 +103,11 @@ def test_encoder_restatement_matches_reference_forward(case):
     assert_close_rms(score.numpy(), g["score"], 1e-5, "score")
 
 
-def test_chamfer_loss_restatement_matches_reference_arithmetic():
+@pytest.mark.parametrize("case", ["autoencoder_b2_n1024", "autoencoder_b2_n5000"])
+def test_chamfer_loss_restatement_matches_reference_arithmetic(case):
     """models/losses.py:237-290 run live (exact flat-L2 stand-in for faiss, oracle/ref_harness.py) vs the numpy
     restatement, on the reference decoder's own predicted cloud."""
-    g = golden("autoencoder_b2_n1024")
+    g = golden(case)
     fwd, bwd, arr = O.chamfer_loss(g["predicted_pc"], g["pc"])
     assert abs(fwd - float(g["forward_loss"])) <= 1e-6 * abs(float(g["forward_loss"]))
     assert abs(bwd - float(g["backward_loss"])) <= 1e-6 * abs(float(g["backward_loss"]))
@@ -117,3 +118,17 @@ def test_chamfer_loss_restatement_matches_reference_arithmetic():
     d = ((p[:, :, :, None] - q[:, :, None, :]) ** 2).sum(1)
     nn = O.chamfer_nn(g["predicted_pc"], g["pc"])
     assert (nn == d.argmin(2)).mean() > 0.999
+
+
+@pytest.mark.parametrize("case", ["segmenter_b2_n256", "segmenter_b2_n1024"])
+def test_encoder_restatement_matches_reference_segmenter_run(case):
+    """The part-segmentation fixtures (reference models/segmenter.py:79-98, som_k_type 'center'): node ids recovered by
+    argmax(mask) and the back-broadcast of the per-node max features to the kN point copies."""
+    g = golden(case)
+    enc_sd, _ = _models_sd(int(g["seed"]))
+    r = O.encoder_forward(enc_sd, torch.from_numpy(g["pc"]), torch.from_numpy(g["sn"]), torch.from_numpy(g["node"]),
+                          torch.from_numpy(g["node_knn_I"]), k=3, som_k=9, som_k_type="center")
+    np.testing.assert_array_equal(r["min_idx"], g["min_idx"])
+    mm, idx = r["first_pn_out_masked_max"].numpy(), r["min_idx"]
+    bb = np.take_along_axis(mm, np.broadcast_to(idx[:, None, :], (mm.shape[0], mm.shape[1], idx.shape[1])), axis=2)
+    assert_close_rms(bb[:, ::8], g["feature_max_first_pn_out"], 1e-5, "back-broadcast of first_pn_out_masked_max")
