@@ -138,3 +138,29 @@ def test_synth_inputs_are_deterministic_and_shaped():
     assert a["pc"].shape == (3, 3, 100) and a["node"].shape == (3, 3, 64) and a["node_knn_I"].shape == (3, 64, 9)
     assert a["node_knn_I"].dtype == torch.int64 and torch.equal(a["node_knn_I"][:, :, 0], torch.arange(64).expand(3, 64))
     assert torch.allclose(a["sn"].norm(dim=1), torch.ones(3, 100), atol=1e-5)
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Arity, argument kinds (pointer / int / long long / float / double) and return types of sonet_hip/_lib.py against
+    the prototypes of include/sonet_hip.h: a drifted binding would pass garbage through ctypes without an error."""
+    from sonet_hip import _lib
+    src = open(os.path.join(ROOT, "include", "sonet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|const\s+char\s*\*)\s*(sonet_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src)
+    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+
+    def kind(param):
+        p = " ".join(param.split())
+        if p in ("void", ""):
+            return None
+        if "*" in p or "sonet_stream_t" in p:
+            return ctypes.c_void_p
+        base = p.rsplit(" ", 1)[0] if " " in p else p            # drop the parameter name
+        return {"int": ctypes.c_int, "int32_t": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float,
+                "double": ctypes.c_double, "size_t": ctypes.c_size_t}[base.replace("const ", "")]
+
+    for ret, name, params in protos:
+        want = [k for k in (kind(p) for p in params.split(",")) if k is not None]
+        assert _lib.SIGNATURES[name] == want, (name, [t.__name__ for t in want], [t.__name__ for t in _lib.SIGNATURES[name]])
+        want_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t}.get(ret, ctypes.c_char_p)
+        assert _lib._RESTYPES.get(name, ctypes.c_int) == want_ret, name
