@@ -359,6 +359,10 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     int ysplit = 1;
     while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
     while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    if (const char *e = getenv("SONET_POINTMLP_YSPLIT")) {  // tuning knob (bench experiments only): output-channel slabs per column group.
+        const int want = atoi(e);                           // 1152 workgroups on 768 resident slots run 1.5 rounds; 2 slabs of half the work
+        if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;   // each would run 3 rounds of half the length (X re-read twice)
+    }
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
