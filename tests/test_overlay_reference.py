@@ -248,3 +248,26 @@ def test_committed_golden_fixtures_regenerate_bit_identically_from_the_live_refe
             assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind in "fc"), (name, k)
     assert json.load(open(os.path.join(str(tmp_path), "state_dict_keys.json"))) == \
         json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+
+
+def test_task_script_imports_resolve_through_the_overlay():
+    """What modelnet/train.py, shrec16/*.py, part-seg/train.py and autoencoder/train.py import besides the models
+    (``util.util``, ``util.visualizer``, ``<task>.options``, ``util.potential_field``, ``data.augmentation``) comes from
+    the reference checkout although ``util`` and ``models`` are overlay packages; BatchSOM.node_init reaches the reference's
+    PotentialField the same way (util/som.py:196-206)."""
+    r = run("""
+        import importlib
+        for m in ("dominate", "dominate.tags", "faiss"):
+            sys.modules.setdefault(m, types.ModuleType(m))
+        out = {}
+        for name in ("util.util", "modelnet.options", "shrec16.options", "util.visualizer", "util.potential_field", "data.augmentation"):
+            out[name] = importlib.import_module(name).__file__
+        from util import som
+        s = som.BatchSOM(2, 2, 3, 0, 3)
+        s.node_init(3)                                   # 4 nodes: the potential-field initialiser runs in well under a second
+        out["node_shape"] = list(s.node.shape)
+        print(json.dumps(out))
+    """)
+    for name in ("util.util", "modelnet.options", "shrec16.options", "util.visualizer", "util.potential_field", "data.augmentation"):
+        assert r[name].startswith(REF), (name, r[name])
+    assert r["node_shape"] == [3, 3, 4]
