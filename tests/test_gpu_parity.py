@@ -324,6 +324,57 @@ def test_encoder_classifier_forward_golden(case):
     assert_close_rms(score.cpu().numpy(), g["score"], tol, "score")
 
 
+def test_forward_properties_at_the_benchmark_shape():
+    """Size-independent properties of the classifier forward at the bench.py workload shape (5000 points, 8x8 SOM, k=3),
+    no oracle needed: (1) a batch shard computed alone equals the same clouds inside the full batch -- the property that
+    lets bench.py / data-parallel inference shard over ranks with no data-path collective; (2) permuting
+    the points of every cloud permutes the node ids and leaves every pooled feature unchanged up to the order of the
+    cluster-mean sums."""
+    from models import networks as NW
+    from sonet_hip import synth
+    B, N = 16, 5000
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), 21)
+    synth.fill_state_dict_(cls.state_dict(), 22)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    inp = synth.make_inputs(B, N, seed=77, device=DEV)
+    pc, sn, node, knn = inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"]
+    with torch.no_grad():
+        feat = enc(pc, sn, node, knn, is_train=False).clone()
+        score = cls(feat).clone()
+        min_idx = enc.min_idx.clone()
+        pooled = enc.first_pn_out_masked_max.clone()
+        som_node = enc.som_node.clone()
+        occupied = enc._lazy["a"].count > 0                                   # B x M
+        # (1) shard alone == slice of the full batch
+        h = B // 2
+        for lo, hi in ((0, h), (h, B)):
+            f_s = enc(pc[lo:hi].contiguous(), sn[lo:hi].contiguous(), node[lo:hi].contiguous(), knn[lo:hi].contiguous(), is_train=False)
+            assert torch.equal(enc.min_idx, min_idx[lo:hi])
+            assert_close_rms(f_s.cpu().numpy(), feat[lo:hi].cpu().numpy(), 1e-6, "feature of a shard vs the full batch")
+            assert_close_rms(cls(f_s).cpu().numpy(), score[lo:hi].cpu().numpy(), 1e-6, "score of a shard vs the full batch")
+        # (2) point permutation
+        gen = torch.Generator().manual_seed(5)
+        perm = torch.stack([torch.randperm(N, generator=gen) for _ in range(B)]).to(DEV)          # B x N
+        idx3 = perm.unsqueeze(1).expand(B, 3, N)
+        f_p = enc(torch.gather(pc, 2, idx3).contiguous(), torch.gather(sn, 2, idx3).contiguous(), node, knn, is_train=False)
+        want = torch.gather(min_idx.view(B, 3, N), 2, idx3).reshape(B, 3 * N)                     # slot-major: [b][s*N + i] = old[b][s*N + perm[i]]
+        assert torch.equal(enc.min_idx, want)
+        assert torch.equal(enc._lazy["a"].count > 0, occupied)
+        assert_close_rms(enc.som_node.cpu().numpy(), som_node.cpu().numpy(), 1e-6, "cluster means under a point permutation")
+        # an EMPTY node takes the features of point copy 0 (the reference's gather at index 0 * mask_row_max,
+        # models/networks.py:185), which a permutation legitimately changes: compare the occupied nodes only
+        occ = occupied.unsqueeze(1).to(pooled.dtype)
+        assert_close_rms((enc.first_pn_out_masked_max * occ).cpu().numpy(), (pooled * occ).cpu().numpy(), 1e-5,
+                         "pooled features under a point permutation")
+        if bool(occupied.all()):
+            assert_close_rms(f_p.cpu().numpy(), feat.cpu().numpy(), 1e-5, "feature under a point permutation")
+
+
 def test_graphed_forward_equals_eager():
     """HIP-graph replay of the classifier forward is bit-identical to the eager launch sequence."""
     from models import networks as NW
