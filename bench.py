@@ -56,7 +56,57 @@ def parse():
                          "(BASELINE configs[4], reported under its own metric name)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--no-other-precisions", action="store_true", help="skip the x3 / exact-f32 throughput keys")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the timed batch (rank 0)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a torch.distributed.run environment: launch the N ranks ourselves (the same
+    command line the driver uses) and hand back their exit code.  Fails loudly when fewer than N GPUs are visible."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to report a smaller job as %d GPUs"
+                         % (args.gpus, have, args.gpus))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parity_check(args, enc, cls, inp, out, enc_sd, cls_sd, n_clouds=4):
+    """The oracle on the first clouds of the TIMED batch vs what the timed path produced for them: node ids bit-exact,
+    feature / score within 1e-5 * max(|ref|, rms(ref)) -- so the number on the line belongs to results that were checked."""
+    import numpy as np
+    from oracle import cpu_oracle as O
+    P = min(n_clouds, args.batch)
+    with torch.no_grad():
+        feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)   # eager twin of the replayed step
+        score_eager = cls(feat)
+    got_idx = enc.min_idx[:P].cpu().numpy()
+    ref = O.encoder_forward(enc_sd, inp["pc"][:P].cpu(), inp["sn"][:P].cpu(), inp["node"][:P].cpu(), inp["node_knn_I"][:P].cpu(),
+                            use_ref_index_max=O.ref_module() is not None)
+    ref_score = O.classifier_forward(cls_sd, ref["feature"])
+
+    def worst(a, b):
+        a, b = a.detach().cpu().double().numpy(), b.detach().double().numpy()
+        bound = 1e-5 * np.maximum(np.abs(b), np.sqrt(np.mean(b ** 2)))
+        return float((np.abs(a - b) / bound).max())
+
+    res = {"clouds": P, "of_the_timed_batch": True, "min_idx_bit_exact": bool(np.array_equal(got_idx, ref["min_idx"])),
+           "feature_err_over_bound": round(worst(feat[:P], ref["feature"]), 4),
+           "score_err_over_bound": round(worst(out[:P], ref_score), 4),
+           "replay_equals_eager": bool(torch.equal(out, score_eager)),
+           "bound": "1e-5 * max(|ref|, rms(ref))", "oracle": "oracle/cpu_oracle.py"}
+    res["ok"] = bool(res["min_idx_bit_exact"] and res["feature_err_over_bound"] <= 1.0 and res["score_err_over_bound"] <= 1.0)
+    if not res["ok"]:
+        raise SystemExit("bench.py: the timed batch does NOT match the oracle: %s" % json.dumps(res))
+    return res
 
 
 def make_opt(dev, B, N):
@@ -137,7 +187,9 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
     dp.broadcast_parameters([enc, cls])
     opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
     opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
-    reducer = dp.GradientAllReducer([enc, cls])
+    # always_reduce: the RCCL collectives run even in a single-rank group, so the 1-GPU line exercises (and prices) the same
+    # hook-driven bucketed exchange the 8-GPU job uses
+    reducer = dp.GradientAllReducer([enc, cls], always_reduce=torch.distributed.is_initialized())
     label = inp["label"]
 
     def step():
@@ -163,6 +215,7 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
     torch.cuda.synchronize()
     elapsed = dp.all_reduce_max(time.perf_counter() - t0, dev)
     assert torch.isfinite(loss)
+    exposed_us = reducer.exposed_ms(last=args.steps) * 1e3
     if rank != 0:
         return
     B, N = args.batch, args.points
@@ -174,7 +227,11 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "vs_baseline": None, "dtype": "f32 (%s forward; backward GEMMs on PyTorch-ROCm)" % ops.POINTMLP_PRECISION, "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
-                                  % (world, nbytes, max(1, len(reducer.buckets)))}}))
+                                  % (world, nbytes, max(1, len(reducer.buckets)))},
+        "allreduce": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None, "bytes_per_step": nbytes,
+                      "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1),
+                      "what": "GPU time between the last backward kernel and the arrival of the last bucket (HIP events around the waits)"},
+        "range_guard": {"enabled": bool(ops.RANGE_GUARD), "arithmetic_at_end": ops.POINTMLP_PRECISION}}))
 
 
 def main():
@@ -184,11 +241,13 @@ def main():
 
     if args.precision:
         ops.POINTMLP_PRECISION = args.precision
-    world, rank, local_rank = dp.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))            # not under torch.distributed.run: start the N ranks ourselves
+    world, rank, local_rank = dp.init_distributed(force=(args.mode == "train"))   # train: a process group even for one rank (RCCL is exercised)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -256,6 +315,30 @@ def main():
                     torch.cuda.synchronize()
             finally:
                 ops.FUSE_POOL = True
+        # the replayed forward's operand-range log (fp16-split arithmetic): a violation would mean clamped features
+        range_bad = graphed.range_violations() if use_graph else []
+        if range_bad:
+            raise SystemExit("bench.py: h3 operand range violated on the synthetic batch: %s" % (range_bad[:3],))
+        # the other two arithmetics of the same path on the same batch (graph replay, same K): extra keys, not `value`
+        other = {}
+        if world == 1 and not args.no_other_precisions and use_graph:
+            from sonet_hip.graph import GraphedForward
+            for mode in ("x3", "f32"):
+                if mode == ops.POINTMLP_PRECISION:
+                    continue
+                with ops.precision(mode):
+                    g2 = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False)),
+                                        (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"]), warmup=2)
+                    for _ in range(3):
+                        g2(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(args.steps):
+                        g2(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t2
+                other[mode] = {"clouds_per_s": round(B * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4)}
+                del g2
     elapsed = dp.all_reduce_max(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
@@ -306,11 +389,13 @@ def main():
     for k in kernels:
         if k["name"] in traffic:
             k["traffic"] = traffic[k["name"]]
+            k["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)"
     dom = next((k for k in kernels if "achieved" in k), None)
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": dom["unit"], "frac": dom["frac"], "traffic": dom.get("traffic")}
+                    "unit": dom["unit"], "frac": dom["frac"], "traffic": dom.get("traffic"),
+                    "traffic_source": dom.get("traffic_source")}
         if dom["bound"] == "mfma" and rank == 0 and ops.POINTMLP_PRECISION == "h3":
             # `peak` is the nominal dense rate (2.4 GHz).  With all 256 CUs on the matrix pipe the chip is power-limited:
             # a pure fp16 MFMA loop on operands with random mantissas holds well under that (finding 8).
@@ -332,12 +417,16 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "points": N,
                    "parallelism": "dp%d: batch shards, no data-path collective" % world},
         "launch_mode": "hip-graph replay" if use_graph else "eager",
+        "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,
+        "range_guard": {"enabled": bool(ops.RANGE_GUARD), "violations": len(range_bad)},
         "eager_instrumented_ms_per_step": round(eager_ms, 4),
         "roofline": roofline,
         "kernel_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 4),
         "kernels": kernels,
         "kernels_store_path": store_path,
     }
+    if not args.no_parity_check:
+        line["parity_checked"] = parity_check(args, enc, cls, inp, out, enc_cpu, cls_cpu)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
     print(json.dumps(line))

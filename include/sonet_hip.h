@@ -52,6 +52,22 @@ int sonet_check_device(void);
  * nominal 2.4 GHz figure (finding 8).  Synchronous: returns after the timed launch has finished. */
 int sonet_diag_mfma_f16_rate(int random_operands, int iters, double *tflops_out, double *ghz_out, sonet_stream_t stream);
 
+/* Range log of the fp16-split ("h3") kernels (no reference counterpart: the reference computes in plain f32).
+ * The three-term fp16 split has an fp16 operand RANGE: |x| <= 2047 (larger inputs are clamped) and relative precision
+ * fades once the largest magnitude of a layer's input drops below ~2^-7; weights likewise (|w| <= 65504).  So that a
+ * caller never gets clamped results unknowingly, every h3 launch (sonet_pointmlp_h3_f32, sonet_pointmlp_h3_gather_f32,
+ * sonet_pointresnet_fused_f32, sonet_pointresnet_fused_pool_f32) reports the magnitudes it saw into the 8-word DEVICE
+ * slot registered for the calling thread (NULL = no report, the default), by atomic max on the IEEE bit patterns
+ * (a NaN sorts above +inf):
+ *   slot[0] = bits of max |x| over the launch's input (for the fused kernels: the network input),
+ *   slot[1] = bits of max |w| (recorded by the pack kernels in the packed weight's trailer),
+ *   slot[2] = fused kernels only: bits of the largest post-BatchNorm-affine activation entering layers 2-4.
+ * The caller zeroes the slot, launches, and reads it back at its next synchronisation point; a word above
+ * bits(2047.0f) (slot[1]: bits(65504.0f)) or a non-zero slot[0] / slot[1] below bits(2^-6) means the launch's
+ * results are not f32-class and must be recomputed with sonet_pointmlp_x3_f32 (f32 range).  sonet_hip/ops.py does
+ * exactly that (ops.range_scope; Encoder.forward falls back to the x3 arithmetic for the batch). */
+int sonet_range_log_set(uint32_t *slot);
+
 /* ------------------------------------------------------------------------------------------------
  * index_max  -- replaces index_max.forward_cuda / forward_cuda_shared_mem
  *   reference: models/index_max_ext/index_max.cpp:132-148 (wrappers), index_max_cuda.cu:10-26,66-82

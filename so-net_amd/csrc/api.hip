@@ -17,7 +17,12 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+static thread_local uint32_t *g_range_log = nullptr;
+uint32_t *range_log() { return g_range_log; }
+
 }  // namespace sonet
+
+extern "C" int sonet_range_log_set(uint32_t *slot) { sonet::g_range_log = slot; return SONET_OK; }
 
 extern "C" int sonet_abi_version(void) { return 1; }
 extern "C" const char *sonet_build_arch(void) { return "gfx950"; }

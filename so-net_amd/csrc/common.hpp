@@ -30,6 +30,10 @@ static inline int launched(const char *what) {
         if (!(cond)) return ::sonet::fail(SONET_ERR_INVALID_ARG, __VA_ARGS__); \
     } while (0)
 
+// Range log of the fp16-split ("h3") kernels: thread-local pointer to the 8-word slot the NEXT h3 launch of this thread
+// reports its operand magnitudes into (sonet_range_log_set; NULL = no report).  See include/sonet_hip.h.
+uint32_t *range_log();
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
 
@@ -42,4 +46,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid % sonet::NUM_XCD, local = bid / sonet::NUM_XCD;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + local;
+}
+
+// ---- operand-range tracking of the fp16-split kernels (two integer max per value pair) ---------------------------
+// |x| as ordered bits over everything a lane has seen: positive floats order as signed ints (mp), negative ones --
+// sign bit set -- order by magnitude as unsigned ints (mn); a NaN of either sign lands above +-inf in one of the two.
+struct RangeAcc { int mp; unsigned mn; };
+__device__ __forceinline__ void range_track(RangeAcc &r, float x0, float x1) {
+    const int a = __float_as_int(x0), b = __float_as_int(x1);
+    r.mp = max(max(r.mp, a), b);                                           // v_max3_i32
+    r.mn = max(max(r.mn, (unsigned)a), (unsigned)b);                       // v_max3_u32
+}
+__device__ __forceinline__ unsigned range_amax_bits(const RangeAcc &r) {   // bits of max |x| (NaN > inf > finite)
+    const unsigned neg = (r.mn & 0x80000000u) ? (r.mn & 0x7FFFFFFFu) : 0u;
+    const unsigned pos = (unsigned)r.mp;
+    return pos > neg ? pos : neg;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// one atomic per wave at most, and only while the wave's value still raises the word
+__device__ __forceinline__ void range_publish(unsigned *word, unsigned wave_max_bits, int lane) {
+    if (lane == 0 && wave_max_bits > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, wave_max_bits);
 }

@@ -82,10 +82,11 @@ __device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsig
 // Wp3[ct][kc][term][lane] (uint4 = 8 bf16 / fp16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
 template <bool F16>
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
-                                                       int Cin, int Cout, int KC, long long total)
+                                                       int Cin, int Cout, int KC, long long total, unsigned *__restrict__ trailer)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
-    if (t >= total) return;
+    if (t >= total) return;                                              // (total is a multiple of 64: whole waves leave)
+    RangeAcc wr = {0, 0u};
     const int lane = (int)(t & 63);
     const long long r = t >> 6;
     const int kc = (int)(r % KC), ct = (int)(r / KC);
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
         const int c = c0 + 2 * p;
         const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
         const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
+        range_track(wr, w0, w1);
         if constexpr (F16) {
             // A side: slice 0 = fp16(w) (meets 32 xh and the scaled x residual), slice 2 = fp16(32 * (w - h)) (meets xh);
             // slice 1 is unused by the fp16 kernel (the packed size is shared with the bf16 flavour)
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
     dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
     dst[64] = make_uint4(m[0], m[1], m[2], m[3]);
     dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
+    range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| of the layer (range log, word 1 of a launch)
 }
 
 template <int MT, int S, bool F16>
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
-    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/)
+    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
+    unsigned *__restrict__ rlog /*optional (fp16 flavour): range-log slot, word 0 = max |x| bits, word 1 = max |w| bits*/)
 {
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
@@ -182,7 +186,9 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
         affine[o - ct_begin * 32] = make_float2(F16 ? scale[o] * 0.03125f : scale[o], shift[o]);   // fp16: accumulators hold 32 W.x
 
+    RangeAcc xr = {0, 0u};
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        const bool track = F16 && rlog != nullptr && ct0 == 0;
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -212,6 +218,10 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             for (int i = 0; i < S; ++i) {
                 unsigned bh[4], bm[4], bl[4];
                 if constexpr (F16) {
+                    if (track) {                                         // wave-uniform: first output-tile group of slab 0 only
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) range_track(xr, raw[i][2 * p], raw[i][2 * p + 1]);
+                    }
 #pragma unroll
                     for (int p = 0; p < 4; ++p) split16_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
                     const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));     // 32 xh
@@ -290,6 +300,14 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             }
         }
     }
+    if constexpr (F16) {
+        if (rlog != nullptr && ct_begin == 0) {
+            // (lanes of padded columns re-read a valid column, a wave past the last group re-reads group 0: real values only)
+            range_publish(rlog, wave_umax(range_amax_bits(xr)), lane);
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wp3 + (long long)CT * KC * 3 * 64)[0]);
+        }
+    }
 }
 
 
@@ -298,7 +316,9 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0) return 0;
-    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 3 * 64 * 16;     // bytes
+    // 3 KiB per (cout tile, K chunk) + a 64-byte trailer: word 0 = bits of max |w| (written by the pack kernels, read by the
+    // fp16-flavour kernel for the range log)
+    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 3 * 64 * 16 + 64;     // bytes
 }
 
 static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
@@ -307,10 +327,12 @@ static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, i
     SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
     const int KC = sonet::ceil_div(Cin, 16);
     const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
+    unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(Wp3) + total * 3);
+    if (hipMemsetAsync(trailer, 0, 64, sonet::as_stream(stream)) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
     if (f16) hipLaunchKernelGGL(x3_pack_kernel<true>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total, trailer);
     else     hipLaunchKernelGGL(x3_pack_kernel<false>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total);
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total, trailer);
     return sonet::launched(what);
 }
 
@@ -368,7 +390,8 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1
+    unsigned *rlog = f16 ? sonet::range_log() : nullptr;
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \

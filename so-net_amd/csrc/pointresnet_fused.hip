@@ -116,7 +116,7 @@ template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v
 // matrix pipe: tools/mfma_bf16_issue.hip).  (volatile asm: instruction selection floats pure VALU ops across
 // sched_barrier and clumps them.)  The activations stay raw in their registers; an in-place affine pass after each
 // layer cost ~4k cycles per tile in serialised LDS reads of the coefficients.
-struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned h[4], m[4], l[4]; };
+struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned h[4], m[4], l[4]; int rm; };   // rm: running max of the post-affine values (range log)
 __device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
 // ReLU and the fp16 range clamp in one instruction (a NaN does not survive it; the exact-f32 mode keeps NaNs)
 __device__ __forceinline__ float pin_relu_clamp(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX)); return r; }
@@ -125,10 +125,12 @@ __device__ __forceinline__ float pin_mul32(float a) { float r; asm volatile("v_m
 // 32*x - (fp16 half of pk = 32 xh) = 32 * (x - xh), exact
 __device__ __forceinline__ float pin_res_lo(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
 __device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
+// range log: max over the post-affine, pre-clamp activations as signed-int-ordered bits (positive side; what ReLU keeps)
+__device__ __forceinline__ int pin_max3_i32(int m, float a, float b) { int r; asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ unsigned pin_scale_dn(unsigned pk) { unsigned r; asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(pk), "v"(F16_2_M5_PK)); return r; }
-// Op I of 44 = two groups of 22 (two value pairs each, neighbours independent): affine x4, relu+clamp x4, 32x x4,
-// 32xh x2, residual x4, 32xm x2, xh = 32xh * 2^-5 x2.
-constexpr int SPLIT_OPS = 44;
+// Op I of 48 = two groups of 24 (two value pairs each, neighbours independent): affine x4, range max x2, relu+clamp x4,
+// 32x x4, 32xh x2, residual x4, 32xm x2, xh = 32xh * 2^-5 x2.
+constexpr int SPLIT_OPS = 48;
 template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
     if constexpr (ABL & 2) {
         if constexpr (I == 0) {
@@ -136,14 +138,15 @@ template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s
             for (int p = 0; p < 4; ++p) s.h[p] = s.m[p] = s.l[p] = __float_as_uint(s.x[0]);
         }
     } else if constexpr (I >= 0 && I < SPLIT_OPS) {
-        constexpr int g = I / 22, k = I % 22;
+        constexpr int g = I / 24, k = I % 24;
         if constexpr (k < 4) { constexpr int e = 4 * g + k; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
-        else if constexpr (k < 8) { constexpr int e = 4 * g + k - 4; s.x[e] = pin_relu_clamp(s.x[e]); }
-        else if constexpr (k < 12) { constexpr int e = 4 * g + (k - 8); s.r[e] = pin_mul32(s.x[e]); }
-        else if constexpr (k < 14) { constexpr int P = 2 * g + (k - 12); s.h[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        else if constexpr (k < 18) { constexpr int e = 4 * g + (k - 14); s.r[e] = (e & 1) ? pin_res_hi(s.h[e >> 1], s.r[e]) : pin_res_lo(s.h[e >> 1], s.r[e]); }
-        else if constexpr (k < 20) { constexpr int P = 2 * g + (k - 18); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        else { constexpr int P = 2 * g + (k - 20); s.l[P] = pin_scale_dn(s.h[P]); }
+        else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); s.rm = pin_max3_i32(s.rm, s.x[e], s.x[e + 1]); }
+        else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; s.x[e] = pin_relu_clamp(s.x[e]); }
+        else if constexpr (k < 14) { constexpr int e = 4 * g + (k - 10); s.r[e] = pin_mul32(s.x[e]); }
+        else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 14); s.h[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+        else if constexpr (k < 20) { constexpr int e = 4 * g + (k - 16); s.r[e] = (e & 1) ? pin_res_hi(s.h[e >> 1], s.r[e]) : pin_res_lo(s.h[e >> 1], s.r[e]); }
+        else if constexpr (k < 22) { constexpr int P = 2 * g + (k - 20); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
+        else { constexpr int P = 2 * g + (k - 22); s.l[P] = pin_scale_dn(s.h[P]); }
     }
 }
 template <int ABL, int I> __device__ __forceinline__ void split_all(SplitState &s) {     // back to back (layer transitions)
@@ -161,10 +164,11 @@ __device__ __forceinline__ B3 split_result(const SplitState &s) {
 // slice s of the stream -> (layer, cout tile, K chunk, split term); one thread per (slice, lane).
 __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2,
                                                                 const float *__restrict__ W3, const float *__restrict__ W4,
-                                                                int Cin0, uint4 *__restrict__ out)
+                                                                int Cin0, uint4 *__restrict__ out, unsigned *__restrict__ trailer)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= NSLICE * 64) return;
+    RangeAcc wr = {0, 0u};
     const int lane = t & 63, s = t >> 6;
     const int i = lane & 31, h = lane >> 5;
     const float *W = nullptr;
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
                 const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
                 v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
             }
+            range_track(wr, v[0], v[1]);
             // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
             const unsigned hh = cvt_pk_f16(v[0], v[1]);
             const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
         }
     }
     out[(long long)s * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| over the four layers (range log, word 1)
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------
@@ -264,7 +270,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
     float *__restrict__ y, int L, int tpc /*128-point tiles per cloud*/, long long ntiles,
     const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0, unsigned *__restrict__ pooled, float *__restrict__ v0, int M,
-    unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/)
+    unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/,
+    unsigned *__restrict__ rlog /*optional range-log slot: [0] max |x in|, [1] max |w|, [2] max post-affine input of layers 2-4 (bits)*/)
 {
     __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 24 KiB
@@ -434,10 +441,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, cz_, 0, 0, 0); \
     }
     // VALU slot behind MFMA number q = TERM * NT + u of the step: the 44 affine+split ops of the next step's B chunk
-    // start after the first PF_SKIP MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles, 5 at 4.
+    // start after the first two MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles (16 slots), 5 at 4.
 #define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
     if constexpr (HAVE) {                                                                            \
-        constexpr int skip_ = (NT) >= 6 ? 3 : 2, q_ = (TERM) * (NT) + (u) - skip_;                   \
+        constexpr int skip_ = 2, q_ = (TERM) * (NT) + (u) - skip_;                                   \
         constexpr int ops_ = (SPLIT_OPS + 3 * (NT) - skip_ - 1) / (3 * (NT) - skip_);                \
         if constexpr (q_ >= 0) {                                                                     \
             split_op<ABL, ops_ * q_>(sp_); split_op<ABL, ops_ * q_ + 1>(sp_); split_op<ABL, ops_ * q_ + 2>(sp_); \
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.h[u_] = PF_LDA(nb_, son_ + NTERM * u_); \
         PF_SB                                                                                        \
-        if constexpr (HAVE) bnext = split_result(sp_);                                               \
+        if constexpr (HAVE) { bnext = split_result(sp_); rmax_ = sp_.rm; }                           \
     }
     // raw values of K chunk kc of an activation array (registers 8q..8q+7 of tile kc>>1) + their 8 (scale, shift)
     // pairs: element e is channel 32t + 16q + (e&3) + 8(e>>2) + 4h of the producing layer (base LB in `aff`)
@@ -516,6 +523,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         sp.sc[2] = make_float2(c1_.x, c1_.y); sp.sc[3] = make_float2(c1_.z, c1_.w);                  \
         sp.sc[4] = make_float2(c2_.x, c2_.y); sp.sc[5] = make_float2(c2_.z, c2_.w);                  \
         sp.sc[6] = make_float2(c3_.x, c3_.y); sp.sc[7] = make_float2(c3_.z, c3_.w);                  \
+        sp.rm = rmax_;                                                                               \
     }
     constexpr int NMID = KC2 * (T1 / GS) + KC3 * (T2 / GS);    // steps of layers 2 and 3 (4 + 16)
     // slice index / tile group of middle step i (layer 2 first, then layer 3)
@@ -548,6 +556,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         }
     };
     prefetch_tile(blockIdx.x);
+    // range log: running max of the post-affine inputs of layers 2-4 (ONE word for the three layers: the kernel sits at
+    // the 512-register limit) and of |network input|, both as ordered bit patterns
+    int rmax_ = 0;
+    unsigned xin_r = 0u;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long b = tile / tpc;
         const int l0 = (int)(tile - b * tpc) * 128 + wave * 32;
@@ -578,6 +590,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         B3 bsave[KC3];                                          // layer 3: the split chunks of act2, made once for both tile groups
         PROF_MARK(1)                                            // tile prologue (ids, x loads issued, accumulators zeroed)
         // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned a0 = __float_as_uint(xin[2 * p]) & 0x7FFFFFFFu, a1 = __float_as_uint(xin[2 * p + 1]) & 0x7FFFFFFFu;
+            xin_r = max(max(xin_r, a0), a1);
+        }
         bq[0] = split_chunk_abl<ABL>(xin);
         PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, true)
         {                                                       // layer transition: nothing to overlap with
@@ -585,6 +602,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             PF_CHUNK_AFF(sp_, act1, 0, 0)
             split_all<ABL, 0>(sp_);
             bq[1] = split_result(sp_);
+            rmax_ = sp_.rm;
         }
         PROF_MARK(6)                                            // layer 1
         // ---- layers 2 and 3: middle steps i = 0 .. NMID-1, set parity (i + 1) & 1 ----
@@ -613,6 +631,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 PF_CHUNK_AFF(sp2_, act2, 0, 32 * T0) \
                 split_all<ABL, 0>(sp2_); \
                 bq[nxt] = split_result(sp2_); \
+                rmax_ = sp2_.rm; \
             } \
         }
         static_assert(NMID == 20 && T2 == 2 * GS, "expand PF_MID to NMID steps; layer 3 = two groups");
@@ -751,6 +770,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         __syncthreads();
         if (blockIdx.x < ntiles) flush_bins();
     }
+    if (rlog != nullptr) {
+        range_publish(rlog, wave_umax(xin_r), lane);
+        range_publish(rlog + 2, wave_umax((unsigned)rmax_), lane);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wst + (long long)NSLICE * 64)[0]);
+    }
     PROF_MARK(5)
     PROF_DUMP
 #undef PF_STEP
@@ -803,7 +827,7 @@ __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__re
 
 }  // namespace
 
-extern "C" size_t sonet_pointresnet_pack_size(void) { return (size_t)NSLICE * 1024; }
+extern "C" size_t sonet_pointresnet_pack_size(void) { return (size_t)NSLICE * 1024 + 64; }   // + trailer: word 0 = bits of max |w|
 
 extern "C" int sonet_pointresnet_pack(const float *W1, const float *W2, const float *W3, const float *W4, int Cin0,
                                       void *stream_out, sonet_stream_t stream)
@@ -811,8 +835,10 @@ extern "C" int sonet_pointresnet_pack(const float *W1, const float *W2, const fl
     const char *what = "sonet_pointresnet_pack";
     SONET_REQUIRE(W1 && W2 && W3 && W4 && stream_out, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin0 >= 1 && Cin0 <= 16, "%s: Cin0=%d must be in [1, 16]", what, Cin0);
+    unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(stream_out) + (size_t)NSLICE * 1024);
+    if (hipMemsetAsync(trailer, 0, 64, sonet::as_stream(stream)) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
     hipLaunchKernelGGL(pointresnet_pack_kernel, dim3(sonet::ceil_div(NSLICE * 64, 256)), dim3(256), 0, sonet::as_stream(stream),
-                       W1, W2, W3, W4, Cin0, reinterpret_cast<uint4 *>(stream_out));
+                       W1, W2, W3, W4, Cin0, reinterpret_cast<uint4 *>(stream_out), trailer);
     return sonet::launched(what);
 }
 
@@ -836,7 +862,7 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
 #define PF_LAUNCH(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream), \
                        x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles, \
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr)
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log())
     switch (abl) { case 1: PF_LAUNCH(1); break; case 2: PF_LAUNCH(2); break; case 4: PF_LAUNCH(4); break; case 7: PF_LAUNCH(7); break; default: PF_LAUNCH(0); }
 #undef PF_LAUNCH
     return sonet::launched(what);
@@ -875,7 +901,7 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
     if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
 #define PF_LAUNCH_POOL(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st, \
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr, \
-                       L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws)
+                       L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log())
     switch (abl) { case 64: PF_LAUNCH_POOL(64); break; case 128: PF_LAUNCH_POOL(128); break; case 4: PF_LAUNCH_POOL(4); break; case 2: PF_LAUNCH_POOL(2); break; case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
                    case 56: PF_LAUNCH_POOL(56); break; default: PF_LAUNCH_POOL(0); }
 #undef PF_LAUNCH_POOL

@@ -329,6 +329,7 @@ class _FusedPointwise(nn.Module):
                     shift = (b - bn.running_mean) * scale + bn.bias.detach()
                 self._affine = (scale.contiguous(), shift.contiguous())
             self._affine_key = key
+            self._affine_gen = getattr(self, '_affine_gen', 0) + 1          # (id() of the tensors can be recycled: count instead)
         return self._affine
 
     def _run(self, x1, x2, epoch):
@@ -354,6 +355,9 @@ class _FusedPointwise(nn.Module):
                 else:
                     bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
                     bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                # the kernel writes the buffers through raw pointers: their _version does not move, so the folded eval
+                # affine (keyed on versions) must be dropped by hand -- or a later eval() would run on stale statistics
+                self._affine_key = None
                 # (F.batch_norm does not touch num_batches_tracked; the reference never increments it)
         else:
             if norm in (None, 'batch'):
@@ -669,10 +673,12 @@ class PointResNet(nn.Module):
             prev = c_out
 
     def _fusable_eval(self, x):
-        """One-kernel path: standard first-PointNet shape, eval BatchNorm + ReLU, no autograd, x3 arithmetic."""
+        """One-kernel path: standard first-PointNet shape, eval BatchNorm + ReLU, no autograd, h3 arithmetic."""
         if self.training or torch.is_grad_enabled():             # training BN / autograd: layer-by-layer path
             return False
-        if _ops.POINTMLP_PRECISION not in ("x3", "h3") or not _ops.FUSE_POINTRESNET or not x.is_cuda:
+        # (the fused kernel computes in the fp16 split: "x3" must stay what the range guard falls back to -- f32 operand range
+        #  end to end -- so it takes the four layer-wise launches)
+        if _ops.POINTMLP_PRECISION != "h3" or not _ops.FUSE_POINTRESNET or not x.is_cuda:
             return False
         if list(self.out_channels_list) != [64, 128, 256, 384] or x.shape[1] > 16:
             return False
@@ -688,7 +694,7 @@ class PointResNet(nn.Module):
                 self._fused_w = _ops.pointresnet_pack(*[l._weight2d().detach().contiguous().float() for l in self.layers])
             self._fused_key = key
         aff = [l._eval_affine() for l in self.layers]                   # cached per layer
-        akey = tuple(id(a[0]) for a in aff)
+        akey = tuple(l._affine_gen for l in self.layers)                 # generation of each layer's folded (scale, shift)
         if getattr(self, '_fused_akey', None) != akey:
             self._fused_aff = torch.stack((torch.cat([a[0] for a in aff]), torch.cat([a[1] for a in aff])), dim=1).contiguous()
             self._fused_akey = akey
@@ -701,12 +707,12 @@ class PointResNet(nn.Module):
         last = self.layers[n - 1]
         if n < 3 or last.normalization is not None or last.activation is not None or not last._fusable():
             return None
+        if self.out_channels_list[0] % 16 != 0:                          # decided BEFORE any layer runs (training BN must not run twice)
+            return None
         skip = self.layers[0](x, epoch)
         t = skip
         for l in range(1, n - 1):
             t = self.layers[l](t, epoch)
-        if skip.shape[1] % 16 != 0:
-            return None
         wp = last._packed(skip.shape[1], t.shape[1])
         return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M)
 

@@ -31,6 +31,26 @@ from util import som
 from .layers import EquivariantLayer, KNNModule, MyLinear, PointNet, PointResNet  # noqa: F401
 
 
+def _head_inference(fn):
+    """Head ``forward`` wrapper: an eval-mode head fed with the tagged outputs of an inference encoder call
+    (``Encoder.forward(is_train=False)``, sonet_hip.ops.mark_inference) runs under ``torch.no_grad()`` even though the
+    reference's ``Model.test_model`` leaves autograd on (models/classifier.py:101-105) -- that is what selects the fused
+    no-autograd kernels of the layers underneath."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        ts = [a for a in args if isinstance(a, torch.Tensor) and a.is_floating_point()]
+        dev = ts[0].device if ts else torch.device("cpu")
+        if torch.is_grad_enabled() and not self.training:
+            if ts and not any(t.requires_grad for t in ts) and any(getattr(t, "_sonet_inference", False) for t in ts):
+                with torch.no_grad():
+                    return _ops.mark_inference(_ops.run_guarded(lambda: fn(self, *args, **kwargs), dev, True))
+        # (the heads' own h3 launches -- the segmenter's point-wise layers, the decoder's 1x1 convs -- are range-guarded too)
+        return _ops.run_guarded(lambda: fn(self, *args, **kwargs), dev, not (torch.is_grad_enabled() or self.training))
+    return wrapper
+
+
 def _bn_kwargs(opt):
     return dict(momentum=opt.bn_momentum, bn_momentum_decay_step=opt.bn_momentum_decay_step,
                 bn_momentum_decay=opt.bn_momentum_decay)
@@ -115,7 +135,7 @@ class Encoder(nn.Module):
         if st.get(name) is None:
             g = _ops.som_group(st["x"], None, st["a"], want_centers=True, want_decentered=True)
             st["centers"], st["x_decentered"] = g["centers"], g["x_decentered"]
-        return st[name]
+        return _ops.mark_inference(st[name]) if getattr(self, "_infer_tag", False) else st[name]
 
     @property
     def first_pn_out(self):
@@ -126,6 +146,8 @@ class Encoder(nn.Module):
             g = _ops.som_group(st["x"], st["sn"], st["a"], want_augmented=st["sn"] is not None, want_decentered=st["sn"] is None)
             with torch.no_grad():
                 self._first_pn_out = self.first_pointnet(g["x_augmented"] if st["sn"] is not None else g["x_decentered"], None)
+        if getattr(self, "_infer_tag", False):
+            _ops.mark_inference(self._first_pn_out)
         return self._first_pn_out
 
     @first_pn_out.setter
@@ -142,7 +164,34 @@ class Encoder(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, sn, node, node_knn_I, is_train=False, epoch=None):
-        """x, sn: B x 3 x N; node: B x 3 x M; node_knn_I: B x M x K' int64 -> B x feature_num."""
+        """x, sn: B x 3 x N; node: B x 3 x M; node_knn_I: B x M x K' int64 -> B x feature_num.
+
+        ``is_train`` is the reference's own signal (models/networks.py:111; ``Model.test_model`` passes False,
+        ``Model.optimize`` True -- models/classifier.py:90,104): ``is_train=False`` on an ``eval()`` encoder is an inference
+        call, and runs under ``torch.no_grad()`` even when the caller did not say so (the reference's ``test_model`` does
+        not), which is what selects the fused no-autograd kernels.  The outputs are tagged so that the heads that consume
+        them (Classifier / Segmenter / Decoder layers in eval mode) do the same.  ``encoder.inference = False`` restores
+        autograd for eval-mode forwards (e.g. fine-tuning with frozen BatchNorm statistics through ``is_train=False``)."""
+        infer = (not is_train) and (not self.training) and getattr(self, "inference", True) and not x.requires_grad
+        if infer and torch.is_grad_enabled():
+            with torch.no_grad():
+                out = self._forward_guarded(x, sn, node, node_knn_I, is_train, epoch)
+        else:
+            out = self._forward_guarded(x, sn, node, node_knn_I, is_train, epoch)
+        self._infer_tag = (not torch.is_grad_enabled()) or infer
+        if self._infer_tag:
+            for t in (out, self.first_pn_out_masked_max, self.final_pn_out, self.som_node, getattr(self, "knn_feature_1", None)):
+                _ops.mark_inference(t)
+        return out
+
+    def _forward_guarded(self, x, sn, node, node_knn_I, is_train, epoch):
+        """The forward inside an operand-range scope of the fp16-split arithmetic (sonet_hip/ops.py ``run_guarded``):
+        no-grad calls are recomputed in the range-safe x3 arithmetic when a launch left the fp16 range; training calls
+        (BatchNorm statistics: must not run twice) are checked one step late and switch the process to x3."""
+        can_rerun = not (torch.is_grad_enabled() or self.training)
+        return _ops.run_guarded(lambda: self._forward(x, sn, node, node_knn_I, is_train, epoch), x.device, can_rerun)
+
+    def _forward(self, x, sn, node, node_knn_I, is_train=False, epoch=None):
         opt = self.opt
         M = node.size()[2]
         xd = x.detach().float().contiguous()
@@ -219,6 +268,7 @@ class Classifier(nn.Module):
         self.dropout1 = nn.Dropout(p=opt.dropout)
         self.dropout2 = nn.Dropout(p=opt.dropout)
 
+    @_head_inference
     def forward(self, feature, epoch=None):
         h = self.fc1(feature, epoch)
         if self.opt.dropout > 0.1:
@@ -252,6 +302,7 @@ class Segmenter(nn.Module):
         self.drop4 = nn.Dropout(p=opt.dropout)
         self.layer5 = EquivariantLayer(128, opt.classes, activation=None, normalization=None)
 
+    @_head_inference
     def forward(self, x_decentered, x, centers, sn, label, first_pn_out, feature_max_first_pn_out,
                 feature_max_knn_feature_1, feature_max_final_pn_out, feature):
         B, N, k = x.size()[0], x.size()[2], self.opt.k
@@ -359,6 +410,14 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
     each gather (autograd falls back to torch.gather when gradients are needed)."""
     encoder.want_first_pn_out = True                  # layer 1 consumes first_pn_out per point copy
     feature = encoder(pc, sn, node, node_knn_I, is_train, epoch)
+    head = lambda: _segmentation_head(encoder, segmenter, pc, sn, label, feature)      # noqa: E731
+    if torch.is_grad_enabled() and not segmenter.training and getattr(encoder, "_infer_tag", False):
+        with torch.no_grad():                          # inference call (test_model leaves autograd on): same path as under no_grad
+            return _ops.run_guarded(head, pc.device, True)
+    return _ops.run_guarded(head, pc.device, not (torch.is_grad_enabled() or segmenter.training))
+
+
+def _segmentation_head(encoder, segmenter, pc, sn, label, feature):
     st = encoder._lazy
     if segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True):
         return segmenter.forward_nodewise(encoder.x_decentered, pc, sn, label, encoder.first_pn_out, encoder.som_node,
@@ -456,6 +515,7 @@ class Decoder(nn.Module):
             self.fc_decoder = DecoderLinear(opt)
         self.conv_decoder = DecoderConv(opt)
 
+    @_head_inference
     def forward(self, x):
         opt = self.opt
         if opt.output_fc_pc_num > 0:

@@ -20,6 +20,7 @@ SIGNATURES = {
     "sonet_build_arch": [],
     "sonet_last_error": [],
     "sonet_check_device": [],
+    "sonet_range_log_set": [_vp],
     "sonet_pooled_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "sonet_bn_running_update_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp],
     "sonet_knn_prepare_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

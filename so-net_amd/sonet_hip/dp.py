@@ -29,10 +29,12 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_distributed(backend=None):
-    """Join the process group described by the environment.  Returns (world, rank, local_rank)."""
+def init_distributed(backend=None, force=False):
+    """Join the process group described by the environment.  Returns (world, rank, local_rank).
+    ``force``: create the group even for a single rank (so that a 1-GPU box still exercises RCCL)."""
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -98,10 +100,15 @@ class GradientAllReducer:
     message of a few MB is latency-bound (module docstring).  ``overlap=False`` keeps the single flat call.
     """
 
-    def __init__(self, modules, bucket_bytes=4 << 20, overlap=True):
+    def __init__(self, modules, bucket_bytes=4 << 20, overlap=True, always_reduce=False):
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         self.bucket_bytes = int(bucket_bytes)
         self.overlap = bool(overlap)
+        self.always_reduce = bool(always_reduce)      # run the collectives even in a single-rank group (tests on one GPU)
+        self._next_launch = 0        # buckets are launched strictly in index order (same order on every rank)
+        self._dirty = False          # a second backward touched a bucket that was already on the wire
+        self._sync = True            # False inside no_sync(): gradient accumulation, hooks stay quiet
+        self._exposed_events = []    # (start, end) HIP events around the waits of every reduce(): the exposed collective time
         self._live = None            # indices into self.params, flat-buffer order
         self._flat = None
         self._slices = {}            # param index -> (offset, numel)
@@ -109,6 +116,7 @@ class GradientAllReducer:
         self._bucket_of = {}
         self._pending = []           # per bucket: gradients still missing this step
         self._work = []              # per bucket: async handle (or None)
+        self._work_done = []
         self._hooks = []
         self._armed = False
 
@@ -139,7 +147,7 @@ class GradientAllReducer:
             for i in members:
                 self._bucket_of[i] = b
         self._flat = torch.zeros(off, dtype=ref.dtype, device=ref.device)
-        if self.overlap and world_size() > 1:
+        if self.overlap and (world_size() > 1 or self.always_reduce):
             for i in live:
                 self._hooks.append(self.params[i].register_post_accumulate_grad_hook(self._make_hook(i)))
             self._arm()
@@ -147,20 +155,53 @@ class GradientAllReducer:
     def _arm(self):
         self._pending = [len(members) for _, _, members in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._next_launch = 0
+        self._dirty = False
         self._armed = True
 
     def _make_hook(self, i):
         def hook(p):
-            if not self._armed or p.grad is None:
+            if not self._armed or not self._sync or p.grad is None:
+                return
+            b = self._bucket_of[i]
+            if self._pending[b] <= 0:
+                # a SECOND backward before reduce() (two losses, accumulation without no_sync()): what is on the wire for
+                # this bucket is a partial sum -- reduce() redoes the exchange from the accumulated .grad tensors
+                self._dirty = True
                 return
             off, n = self._slices[i]
             self._flat[off:off + n].copy_(p.grad.reshape(-1))
-            b = self._bucket_of[i]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
-                bo, bn, _ = self.buckets[b]
-                self._work[b] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
+            # launch every complete bucket up to the first incomplete one, in index order: a rank whose autograd graph
+            # finishes bucket 2 before bucket 1 still issues the collectives in the order every other rank does
+            while self._next_launch < len(self.buckets) and self._pending[self._next_launch] == 0:
+                bo, bn, _ = self.buckets[self._next_launch]
+                self._work[self._next_launch] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
+                self._next_launch += 1
         return hook
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate into ``.grad``; the
+        exchange happens on the first backward + ``reduce()`` outside (which sends the accumulated gradients)."""
+        red = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                red._sync = False
+
+            def __exit__(self_inner, *exc):
+                red._sync = True
+                return False
+        return _NoSync()
+
+    def exposed_ms(self, last=None):
+        """Mean GPU time per ``reduce()`` (over the last ``last`` calls) between "backward has queued its last kernel" and
+        "every bucket has arrived": the part of the gradient exchange that was NOT hidden behind backward.  Synchronises."""
+        evs = self._exposed_events[-last:] if last else self._exposed_events
+        if not evs:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
 
     def remove_hooks(self):
         for h in self._hooks:
@@ -173,9 +214,17 @@ class GradientAllReducer:
         if first:
             self._setup()
         w = world_size()
-        if w == 1 or not self._live:
+        if (w == 1 and not self.always_reduce) or not self._live:
             return 0
-        overlapped = self._armed and not first
+        ev = None
+        if self._flat.is_cuda:                                            # GPU time the compute stream spends waiting for the collectives
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        overlapped = self._armed and not first and not self._dirty
+        if self._armed and not first and self._dirty:
+            for wk in self._work:                                         # drain what the first backward put on the wire
+                if wk is not None:
+                    wk.wait()
         if overlapped:
             for b, (bo, bn, members) in enumerate(self.buckets):
                 if self._pending[b] != 0:
@@ -191,11 +240,15 @@ class GradientAllReducer:
                 off, n = self._slices[i]
                 self._flat[off:off + n].copy_(g.reshape(-1))
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
+            self._exposed_events.append(ev)
         self._flat.div_(w)
         for i in self._live:
             g = self.params[i].grad
             off, n = self._slices[i]
             g.copy_(self._flat[off:off + n].view_as(g))
+        self._work_done = list(self._work)                            # (what the hooks launched during this step: tests look at it)
         if self._armed:
             self._arm()                                               # next backward
         return self._flat.numel() * self._flat.element_size()

@@ -28,8 +28,17 @@ class GraphedForward:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # ONE operand-range scope for the whole captured forward (sonet_hip/ops.py): its memset and the per-launch slot
+        # pointers are baked into the graph, every replay refills the same log; ``range_violations()`` reads it back.
+        from . import ops as _ops
+        self.range = _ops.range_scope(dev)
+        with torch.no_grad(), torch.cuda.graph(self.graph), self.range:
             self.static_output = fn(*self.static_inputs)
+
+    def range_violations(self):
+        """After a replay: the h3 launches of the captured forward whose operands left the fp16-split range ([] = none;
+        synchronises).  Valid until another range scope runs on the same device."""
+        return self.range.violations()
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_inputs, inputs):

@@ -307,6 +307,218 @@ FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
 GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
 
 
+# ---- operand-range guard of the fp16-split ("h3") arithmetic ------------------------------------------------------------------
+# h3 has an fp16 operand RANGE (include/sonet_hip.h, "Range log"): every h3 launch inside a ``range_scope`` reports max |x|,
+# max |w| (and, for the fused first PointNet, the largest hidden activation) into its own 8-word slot of a per-device log;
+# ``violations()`` reads the log back (ONE 1 KiB copy, synchronising) and names the launches whose results are not f32-class.
+# Encoder.forward (models/networks.py) wraps itself in a scope and recomputes the batch in the range-safe "x3" arithmetic when
+# the log says so -- so the default arithmetic can never hand back clamped features silently.  SONET_RANGE_GUARD=0 turns the
+# whole mechanism off (no log, no read-back).
+RANGE_GUARD = _os.environ.get("SONET_RANGE_GUARD", "1") != "0"
+_RANGE_SLOTS = 32
+_B_2047, _B_65504, _B_XLOW, _B_WLOW = 0x44FFE000, 0x477FE000, 0x3C800000, 0x3B800000     # bits of 2047, 65504, 2^-6, 2^-8
+_range_logs = {}            # device index -> int32[_RANGE_SLOTS * 8]
+_range_active = None        # the innermost open scope
+_range_ptr_set = False      # whether the library currently holds a non-NULL slot pointer for this thread
+
+
+def _bits_to_float(u):
+    import struct
+    return struct.unpack("<f", struct.pack("<I", int(u) & 0xFFFFFFFF))[0]
+
+
+class range_scope:
+    """``with ops.range_scope(device) as rs: <h3 launches>`` then ``rs.violations()`` (synchronises; [] = all launches in range).
+    Scopes of one device share its log: read a scope's result before opening the next one on that device."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.names = []
+        self.enabled = RANGE_GUARD and self.device.type == "cuda"
+        self.log = None
+        self._prev = None
+
+    def __enter__(self):
+        global _range_active
+        self._prev = _range_active
+        if self.enabled:
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            log = _range_logs.get(idx)
+            if log is None:
+                log = torch.zeros((_RANGE_SLOTS * 8,), dtype=torch.int32, device=self.device)
+                _range_logs[idx] = log
+            else:
+                log.zero_()                                   # one memset node (captured like any launch under a HIP graph)
+            self.log = log
+            _range_active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _range_active
+        _range_active = self._prev
+        _range_unset()
+        return False
+
+    def _slot(self, name):
+        i = min(len(self.names), _RANGE_SLOTS - 1)            # more launches than slots: the last slot is shared (max still holds)
+        self.names.append(name)
+        return self.log.data_ptr() + i * 32
+
+    def violations(self):
+        """-> list of (launch name, what) for the launches of this scope whose operands left the fp16-split range."""
+        if not self.enabled or not self.names:
+            return []
+        w = self.log.cpu().view(_RANGE_SLOTS, 8).tolist()     # synchronises with the launches
+        shared = {}
+        out = []
+        for n, name in enumerate(self.names):
+            i = min(n, _RANGE_SLOTS - 1)
+            if i in shared:
+                continue
+            shared[i] = True
+            x, wt, hid = (v & 0xFFFFFFFF for v in w[i][:3])
+            low_ok = n < _RANGE_SLOTS - 1                     # a shared slot cannot tell which launch was small
+            if x > _B_2047:
+                out.append((name, "max |x| = %g exceeds 2047" % _bits_to_float(x)))
+            elif low_ok and 0 < x < _B_XLOW:
+                out.append((name, "max |x| = %g is below 2^-6 (fp16 residuals go subnormal)" % _bits_to_float(x)))
+            if wt > _B_65504:
+                out.append((name, "max |w| = %g exceeds 65504" % _bits_to_float(wt)))
+            elif low_ok and 0 < wt < _B_WLOW:
+                out.append((name, "max |w| = %g is below 2^-8" % _bits_to_float(wt)))
+            if hid > _B_2047:
+                out.append((name, "a hidden activation reaches %g > 2047" % _bits_to_float(hid)))
+        return out
+
+
+_range_warned = False
+_range_pending = []         # training: (event, pinned host copy, names) of steps whose log has not been looked at yet
+
+
+def range_warn(bad):
+    global _range_warned
+    if not _range_warned:
+        import warnings
+        warnings.warn("sonet_hip: fp16-split (h3) operand range left by %d launch(es), e.g. %s: %s -- recomputing in the "
+                      "range-safe x3 arithmetic (SONET_POINTMLP_PRECISION=x3 selects it from the start)"
+                      % (len(bad), bad[0][0], bad[0][1]), RuntimeWarning, stacklevel=3)
+        _range_warned = True
+
+
+def _range_defer(scope):
+    """Queue a scope's log for a later look: async copy to pinned memory + an event, no host wait."""
+    if not scope.enabled or not scope.names or torch.cuda.is_current_stream_capturing():
+        return
+    host = torch.empty((_RANGE_SLOTS * 8,), dtype=torch.int32, pin_memory=True)
+    host.copy_(scope.log, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _range_pending.append((ev, host, list(scope.names)))
+
+
+range_scope.defer = _range_defer
+
+
+def range_deferred_check():
+    """Look at every queued log whose copy has completed (no waiting).  A violation switches the process to the x3
+    arithmetic (with a warning): the steps already taken ran on clamped activations, the following ones do not."""
+    global POINTMLP_PRECISION
+    while _range_pending and _range_pending[0][0].query():
+        _, host, names = _range_pending.pop(0)
+        probe = range_scope.__new__(range_scope)
+        probe.enabled, probe.names, probe.log = True, names, host
+        bad = probe.violations()
+        if bad:
+            range_warn(bad)
+            POINTMLP_PRECISION = "x3"
+            _range_pending.clear()
+            return bad
+    return []
+
+
+def run_guarded(call, device, can_rerun):
+    """Run ``call()`` (a forward made of h3 launches) inside an operand-range scope.
+
+    can_rerun (no-grad forwards): the log is read right away -- one small synchronising copy -- and, if any launch left the
+    fp16 range, ``call()`` runs again in the range-safe x3 arithmetic: the caller always gets f32-class results.
+    not can_rerun (training forwards, which update BatchNorm statistics and must not run twice): the log is queued and
+    looked at, without waiting for the GPU, at the next guarded training call; a violation switches the process to x3.
+    Nested calls (an encoder inside a guarded model-level forward, anything inside a HIP-graph capture that opened
+    its own scope) join the outer scope."""
+    device = torch.device(device)
+    if POINTMLP_PRECISION != "h3" or not RANGE_GUARD or device.type != "cuda" or _range_active is not None:
+        return call()
+    if not can_rerun:
+        range_deferred_check()                                           # may switch POINTMLP_PRECISION to "x3"
+        if POINTMLP_PRECISION != "h3":
+            return call()
+        with range_scope(device) as rs:
+            out = call()
+        rs.defer()
+        return out
+    with range_scope(device) as rs:
+        out = call()
+    if torch.cuda.is_current_stream_capturing():
+        return out
+    bad = rs.violations()
+    if bad:
+        range_warn(bad)
+        with precision("x3"):
+            out = call()
+    return out
+
+
+def mark_inference(t):
+    """Tag a tensor as the product of an inference call (Encoder.forward(is_train=False) on an eval() encoder): eval-mode
+    layers that receive it run their no-autograd kernels even when the caller left autograd enabled."""
+    if isinstance(t, torch.Tensor) and not t.requires_grad:
+        t._sonet_inference = True
+    return t
+
+
+def is_inference(*ts):
+    """True when autograd is off, or every given tensor carries the inference tag and none requires grad."""
+    if not torch.is_grad_enabled():
+        return True
+    return bool(ts) and all(isinstance(t, torch.Tensor) and getattr(t, "_sonet_inference", False) and not t.requires_grad for t in ts)
+
+
+def _range_unset():
+    global _range_ptr_set
+    if _range_ptr_set:
+        _lib.load().sonet_range_log_set(None)
+        _range_ptr_set = False
+
+
+def _range_arm(name):
+    """Right before an h3 launch: point the library at this launch's slot (or at nothing outside a scope)."""
+    global _range_ptr_set
+    if _range_active is None:
+        _range_unset()
+        return
+    import ctypes
+    _lib.load().sonet_range_log_set(ctypes.c_void_p(_range_active._slot(name)))
+    _range_ptr_set = True
+
+
+class precision:
+    """``with ops.precision("x3"): ...`` -- temporarily select the point-wise arithmetic (the range guard's fallback)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global POINTMLP_PRECISION
+        self.prev = POINTMLP_PRECISION
+        POINTMLP_PRECISION = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global POINTMLP_PRECISION
+        POINTMLP_PRECISION = self.prev
+        return False
+
+
 def x3_supported(C1, C2, Cout):
     return Cout % 32 == 0 and (C2 == 0 or C1 % 16 == 0)
 
@@ -361,7 +573,10 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     if y.numel() == 0:
         return y
     fn = lib.sonet_pointmlp_h3_f32 if h3 else lib.sonet_pointmlp_x3_f32 if x3 else lib.sonet_pointmlp_f32
-    with torch.cuda.device(dev), _timed("pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)):
+    name = "pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)
+    if h3:
+        _range_arm(name)
+    with torch.cuda.device(dev), _timed(name):
         if gidx is not None:
             check(lib.sonet_pointmlp_h3_gather_f32(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
                                                    ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_h3_gather_f32")
@@ -397,6 +612,7 @@ def pointresnet_fused(x, wstream, affine):
     y = torch.empty((B, 384, L), dtype=torch.float32, device=dev)
     if y.numel() == 0:
         return y
+    _range_arm("pointresnet_fused_L%d" % L)
     with torch.cuda.device(dev), _timed("pointresnet_fused_L%d" % L):
         check(_lib.load().sonet_pointresnet_fused_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
               "sonet_pointresnet_fused_f32")
@@ -414,6 +630,7 @@ def pointresnet_fused_pool(sg, wstream, affine, M):
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pointresnet_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
     out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
+    _range_arm("pointresnet_fused_pool_L%d" % L)
     with torch.cuda.device(dev), _timed("pointresnet_fused_pool_L%d" % L):
         check(lib.sonet_pointresnet_fused_pool_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
                                                    ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),

@@ -80,6 +80,21 @@ def _worker(rank, world, port, q):
         for pa, pb in zip(net.parameters(), net_flat.parameters()):
             assert torch.equal(pa.grad, pb.grad), step
     assert len(r_b.buckets) >= 3 and r_b.buckets[0][2][0] == len(r_b.params) - 1 and len(r_f.buckets) == 1
+    # gradient accumulation -- two backward passes per reduce() -- with no_sync() (hooks quiet on the first) and without
+    # (the buckets of the first backward are already on the wire: reduce() redoes the exchange): both equal ONE exchange
+    # of the accumulated gradients
+    for use_ctx in (True, False):
+        for m, r in ((net, r_b), (net_flat, r_f)):
+            m.zero_grad(set_to_none=True)
+            if use_ctx and r is r_b:
+                with r.no_sync():
+                    m(xs).pow(2).sum().backward()
+            else:
+                m(xs).pow(2).sum().backward()
+            m(xs * 2).pow(2).sum().backward()
+            r.reduce()
+        for pa, pb in zip(net.parameters(), net_flat.parameters()):
+            assert torch.allclose(pa.grad, pb.grad, rtol=1e-6, atol=1e-7), use_ctx
     net.zero_grad(set_to_none=True)
     net[0](xs).sum().backward()                                               # the last two layers get no gradient
     try:

@@ -1,0 +1,422 @@
+"""GPU tests added in round 2: operand-range guard of the fp16-split arithmetic, the no-autograd fast path as the
+reference's unmodified ``Model.test_model`` reaches it, BatchNorm running-statistics invalidation, the level-1 drop-in
+(the reference's dense ``Encoder.forward`` data flow on the overlay operators), RCCL gradient all-reduce.
+
+Float bound everywhere: |got-ref| <= 1e-5 * max(|ref|, rms(ref)); integer / index outputs bit-exact."""
+import os
+import subprocess
+import sys
+import warnings
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_close_rms, golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def make_opt(B, N, k=3, som_k=9, sn=True, classes=40):
+    return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=sn,
+                     feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64,
+                     k=k, som_k=som_k, som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None,
+                     bn_momentum_decay=0.6, classes=classes)
+
+
+def build(B, N, seed=11, **kw):
+    from models import networks as NW
+    from sonet_hip import synth
+    opt = make_opt(B, N, **kw)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    enc_sd = synth.fill_state_dict_(enc.state_dict(), seed)
+    cls_sd = synth.fill_state_dict_(cls.state_dict(), seed + 1)
+    return enc, cls, {k: v.clone() for k, v in enc_sd.items()}, {k: v.clone() for k, v in cls_sd.items()}
+
+
+# ------------------------------------------------------------------------------------------ range guard: kernels
+def _h3_layer(x, Cout=64, seed=0):
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(seed)
+    W = (torch.randn(Cout, x.shape[1], generator=g) * 0.2).to(DEV)
+    wp = ops.pointmlp_pack(W, "h3")
+    one, zero = ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV)
+    return ops.pointmlp(x, wp, one, zero, False, Cout), W
+
+
+@pytest.mark.parametrize("what,expect", [("normal", None), ("big", "exceeds 2047"), ("neg_big", "exceeds 2047"), ("nan", "exceeds 2047"),
+                                         ("neg_nan", "exceeds 2047"), ("inf", "exceeds 2047"), ("tiny", "below 2^-6"), ("zero", None)])
+def test_h3_layer_reports_operand_range(what, expect):
+    """Every h3 launch logs max |x| and max |w|; the scope names the launches that left the fp16-split range."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 48, 1000, generator=g)
+    if what == "big":
+        x[1, 7, 123] = 5000.0
+    elif what == "neg_big":
+        x[2, 47, 999] = -2048.5
+    elif what == "nan":
+        x[0, 0, 0] = float("nan")
+    elif what == "neg_nan":
+        x[0, 31, 17] = torch.tensor([0xFFC00000], dtype=torch.int64).to(torch.int32).view(torch.float32)[0]
+    elif what == "inf":
+        x[2, 5, 5] = float("-inf")
+    elif what == "tiny":
+        x = x * 1e-4
+    elif what == "zero":
+        x = torch.zeros_like(x)
+    with ops.range_scope(DEV) as rs:
+        _h3_layer(x.to(DEV))
+    bad = rs.violations()
+    if expect is None:
+        assert bad == []
+    else:
+        assert len(bad) == 1 and expect in bad[0][1], bad
+    # outside a scope nothing is logged and nothing breaks
+    _h3_layer(x.to(DEV))
+    torch.cuda.synchronize()
+
+
+def test_h3_weight_range_is_logged():
+    from sonet_hip import ops
+    x = torch.randn(2, 32, 257).to(DEV)
+    for scale, expect in ((1.0, None), (1e6, "max |w|"), (1e-4, "max |w|")):
+        W = (torch.randn(64, 32) * 0.2 * scale).to(DEV)
+        wp = ops.pointmlp_pack(W, "h3")
+        with ops.range_scope(DEV) as rs:
+            ops.pointmlp(x, wp, ops.const_vec(64, 1.0, DEV), ops.const_vec(64, 0.0, DEV), False, 64)
+        bad = rs.violations()
+        assert (bad == []) if expect is None else (len(bad) == 1 and expect in bad[0][1]), (scale, bad)
+
+
+def test_fused_kernel_reports_hidden_activation_range():
+    """The fused first PointNet logs |input|, |w| and the largest post-BatchNorm activation entering layers 2-4."""
+    from models import layers as L
+    from sonet_hip import ops, synth
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    x = torch.randn(2, 6, 700).to(DEV)
+    with torch.no_grad():
+        with ops.range_scope(DEV) as rs:
+            pr(x)
+        assert rs.violations() == []
+        pr.layers[1].norm.weight.data[5] = 4.0e4            # one channel of layer 2's BatchNorm blows up
+        with ops.range_scope(DEV) as rs:
+            pr(x)
+        bad = rs.violations()
+        assert bad and "hidden activation" in bad[0][1] and bad[0][0].startswith("pointresnet_fused"), bad
+        with ops.range_scope(DEV) as rs:
+            pr(x * 1e4)
+        assert any("max |x|" in b[1] for b in rs.violations())
+
+
+# ------------------------------------------------------------------------------------------ range guard: model level
+@pytest.mark.parametrize("case", ["act_1e4", "act_1e5_bn", "input_3e4", "nan_input"])
+def test_encoder_out_of_range_activations_fall_back_to_x3(case):
+    """Weights / inputs scaled so that activations leave the fp16-split range: the default (h3) forward must still match
+    the oracle at 1e-5 -- through the guard's x3 recomputation -- and say so once."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops, synth
+    B, N = 2, 600
+    enc, cls, enc_sd, cls_sd = build(B, N, seed=21)
+    inp = synth.make_inputs(B, N, seed=9)
+    if case == "act_1e4":                                    # hidden activations of the first PointNet reach ~1e4
+        for sd in (enc.state_dict(), enc_sd):
+            sd["first_pointnet.layers.0.norm.weight"].mul_(3.0e3)
+            sd["first_pointnet.layers.1.conv.weight"].mul_(1.0 / 3.0e3)      # keeps the rest of the net at its usual scale
+    elif case == "act_1e5_bn":                               # first_pn_out ~1e5 -> the KNN module's h3 layers see it
+        for sd in (enc.state_dict(), enc_sd):
+            sd["first_pointnet.layers.3.conv.weight"].mul_(2.0e4)
+            sd["knnlayer.layers.0.conv.weight"][:, 3:].mul_(1.0 / 2.0e4)
+    elif case == "input_3e4":                                # de-centred coordinates ~1e4
+        for key in ("pc", "node"):
+            inp[key] = inp[key] * 3.0e4
+    elif case == "nan_input":
+        inp["sn"][1, 2, 77] = float("nan")
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    ops._range_warned = False
+    old = ops.POINTMLP_PRECISION
+    ops.POINTMLP_PRECISION = "h3"
+    try:
+        with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            feat = enc(inp["pc"].to(DEV), inp["sn"].to(DEV), inp["node"].to(DEV), inp["node_knn_I"].to(DEV))
+        assert any("x3" in str(x.message) for x in w), "the guard did not report the fallback"
+    finally:
+        ops.POINTMLP_PRECISION = old
+    ref = O.encoder_forward(enc_sd, inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+    np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), ref["min_idx"])
+    got, want = feat.cpu().numpy(), ref["feature"].numpy()
+    if case == "nan_input":                                  # (the per-node arg-max skips a NaN column, so the features are usually finite)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), "NaN must be treated as in the reference"
+        got, want = np.nan_to_num(got), np.nan_to_num(want)
+    assert_close_rms(got, want, 1e-5, "feature (%s)" % case)
+    assert_close_rms(enc.first_pn_out_masked_max.cpu().numpy(), ref["first_pn_out_masked_max"].numpy(), 1e-5, "masked_max (%s)" % case)
+
+
+def test_encoder_in_range_forward_does_not_fall_back():
+    from sonet_hip import ops, synth
+    enc, cls, _, _ = build(2, 500)
+    enc.to(DEV).eval()
+    inp = synth.make_inputs(2, 500, seed=1, device=DEV)
+    with torch.no_grad(), ops.kernel_timing() as rec:
+        enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+    names = [n for n, _, _ in rec.records]
+    assert sum(n.startswith("pointresnet_fused_pool") for n in names) == 1 and not any(n.startswith("pointmlpx3") for n in names), names
+
+
+def test_graphed_forward_exposes_the_range_log():
+    from sonet_hip import synth
+    from sonet_hip.graph import GraphedForward
+    enc, cls, _, _ = build(2, 400)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    inp = synth.make_inputs(2, 400, seed=2, device=DEV)
+    args = (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), args)
+    fwd(*args)
+    assert fwd.range_violations() == []
+    big = (args[0] * 1.0e5, args[1], args[2] * 1.0e5, args[3])
+    fwd(*big)
+    assert fwd.range_violations(), "a replay on out-of-range data must show up in the log"
+    fwd(*args)
+    assert fwd.range_violations() == []
+
+
+def test_training_forward_range_violation_switches_to_x3_one_step_late():
+    from sonet_hip import ops, synth
+    enc, cls, _, _ = build(4, 300, seed=5)
+    enc.to(DEV).train()
+    inp = synth.make_inputs(4, 300, seed=3, device=DEV)
+    old = ops.POINTMLP_PRECISION
+    ops.POINTMLP_PRECISION, ops._range_warned = "h3", False
+    ops._range_pending.clear()
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            enc(inp["pc"] * 1.0e5, inp["sn"], inp["node"] * 1.0e5, inp["node_knn_I"], is_train=True).sum().backward()
+            torch.cuda.synchronize()
+            assert ops.POINTMLP_PRECISION == "h3"                        # not looked at yet
+            enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True)
+            assert ops.POINTMLP_PRECISION == "x3" and any("x3" in str(x.message) for x in w)
+    finally:
+        ops.POINTMLP_PRECISION = old
+        ops._range_pending.clear()
+
+
+# ------------------------------------------------------------------------------------------ stale eval statistics
+def test_running_stat_update_invalidates_the_folded_eval_affine():
+    """A train-mode forward that changes ONLY the running statistics (no optimizer step) must be seen by the next eval."""
+    from models import layers as L
+    from sonet_hip import synth
+    layer = L.EquivariantLayer(16, 32, "relu", "batch", 0.5)
+    synth.fill_state_dict_(layer.state_dict(), 3)
+    layer.to(DEV)
+    x = (torch.randn(4, 16, 300) * 3 + 1).to(DEV)
+    with torch.no_grad():
+        layer.eval()
+        y0 = layer(x).clone()
+        layer.train()
+        layer(x)                                             # updates running_mean / running_var through the kernel
+        layer.eval()
+        y1 = layer(x)
+        bn = layer.norm
+        ref = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv1d(x, layer.conv.weight, layer.conv.bias),
+                                                        bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+    assert not torch.allclose(y0, y1), "the statistics did change"
+    assert_close_rms(y1.cpu().numpy(), ref.cpu().numpy(), 1e-5, "eval after a stats-only update")
+    # ... and the fused first PointNet keys on the same thing
+    pr = L.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.5, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), 4)
+    pr.to(DEV)
+    xp = torch.randn(2, 6, 500).to(DEV)
+    with torch.no_grad():
+        pr.eval()
+        a = pr(xp).clone()
+        pr.train()
+        pr(xp)
+        pr.eval()
+        b = pr(xp)
+        pr.layers[3].conv.bias.data.add_(1.0)               # bias-only change of the norm-free last layer
+        c = pr(xp)
+    assert not torch.allclose(a, b)
+    assert_close_rms((c - b).cpu().numpy(), np.ones(tuple(b.shape), dtype=np.float32), 1e-4, "bias-only change reaches the fused kernel")
+
+
+# ------------------------------------------------------------------------------------------ the reference's callers, unmodified
+def test_reference_shaped_test_model_reaches_the_fast_path():
+    """models/classifier.py:101-105 runs eval WITHOUT torch.no_grad(): ``encoder.eval(); forward(is_train=False)``.
+    That call must take the fused no-autograd kernels and give the same numbers as under no_grad."""
+    from sonet_hip import ops, synth
+    enc, cls, _, _ = build(2, 700, seed=13)
+    enc.to(DEV)
+    cls.to(DEV)
+    inp = synth.make_inputs(2, 700, seed=4, device=DEV)
+    args = (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+
+    class Model:                                             # the shape of the reference's task Model (classifier.py:74-76,101-105)
+        def forward(self, is_train=False, epoch=None):
+            self.feature = enc(*args, is_train, epoch)
+            self.score = cls(self.feature, epoch)
+
+        def test_model(self):
+            enc.eval()
+            cls.eval()
+            self.forward(is_train=False)
+            self.loss = torch.nn.functional.cross_entropy(self.score, inp["label"])
+
+    m = Model()
+    assert torch.is_grad_enabled()
+    with ops.kernel_timing() as rec:
+        m.test_model()
+    names = [n for n, _, _ in rec.records]
+    assert any(n.startswith("pointresnet_fused_pool") for n in names), names
+    assert sum(n.startswith("linear_act") for n in names) == 3, names
+    assert not any(n.startswith("index_max") for n in names)
+    assert not m.score.requires_grad and torch.isfinite(m.loss)
+    with torch.no_grad():
+        ref = cls(enc(*args, is_train=False))
+    assert torch.equal(ref, m.score)
+    # opting out restores autograd through an eval-mode forward (fine-tuning with frozen BatchNorm statistics)
+    enc.inference = False
+    feat = enc(*args, is_train=False)
+    assert feat.requires_grad
+    feat.sum().backward()
+    assert enc.first_pointnet.layers[0].conv.weight.grad is not None
+    assert_close_rms(feat.detach().cpu().numpy(), m.feature.cpu().numpy(), 1e-5, "autograd eval vs fast path")
+    # a training call is untouched
+    enc.inference = True
+    enc.train()
+    assert enc(*args, is_train=True).requires_grad
+
+
+def test_reference_shaped_segmenter_test_model_reaches_the_fast_path():
+    """models/segmenter.py:79-109,126-128 (eval without no_grad): mask argmax -> three gathers -> Segmenter, unmodified."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 2, 384
+    opt = make_opt(B, N, classes=50)
+    enc, seg = NW.Encoder(opt), NW.Segmenter(opt)
+    synth.fill_state_dict_(enc.state_dict(), 31)
+    synth.fill_state_dict_(seg.state_dict(), 32)
+    enc.to(DEV).eval()
+    seg.to(DEV).eval()
+    inp = synth.make_inputs(B, N, seed=6, device=DEV)
+    label = torch.randint(0, 16, (B,), device=DEV)
+
+    def reference_model_forward():
+        feature = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], False, None)
+        idx = torch.max(enc.mask, dim=2)[1].unsqueeze(1)
+        kN = idx.shape[2]
+        g1 = torch.gather(enc.first_pn_out_masked_max, 2, idx.expand(B, 384, kN))
+        g2 = torch.gather(enc.knn_feature_1, 2, idx.expand(B, 512, kN))
+        g3 = torch.gather(enc.final_pn_out, 2, idx.expand(B, 1024, kN))
+        return seg(enc.x_decentered, inp["pc"], enc.centers, inp["sn"], label, enc.first_pn_out, g1, g2, g3, feature)
+
+    enc.want_first_pn_out = True
+    with ops.kernel_timing() as rec:
+        score = reference_model_forward()
+    names = [n for n, _, _ in rec.records]
+    assert not score.requires_grad
+    assert any(n.startswith("pointresnet_fused_L") for n in names), names       # one-kernel first PointNet (store variant)
+    with torch.no_grad():
+        ref = reference_model_forward()
+    assert torch.equal(ref, score)
+    with torch.no_grad():
+        nodewise = NW.segmentation_forward(enc, seg, inp["pc"], inp["sn"], label, inp["node"], inp["node_knn_I"])
+    assert_close_rms(nodewise.cpu().numpy(), score.cpu().numpy(), 1e-5, "node-wise layer 1 vs the dense head")
+
+
+# ------------------------------------------------------------------------------------------ level 1 on hardware
+def level1_encoder_forward(enc, x, sn, node, node_knn_I):
+    """The reference's DENSE Encoder.forward data flow (models/networks.py:124-199), restated on the level-1 drop-in
+    operators only: BatchSOM.query_topk's one-hot mask, masked mean through a B x 3 x kN x M product, centres as a
+    mask-weighted node sum, index_max.forward_cuda + Tensor.gather, the KNN module and the final PointNet as modules."""
+    import index_max
+    opt = enc.opt
+    sb = enc.som_builder
+    sb.node = node.clone()                                                              # :124
+    mask, row_max, min_idx = sb.query_topk(x, k=opt.k)                                  # :127   B x kN x M, B x M, B x kN
+    counts = mask.sum(dim=1)                                                            # :128
+    maskf = mask.unsqueeze(1).float()                                                   # B x 1 x kN x M
+    xs, sns = x.repeat(1, 1, opt.k), sn.repeat(1, 1, opt.k)                             # :131-137
+    mean = (xs.unsqueeze(3) * maskf).sum(dim=2) / (counts.unsqueeze(1).float() + 1e-5)  # :140-142
+    sb.node = mean                                                                      # :143
+    centers = (maskf * mean.unsqueeze(2)).sum(dim=3)                                    # :168-169
+    xdec = xs - centers                                                                 # :171
+    first = enc.first_pointnet(torch.cat((xdec, sns), dim=1))                           # :172-176
+    M = node.shape[2]
+    gi = index_max.forward_cuda(first.detach(), min_idx.int(), M).long()                # :180-184
+    pooled = first.gather(dim=2, index=gi * row_max.unsqueeze(1).long())                # :185
+    center1, feat1 = enc.knnlayer(mean, pooled, node_knn_I, opt.som_k, opt.som_k_type)  # :189
+    final = enc.final_pointnet(torch.cat((center1, feat1), dim=1))                      # :192
+    return dict(min_idx=min_idx, mask=mask, som_node=mean, centers=centers, x_decentered=xdec, first_pn_out=first,
+                first_pn_out_masked_max=pooled, knn_center_1=center1, knn_feature_1=feat1, final_pn_out=final,
+                feature=final.max(dim=2)[0])                                            # :197
+
+
+@pytest.mark.parametrize("case", ["classifier_b8_n1024", "classifier_b2_n5000"])
+@pytest.mark.parametrize("mode", ["h3", "x3", "f32"])
+def test_level1_dense_encoder_flow_on_the_overlay_ops_golden(case, mode):
+    """both drop-in levels must pass the same oracle tests.  Level 1 = the reference's own forward on top of
+    the new index_max / BatchSOM / layers / operations; checked here against the live-reference fixture."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    g = golden(case)
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = make_opt(B, N, k=int(g["k"]), som_k=int(g["som_k"]))
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(cls.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    with ops.precision(mode), torch.no_grad(), ops.kernel_timing() as rec:
+        r = level1_encoder_forward(enc, cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
+        score = cls(r["feature"])
+    names = [n for n, _, _ in rec.records]
+    assert "index_max" in names and "som_mask" in names and "som_assign" in names, names
+    np.testing.assert_array_equal(r["min_idx"].cpu().numpy(), g["min_idx"])
+    np.testing.assert_array_equal(r["mask"].sum(1).cpu().numpy(), g["mask_row_sum"])
+    tol = 1e-5
+    assert_close_rms(r["som_node"].cpu().numpy(), g["som_node"], tol, "som_node")
+    assert_close_rms(r["centers"][:, :, ::7].cpu().numpy(), g["centers"], tol, "centers")
+    assert_close_rms(r["x_decentered"][:, :, ::7].cpu().numpy(), g["x_decentered"], tol, "x_decentered")
+    assert_close_rms(r["first_pn_out"][:, ::16, ::5].cpu().numpy(), g["first_pn_out_sub"], tol, "first_pn_out")
+    assert_close_rms(r["first_pn_out_masked_max"].cpu().numpy(), g["first_pn_out_masked_max"], tol, "masked_max")
+    assert_close_rms(r["knn_feature_1"][:, ::4].cpu().numpy(), g["knn_feature_1"], tol, "knn_feature_1")
+    assert_close_rms(r["final_pn_out"][:, ::4].cpu().numpy(), g["final_pn_out"], tol, "final_pn_out")
+    assert_close_rms(r["feature"].cpu().numpy(), g["feature"], tol, "feature")
+    assert_close_rms(score.cpu().numpy(), g["score"], tol, "score")
+
+
+# ------------------------------------------------------------------------------------------ RCCL
+def test_gradient_all_reducer_on_rccl():
+    """GradientAllReducer with backend nccl (= RCCL) at world_size = the visible GPUs (1 is allowed: the process group,
+    the hooks and the collective calls are the same code; 2+ also checks the averaged values)."""
+    n = torch.cuda.device_count()
+    script = os.path.join(ROOT, "tests", "dp_rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", "29631", script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RCCL_OK world=%d" % n in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0 and "only %d GPU" % n in (r.stdout + r.stderr)
