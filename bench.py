@@ -220,7 +220,7 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         return
     B, N = args.batch, args.points
     from sonet_hip import ops
-    print(json.dumps({
+    return ({
         "metric": "point-clouds/sec training step (forward+backward+all-reduce+Adam), ModelNet40 5k-pt 8x8 SOM",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
@@ -231,7 +231,7 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "allreduce": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None, "bytes_per_step": nbytes,
                       "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1),
                       "what": "GPU time between the last backward kernel and the arrival of the last bucket (HIP events around the waits)"},
-        "range_guard": {"enabled": bool(ops.RANGE_GUARD), "arithmetic_at_end": ops.POINTMLP_PRECISION}}))
+        "range_guard": {"enabled": bool(ops.RANGE_GUARD), "arithmetic_at_end": ops.POINTMLP_PRECISION}})
 
 
 def main():
@@ -429,12 +429,18 @@ def main():
         line["parity_checked"] = parity_check(args, enc, cls, inp, out, enc_cpu, cls_cpu)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
-    print(json.dumps(line))
+    return line
 
 
 if __name__ == "__main__":
+    _line = None
     try:
-        main()
+        _line = main()
     finally:
         from sonet_hip import dp as _dp
-        _dp.shutdown()
+        _dp.shutdown()                     # (RCCL prints its banner on stdout: leave the group first, the JSON line goes LAST)
+    if _line is not None:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)     # RCCL's banner sits in the C stdio buffer of a piped stdout: out with it first
+        print(json.dumps(_line), flush=True)

@@ -88,6 +88,9 @@ int sonet_index_max_bf16(const uint16_t *data, const int32_t *index, int32_t *ou
 int sonet_index_max_gather_f32(const float *data, const int32_t *index, const int32_t *row_max,
                                int32_t *out_idx, float *out_val,
                                int B, int C, int Np, int K, sonet_stream_t stream);
+int sonet_index_max_gather_bf16(const uint16_t *data, const int32_t *index, const int32_t *row_max,
+                                int32_t *out_idx, float *out_val, int B, int C, int Np, int K,
+                                sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * som_assign  -- replaces the body of BatchSOM.query_topk (and BatchSOM.query for k = 1)
@@ -205,6 +208,21 @@ int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_s
 int sonet_pointmlp_h3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,
                           const float *scale, const float *shift, int relu, float *y,
                           int B, int Cout, int L, sonet_stream_t stream);
+
+/* The same layer with bf16 STORAGE and bf16 MFMA (BASELINE configs[1] "bf16"; the reference is f32-only, so this is the
+ * reduced-precision twin of models/layers.py:282-296, not a bit-compatible replacement): x1, x2, y are bfloat16 bit
+ * patterns [B][C][L], one v_mfma_f32_32x32x16_bf16 per product with f32 accumulation, the epilogue
+ * act(acc * scale + shift) in f32, rounded to nearest-even bf16 on the store.  Requires Cout % 32 == 0 and, with a second
+ * input, C1 % 16 == 0.  Wp = sonet_pointmlp_bf16_pack_size(Cin, Cout) BYTES from sonet_pointmlp_bf16_pack (f32 weights in).
+ * _gather: column l of x1 ([B][C1][L1]) is x1[b][:, gidx[b][l]] (zeros when out of range), as sonet_pointmlp_h3_gather_f32. */
+size_t sonet_pointmlp_bf16_pack_size(int Cin, int Cout);
+int sonet_pointmlp_bf16_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream);
+int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                        const float *scale, const float *shift, int relu, uint16_t *y,
+                        int B, int Cout, int L, sonet_stream_t stream);
+int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t *gidx, const uint16_t *x2, int C2, const void *Wp,
+                               const float *scale, const float *shift, int relu, uint16_t *y,
+                               int B, int Cout, int L, sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pointresnet_fused -- the encoder's first PointNet as ONE kernel (eval mode, 3xbf16-split arithmetic)

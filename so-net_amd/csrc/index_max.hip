@@ -174,3 +174,11 @@ extern "C" int sonet_index_max_gather_f32(const float *data, const int32_t *inde
     return launch_index_max<float>(data, index, row_max, out_idx, out_val, B, C, Np, K, sonet::as_stream(stream),
                                    "sonet_index_max_gather_f32");
 }
+
+extern "C" int sonet_index_max_gather_bf16(const uint16_t *data, const int32_t *index, const int32_t *row_max,
+                                           int32_t *out_idx, float *out_val, int B, int C, int Np, int K,
+                                           sonet_stream_t stream) {
+    SONET_REQUIRE(out_val, "sonet_index_max_gather_bf16: out_val is NULL");
+    return launch_index_max<uint16_t>(data, index, row_max, out_idx, out_val, B, C, Np, K, sonet::as_stream(stream),
+                                      "sonet_index_max_gather_bf16");
+}

@@ -1,0 +1,334 @@
+// pointmlp_bf16.hip -- the fused point-wise layer with bf16 STORAGE and bf16 MFMA (BASELINE configs[1]: "bf16").
+//
+//   y[b][o][l] = act( (sum_i W[o][i] * xcat[b][i][l]) * scale[o] + shift[o] ),   x, y: bfloat16 [B][C][L]; f32 accumulate
+//
+// Same operator as pointmlp.hip / pointmlp_x3.hip (models/layers.py:282-296 with the BatchNorm of :60-70 folded into
+// (scale, shift)); the reference computes in f32 only, this is the reduced-precision twin SURVEY.md 7 (step 5) schedules:
+// ONE v_mfma_f32_32x32x16_bf16 per product (the f32-class paths issue 3 or 6), half the activation bytes.  At 2.5 PFLOP/s
+// dense the 320 -> 384 layer has 175 flop per HBM byte, under the machine balance of ~310: the layer-wise kernel is
+// HBM-bound again, so it is built around bytes: dword accesses only, every A fragment used twice.
+//
+// Wave tile = 64 points x (MT x 32) output channels.  The two 32-column MFMA tiles of a wave are the EVEN and the ODD
+// points of its 64: lane j reads ONE dword (points 2j, 2j+1) per channel row -- 128 contiguous bytes per half-wave and
+// row, exactly the f32 kernels' access pattern at half the bytes -- and a v_perm_b32 pair per two channels sorts the
+// halves into the two B fragments (8 VALU per 16-channel chunk; the f32-class split costs 44-52).  On the way out the
+// accumulators of the two tiles meet again: v_cvt_pk_bf16_f32(acc_even, acc_odd) is the dword to store.  W goes through
+// LDS in stages shared by the 4 waves as in pointmlp_x3.hip (one 1-KiB slice per (cout tile, K chunk)); each slice read
+// from LDS feeds two MFMAs, which keeps the LDS at half its bandwidth when the matrix pipe is full.
+// Odd L (rows not dword aligned) and the gather variant (columns picked by an index) take 2-byte loads / stores instead.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BF_THREADS = 256;
+constexpr int BF_WAVES = 4;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // round to nearest even, NaN stays NaN
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// Wp[ct][kc][lane] (uint4 = 8 bf16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7, zero padded
+__global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp, int Cin, int Cout, int KC, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const long long r = t >> 6;
+    const int kc = (int)(r % KC), ct = (int)(r / KC);
+    const int o = ct * 32 + (lane & 31);
+    const int c0 = kc * 16 + 8 * (lane >> 5);
+    unsigned w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + 2 * p;
+        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
+        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
+        w[p] = cvt_pk_bf16(w0, w1);
+    }
+    Wp[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// PAIRED: L even -> one dword per (lane, channel row) covers the lane's two points.  Otherwise 2-byte accesses with two
+// independent column offsets per lane (odd L; the gather variant).
+template <int MT, int S, bool PAIRED>
+__global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_kernel(      // <= 4 tiles: two workgroups per CU (<= 256 VGPRs)
+    const uint16_t *__restrict__ x1, int C1, const uint16_t *__restrict__ x2, int C2, const uint4 *__restrict__ Wp,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
+    int Cout, int L, int gpc /*64-column groups per cloud*/, long long ngroups, int CT, int KC, int ct_per_y,
+    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/)
+{
+    constexpr int NSL = S * MT;                              // 1 KiB W slices per stage
+    constexpr int NS = (NSL + BF_WAVES - 1) / BF_WAVES;
+    __shared__ uint4 wsm[2][NS * BF_WAVES][64];
+    __shared__ float2 affine[1024];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    long long q = (long long)blockIdx.x * BF_WAVES + wave;
+    const bool wave_valid = q < ngroups;
+    q = wave_valid ? q : 0;
+    const long long b = q / gpc;
+    const int l0 = (int)(q - b * gpc) * 64;
+    const int ca = l0 + 2 * j, cb = ca + 1;                   // the lane's two columns (even tile, odd tile)
+    const bool pva = wave_valid && ca < L, pvb = wave_valid && cb < L;
+    const int cca = ca < L ? ca : l0, ccb = cb < L ? cb : cca;   // clamped: padded lanes re-read a valid column
+
+    const unsigned rowB = (unsigned)L * 2u, rowB1 = (unsigned)L1 * 2u;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(x1 + b * (long long)C1 * L1), 0, (int)((unsigned)C1 * rowB1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(Wp), 0, (int)((unsigned)CT * (unsigned)KC * 1024u), 0x00020000);
+    // lane byte offsets inside a 16-channel chunk (rows 8h .. 8h+7 of the chunk)
+    const unsigned voa = (unsigned)(8 * h * L + cca) * 2u, vob = (unsigned)(8 * h * L + ccb) * 2u;
+    unsigned voa1 = voa, vob1 = vob;                          // ... of x1 (through the gather index when there is one)
+    if (gidx) {
+        const int sa = gidx[b * L + cca], sb = gidx[b * L + ccb];
+        voa1 = (unsigned)sa < (unsigned)L1 ? (unsigned)(8 * h * L1 + sa) * 2u : 0x7FFFFF00u;   // out of range: zeros
+        vob1 = (unsigned)sb < (unsigned)L1 ? (unsigned)(8 * h * L1 + sb) * 2u : 0x7FFFFF00u;
+    }
+    const unsigned voya = (unsigned)(4 * h * L + cca) * 2u, voyb = (unsigned)(4 * h * L + ccb) * 2u;
+    const unsigned vow = (unsigned)lane * 16u;
+
+    const int KC1 = C2 > 0 ? (C1 >> 4) : KC;                  // chunks fed by x1 (C1 % 16 == 0 when x2 exists)
+    const int nstage = (KC + S - 1) / S;
+    constexpr int NR = PAIRED ? 8 : 16;                       // raw registers per chunk
+
+    auto load_b = [&](unsigned (&raw)[S][NR], int st) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int kc = st * S + i;
+            const bool second = kc >= KC1;
+            const unsigned rb = second ? rowB : rowB1;
+            const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rb;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned so = row0 + (unsigned)t * rb;
+                if constexpr (PAIRED) {
+                    raw[i][t] = (unsigned)(second ? __builtin_amdgcn_raw_buffer_load_b32(r2, voa, so, 0)
+                                                  : __builtin_amdgcn_raw_buffer_load_b32(r1, voa1, so, 0));
+                } else {
+                    raw[i][2 * t] = (unsigned)(unsigned short)(second ? __builtin_amdgcn_raw_buffer_load_b16(r2, voa, so, 0)
+                                                                      : __builtin_amdgcn_raw_buffer_load_b16(r1, voa1, so, 0));
+                    raw[i][2 * t + 1] = (unsigned)(unsigned short)(second ? __builtin_amdgcn_raw_buffer_load_b16(r2, vob, so, 0)
+                                                                          : __builtin_amdgcn_raw_buffer_load_b16(r1, vob1, so, 0));
+                }
+            }
+        }
+    };
+
+    const int ct_begin = blockIdx.y * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += BF_THREADS)
+        affine[o - ct_begin * 32] = make_float2(scale[o], shift[o]);
+
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
+
+        // slice sl of a stage: chunk i = sl / MT, cout tile mt = sl % MT
+        auto stage_load = [&](i32x4_t (&w)[NS], int st) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                int sl = wave + t * BF_WAVES;
+                sl = sl < NSL ? sl : NSL - 1;
+                const int i = sl / MT, mt = sl - i * MT;
+                int kc = st * S + i;
+                kc = kc < KC ? kc : KC - 1;
+                w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)((ct0 + mt) * KC + kc) * 1024u, 0);
+            }
+        };
+        auto stage_write = [&](const i32x4_t (&w)[NS], int slot) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                wsm[slot][wave + t * BF_WAVES][lane] = __builtin_bit_cast(uint4, w[t]);
+        };
+        auto compute = [&](const unsigned (&raw)[S][NR], int slot, int st) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                if (st * S + i >= KC) break;                  // (a padded last stage: its W slices repeat the last chunk)
+                unsigned ba[4], bb[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if constexpr (PAIRED) {                   // channel rows 2p, 2p+1: (even, odd) point halves of two dwords
+                        ba[p] = __builtin_amdgcn_perm(raw[i][2 * p + 1], raw[i][2 * p], 0x05040100u);
+                        bb[p] = __builtin_amdgcn_perm(raw[i][2 * p + 1], raw[i][2 * p], 0x07060302u);
+                    } else {
+                        ba[p] = raw[i][4 * p] | (raw[i][4 * p + 2] << 16);
+                        bb[p] = raw[i][4 * p + 1] | (raw[i][4 * p + 3] << 16);
+                    }
+                }
+                const bf16x8 Ba = __builtin_bit_cast(bf16x8, make_uint4(ba[0], ba[1], ba[2], ba[3]));
+                const bf16x8 Bb = __builtin_bit_cast(bf16x8, make_uint4(bb[0], bb[1], bb[2], bb[3]));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 A = __builtin_bit_cast(bf16x8, wsm[slot][i * MT + mt][lane]);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Ba, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bb, acc[mt][1], 0, 0, 0);
+                }
+            }
+        };
+
+        i32x4_t wreg[NS];
+        unsigned b0[S][NR], b1[S][NR];
+        __syncthreads();
+        stage_load(wreg, 0);
+        load_b(b0, 0);
+        stage_write(wreg, 0);
+        stage_load(wreg, nstage > 1 ? 1 : 0);
+#define BF_STAGE(st, bcur, bnxt, slot)                                        \
+        {                                                                    \
+            __syncthreads();                                                 \
+            stage_write(wreg, (slot) ^ 1);                                   \
+            stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
+            load_b(bnxt, (st) + 1);                                          \
+            compute(bcur, slot, st);                                         \
+        }
+        int st = 0;
+        for (; st + 2 <= nstage; st += 2) {
+            BF_STAGE(st, b0, b1, 0)
+            BF_STAGE(st + 1, b1, b0, 1)
+        }
+        if (st < nstage) BF_STAGE(st, b0, b1, 0)
+#undef BF_STAGE
+
+        if (pva) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
+                    if (relu) { va = (va < 0.f) ? 0.f : va; vb = (vb < 0.f) ? 0.f : vb; }     // NaN propagates
+                    const unsigned pk = cvt_pk_bf16(va, vb);
+                    const unsigned so = so_tile + (unsigned)orow * rowB;
+                    if constexpr (PAIRED) {
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pk, ry, voya, so, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b16((short)(pk & 0xFFFFu), ry, voya, so, 0);
+                        if (pvb) __builtin_amdgcn_raw_buffer_store_b16((short)(pk >> 16), ry, voyb, so, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sonet_pointmlp_bf16_pack_size(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 64 * 16;     // bytes
+}
+
+extern "C" int sonet_pointmlp_bf16_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_pack";
+    SONET_REQUIRE(W && Wp, "%s: NULL pointer", what);
+    SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
+    const int KC = sonet::ceil_div(Cin, 16);
+    const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       W, reinterpret_cast<uint4 *>(Wp), Cin, Cout, KC, total);
+    return sonet::launched(what);
+}
+
+static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                         const float *scale, const float *shift, int relu, uint16_t *y,
+                         int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0)
+{
+    if (!gidx) L1 = L;
+    SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
+    SONET_REQUIRE(x1 && Wp && scale && shift && y, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
+    SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
+    if (Cout % 32 != 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 32", what, Cout);
+    const int Cin = C1 + C2;
+    const int CT = Cout / 32, KC = sonet::ceil_div(Cin, 16);
+    const int gpc = sonet::ceil_div(L, 64);
+    const long long ngroups = (long long)B * gpc;
+    if ((double)C1 * L1 * 2.0 >= 2.0e9 || (double)(C1 > C2 ? C1 : C2) * L * 2.0 >= 2.0e9 || (double)Cout * L * 2.0 >= 4.0e9 || (double)CT * KC * 1024.0 >= 4.0e9)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
+    const long long nwg_x = sonet::ceil_div64(ngroups, (long long)BF_WAVES);
+    if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+    int MT = 1, S = 2;
+    if (CT % 12 == 0 && nwg_x >= 512) MT = 12;               // big layers: every X byte is read ONCE (the layer is HBM-bound in bf16)
+    else if (CT % 6 == 0) MT = 6;
+    else if (CT % 4 == 0) MT = 4;
+    else if (CT % 2 == 0) MT = 2;
+    if (const char *e = getenv("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
+        const int want = atoi(e);
+        if ((want == 12 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
+    }
+    if (const char *e = getenv("SONET_BF16_S")) {
+        const int want = atoi(e);
+        if (want == 1 || want == 2) S = want;
+    }
+    if (KC == 1) S = 1;
+    int ysplit = 1;
+    while (nwg_x * ysplit < 512 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;      // small launches: spread the output channels too
+    while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    if (const char *e = getenv("SONET_BF16_YSPLIT")) {
+        const int want = atoi(e);
+        if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;
+    }
+    const int ct_per_y = CT / ysplit;
+    if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
+    const bool paired = (L % 2 == 0) && (L1 % 2 == 0) && gidx == nullptr &&
+                        ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(y)) & 3) == 0;
+    dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
+    hipStream_t st = sonet::as_stream(stream);
+    const uint4 *wp = reinterpret_cast<const uint4 *>(Wp);
+#define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1
+#define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
+                                         else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, true>), BF_ARGS); } \
+                           else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
+                                         else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, false>), BF_ARGS); } } while (0)
+    if (MT == 12) S = 1;                                      // (12 slices per chunk already: one chunk per stage)
+    switch (MT) {
+        case 12: BF_LAUNCH(12); break;
+        case 6: BF_LAUNCH(6); break;
+        case 4: BF_LAUNCH(4); break;
+        case 2: BF_LAUNCH(2); break;
+        default: BF_LAUNCH(1);
+    }
+#undef BF_LAUNCH
+#undef BF_ARGS
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                   const float *scale, const float *shift, int relu, uint16_t *y,
+                                   int B, int Cout, int L, sonet_stream_t stream)
+{
+    return bf16_run_impl("sonet_pointmlp_bf16", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream);
+}
+
+extern "C" int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t *gidx, const uint16_t *x2, int C2, const void *Wp,
+                                          const float *scale, const float *shift, int relu, uint16_t *y,
+                                          int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_gather";
+    SONET_REQUIRE(gidx, "%s: NULL pointer", what);
+    return bf16_run_impl(what, x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, gidx, L1);
+}

@@ -281,8 +281,10 @@ class _FusedPointwise(nn.Module):
         """Packed weight for the current arithmetic mode (``sonet_hip.ops.POINTMLP_PRECISION``)."""
         w = self.conv.weight
         mode = _ops.POINTMLP_PRECISION
-        if mode in ("x3", "h3") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
+        if mode in ("x3", "h3", "bf16") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
             mode = "f32"
+        if mode == "bf16" and (torch.is_grad_enabled() or (self.normalization == 'batch' and self.norm.training)):
+            mode = "x3"                      # bf16 storage is the no-grad / eval arithmetic; autograd keeps the f32-class kernels
         key = (w._version, w.data_ptr(), w.device, mode)
         if getattr(self, '_wp_key', None) != key:
             with torch.no_grad():
@@ -291,21 +293,22 @@ class _FusedPointwise(nn.Module):
         return self._wp
 
     def _packed_rotated(self, lead):
-        """h3 pack of the weight with its first ``lead`` input channels moved behind the others: a caller that feeds
+        """h3 (or bf16) pack of the weight with its first ``lead`` input channels moved behind the others: a caller that feeds
         cat(a, b) with a narrow ``a`` (3 coordinate rows) passes (b, a) as (x1, x2) instead, so that x1 is 16-aligned."""
         w = self.conv.weight
-        key = (w._version, w.data_ptr(), w.device, lead)
+        mode = "bf16" if _ops.POINTMLP_PRECISION == "bf16" else "h3"
+        key = (w._version, w.data_ptr(), w.device, lead, mode)
         if getattr(self, '_wpr_key', None) != key:
             with torch.no_grad():
                 w2 = self._weight2d().detach().float()
-                self._wpr = _ops.pointmlp_pack(torch.cat((w2[:, lead:], w2[:, :lead]), dim=1).contiguous(), "h3")
+                self._wpr = _ops.pointmlp_pack(torch.cat((w2[:, lead:], w2[:, :lead]), dim=1).contiguous(), mode)
             self._wpr_key = key
         return self._wpr
 
     def _direct_ok(self, x):
-        """Eval-mode, no-grad, h3: the caller may launch the kernel itself with this layer's pack and folded affine."""
-        return (_ops.GATHER_NODE_STAGE and _ops.POINTMLP_PRECISION == "h3" and not torch.is_grad_enabled() and x.is_cuda
-                and x.dtype == torch.float32 and self._fusable() and self.conv.out_channels % 32 == 0
+        """Eval-mode, no-grad, h3 / bf16: the caller may launch the kernel itself with this layer's pack and folded affine."""
+        return (_ops.GATHER_NODE_STAGE and _ops.POINTMLP_PRECISION in ("h3", "bf16") and not torch.is_grad_enabled() and x.is_cuda
+                and x.dtype in (torch.float32, torch.bfloat16) and self._fusable() and self.conv.out_channels % 32 == 0
                 and self.normalization in (None, 'batch') and not (self.normalization == 'batch' and self.norm.training)
                 and self.activation in (None, 'relu'))
 
@@ -344,6 +347,11 @@ class _FusedPointwise(nn.Module):
                                                   or self.conv.weight.requires_grad)
         fuse_act = relu_fused and (norm in (None, 'batch'))
         wp = self._packed(x1.shape[1], x2.shape[1] if x2 is not None else 0)
+        want = torch.bfloat16 if wp.dtype == torch.int16 else torch.float32     # the pack decides the kernel, the kernel the storage type
+        if x1.dtype != want:
+            x1 = x1.to(want)
+        if x2 is not None and x2.dtype != want:
+            x2 = x2.to(want)
         if train_bn:
             y, mean, var = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
                                               fuse_act, 'batch', bn.eps)
@@ -377,7 +385,7 @@ class _FusedPointwise(nn.Module):
         if not x.is_cuda:
             raise _ops.SonetHipError("fused point-wise layers run on the MI355X only (got a CPU tensor); "
                                      "there is no CPU fallback")
-        if x.dtype != torch.float32:
+        if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         return x.contiguous()
 
@@ -583,14 +591,15 @@ class KNNModule(nn.Module):
                 and self.layers[0].conv.in_channels == 3 + x.shape[1]):
             # no-grad h3 path: only the 3 de-centred coordinate rows are materialised (k-major); the features are gathered by
             # the first layer's operand loads; the max over the K neighbours reads k-major planes (coalesced)
-            center, dec, gidx = _ops.knn_prepare(coord.contiguous(), knn_I, center_type == 'avg')
+            center, dec, gidx = _ops.knn_prepare(coord.float().contiguous(), knn_I, center_type == 'avg')
             l1, l2 = self.layers
             s1, t1 = l1._eval_affine()
-            h = _ops.pointmlp(x.contiguous(), l1._packed_rotated(3), s1, t1, l1.activation == 'relu', l1.conv.out_channels,
-                              x2=dec, gidx=gidx)                          # B x C1 x (K*M), k-major columns
+            sdt = torch.bfloat16 if _ops.POINTMLP_PRECISION == "bf16" else torch.float32
+            h = _ops.pointmlp(x.to(sdt).contiguous(), l1._packed_rotated(3), s1, t1, l1.activation == 'relu', l1.conv.out_channels,
+                              x2=dec.to(sdt), gidx=gidx)                  # B x C1 x (K*M), k-major columns
             s2, t2 = l2._eval_affine()
             h = _ops.pointmlp(h, l2._packed(h.shape[1], 0), s2, t2, l2.activation == 'relu', l2.conv.out_channels)
-            feature = _ops.planes_max(h, K)                               # B x C2 x M
+            feature = _ops.planes_max(h, K)                               # B x C2 x M (storage type of h)
             return center, feature
         if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
             # no-grad path: gathers, centre, de-centring and the concat in one kernel; max over K in one kernel
@@ -645,8 +654,9 @@ class PointNet(nn.Module):
         if x.shape[1] % 16 == 0 and all(l._direct_ok(x) for l in self.layers):
             first = self.layers[0]
             s, t = first._eval_affine()
-            h = _ops.pointmlp(x.contiguous(), first._packed_rotated(lead.shape[1]), s, t, first.activation == 'relu',
-                              first.conv.out_channels, x2=lead.contiguous())
+            sdt = torch.bfloat16 if _ops.POINTMLP_PRECISION == "bf16" else torch.float32
+            h = _ops.pointmlp(x.to(sdt).contiguous(), first._packed_rotated(lead.shape[1]), s, t, first.activation == 'relu',
+                              first.conv.out_channels, x2=lead.to(sdt).contiguous())
             for layer in self.layers[1:]:
                 h = layer(h, epoch)
             return h

@@ -41,6 +41,11 @@ SIGNATURES = {
     "sonet_pointmlp_pack_size": [_i, _i],
     "sonet_pointmlp_pack_f32": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_pack_size": [_i, _i],
+    "sonet_pointmlp_bf16_pack": [_vp, _vp, _i, _i, _vp],
+    "sonet_pointmlp_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_gather": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_index_max_gather_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -70,6 +75,7 @@ _RESTYPES = {
     "sonet_last_error": ctypes.c_char_p,
     "sonet_pointmlp_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
+    "sonet_pointmlp_bf16_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,

@@ -101,7 +101,9 @@ def index_max(data, index, K):
 
 def index_max_gather(data, index, K, row_max=None):
     """index_max + the masked gather of models/networks.py:185 in one pass -> (idx i32, val f32) BxCxK."""
-    _chk(data, "data", torch.float32, 3)
+    _chk(data, "data", dim=3)
+    if data.dtype not in (torch.float32, torch.bfloat16):
+        raise SonetHipError("data must be float32 or bfloat16, got %s" % data.dtype)
     _chk(index, "index", torch.int32, 2)
     B, C, Np = data.shape
     if tuple(index.shape) != (B, Np):
@@ -111,9 +113,10 @@ def index_max_gather(data, index, K, row_max=None):
     dev = _same_device(data, index, row_max)
     idx = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
     val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("index_max_gather"):
-        check(_lib.load().sonet_index_max_gather_f32(ptr(data), ptr(index), ptr(row_max), ptr(idx), ptr(val),
-                                                     B, C, Np, int(K), stream_ptr()), "sonet_index_max_gather_f32")
+    lib = _lib.load()
+    fn = lib.sonet_index_max_gather_f32 if data.dtype == torch.float32 else lib.sonet_index_max_gather_bf16
+    with torch.cuda.device(dev), _timed("index_max_gather" if data.dtype == torch.float32 else "index_max_gather_bf16"):
+        check(fn(ptr(data), ptr(index), ptr(row_max), ptr(idx), ptr(val), B, C, Np, int(K), stream_ptr()), "sonet_index_max_gather")
     return idx, val
 
 
@@ -258,6 +261,8 @@ def knn_group(coord, feat, knn_I, center_avg):
 
 def lastdim_max(x):
     """max over the last (contiguous) axis, values only; NaN propagates like torch.amax."""
+    if x.dtype == torch.bfloat16:                     # node-level tensors (B x C x M): widening is exact and cheap
+        x = x.float()
     if not x.is_contiguous() or x.dtype != torch.float32:
         raise SonetHipError("lastdim_max needs a contiguous float32 tensor")
     dev = _same_device(x)
@@ -292,6 +297,8 @@ import os as _os
 #   "f32": exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an f32 fma chain
 #   "x3" : bf16 MFMA on a 3-way bf16 split of both operands (six terms), f32 accumulate: f32-class accuracy (the
 #          reference fixtures are met at the same 1e-5 tolerance), f32 operand range, 1.4-1.7x faster than "f32"
+#   "bf16": bf16 STORAGE of the activations and one bf16 MFMA per product, f32 accumulate (BASELINE configs[1]); reduced
+#          precision by design (features within ~1e-2 of the f32 reference), indices bit-exact on the same bf16 data
 #   "h3" : fp16 MFMA on a two-piece fp16 split with scaled residuals (three terms): the same accuracy at half the
 #          matrix work, fp16 operand RANGE (|x| <= 2047 clamped, relative precision fades below ~1e-4) -- DEFAULT for
 #          the forward layers (coordinates, normalised activations); gradients (dgrad) always use "x3"
@@ -533,6 +540,9 @@ def pointmlp_pack(weight2d, mode="f32"):
         if mode == "x3":
             wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin, Cout),), dtype=torch.uint8, device=dev)
             check(lib.sonet_pointmlp_x3_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_x3_pack")
+        elif mode == "bf16":                                 # bf16 storage / bf16 MFMA (int16 marks the flavour)
+            wp = torch.empty((lib.sonet_pointmlp_bf16_pack_size(Cin, Cout) // 2,), dtype=torch.int16, device=dev)
+            check(lib.sonet_pointmlp_bf16_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_bf16_pack")
         elif mode == "h3":                                   # same size; int8 marks the fp16 flavour
             wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin, Cout),), dtype=torch.int8, device=dev)
             check(lib.sonet_pointmlp_h3_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_h3_pack")
@@ -546,17 +556,19 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``.
     ``gidx`` (B x L i32, h3 packs only): column l of x1 (B x C1 x L1) is taken from x1[:, :, gidx[b, l]] -- zeros when the
     index is out of range -- i.e. the layer runs on the gathered tensor without materialising it."""
-    _chk(x1, "x", torch.float32, 3)
+    bf16 = wp.dtype == torch.int16
+    xdt = torch.bfloat16 if bf16 else torch.float32
+    _chk(x1, "x", xdt, 3)
     B, C1, L = x1.shape
     L1 = L
     if gidx is not None:
         _chk(gidx, "gidx", torch.int32, 2)
-        if wp.dtype != torch.int8 or gidx.shape[0] != B:
-            raise SonetHipError("pointmlp: a gather index needs an h3 pack and B rows")
+        if wp.dtype not in (torch.int8, torch.int16) or gidx.shape[0] != B:
+            raise SonetHipError("pointmlp: a gather index needs an h3 or bf16 pack and B rows")
         L = gidx.shape[1]
     C2 = 0
     if x2 is not None:
-        _chk(x2, "x2", torch.float32, 3)
+        _chk(x2, "x2", xdt, 3)
         if x2.shape[0] != B or x2.shape[2] != L:
             raise SonetHipError("x2 must be B x C2 x L")
         C2 = x2.shape[1]
@@ -566,11 +578,23 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     lib = _lib.load()
     h3 = wp.dtype == torch.int8
     x3 = wp.dtype == torch.uint8 or h3
-    want = lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout) if x3 else lib.sonet_pointmlp_pack_size(C1 + C2, Cout)
+    want = (lib.sonet_pointmlp_bf16_pack_size(C1 + C2, Cout) // 2 if bf16 else lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout) if x3
+            else lib.sonet_pointmlp_pack_size(C1 + C2, Cout))
     if wp.numel() != want:
         raise SonetHipError("packed weight has %d elements, expected %d for Cin=%d Cout=%d" % (wp.numel(), want, C1 + C2, Cout))
-    y = out if out is not None else torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    y = out if out is not None else torch.empty((B, Cout, L), dtype=xdt, device=dev)
     if y.numel() == 0:
+        return y
+    if bf16:
+        if y.dtype != torch.bfloat16:
+            raise SonetHipError("pointmlp: a bf16 pack writes a bfloat16 output")
+        with torch.cuda.device(dev), _timed("pointmlpbf16_%dx%d_L%d" % (C1 + C2, Cout, L)):
+            if gidx is not None:
+                check(lib.sonet_pointmlp_bf16_gather(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
+                                                     ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_bf16_gather")
+            else:
+                check(lib.sonet_pointmlp_bf16(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y),
+                                              B, Cout, L, stream_ptr()), "sonet_pointmlp_bf16")
         return y
     fn = lib.sonet_pointmlp_h3_f32 if h3 else lib.sonet_pointmlp_x3_f32 if x3 else lib.sonet_pointmlp_f32
     name = "pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)
@@ -833,6 +857,8 @@ def knn_prepare(coord, knn_I, center_avg):
 
 def planes_max(x, K):
     """x B x C x (K*M) with k-major columns -> B x C x M, max over the K planes (values only, NaN-propagating)."""
+    if x.dtype == torch.bfloat16:
+        x = x.float()
     _chk(x, "x", torch.float32, 3)
     B, C, L = x.shape
     if K <= 0 or L % K:

@@ -1,0 +1,180 @@
+"""GPU tests of the bf16 path (BASELINE configs[1] "bf16"): bf16-storage point-wise layers on bf16 MFMA, index_max on bf16
+features, the encoder forward in bf16.
+
+The reference is f32-only (models/index_max_ext/index_max_cuda.cu:75-76 dispatches float), so the bar is the one
+SURVEY.md 7 (step 5) sets: integer outputs bit-exact ON THE SAME bf16 INPUTS, float outputs within a stated bf16 tolerance of
+the f32 fixture:  |got - ref| <= BF16_TOL * max(|ref|, rms(ref))  with BF16_TOL = 5e-2 for the WORST element (bf16 has 8
+significand bits, 2^-9 = 2e-3 per rounding; the encoder rounds seven layer outputs in a row and passes three max-pools;
+measured worst elements on the three fixtures: 1.4e-2 .. 3.3e-2, printed by the test)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_rms, golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16_TOL = 5e-2
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def ref_layer(x1, x2, W, scale, shift, relu, gidx=None):
+    """The layer on the SAME bf16 operands, float64 accumulate (what the MFMA computes up to summation order)."""
+    xs = x1.double()
+    if gidx is not None:
+        B, C1, L1 = x1.shape
+        idx = gidx.long()
+        ok = (idx >= 0) & (idx < L1)
+        xs = torch.gather(xs, 2, idx.clamp(0, L1 - 1).unsqueeze(1).expand(B, C1, idx.shape[1])) * ok.unsqueeze(1)
+    if x2 is not None:
+        xs = torch.cat((xs, x2.double()), dim=1)
+    Wb = W.to(torch.bfloat16).double()
+    y = torch.einsum("oc,bcl->bol", Wb, xs) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1)
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L,relu", [
+    (2, 6, 0, 64, 300, True), (3, 64, 0, 128, 1000, True), (2, 64, 256, 384, 1501, False), (2, 64, 256, 384, 1500, False),
+    (1, 387, 0, 512, 576, True), (2, 512, 0, 512, 64, True), (2, 515, 0, 768, 64, True), (1, 768, 0, 1024, 64, False),
+    (2, 16, 3, 32, 1, False), (1, 128, 0, 256, 15000, True), (2, 48, 0, 96, 130, True)])
+def test_pointmlp_bf16_vs_same_operand_reference(B, C1, C2, Cout, L, relu):
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 * 7 + L)
+    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16)
+    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16) if C2 else None
+    if C2 and C1 % 16:
+        pytest.skip("second panel needs C1 % 16 == 0")
+    W = torch.randn(Cout, C1 + C2, generator=g) * (2.0 / (C1 + C2)) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    wp = ops.pointmlp_pack(W.to(DEV), "bf16")
+    y = ops.pointmlp(x1.to(DEV), wp, scale.to(DEV), shift.to(DEV), relu, Cout, x2=x2.to(DEV) if x2 is not None else None)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, Cout, L)
+    ref = ref_layer(x1, x2, W, scale, shift, relu)
+    got = y.cpu().double()
+    # the f32 accumulator differs from the float64 one by summation order only: the bf16 rounding of the result may differ by
+    # one unit in the last place (2^-8 relative) where the exact value sits near a rounding boundary
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-6 * ref.abs().max()
+    assert bool((err <= bound).all()), "worst err/bound %.3g" % float((err / bound).max())
+    # and on average it is the correctly rounded value
+    exact = ref.to(torch.bfloat16).double()
+    assert float((got != exact).double().mean()) < 0.02
+
+
+@pytest.mark.parametrize("mt", ["12", "6", "4", "2", "1"])
+def test_pointmlp_bf16_tile_variants_agree(mt, monkeypatch):
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(2, 64, 700, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(2, 256, 700, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(384, 320, generator=g) * 0.08).to(DEV)
+    wp = ops.pointmlp_pack(W, "bf16")
+    one, zero = ops.const_vec(384, 1.0, DEV), ops.const_vec(384, 0.0, DEV)
+    base = ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2).clone()
+    monkeypatch.setenv("SONET_BF16_MT", mt)
+    for s in ("1", "2"):
+        monkeypatch.setenv("SONET_BF16_S", s)
+        assert torch.equal(ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2), base), (mt, s)   # same K order: bit-identical
+
+
+def test_pointmlp_bf16_gather_matches_materialised():
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(9)
+    B, C1, M, K = 2, 384, 64, 9
+    x1 = torch.randn(B, C1, M, generator=g).to(torch.bfloat16)
+    gidx = torch.randint(-1, M + 1, (B, K * M), generator=g, dtype=torch.int32)         # -1 and M: out of range -> zeros
+    x2 = torch.randn(B, 3, K * M, generator=g).to(torch.bfloat16)
+    W = torch.randn(512, C1 + 3, generator=g) * 0.07
+    scale, shift = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g) * 0.3
+    wp = ops.pointmlp_pack(W.to(DEV), "bf16")
+    y = ops.pointmlp(x1.to(DEV), wp, scale.to(DEV), shift.to(DEV), True, 512, x2=x2.to(DEV), gidx=gidx.to(DEV))
+    ref = ref_layer(x1, x2, W, scale, shift, True, gidx=gidx)
+    err = (y.cpu().double() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-6 * ref.abs().max()
+    assert bool((err <= bound).all())
+
+
+def test_index_max_gather_bf16_same_input_bit_exact():
+    """bf16 features make exact ties common: positions must equal the reference scan on the same (widened) values."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, N, K = 3, 384, 15000, 64
+    data = (torch.randn(B, C, N, generator=g) * 0.5).to(torch.bfloat16)
+    index = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32)
+    index[1, :] = index[1, :] % 7                                                       # leaves empty nodes
+    row_max = torch.stack([(torch.bincount(index[b].long(), minlength=K) > 0) for b in range(B)]).to(torch.int32)
+    ref = O.index_max(data.float().numpy(), index.numpy(), K)
+    idx, val = ops.index_max_gather(data.to(DEV), index.to(DEV), K, row_max.to(DEV))
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    exp = torch.gather(data.float(), 2, torch.from_numpy(ref).long() * row_max.unsqueeze(1).long())
+    np.testing.assert_array_equal(val.cpu().numpy(), exp.numpy())
+    np.testing.assert_array_equal(ops.index_max(data.to(DEV), index.to(DEV), K).cpu().numpy(), ref)
+
+
+def make_opt(g, B, N):
+    return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True,
+                     feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64,
+                     k=int(g["k"]), som_k=int(g["som_k"]), som_k_type=str(g["som_k_type"]), bn_momentum=0.1,
+                     bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+
+
+@pytest.mark.parametrize("case", ["classifier_b2_n5000", "classifier_b8_n1024", "classifier_b2_n256"])
+def test_encoder_classifier_forward_bf16(case):
+    """configs[1] shape (and two smaller ones) in bf16: node assignment bit-exact vs the fixture (it is computed in f32),
+    arg-max positions bit-exact against the reference scan of the SAME bf16 first_pn_out, float outputs within BF16_TOL."""
+    from models import networks as NW
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops, synth
+    g = golden(case)
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = make_opt(g, B, N)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(cls.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    enc.want_first_pn_out = True                                   # keep first_pn_out (bf16) for the same-input index check
+    with ops.precision("bf16"), torch.no_grad(), ops.kernel_timing() as rec:
+        feat = enc(cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]), is_train=False)
+        score = cls(feat)
+    names = [n for n, _, _ in rec.records]
+    assert any(n.startswith("pointmlpbf16") for n in names) and not any(n.startswith(("pointmlph3", "pointmlpx3", "pointresnet_fused")) for n in names), names
+    np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), g["min_idx"])
+    first = enc.first_pn_out
+    assert first.dtype == torch.bfloat16
+    ref_pos = O.index_max(first.float().cpu().numpy(), enc.min_idx.int().cpu().numpy(), 64)
+    got_pos, got_val = ops.index_max_gather(first, enc.min_idx.int().contiguous(), 64, (enc._lazy["a"].count > 0).to(torch.int32))
+    np.testing.assert_array_equal(got_pos.cpu().numpy(), ref_pos)
+    np.testing.assert_array_equal(got_val.cpu().numpy(), enc.first_pn_out_masked_max.float().cpu().numpy())
+    worst = {}
+
+    def close(name, got, ref):
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        rms = np.sqrt(np.mean(ref ** 2))
+        worst[name] = float((np.abs(got - ref) / np.maximum(np.abs(ref), rms)).max())
+        assert_close_rms(got, ref, BF16_TOL, name)
+
+    try:
+        close("som_node", enc.som_node.cpu().numpy(), g["som_node"])
+        close("first_pn_out", first[:, ::16, ::5].float().cpu().numpy(), g["first_pn_out_sub"])
+        close("masked_max", enc.first_pn_out_masked_max.float().cpu().numpy(), g["first_pn_out_masked_max"])
+        close("knn_feature_1", enc.knn_feature_1[:, ::4].float().cpu().numpy(), g["knn_feature_1"])
+        close("final_pn_out", enc.final_pn_out[:, ::4].float().cpu().numpy(), g["final_pn_out"])
+        close("feature", feat.float().cpu().numpy(), g["feature"])
+        close("score", score.float().cpu().numpy(), g["score"])
+    finally:
+        print("bf16 worst err / max(|ref|, rms):", {k: "%.2e" % v for k, v in worst.items()})
+    # bf16 keeps the decision: same predicted class as the f32 reference wherever the reference's margin is not razor thin
+    ref_score = torch.from_numpy(g["score"])
+    top2 = ref_score.topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05 * ref_score.abs().max()
+    assert bool((score.cpu().argmax(1) == ref_score.argmax(1))[clear].all())

@@ -111,7 +111,7 @@ def test_fused_kernel_reports_hidden_activation_range():
         with ops.range_scope(DEV) as rs:
             pr(x)
         assert rs.violations() == []
-        pr.layers[1].norm.weight.data[5] = 4.0e4            # one channel of layer 2's BatchNorm blows up
+        pr.layers[1].norm.weight[5] = 4.0e4                 # one channel of layer 2's BatchNorm blows up (in place: the version moves)
         with ops.range_scope(DEV) as rs:
             pr(x)
         bad = rs.violations()
@@ -185,7 +185,7 @@ def test_graphed_forward_exposes_the_range_log():
     cls.to(DEV).eval()
     inp = synth.make_inputs(2, 400, seed=2, device=DEV)
     args = (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
-    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), args)
+    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), tuple(t.clone() for t in args))
     fwd(*args)
     assert fwd.range_violations() == []
     big = (args[0] * 1.0e5, args[1], args[2] * 1.0e5, args[3])
@@ -249,7 +249,7 @@ def test_running_stat_update_invalidates_the_folded_eval_affine():
         pr(xp)
         pr.eval()
         b = pr(xp)
-        pr.layers[3].conv.bias.data.add_(1.0)               # bias-only change of the norm-free last layer
+        pr.layers[3].conv.bias.add_(1.0)                    # bias-only change of the norm-free last layer
         c = pr(xp)
     assert not torch.allclose(a, b)
     assert_close_rms((c - b).cpu().numpy(), np.ones(tuple(b.shape), dtype=np.float32), 1e-4, "bias-only change reaches the fused kernel")
