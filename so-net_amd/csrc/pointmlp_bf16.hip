@@ -27,6 +27,8 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BF_THREADS = 256;
 constexpr int BF_WAVES = 4;
+struct T1 { static constexpr bool value = true; };
+struct T0 { static constexpr bool value = false; };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // round to nearest even, NaN stays NaN
     unsigned r;
@@ -232,6 +234,170 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     }
 }
 
+// ---- the big-L variant: the wave's X tile lives in REGISTERS, W goes by in groups ---------------------------------------
+// In bf16 the 320 -> 384 layer carries 175 flop per HBM byte: whatever re-reads X loses.  Here a wave loads its 64 columns x
+// all Cin channels ONCE (KC x 8 dwords per lane: 160 registers at Cin = 320) and walks the output channels in G groups of
+// MT tiles; the group's weights (KC x MT KiB) sit in one of two LDS buffers shared by the 4 waves, the next group's being
+// staged (buffer_load -> registers -> ds_write, one slice per wave and K chunk, two chunks of latency) while this one is
+// multiplied.  One barrier per group instead of one per K stage, no X traffic beyond the first touch, and the registers of X
+// are refilled with the NEXT tile's columns chunk by chunk during the last group (each right after its last use), so the
+// persistent workgroup never waits for a cold load.  G == 1 (all of W in one buffer): W is staged once, no barrier at all.
+template <int KC, int MT>
+__global__ __launch_bounds__(BF_THREADS, 1) void pointmlp_bf16_xreg_kernel(
+    const uint16_t *__restrict__ x1, int C1, const uint16_t *__restrict__ x2, int C2, const uint4 *__restrict__ Wp,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
+    int Cout, int L, int gpc, long long ngroups, int G /*groups of MT cout tiles*/, int KC1 /*chunks fed by x1*/)
+{
+    constexpr int NSL = KC * MT;                              // slices per W group
+    __shared__ uint4 wbuf[2][NSL][64];
+    __shared__ float2 aff[1024];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned rowB = (unsigned)L * 2u;
+    const unsigned vow = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(Wp), 0, (int)((unsigned)G * MT * KC * 1024u), 0x00020000);
+
+    for (int o = threadIdx.x; o < Cout; o += BF_THREADS) aff[o] = make_float2(scale[o], shift[o]);
+    // group 0 of W, cooperatively (every tile starts with it: restaged only when G > 1)
+    for (int sl = wave; sl < NSL; sl += BF_WAVES) {
+        const int kc = sl / MT, mt = sl - kc * MT;
+        wbuf[0][sl][lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(mt * KC + kc) * 1024u, 0));
+    }
+    __syncthreads();
+
+    const long long ntile = (ngroups + BF_WAVES - 1) / BF_WAVES;
+    unsigned X[KC][8];
+    long long nbuf = 0;                                         // running group counter: buffer = nbuf & 1
+
+    // column bookkeeping of tile t for this wave
+    struct Tile { __amdgpu_buffer_rsrc_t r1, r2, ry; unsigned vo, voy; bool pv; };
+    auto tile_of = [&](long long t) {
+        long long q = t * BF_WAVES + wave;
+        const bool valid = q < ngroups;
+        q = valid ? q : 0;
+        const long long b = q / gpc;
+        const int l0 = (int)(q - b * gpc) * 64;
+        const int ca = l0 + 2 * j;
+        const int cca = ca < L ? ca : l0;
+        Tile T;
+        T.r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(x1 + b * (long long)C1 * L), 0, (int)((unsigned)C1 * rowB), 0x00020000);
+        T.r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
+        T.ry = __builtin_amdgcn_make_buffer_rsrc(y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
+        T.vo = (unsigned)(8 * h * L + cca) * 2u;
+        T.voy = (unsigned)(4 * h * L + cca) * 2u;
+        T.pv = valid && ca < L;
+        return T;
+    };
+    auto load_chunk = [&](unsigned (&dst)[8], const Tile &T, int kc) {
+        const bool second = kc >= KC1;
+        const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rowB;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            dst[t] = (unsigned)(second ? __builtin_amdgcn_raw_buffer_load_b32(T.r2, T.vo, row0 + (unsigned)t * rowB, 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b32(T.r1, T.vo, row0 + (unsigned)t * rowB, 0));
+    };
+
+    Tile cur = tile_of(blockIdx.x);
+    if ((long long)blockIdx.x < ntile) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) load_chunk(X[kc], cur, kc);
+    }
+    // One group of MT cout tiles over the whole K range.  STAGE: the next group's W is staged meanwhile (every wave moves one
+    // slice per K chunk during the first NSL / 4 chunks: buffer_load now, ds_write two chunks later).  PREF: each chunk's X
+    // registers are refilled with the next tile's columns right after their last use.  Both are compile-time, so the K loop
+    // is straight-line code: the A fragments of chunk kc + 1 are read from LDS before the MFMAs of chunk kc are issued and
+    // every wait is a counted one.
+    constexpr int NSTG = NSL / BF_WAVES;                        // staging chunks (NSL % 4 == 0 whenever G > 1 is possible)
+    auto group_pass = [&](auto stage_c, auto pref_c, int g, int gn, int buf, long long tnext) {
+        constexpr bool STAGE = decltype(stage_c)::value, PREF = decltype(pref_c)::value;
+        Tile nxt;
+        if constexpr (PREF) nxt = tile_of(tnext);
+        f32x16 acc[MT][2];
+        i32x4_t st[3];
+        uint4 Af[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Af[0][mt] = wbuf[buf][mt][lane];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            __builtin_amdgcn_sched_barrier(0);                  // chunk boundary: nothing moves across (the compiler otherwise sinks
+                                                                // every LDS read next to its MFMA and waits for it there)
+            if constexpr (STAGE) {
+                if (kc >= 2 && kc - 2 < NSTG) wbuf[buf ^ 1][(kc - 2) * BF_WAVES + wave][lane] = __builtin_bit_cast(uint4, st[(kc - 2) % 3]);
+                if (kc < NSTG) {
+                    const int sl = kc * BF_WAVES + wave;        // slice of the staged group: K chunk sl / MT, tile sl % MT
+                    const int skc = sl / MT, smt = sl - skc * MT;
+                    st[kc % 3] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)((gn * MT + smt) * KC + skc) * 1024u, 0);
+                }
+            }
+            if (kc + 1 < KC) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) Af[(kc + 1) & 1][mt] = wbuf[buf][(kc + 1) * MT + mt][lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // the next chunk's A fragments are requested BEFORE this chunk's MFMAs
+            unsigned ba[4], bb[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ba[p] = __builtin_amdgcn_perm(X[kc][2 * p + 1], X[kc][2 * p], 0x05040100u);
+                bb[p] = __builtin_amdgcn_perm(X[kc][2 * p + 1], X[kc][2 * p], 0x07060302u);
+            }
+            if constexpr (PREF) load_chunk(X[kc], nxt, kc);   // this chunk's registers are free now: next tile's columns
+            const bf16x8 Ba = __builtin_bit_cast(bf16x8, make_uint4(ba[0], ba[1], ba[2], ba[3]));
+            const bf16x8 Bb = __builtin_bit_cast(bf16x8, make_uint4(bb[0], bb[1], bb[2], bb[3]));
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 A = __builtin_bit_cast(bf16x8, Af[kc & 1][mt]);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Ba, kc == 0 ? zero : acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bb, kc == 0 ? zero : acc[mt][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAGE) {
+#pragma unroll
+            for (int kc = (KC >= 2 ? KC - 2 : 0); kc < KC; ++kc)
+                if (kc < NSTG) wbuf[buf ^ 1][kc * BF_WAVES + wave][lane] = __builtin_bit_cast(uint4, st[kc % 3]);
+        }
+        if (cur.pv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_sched_barrier(0);              // (keeps the coefficient reads of all tiles from being hoisted at once)
+                const int ct = g * MT + mt;
+                const unsigned so_tile = (unsigned)(ct * 32) * rowB;
+                const float2 *ap = aff + ct * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = ap[orow];
+                    float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
+                    if (relu) { va = (va < 0.f) ? 0.f : va; vb = (vb < 0.f) ? 0.f : vb; }
+                    __builtin_amdgcn_raw_buffer_store_b32((int)cvt_pk_bf16(va, vb), cur.ry, cur.voy, so_tile + (unsigned)orow * rowB, 0);
+                }
+            }
+        }
+    };
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const bool has_next = tile + gridDim.x < ntile;
+        const long long nxt = tile + gridDim.x;
+        for (int g = 0; g < G; ++g) {
+            const int buf = (int)(nbuf & 1);
+            const bool last = g == G - 1;
+            const int gn = last ? 0 : g + 1;                    // the group staged meanwhile (the next tile starts with group 0 again)
+            const bool stage = G > 1 && (!last || has_next);
+            const bool pref = last && has_next;
+            if (stage) { if (pref) group_pass(T1{}, T1{}, g, gn, buf, nxt); else group_pass(T1{}, T0{}, g, gn, buf, nxt); }
+            else       { if (pref) group_pass(T0{}, T1{}, g, gn, buf, nxt); else group_pass(T0{}, T0{}, g, gn, buf, nxt); }
+            if (G > 1) {
+                __syncthreads();                                // the staged group is complete, this buffer is free
+                nbuf += stage ? 1 : 0;
+            }
+        }
+        if (has_next) cur = tile_of(nxt);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t sonet_pointmlp_bf16_pack_size(int Cin, int Cout)
@@ -272,9 +438,10 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     const long long nwg_x = sonet::ceil_div64(ngroups, (long long)BF_WAVES);
     if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
     int MT = 1, S = 2;
-    if (CT % 12 == 0 && nwg_x >= 512) MT = 12;               // big layers: every X byte is read ONCE (the layer is HBM-bound in bf16)
+    // measured on the first PointNet's shapes (profiles/r02b_bench_bf16_kernel_streaming.log): 4 tiles x 2 chunks per stage wins
+    // everywhere it divides (two workgroups per CU); 12 tiles -- X read once -- leaves one starved wave per SIMD (3x slower)
+    if (CT % 4 == 0) MT = 4;
     else if (CT % 6 == 0) MT = 6;
-    else if (CT % 4 == 0) MT = 4;
     else if (CT % 2 == 0) MT = 2;
     if (const char *e = getenv("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
         const int want = atoi(e);
@@ -296,9 +463,43 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     const bool paired = (L % 2 == 0) && (L1 % 2 == 0) && gidx == nullptr &&
                         ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(y)) & 3) == 0;
-    dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp);
+    // big launches with dword-aligned rows: X tile in registers, W by groups (above).  (KC, MT) pairs that are instantiated:
+    // K chunks 1 / 4 / 8 / 16 / 20 / 24 with the tile count that keeps two W buffers inside the LDS
+    {
+        int xmt = 0;
+        switch (KC) { case 1: xmt = 2; break; case 4: case 8: case 16: xmt = 4; break; case 20: xmt = 3; break; case 24: xmt = 2; break; default: break; }
+        // Opt-in (SONET_BF16_XREG=1; 2 = whenever the shape allows, for the tests): bit-identical to the streaming kernel but
+        // measured SLOWER on every first-PointNet shape (0.54 vs 0.46 ms on 320 -> 384 at B = 64): one wave per SIMD, and the
+        // 160 prefetch loads of the next tile pile up behind the 6-bit vmcnt during the last group.  Kept as the record of
+        // the experiment and as the skeleton of the fused bf16 kernel (pointresnet_bf16.hip), where X never comes from HBM.
+        const char *e = getenv("SONET_BF16_XREG");
+        const bool want = e && atoi(e) >= 1, force = e && atoi(e) == 2;
+        if (want && paired && xmt > 0 && CT % xmt == 0 && Cout <= 1024 && (nwg_x >= 512 || force) && (getenv("SONET_BF16_MT") == nullptr || force)) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            }
+            const int KC1x = C2 > 0 ? (C1 >> 4) : KC;
+            const int Gx = CT / xmt;
+            dim3 gridx((unsigned)(nwg_x < cus ? nwg_x : cus)), blockx(BF_THREADS);
+#define BFX_LAUNCH(KK, MM) hipLaunchKernelGGL((pointmlp_bf16_xreg_kernel<KK, MM>), gridx, blockx, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, \
+                                              Cout, L, gpc, ngroups, Gx, KC1x)
+            switch (KC) {
+                case 1: BFX_LAUNCH(1, 2); break;
+                case 4: BFX_LAUNCH(4, 4); break;
+                case 8: BFX_LAUNCH(8, 4); break;
+                case 16: BFX_LAUNCH(16, 4); break;
+                case 20: BFX_LAUNCH(20, 3); break;
+                default: BFX_LAUNCH(24, 2); break;
+            }
+#undef BFX_LAUNCH
+            return sonet::launched(what);
+        }
+    }
+    dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
 #define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, true>), BF_ARGS); } \

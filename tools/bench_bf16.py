@@ -36,6 +36,15 @@ def run(C1, C2, Cout, L, iters=20):
 shapes = [(6, 0, 64, 15000), (64, 0, 128, 15000), (128, 0, 256, 15000), (64, 256, 384, 15000), (384, 0, 512, 576), (512, 0, 512, 576),
           (512, 0, 768, 64), (768, 0, 1024, 64)]
 for C1, C2, Cout, L in shapes:
+    os.environ.pop("SONET_BF16_MT", None), os.environ.pop("SONET_BF16_S", None)
+    for xr in ("1", "0"):
+        os.environ["SONET_BF16_XREG"] = xr
+        ms, gbs, tf = run(C1, C2, Cout, L)
+        print("%4d+%-3d -> %-4d L=%-5d default XREG=%s  %.4f ms  %7.0f GB/s (%.2f of 8000)  %6.1f TF (%.3f of 2500)"
+              % (C1, C2, Cout, L, xr, ms, gbs, gbs / 8000, tf, tf / 2500), flush=True)
+    os.environ.pop("SONET_BF16_XREG")
+    if os.environ.get("SWEEP", "0") != "1":
+        continue
     CT = Cout // 32
     for mt in ("12", "6", "4", "2"):
         if CT % int(mt):
@@ -47,4 +56,4 @@ for C1, C2, Cout, L in shapes:
             ms, gbs, tf = run(C1, C2, Cout, L)
             print("%4d+%-3d -> %-4d L=%-5d MT=%-2s S=%s  %.4f ms  %7.0f GB/s (%.2f of 8000)  %6.1f TF (%.3f of 2500)"
                   % (C1, C2, Cout, L, mt, s, ms, gbs, gbs / 8000, tf, tf / 2500), flush=True)
-os.environ.pop("SONET_BF16_MT"), os.environ.pop("SONET_BF16_S")
+os.environ.pop("SONET_BF16_MT", None), os.environ.pop("SONET_BF16_S", None)
