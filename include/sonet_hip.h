@@ -240,6 +240,24 @@ int sonet_pointresnet_pack(const float *W1, const float *W2, const float *W3, co
 int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void *wstream, const float *affine,
                                 float *y, int B, int L, sonet_stream_t stream);
 
+/* bf16 twin of sonet_pointresnet_fused_f32 (BASELINE configs[1] "bf16"): one bf16 MFMA per product, activations rounded to
+ * bf16 between the layers (what the layer-wise sonet_pointmlp_bf16 launches would store), f32 accumulation; x [B][Cin0][L] f32
+ * -> y [B][384][L] bfloat16 bits.  wstream: sonet_pointresnet_bf16_pack_size() bytes from sonet_pointresnet_bf16_pack (the
+ * same four row-major f32 weights); affine as above (832 (scale, shift) pairs). */
+size_t sonet_pointresnet_bf16_pack_size(void);
+int sonet_pointresnet_bf16_pack(const float *W1, const float *W2, const float *W3, const float *W4, int Cin0,
+                                void *wstream, sonet_stream_t stream);
+int sonet_pointresnet_bf16(const float *x, int Cin0, const void *wstream, const float *affine,
+                           uint16_t *y, int B, int L, sonet_stream_t stream);
+
+/* ... and of sonet_pointresnet_fused_pool_f32 (same inputs from sonet_som_sort_group_f32, same workspace protocol with
+ * sonet_pointresnet_bf16_pool_ws_size bytes): out [B][384][M] f32 = per-node maximum of the bf16 features, i.e. exactly
+ * index_max_gather_bf16 of the tensor sonet_pointresnet_bf16 would write (bf16 rounding is monotone), which never reaches HBM. */
+size_t sonet_pointresnet_bf16_pool_ws_size(int B, int L, int M);
+int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream);
+
 /* Fused first PointNet + per-node max-pool (the no-grad classifier / autoencoder path): nothing of the 23 MB/cloud
  * first_pn_out reaches HBM.  Replaces models/networks.py:175-185 (PointResNet, index_max, masked gather) when only
  * first_pn_out_masked_max is needed.  Inputs come from sonet_som_sort_group_f32 (point copies sorted by node):

@@ -688,7 +688,7 @@ class PointResNet(nn.Module):
             return False
         # (the fused kernel computes in the fp16 split: "x3" must stay what the range guard falls back to -- f32 operand range
         #  end to end -- so it takes the four layer-wise launches)
-        if _ops.POINTMLP_PRECISION != "h3" or not _ops.FUSE_POINTRESNET or not x.is_cuda:
+        if _ops.POINTMLP_PRECISION not in ("h3", "bf16") or not _ops.FUSE_POINTRESNET or not x.is_cuda:
             return False
         if list(self.out_channels_list) != [64, 128, 256, 384] or x.shape[1] > 16:
             return False
@@ -698,10 +698,12 @@ class PointResNet(nn.Module):
 
     def _fused_state(self):
         ws = [l.conv.weight for l in self.layers]
-        key = tuple((w._version, w.data_ptr()) for w in ws) + (ws[0].device,)
+        bf16 = _ops.POINTMLP_PRECISION == "bf16"
+        key = tuple((w._version, w.data_ptr()) for w in ws) + (ws[0].device, bf16)
         if getattr(self, '_fused_key', None) != key:
             with torch.no_grad():
-                self._fused_w = _ops.pointresnet_pack(*[l._weight2d().detach().contiguous().float() for l in self.layers])
+                pack = _ops.pointresnet_bf16_pack if bf16 else _ops.pointresnet_pack
+                self._fused_w = pack(*[l._weight2d().detach().contiguous().float() for l in self.layers])
             self._fused_key = key
         aff = [l._eval_affine() for l in self.layers]                   # cached per layer
         akey = tuple(l._affine_gen for l in self.layers)                 # generation of each layer's folded (scale, shift)
@@ -729,7 +731,9 @@ class PointResNet(nn.Module):
     def forward(self, x, epoch=None):
         if self._fusable_eval(x):
             wstream, affine = self._fused_state()
-            return _ops.pointresnet_fused(_FusedPointwise._prep(x), wstream, affine)
+            if _ops.POINTMLP_PRECISION == "bf16":
+                return _ops.pointresnet_bf16(x.float().contiguous(), wstream, affine)
+            return _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine)
         n = len(self.out_channels_list)
         skip = self.layers[0](x, epoch)
         t = skip

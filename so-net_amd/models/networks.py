@@ -212,7 +212,8 @@ class Encoder(nn.Module):
             self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None, centers=None, x_decentered=None)
             self._first_pn_out = None                                    # lazy (property)
             wstream, affine = self.first_pointnet._fused_state()
-            self.first_pn_out_masked_max = _ops.pointresnet_fused_pool(g, wstream, affine, M)
+            pool = _ops.pointresnet_bf16_pool if _ops.POINTMLP_PRECISION == "bf16" else _ops.pointresnet_fused_pool
+            self.first_pn_out_masked_max = pool(g, wstream, affine, M)
         else:
             g = _ops.som_group(xd, snd, a, want_decentered=not use_sn, want_augmented=use_sn)            # :140-172
             sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes

@@ -51,6 +51,11 @@ SIGNATURES = {
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_h3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_h3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointresnet_bf16_pack_size": [],
+    "sonet_pointresnet_bf16_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "sonet_pointresnet_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "sonet_pointresnet_bf16_pool_ws_size": [_i, _i, _i],
+    "sonet_pointresnet_bf16_pool": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_pointresnet_pack_size": [],
     "sonet_pointresnet_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sonet_pointresnet_fused_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
@@ -77,6 +82,8 @@ _RESTYPES = {
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_bf16_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pack_size": ctypes.c_size_t,
+    "sonet_pointresnet_bf16_pack_size": ctypes.c_size_t,
+    "sonet_pointresnet_bf16_pool_ws_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
 }

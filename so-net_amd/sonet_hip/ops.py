@@ -662,6 +662,56 @@ def pointresnet_fused_pool(sg, wstream, affine, M):
     return out
 
 
+def pointresnet_bf16_pack(w1, w2, w3, w4):
+    """Weight stream of the fused bf16 first PointNet (``sonet_pointresnet_bf16_pack``)."""
+    for i, w in enumerate((w1, w2, w3, w4)):
+        _chk(w, "w%d" % (i + 1), torch.float32, 2)
+    if (w1.shape[0], tuple(w2.shape), tuple(w3.shape), tuple(w4.shape)) != (64, (128, 64), (256, 128), (384, 320)) or w1.shape[1] > 16:
+        raise SonetHipError("pointresnet_bf16 supports Cin0<=16 -> 64 -> 128 -> 256 -> [320] -> 384 only")
+    dev = _same_device(w1, w2, w3, w4)
+    lib = _lib.load()
+    ws = torch.empty((lib.sonet_pointresnet_bf16_pack_size(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.sonet_pointresnet_bf16_pack(ptr(w1), ptr(w2), ptr(w3), ptr(w4), w1.shape[1], ptr(ws), stream_ptr()),
+              "sonet_pointresnet_bf16_pack")
+    return ws
+
+
+def pointresnet_bf16(x, wstream, affine):
+    """x B x Cin0 x L f32 -> B x 384 x L bfloat16: whole first PointNet in bf16 (eval BN folded into ``affine`` 832 x 2)."""
+    _chk(x, "x", torch.float32, 3)
+    _chk(affine, "affine", torch.float32, 2)
+    if tuple(affine.shape) != (832, 2):
+        raise SonetHipError("affine must be 832 x 2 (scale, shift)")
+    dev = _same_device(x, wstream, affine)
+    B, Cin0, L = x.shape
+    y = torch.empty((B, 384, L), dtype=torch.bfloat16, device=dev)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(dev), _timed("pointresnet_bf16_L%d" % L):
+        check(_lib.load().sonet_pointresnet_bf16(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
+              "sonet_pointresnet_bf16")
+    return y
+
+
+def pointresnet_bf16_pool(sg, wstream, affine, M):
+    """bf16 first PointNet + per-node max-pool in one pass over node-sorted points (``sg`` = som_sort_group result)
+    -> B x 384 x M f32 holding bf16-representable values (the maxima of the bf16 features the store variant writes)."""
+    x_sorted = sg["x_aug_sorted"]
+    _chk(x_sorted, "x_sorted", torch.float32, 3)
+    _chk(affine, "affine", torch.float32, 2)
+    dev = _same_device(x_sorted, wstream, affine, sg["ids_sorted"], sg["pos0"], sg["node_off"], sg["count"])
+    B, Cin0, L = x_sorted.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.sonet_pointresnet_bf16_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("pointresnet_bf16_pool_L%d" % L):
+        check(lib.sonet_pointresnet_bf16_pool(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
+                                              ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
+              "sonet_pointresnet_bf16_pool")
+    return out
+
+
 def channel_stats(y):
     """per-channel (mean, biased var) over (B, L) of y B x C x L."""
     _chk(y, "y", torch.float32, 3)

@@ -139,6 +139,65 @@ def test_index_max_gather_bf16_same_input_bit_exact():
     np.testing.assert_array_equal(ops.index_max(data.to(DEV), index.to(DEV), K).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("B,Cin0,L", [(2, 6, 300), (3, 6, 15000), (1, 6, 1), (2, 3, 129), (1, 6, 257), (5, 6, 1024)])
+def test_pointresnet_bf16_fused_vs_layerwise(B, Cin0, L):
+    """One-kernel bf16 first PointNet == the four bf16 layer launches up to one bf16 unit in the last place on a few
+    elements (same operands and roundings; the chained channel order changes the summation order inside a K chunk)."""
+    from models import layers as Lm
+    from sonet_hip import ops, synth
+    pr = Lm.PointResNet(Cin0, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    x = torch.randn(B, Cin0, L, generator=torch.Generator().manual_seed(L)).to(DEV)
+    old = ops.FUSE_POINTRESNET
+    try:
+        with ops.precision("bf16"), torch.no_grad():
+            ops.FUSE_POINTRESNET = True
+            with ops.kernel_timing() as rec:
+                y_fused = pr(x)
+            assert any(n.startswith("pointresnet_bf16") for n, _, _ in rec.records), "fused bf16 kernel did not run"
+            ops.FUSE_POINTRESNET = False
+            y_layer = pr(x)
+    finally:
+        ops.FUSE_POINTRESNET = old
+    assert y_fused.dtype == torch.bfloat16 and y_layer.dtype == torch.bfloat16 and tuple(y_fused.shape) == (B, 384, L)
+    a, b = y_fused.float().cpu().double(), y_layer.float().cpu().double()
+    rms = float(b.pow(2).mean().sqrt())
+    err = (a - b).abs()
+    # a flipped bf16 rounding in a hidden layer moves an output by a few parts in a thousand of the output scale
+    assert bool((err <= 2.0 ** -7 * b.abs() + 2.0 ** -7 * rms).all()), "worst %.3g of rms" % float((err / rms).max())
+    assert float((a != b).double().mean()) < 0.25
+
+
+@pytest.mark.parametrize("B,N,M,k,kind", [(3, 5000, 64, 3, "som"), (2, 333, 64, 3, "uniform"), (2, 40, 64, 1, "uniform"), (1, 1, 64, 3, "uniform"),
+                                          (4, 700, 16, 2, "som"), (2, 2000, 100, 3, "uniform")])
+def test_pointresnet_bf16_pool_equals_store_plus_index_max(B, N, M, k, kind):
+    """Pool variant (nothing of first_pn_out reaches HBM) == index_max_gather_bf16 of what the store variant writes, bit for bit
+    (same MFMA order, bf16 rounding is monotone), including empty nodes (features of original copy 0)."""
+    from models import layers as Lm
+    from sonet_hip import ops, synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    inp = synth.make_inputs(B, N, M=M, som_k=min(9, M), seed=N + k, node_kind=kind)
+    x, sn = inp["pc"].to(DEV), inp["sn"].to(DEV)
+    a = ops.som_assign(x, inp["node"].to(DEV), k)
+    sg = ops.som_sort_group(x, sn, a)
+    with ops.precision("bf16"), torch.no_grad():
+        wstream, affine = pr._fused_state()
+        first_sorted = ops.pointresnet_bf16(sg["x_aug_sorted"], wstream, affine)         # bf16, node-sorted columns
+        got = ops.pointresnet_bf16_pool(sg, wstream, affine, M)
+    # reference semantics on the sorted tensor: positions are in sorted order, an empty node gathers ORIGINAL copy 0 = sorted pos0
+    idx, _ = ops.index_max_gather(first_sorted, sg["ids_sorted"], M, None)
+    val = torch.gather(first_sorted.float(), 2, idx.long())
+    beat = torch.gather(first_sorted.float(), 2, idx.long()) > -1000.0
+    occupied = (a.count > 0).unsqueeze(1)
+    copy0 = torch.gather(first_sorted.float(), 2, sg["pos0"].long().view(B, 1, 1).expand(B, 384, 1)).expand(B, 384, M)
+    exp = torch.where(occupied & beat, val, copy0)
+    assert tuple(got.shape) == (B, 384, M)
+    assert torch.equal(got, exp), "max |diff| %.3g at %d elements" % (float((got - exp).abs().max()), int((got != exp).sum()))
+
+
 def make_opt(g, B, N):
     return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True,
                      feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64,
@@ -167,6 +226,7 @@ def test_encoder_classifier_forward_bf16(case):
         score = cls(feat)
     names = [n for n, _, _ in rec.records]
     assert any(n.startswith("pointmlpbf16") for n in names) and not any(n.startswith(("pointmlph3", "pointmlpx3", "pointresnet_fused")) for n in names), names
+    assert any(n.startswith("pointresnet_bf16") for n in names), names
     np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), g["min_idx"])
     first = enc.first_pn_out
     assert first.dtype == torch.bfloat16

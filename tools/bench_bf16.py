@@ -33,6 +33,67 @@ def run(C1, C2, Cout, L, iters=20):
     return ms, byt / ms / 1e6, fl / ms / 1e9
 
 
+def run_fused(iters=20):
+    from models import layers as Lm
+    from sonet_hip import synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    x = torch.randn(B, 6, 15000, device=DEV)
+    with ops.precision("bf16"), torch.no_grad():
+        for _ in range(3):
+            pr(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            pr(x)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * (6 * 64 + 64 * 128 + 128 * 256 + 320 * 384) * B * 15000
+    print("fused bf16 first PointNet (store variant) B=%d L=15000: %.4f ms  %.1f TF (%.3f of 2500)  output %.0f GB/s"
+          % (B, ms, fl / ms / 1e9, fl / ms / 1e9 / 2500, B * 384 * 15000 * 2 / ms / 1e6), flush=True)
+
+
+def run_pool(iters=20):
+    from models import layers as Lm
+    from sonet_hip import synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    inp = synth.make_inputs(B, 5000, seed=1, device=DEV)
+    a = ops.som_assign(inp["pc"], inp["node"], 3)
+    sg = ops.som_sort_group(inp["pc"], inp["sn"], a)
+    with ops.precision("bf16"), torch.no_grad():
+        wstream, affine = pr._fused_state()
+        for _ in range(3):
+            ops.pointresnet_bf16_pool(sg, wstream, affine, 64)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.pointresnet_bf16_pool(sg, wstream, affine, 64)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * (6 * 64 + 64 * 128 + 128 * 256 + 320 * 384) * B * 15000
+    print("fused bf16 first PointNet + per-node max-pool B=%d L=15000: %.4f ms  %.1f TF (%.3f of 2500)" % (B, ms, fl / ms / 1e9, fl / ms / 1e9 / 2500), flush=True)
+
+
+run_pool()
+for a in os.environ.get("POOL_ABL", "").split():
+    os.environ["SONET_BF16_FUSED_ABLATE"] = a
+    print("  (ablate %s:)" % a, end=" ")
+    run_pool()
+os.environ.pop("SONET_BF16_FUSED_ABLATE", None)
+run_fused()
+os.environ["SONET_BF16_FUSED_ABLATE"] = "1"
+print("  (no stores:)", end=" ")
+run_fused()
+os.environ.pop("SONET_BF16_FUSED_ABLATE")
+if os.environ.get("LAYERS", "1") != "1":
+    sys.exit(0)
 shapes = [(6, 0, 64, 15000), (64, 0, 128, 15000), (128, 0, 256, 15000), (64, 256, 384, 15000), (384, 0, 512, 576), (512, 0, 512, 576),
           (512, 0, 768, 64), (768, 0, 1024, 64)]
 for C1, C2, Cout, L in shapes:
