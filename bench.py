@@ -231,7 +231,9 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "metric": "point-clouds/sec training step (forward+backward+all-reduce+Adam), ModelNet40 5k-pt 8x8 SOM",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (%s forward; backward GEMMs on PyTorch-ROCm)" % ops.POINTMLP_PRECISION, "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16 (bf16 storage of activations and gradients, one bf16 MFMA per product, f32 accumulate, f32 master weights; "
+                                       "wgrad: hipBLASLt bf16 -> f32)" if ops.POINTMLP_PRECISION == "bf16"
+                                       else "f32 (%s forward, x3 dgrad; wgrad GEMMs on hipBLASLt f32)" % ops.POINTMLP_PRECISION), "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
                                   % (world, nbytes, max(1, len(reducer.buckets)))},

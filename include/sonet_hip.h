@@ -277,6 +277,18 @@ int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min
                              float *x_aug_sorted, int32_t *ids_sorted, int32_t *pos0, int32_t *node_off,
                              int32_t *cursor_ws, sonet_stream_t stream);
 
+/* bf16 twins of the training-mode element-wise passes below (BASELINE configs[1]: bf16 forward + backward): tensors are
+ * bfloat16 bit patterns [B][C][L], the arithmetic is the f32 / f64 one of the *_f32 entry points on the widened values, results
+ * are rounded to nearest-even bf16.  sonet_channel_stats_bf16 = sonet_channel_stats_f32 (mean, biased variance, f64 sums). */
+int sonet_channel_stats_bf16(const uint16_t *y, int B, int C, int L, double *stat_ws, float *mean, float *var, sonet_stream_t stream);
+int sonet_channel_affine_act_out_bf16(const uint16_t *x, const float *scale, const float *shift, int relu, uint16_t *y,
+                                      int B, int C, int L, sonet_stream_t stream);
+int sonet_pointwise_bwd_stats_bf16(const uint16_t *gy, const uint16_t *raw, const float *scale, const float *shift,
+                                   int relu, int B, int C, int L, double *sums, sonet_stream_t stream);
+int sonet_pointwise_bwd_apply_bf16(const uint16_t *gy, const uint16_t *raw, const float *scale, const float *shift, int relu,
+                                   const float *a, const float *b, const float *c0, uint16_t *g_raw, int B, int C, int L,
+                                   sonet_stream_t stream);
+
 /* Backward of act(BN(W x + b)) around the GEMMs (training-mode models/layers.py:282-296, :60-70), two passes:
  *   stats: sums[c] = sum gy*mask, sums[C+c] = sum gy*mask*raw over (b, l), f64 (zeroed by the callee);
  *   apply: g_raw = a[c]*(gy*mask) + b[c]*raw + c0[c];
@@ -315,6 +327,11 @@ int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const floa
                            float *gw_partial, sonet_stream_t stream);
 int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                            int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
+/* bf16 training path: x read as bfloat16 bits (sonet_pooled_wgrad_xbf16), gradients written as bfloat16 bits (sonet_pooled_dgrad_obf16) */
+int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
+                             float *gw_partial, sonet_stream_t stream);
+int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                             int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream);
 
 /* Per-channel coefficients of training BatchNorm, forward (invstd = 1/sqrt(var+eps), scale = gamma*invstd,
  * shift = beta - mean*scale) and backward (from the two sums of sonet_pointwise_bwd_stats_f32, n = B*L:

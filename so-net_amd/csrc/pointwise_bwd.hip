@@ -164,7 +164,194 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double *__rest
     g_beta[c] = (float)s1;
 }
 
+// ---- bf16 twins of the element-wise passes (BASELINE configs[1]: bf16 training): same arithmetic in f32 / f64 on values
+// widened from bf16, results rounded to nearest-even bf16.  Two elements (one dword) per lane when the rows are dword aligned.
+__device__ __forceinline__ float bf_lo(unsigned d) { return __uint_as_float(d << 16); }
+__device__ __forceinline__ float bf_hi(unsigned d) { return __uint_as_float(d & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned bf_pack(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf_at(const uint16_t *p, long long i) { return __uint_as_float((unsigned)p[i] << 16); }
+
+// grid (chunks, C) as bwd_stats_kernel / channel_stats_kernel; raw == nullptr: plain statistics of gy (sum, sum of squares)
+template <bool PAIR>
+__global__ __launch_bounds__(BW_THREADS) void bwd_stats_bf16_kernel(const uint16_t *__restrict__ gy, const uint16_t *__restrict__ raw,
+                                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                     int relu, int B, int C, int L, double *__restrict__ ws)
+{
+    const int c = blockIdx.y;
+    constexpr int V = PAIR ? 2 : 1;
+    const int Lv = L / V;
+    const long long per_c = (long long)B * Lv;
+    const long long chunk = (per_c + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * chunk, end = min(per_c, beg + chunk);
+    const float sc = raw ? scale[c] : 0.f, sh = raw ? shift[c] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+    for (long long t = beg + threadIdx.x; t < end; t += BW_THREADS) {
+        const long long b = t / Lv;
+        const long long o = (b * C + c) * (long long)L + (t - b * Lv) * V;
+        float g[V], r[V];
+        if constexpr (PAIR) {
+            const unsigned dg = *reinterpret_cast<const unsigned *>(gy + o);
+            g[0] = bf_lo(dg); g[1] = bf_hi(dg);
+            if (raw) { const unsigned dr = *reinterpret_cast<const unsigned *>(raw + o); r[0] = bf_lo(dr); r[1] = bf_hi(dr); }
+        } else {
+            g[0] = bf_at(gy, o);
+            if (raw) r[0] = bf_at(raw, o);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (raw) {
+                float gv = g[v];
+                if (relu && !(__fmaf_rn(r[v], sc, sh) > 0.f)) gv = 0.f;
+                s1 += (double)gv;
+                s2 += (double)gv * (double)r[v];
+            } else {
+                s1 += (double)g[v];
+                s2 += (double)g[v] * (double)g[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    __shared__ double red[2][BW_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, a2 = 0.0;
+        for (int w = 0; w < BW_THREADS / 64; ++w) { a += red[0][w]; a2 += red[1][w]; }
+        unsafeAtomicAdd(&ws[c], a);
+        unsafeAtomicAdd(&ws[C + c], a2);
+    }
+}
+
+// one workgroup row = one (b, c) row.  MODE 0: out = act(x * scale + shift) (forward normalise + ReLU);
+// MODE 1: out = a * (gy * mask) + b * raw + c0 with mask from (raw, scale, shift) (backward apply).
+template <int MODE, bool PAIR>
+__global__ __launch_bounds__(256) void rowwise_bf16_kernel(const uint16_t *__restrict__ gy, const uint16_t *__restrict__ raw,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                            const float *__restrict__ ca, const float *__restrict__ cb,
+                                                            const float *__restrict__ cc, uint16_t *__restrict__ out, int C, int L)
+{
+    const long long row = blockIdx.x;
+    const int c = (int)(row % C);
+    const float sc = scale[c], sh = shift[c];
+    const float a = MODE == 1 ? ca[c] : 0.f, b = MODE == 1 ? cb[c] : 0.f, c0 = MODE == 1 ? cc[c] : 0.f;
+    const uint16_t *r = raw + row * L, *g = MODE == 1 ? gy + row * L : nullptr;
+    uint16_t *o = out + row * L;
+    auto f = [&](float rv, float gv) {
+        if constexpr (MODE == 0) {
+            float v = __fmaf_rn(rv, sc, sh);
+            if (relu) v = (v < 0.f) ? 0.f : v;
+            return v;
+        } else {
+            if (relu && !(__fmaf_rn(rv, sc, sh) > 0.f)) gv = 0.f;
+            return __fmaf_rn(a, gv, __fmaf_rn(b, rv, c0));
+        }
+    };
+    if constexpr (PAIR) {
+        const int Lv = L >> 1;
+        for (int t = blockIdx.y * 256 + threadIdx.x; t < Lv; t += gridDim.y * 256) {
+            const unsigned dr = reinterpret_cast<const unsigned *>(r)[t];
+            const unsigned dg = MODE == 1 ? reinterpret_cast<const unsigned *>(g)[t] : 0u;
+            reinterpret_cast<unsigned *>(o)[t] = bf_pack(f(bf_lo(dr), bf_lo(dg)), f(bf_hi(dr), bf_hi(dg)));
+        }
+    } else {
+        for (int t = blockIdx.y * 256 + threadIdx.x; t < L; t += gridDim.y * 256)
+            o[t] = (uint16_t)(bf_pack(f(bf_at(r, t), MODE == 1 ? bf_at(g, t) : 0.f), 0.f) & 0xFFFFu);
+    }
+}
+
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const double *__restrict__ ws, int C, double inv_n,
+                                                             float *__restrict__ mean, float *__restrict__ var)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double m = ws[c] * inv_n;
+    double v = ws[C + c] * inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+}
+
 }  // namespace
+
+static bool bf_pair_ok(int L, const void *p0, const void *p1, const void *p2)
+{
+    return (L % 2 == 0) && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 3) == 0;
+}
+
+// bf16 twins (raw bfloat16 bit patterns [B][C][L]); sums / coefficients stay f64 / f32 exactly as in the f32 entry points.
+// sonet_channel_stats_bf16: raw == NULL in the stats kernel -> (sum, sum of squares) -> mean, biased variance.
+extern "C" int sonet_pointwise_bwd_stats_bf16(const uint16_t *gy, const uint16_t *raw, const float *scale, const float *shift,
+                                              int relu, int B, int C, int L, double *sums, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointwise_bwd_stats_bf16";
+    SONET_REQUIRE(gy && raw && scale && shift && sums, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0 && C <= 65535, "%s: bad size", what);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(bwd_ws_zero_kernel, dim3(sonet::ceil_div(2 * C, 256)), dim3(256), 0, st, sums, 2 * C);
+    const long long per_c = (long long)B * L;
+    int chunks = (int)sonet::ceil_div64(per_c, 16384);
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    if (bf_pair_ok(L, gy, raw, nullptr)) hipLaunchKernelGGL(bwd_stats_bf16_kernel<true>, dim3(chunks, C), dim3(BW_THREADS), 0, st, gy, raw, scale, shift, relu, B, C, L, sums);
+    else hipLaunchKernelGGL(bwd_stats_bf16_kernel<false>, dim3(chunks, C), dim3(BW_THREADS), 0, st, gy, raw, scale, shift, relu, B, C, L, sums);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_channel_stats_bf16(const uint16_t *y, int B, int C, int L, double *sums, float *mean, float *var, sonet_stream_t stream)
+{
+    const char *what = "sonet_channel_stats_bf16";
+    SONET_REQUIRE(y && sums && mean && var, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0 && C <= 65535, "%s: bad size", what);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(bwd_ws_zero_kernel, dim3(sonet::ceil_div(2 * C, 256)), dim3(256), 0, st, sums, 2 * C);
+    const long long per_c = (long long)B * L;
+    int chunks = (int)sonet::ceil_div64(per_c, 16384);
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    if (bf_pair_ok(L, y, nullptr, nullptr)) hipLaunchKernelGGL(bwd_stats_bf16_kernel<true>, dim3(chunks, C), dim3(BW_THREADS), 0, st, y, (const uint16_t *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, B, C, L, sums);
+    else hipLaunchKernelGGL(bwd_stats_bf16_kernel<false>, dim3(chunks, C), dim3(BW_THREADS), 0, st, y, (const uint16_t *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, B, C, L, sums);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, st, sums, C, 1.0 / ((double)B * L), mean, var);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_pointwise_bwd_apply_bf16(const uint16_t *gy, const uint16_t *raw, const float *scale, const float *shift, int relu,
+                                              const float *a, const float *b, const float *c0, uint16_t *g_raw, int B, int C, int L,
+                                              sonet_stream_t stream)
+{
+    const char *what = "sonet_pointwise_bwd_apply_bf16";
+    SONET_REQUIRE(gy && raw && scale && shift && a && b && c0 && g_raw, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0, "%s: bad size", what);
+    const long long rows = (long long)B * C;
+    if (rows > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many rows", what);
+    int ysplit = sonet::ceil_div(L, 256 * 8);
+    ysplit = ysplit < 1 ? 1 : (ysplit > 16 ? 16 : ysplit);
+    dim3 grid((unsigned)rows, (unsigned)ysplit);
+    if (bf_pair_ok(L, gy, raw, g_raw)) hipLaunchKernelGGL((rowwise_bf16_kernel<1, true>), grid, dim3(256), 0, sonet::as_stream(stream), gy, raw, scale, shift, relu, a, b, c0, g_raw, C, L);
+    else hipLaunchKernelGGL((rowwise_bf16_kernel<1, false>), grid, dim3(256), 0, sonet::as_stream(stream), gy, raw, scale, shift, relu, a, b, c0, g_raw, C, L);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_channel_affine_act_out_bf16(const uint16_t *x, const float *scale, const float *shift, int relu, uint16_t *y,
+                                                 int B, int C, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_channel_affine_act_out_bf16";
+    SONET_REQUIRE(x && scale && shift && y, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && L > 0, "%s: bad size", what);
+    const long long rows = (long long)B * C;
+    if (rows > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many rows", what);
+    int ysplit = sonet::ceil_div(L, 256 * 8);
+    ysplit = ysplit < 1 ? 1 : (ysplit > 16 ? 16 : ysplit);
+    dim3 grid((unsigned)rows, (unsigned)ysplit);
+    if (bf_pair_ok(L, x, y, nullptr)) hipLaunchKernelGGL((rowwise_bf16_kernel<0, true>), grid, dim3(256), 0, sonet::as_stream(stream), (const uint16_t *)nullptr, x, scale, shift, relu, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, y, C, L);
+    else hipLaunchKernelGGL((rowwise_bf16_kernel<0, false>), grid, dim3(256), 0, sonet::as_stream(stream), (const uint16_t *)nullptr, x, scale, shift, relu, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, y, C, L);
+    return sonet::launched(what);
+}
 
 extern "C" int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, const float *gamma, const float *beta, float eps, int C,
                                        float *invstd, float *scale, float *shift, sonet_stream_t stream)
@@ -306,10 +493,17 @@ __global__ __launch_bounds__(256) void pooled_bucket_kernel(const int32_t *__res
     }
 }
 
+__device__ __forceinline__ void pd_store(float *p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void pd_store(uint16_t *p, size_t i, float v) {     // bfloat16, round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(v));
+    p[i] = (uint16_t)(r & 0xFFFFu);
+}
+template <typename TO>
 __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
                                                            const float *__restrict__ ent_val, const float *__restrict__ W,
                                                            int E, int M, int Cin, int C1, int L, int ntile,
-                                                           float *__restrict__ gx1, float *__restrict__ gx2)
+                                                           TO *__restrict__ gx1, TO *__restrict__ gx2)
 {
     extern __shared__ float sm_f[];              // acc[PD_TL][Cin + 1] | keys[PD_SORT] | vals[PD_SORT]
     const int ld = Cin + 1;
@@ -390,8 +584,8 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
         const int i = idx / PD_TL, col = idx - i * PD_TL;
         if (l0 + col >= L) continue;
         const float v = acc[col * ld + i];
-        if (i < C1) gx1[((size_t)b * C1 + i) * L + l0 + col] = v;
-        else gx2[((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col] = v;
+        if (i < C1) pd_store(gx1, ((size_t)b * C1 + i) * L + l0 + col, v);
+        else pd_store(gx2, ((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col, v);
     }
 }
 
@@ -414,8 +608,9 @@ extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
 constexpr int PW_R = 2;                                      // x rows resident in LDS at a time
 constexpr int PW_G = 8;                                      // row pairs per workgroup (the entries are loaded once for all of them)
 constexpr int PW_M = 64;                                     // entries per output channel kept in registers (M <= PW_M)
+template <typename TX>
 __global__ __launch_bounds__(384) void pooled_wgrad_kernel(const float *__restrict__ g, const int32_t *__restrict__ pos,
-                                                            const float *__restrict__ x, int C, int M, int Ci, int L,
+                                                            const TX *__restrict__ x, int C, int M, int Ci, int L,
                                                             float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];           // [PW_R][L]
@@ -435,14 +630,27 @@ __global__ __launch_bounds__(384) void pooled_wgrad_kernel(const float *__restri
         const int ci0 = (blockIdx.x * PW_G + gi) * PW_R;
         if (ci0 >= Ci) break;
         const int nr = min(PW_R, Ci - ci0);
-        const float *xb = x + ((size_t)b * Ci + ci0) * L;
+        const TX *xb = x + ((size_t)b * Ci + ci0) * L;
         __syncthreads();                                                  // the previous pair has been consumed
-        if ((L & 3) == 0 && ((size_t)xb & 15) == 0) {
-            const float4 *x4 = reinterpret_cast<const float4 *>(xb);
-            float4 *r4 = reinterpret_cast<float4 *>(rows);
-            for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) r4[i] = x4[i];
-        } else {
-            for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = xb[i];
+        if constexpr (sizeof(TX) == 4) {
+            if ((L & 3) == 0 && ((size_t)xb & 15) == 0) {
+                const float4 *x4 = reinterpret_cast<const float4 *>(xb);
+                float4 *r4 = reinterpret_cast<float4 *>(rows);
+                for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) r4[i] = x4[i];
+            } else {
+                for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = (float)xb[i];
+            }
+        } else {                                                          // bfloat16 rows: widened on the way into LDS
+            if ((L & 3) == 0 && ((size_t)xb & 7) == 0) {
+                const uint2 *x2 = reinterpret_cast<const uint2 *>(xb);
+                float4 *r4 = reinterpret_cast<float4 *>(rows);
+                for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) {
+                    const uint2 d = x2[i];
+                    r4[i] = make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xFFFF0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xFFFF0000u));
+                }
+            } else {
+                for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = __uint_as_float((unsigned)xb[i] << 16);
+            }
         }
         __syncthreads();
         if (c < C) {
@@ -461,26 +669,39 @@ __global__ __launch_bounds__(384) void pooled_wgrad_kernel(const float *__restri
     }
 }
 
-extern "C" int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
-                                      float *gw_partial, sonet_stream_t stream)
+template <typename TX>
+static int pooled_wgrad_impl(const char *what, const float *g_pooled, const int32_t *pos, const TX *x, int B, int C, int M, int Ci, int L,
+                             float *gw_partial, sonet_stream_t stream)
 {
-    const char *what = "sonet_pooled_wgrad_f32";
     SONET_REQUIRE(g_pooled && pos && x && gw_partial, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && Ci > 0 && L > 0 && B <= 65535, "%s: bad size B=%d C=%d M=%d Ci=%d L=%d", what, B, C, M, Ci, L);
     if (C > 384 || M > PW_M) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d > 384 or M=%d > %d", what, C, M, PW_M);
     const size_t lds = (size_t)PW_R * L * sizeof(float);
     if (lds > 152 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d rows do not fit LDS", what, L);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel<TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
-    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(384), lds, sonet::as_stream(stream),
+    hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(384), lds, sonet::as_stream(stream),
                        g_pooled, pos, x, C, M, Ci, L, gw_partial);
     return sonet::launched(what);
 }
 
-extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
-                                      int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream)
+extern "C" int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
+                                      float *gw_partial, sonet_stream_t stream)
 {
-    const char *what = "sonet_pooled_dgrad_f32";
+    return pooled_wgrad_impl<float>("sonet_pooled_wgrad_f32", g_pooled, pos, x, B, C, M, Ci, L, gw_partial, stream);
+}
+
+/* x as bfloat16 bit patterns (the bf16 training path keeps its activations in bf16); everything else as above */
+extern "C" int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
+                                        float *gw_partial, sonet_stream_t stream)
+{
+    return pooled_wgrad_impl<uint16_t>("sonet_pooled_wgrad_xbf16", g_pooled, pos, x, B, C, M, Ci, L, gw_partial, stream);
+}
+
+template <typename TO>
+static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                             int L, void *ws, TO *gx1, TO *gx2, sonet_stream_t stream)
+{
     SONET_REQUIRE(g_pooled && pos && W && ws && gx1, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
@@ -494,9 +715,22 @@ extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos,
     int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
     hipStream_t st = sonet::as_stream(stream);
     hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(256), (size_t)(2 * ntile + 1) * 4, st, pos, g_pooled, E, L, ntile, tile_off, ent_key, ent_val);
-    hipLaunchKernelGGL(pooled_dgrad_kernel, dim3(ntile, B), dim3(320), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1, L, ntile, gx1,
+    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B), dim3(320), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1, L, ntile, gx1,
                        gx2 ? gx2 : gx1);
     return sonet::launched(what);
+}
+
+extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                      int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream)
+{
+    return pooled_dgrad_impl<float>("sonet_pooled_dgrad_f32", g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream);
+}
+
+/* gradients written as bfloat16 bit patterns (f32 accumulation in LDS as above, one rounding on the store) */
+extern "C" int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                        int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream)
+{
+    return pooled_dgrad_impl<uint16_t>("sonet_pooled_dgrad_obf16", g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream);
 }
 
 // ---- small-batch fully connected layer (classifier / decoder heads in eval mode) --------------------------------------

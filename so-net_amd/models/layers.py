@@ -88,6 +88,7 @@ def _pack_transposed(weight2d, C1, C2):
     mode = _ops.POINTMLP_PRECISION
     if mode == "h3":
         mode = "x3"                                   # gradients span the f32 exponent range: bf16 pieces, not fp16
+    # ("bf16": gradients in bf16 storage too -- same exponent range as f32 -- on one bf16 MFMA per product)
     out = []
     lo = 0
     for Ci in (C1, C2):
@@ -113,8 +114,23 @@ def _pack_transposed(weight2d, C1, C2):
 def _dgrad(g_raw, pack):
     """W^T . g_raw through the fused 1x1-conv kernel (pack from _pack_transposed)."""
     wpt, Ci, Cp = pack
+    want = torch.bfloat16 if wpt.dtype == torch.int16 else torch.float32
+    if g_raw.dtype != want:
+        g_raw = g_raw.to(want)
     y = _ops.pointmlp(g_raw, wpt, _ops.const_vec(Cp, 1.0, g_raw.device), _ops.const_vec(Cp, 0.0, g_raw.device), False, Cp)
     return y if Cp == Ci else y[:, :Ci]
+
+
+def _wgrad(g_raw, x):
+    """sum over clouds of g_raw[b] . x[b]^T  (Cout x Ci, f32).  One batched GEMM (hipBLASLt; K = L is the long axis); bf16
+    operands accumulate and come out in f32 (a bf16 per-cloud partial would cost three of the eight significand bits)."""
+    if g_raw.dtype == torch.bfloat16:
+        xt = x.transpose(1, 2)
+        try:
+            return torch.bmm(g_raw, xt, out_dtype=torch.float32).sum(0)
+        except (TypeError, RuntimeError):
+            return torch.bmm(g_raw.float(), xt.float()).sum(0)
+    return torch.bmm(g_raw, x.transpose(1, 2)).sum(0)
 
 
 class _PointwiseFn(torch.autograd.Function):
@@ -174,9 +190,9 @@ class _PointwiseFn(torch.autograd.Function):
             g_bias = zeros.clone()                                        # a bias in front of BatchNorm has no gradient
         g_w = None
         if ctx.needs_input_grad[2]:
-            parts = [torch.bmm(g_raw, x1.transpose(1, 2)).sum(0)]
+            parts = [_wgrad(g_raw, x1)]
             if ctx.has_x2:
-                parts.append(torch.bmm(g_raw, x2.transpose(1, 2)).sum(0))
+                parts.append(_wgrad(g_raw, x2))
             g_w = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
         g_x1 = g_x2 = None
         need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
@@ -228,22 +244,24 @@ class _PooledLastLayerFn(torch.autograd.Function):
         if not sparse:
             G = g_y.contiguous().clone() if g_mm is not None else g_y.contiguous()
             if g_mm is not None:
-                G.scatter_add_(2, gi.long(), g_mm)                        # the gather's backward (duplicates accumulate)
+                G.scatter_add_(2, gi.long(), g_mm.to(G.dtype))            # the gather's backward (duplicates accumulate)
         g_bias = None
         if ctx.needs_input_grad[3]:
             # sparse: the gradient of first_pn_out is the scatter of g_mm and nothing else (never built): its sum is the sum of g_mm
-            g_bias = g_mm.sum(dim=(0, 2)) if sparse else G.sum(dim=(0, 2))
+            g_bias = g_mm.float().sum(dim=(0, 2)) if sparse else G.float().sum(dim=(0, 2))
         g_w = None
         if ctx.needs_input_grad[2]:
+            if g_mm is not None and g_mm.dtype != torch.float32:
+                g_mm = g_mm.float()
             if sparse and g_mm.shape[1] <= 384 and g_mm.shape[2] <= 64 and L * 8 <= 152 * 1024:
                 # 24,576 entries per cloud instead of a dense GEMM over kN columns (the kernel's limits: C, M, two rows in LDS)
                 g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()     # B x M x C: coalesced entry loads
                 g_w = torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1), _ops.pooled_wgrad(g_t, gi_t, x2)), dim=1)
             else:
                 if G is None:
-                    G = torch.zeros((B, weight2d.shape[0], L), dtype=torch.float32, device=x1.device)
-                    G.scatter_add_(2, gi.long(), g_mm)
-                g_w = torch.cat((torch.bmm(G, x1.transpose(1, 2)).sum(0), torch.bmm(G, x2.transpose(1, 2)).sum(0)), dim=1)
+                    G = torch.zeros((B, weight2d.shape[0], L), dtype=x1.dtype, device=x1.device)
+                    G.scatter_add_(2, gi.long(), g_mm.to(x1.dtype))
+                g_w = torch.cat((_wgrad(G, x1), _wgrad(G, x2)), dim=1)
         g_x1 = g_x2 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if sparse:
@@ -251,10 +269,10 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 # column 0 (left in the sparse kernel they would pile thousands of entries onto a single tile)
                 w = weight2d.detach().float().contiguous()
                 occ = row_max.unsqueeze(1) > 0
-                g_x1, g_x2 = _ops.pooled_dgrad(g_mm, torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L)
-                col0 = torch.matmul((g_mm * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
-                g_x1[:, :, 0] += col0[:, :C1]
-                g_x2[:, :, 0] += col0[:, C1:]
+                g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype)
+                col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
+                g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
+                g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)
             else:
                 packs = _pack_transposed(weight2d.detach(), C1, C2)
                 outs = []
@@ -283,8 +301,6 @@ class _FusedPointwise(nn.Module):
         mode = _ops.POINTMLP_PRECISION
         if mode in ("x3", "h3", "bf16") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
             mode = "f32"
-        if mode == "bf16" and (torch.is_grad_enabled() or (self.normalization == 'batch' and self.norm.training)):
-            mode = "x3"                      # bf16 storage is the no-grad / eval arithmetic; autograd keeps the f32-class kernels
         key = (w._version, w.data_ptr(), w.device, mode)
         if getattr(self, '_wp_key', None) != key:
             with torch.no_grad():

@@ -251,6 +251,8 @@ class Encoder(nn.Module):
             self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)     # :197; amax would split the gradient over ties
         else:
             self.feature = _ops.lastdim_max(self.final_pn_out.contiguous())
+        if self.feature.dtype != torch.float32:
+            self.feature = self.feature.float()                                       # bf16 storage ends here: the heads' FC layers are f32
         return self.feature
 
 

@@ -67,11 +67,17 @@ SIGNATURES = {
     "sonet_node_add_affine_act_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sonet_linear_act_f32": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pooled_dgrad_ws_size": [_i, _i, _i, _i],
+    "sonet_pooled_wgrad_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "sonet_pooled_dgrad_obf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_channel_stats_bf16": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_channel_affine_act_out_bf16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointwise_bwd_stats_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "sonet_pointwise_bwd_apply_bf16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
 }

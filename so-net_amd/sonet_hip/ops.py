@@ -713,16 +713,19 @@ def pointresnet_bf16_pool(sg, wstream, affine, M):
 
 
 def channel_stats(y):
-    """per-channel (mean, biased var) over (B, L) of y B x C x L."""
-    _chk(y, "y", torch.float32, 3)
+    """per-channel (mean, biased var) over (B, L) of y B x C x L (f32 or bf16 storage; f64 sums either way)."""
+    _chk(y, "y", dim=3)
+    if y.dtype not in (torch.float32, torch.bfloat16):
+        raise SonetHipError("channel_stats: float32 or bfloat16, got %s" % y.dtype)
     dev = _same_device(y)
     B, C, L = y.shape
     ws = torch.empty((2 * C,), dtype=torch.float64, device=dev)
     mean = torch.empty((C,), dtype=torch.float32, device=dev)
     var = torch.empty((C,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("channel_stats"):
-        check(_lib.load().sonet_channel_stats_f32(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()),
-              "sonet_channel_stats_f32")
+    lib = _lib.load()
+    fn = lib.sonet_channel_stats_f32 if y.dtype == torch.float32 else lib.sonet_channel_stats_bf16
+    with torch.cuda.device(dev), _timed("channel_stats" if y.dtype == torch.float32 else "channel_stats_bf16"):
+        check(fn(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_channel_stats")
     return mean, var
 
 
@@ -737,14 +740,15 @@ def channel_affine_act_(y, scale, shift, relu):
 
 
 def channel_affine_act(x, scale, shift, relu):
-    """y = act(x * scale[c] + shift[c]) out of place, x B x C x L."""
-    _chk(x, "x", torch.float32, 3)
+    """y = act(x * scale[c] + shift[c]) out of place, x B x C x L (f32 or bf16 storage)."""
+    _chk(x, "x", dim=3)
     dev = _same_device(x, scale, shift)
     B, C, L = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(dev), _timed("channel_affine_act"):
-        check(_lib.load().sonet_channel_affine_act_out_f32(ptr(x), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, C, L, stream_ptr()),
-              "sonet_channel_affine_act_out_f32")
+    lib = _lib.load()
+    fn = lib.sonet_channel_affine_act_out_f32 if x.dtype == torch.float32 else lib.sonet_channel_affine_act_out_bf16
+    with torch.cuda.device(dev), _timed("channel_affine_act" if x.dtype == torch.float32 else "channel_affine_act_bf16"):
+        check(fn(ptr(x), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, C, L, stream_ptr()), "sonet_channel_affine_act_out")
     return y
 
 
@@ -786,14 +790,15 @@ def bn_bwd_coeffs(sums, mean, invstd, gamma, n):
 
 def pointwise_bwd_stats(gy, raw, scale, shift, relu, want_sums=False):
     """-> (s1, s2) float64 [C]: sum gy*mask, sum gy*mask*raw over (b, l); mask = (raw*scale+shift > 0) if relu."""
-    _chk(gy, "gy", torch.float32, 3)
-    _chk(raw, "raw", torch.float32, 3)
+    _chk(gy, "gy", dim=3)
+    _chk(raw, "raw", gy.dtype, 3)
     dev = _same_device(gy, raw, scale, shift)
     B, C, L = gy.shape
     sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev), _timed("pointwise_bwd_stats"):
-        check(_lib.load().sonet_pointwise_bwd_stats_f32(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), B, C, L,
-                                                        ptr(sums), stream_ptr()), "sonet_pointwise_bwd_stats_f32")
+    lib = _lib.load()
+    fn = lib.sonet_pointwise_bwd_stats_f32 if gy.dtype == torch.float32 else lib.sonet_pointwise_bwd_stats_bf16
+    with torch.cuda.device(dev), _timed("pointwise_bwd_stats" if gy.dtype == torch.float32 else "pointwise_bwd_stats_bf16"):
+        check(fn(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), B, C, L, ptr(sums), stream_ptr()), "sonet_pointwise_bwd_stats")
     if want_sums:
         return sums
     return sums[:C], sums[C:]
@@ -801,18 +806,20 @@ def pointwise_bwd_stats(gy, raw, scale, shift, relu, want_sums=False):
 
 def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     """g_raw = a[c] * (gy * mask) + b[c] * raw + c0[c]."""
-    _chk(gy, "gy", torch.float32, 3)
-    _chk(raw, "raw", torch.float32, 3)
+    _chk(gy, "gy", dim=3)
+    _chk(raw, "raw", gy.dtype, 3)
     dev = _same_device(gy, raw, scale, shift, a, b, c0)
     B, C, L = gy.shape
     out = torch.empty_like(gy)
-    with torch.cuda.device(dev), _timed("pointwise_bwd_apply"):
-        check(_lib.load().sonet_pointwise_bwd_apply_f32(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), ptr(a), ptr(b),
-                                                        ptr(c0), ptr(out), B, C, L, stream_ptr()), "sonet_pointwise_bwd_apply_f32")
+    lib = _lib.load()
+    fn = lib.sonet_pointwise_bwd_apply_f32 if gy.dtype == torch.float32 else lib.sonet_pointwise_bwd_apply_bf16
+    with torch.cuda.device(dev), _timed("pointwise_bwd_apply" if gy.dtype == torch.float32 else "pointwise_bwd_apply_bf16"):
+        check(fn(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), ptr(a), ptr(b), ptr(c0), ptr(out), B, C, L, stream_ptr()),
+              "sonet_pointwise_bwd_apply")
     return out
 
 
-def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L):
+def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32):
     """Sparse W^T . g for a gradient that exists only at the pooled positions: g_pooled, pos B x C x M -> (gx1 B x C1 x L, gx2 B x C2 x L)."""
     _chk(g_pooled, "g_pooled", torch.float32, 3)
     _chk(pos_i32, "pos", torch.int32, 3)
@@ -821,11 +828,12 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L):
     B, C, M = g_pooled.shape
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pooled_dgrad_ws_size(B, C, M, int(L)),), dtype=torch.uint8, device=dev)
-    gx1 = torch.empty((B, C1, int(L)), dtype=torch.float32, device=dev)
-    gx2 = torch.empty((B, C2, int(L)), dtype=torch.float32, device=dev) if C2 else None
+    gx1 = torch.empty((B, C1, int(L)), dtype=out_dtype, device=dev)
+    gx2 = torch.empty((B, C2, int(L)), dtype=out_dtype, device=dev) if C2 else None
+    fn = lib.sonet_pooled_dgrad_f32 if out_dtype == torch.float32 else lib.sonet_pooled_dgrad_obf16
     with torch.cuda.device(dev), _timed("pooled_dgrad"):
-        check(lib.sonet_pooled_dgrad_f32(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2),
-                                         stream_ptr()), "sonet_pooled_dgrad_f32")
+        check(fn(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2), stream_ptr()),
+              "sonet_pooled_dgrad")
     return gx1, gx2
 
 
@@ -834,14 +842,15 @@ def pooled_wgrad(g_pooled_t, pos_i32_t, x):
     (= sum over clouds and entries of g * x[:, pos]; per-cloud partials summed in a fixed order)."""
     _chk(g_pooled_t, "g_pooled_t", torch.float32, 3)
     _chk(pos_i32_t, "pos_t", torch.int32, 3)
-    _chk(x, "x", torch.float32, 3)
+    _chk(x, "x", dim=3)
     dev = _same_device(g_pooled_t, pos_i32_t, x)
     B, M, C = g_pooled_t.shape
     Ci, L = x.shape[1], x.shape[2]
     part = torch.empty((B, C, Ci), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    fn = lib.sonet_pooled_wgrad_f32 if x.dtype == torch.float32 else lib.sonet_pooled_wgrad_xbf16
     with torch.cuda.device(dev), _timed("pooled_wgrad"):
-        check(_lib.load().sonet_pooled_wgrad_f32(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()),
-              "sonet_pooled_wgrad_f32")
+        check(fn(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()), "sonet_pooled_wgrad")
     return part.sum(0)
 
 

@@ -257,3 +257,92 @@ def test_encoder_classifier_forward_bf16(case):
     top2 = ref_score.topk(2, dim=1)[0]
     clear = (top2[:, 0] - top2[:, 1]) > 0.05 * ref_score.abs().max()
     assert bool((score.cpu().argmax(1) == ref_score.argmax(1))[clear].all())
+
+
+# ------------------------------------------------------------------------------------------ bf16 training (configs[1]: forward + backward)
+def test_bf16_layer_backward_vs_float64():
+    """Training-mode layer (bf16 conv -> batch statistics -> normalise + ReLU) forward and backward in bf16 storage against
+    float64 autograd of the same math on the same bf16-rounded inputs: bf16 tolerance (2e-2 of the tensor's rms)."""
+    from models import layers as Lm
+    from sonet_hip import ops, synth
+    layer = Lm.EquivariantLayer(64, 128, "relu", "batch", 0.1)
+    synth.fill_state_dict_(layer.state_dict(), 5)
+    layer.to(DEV).train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 64, 2000, generator=g).to(torch.bfloat16)
+    gy = torch.randn(6, 128, 2000, generator=g).to(torch.bfloat16)
+    xd = x.to(DEV).requires_grad_(True)
+    with ops.precision("bf16"), ops.kernel_timing() as rec:
+        y = layer(xd)
+        y.backward(gy.to(DEV))
+    names = [n for n, _, _ in rec.records]
+    assert y.dtype == torch.bfloat16 and xd.grad.dtype == torch.bfloat16
+    assert any(n.startswith("pointmlpbf16") for n in names) and "pointwise_bwd_apply_bf16" in names and "channel_stats_bf16" in names, names
+    # float64 reference
+    W = layer.conv.weight.detach().cpu().double()[:, :, 0].to(torch.bfloat16).double().requires_grad_(True)
+    b64 = layer.conv.bias.detach().cpu().double().requires_grad_(True)
+    gam, bet = layer.norm.weight.detach().cpu().double().requires_grad_(True), layer.norm.bias.detach().cpu().double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    raw = torch.einsum("oc,bcl->bol", W, x64) + b64.view(1, -1, 1)
+    mean, var = raw.mean(dim=(0, 2), keepdim=True), raw.var(dim=(0, 2), unbiased=False, keepdim=True)
+    y64 = torch.relu((raw - mean) / torch.sqrt(var + layer.norm.eps) * gam.view(1, -1, 1) + bet.view(1, -1, 1))
+    y64.backward(gy.double())
+
+    def rel(a, r):
+        a, r = a.detach().cpu().double(), r.detach().double()
+        return float((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt())
+
+    errs = dict(y=rel(y, y64), gx=rel(xd.grad, x64.grad), gw=rel(layer.conv.weight.grad[:, :, 0], W.grad),
+                ggamma=rel(layer.norm.weight.grad, gam.grad), gbeta=rel(layer.norm.bias.grad, bet.grad))
+    print("bf16 layer fwd/bwd rel-rms errors:", {k: "%.2e" % v for k, v in errs.items()})
+    assert all(v < 2e-2 for v in errs.values()), errs
+
+
+def test_classifier_training_step_bf16():
+    """One training step of the classifier in bf16 storage (configs[1] shape family) vs the reference's float64 run of the same
+    step: loss and feature at bf16 tolerance, gradients aligned with the float64 ones (cosine), running statistics updated."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    g = golden("train_step_b16_n512")
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(cls.state_dict(), seed + 1)
+    enc.to(DEV).train()
+    cls.to(DEV).train()
+    with ops.precision("bf16"), ops.kernel_timing() as rec:
+        feat = enc(cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]), is_train=True, epoch=0)
+        score = cls(feat, 0)
+        loss = torch.nn.functional.cross_entropy(score, cu(g["label"]))
+        loss.backward()
+    names = set(n for n, _, _ in rec.records)
+    assert any(n.startswith("pointmlpbf16") for n in names) and not any(n.startswith(("pointmlph3", "pointmlpx3")) for n in names), names
+    assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad", "pooled_wgrad",
+            "index_max_gather_bf16"} <= names, names
+    # train-mode BatchNorm divides by batch statistics of bf16-rounded activations and the feature passes three max-pools whose
+    # winners may change: bound the rms error (2e-2) and the worst element (1.5e-1 of max(|ref|, rms))
+    f_got, f_ref = feat.detach().cpu().double().numpy(), g["feature"].astype(np.float64)
+    f_rel = float(np.sqrt(np.mean((f_got - f_ref) ** 2)) / np.sqrt(np.mean(f_ref ** 2)))
+    print("bf16 training forward: feature rel-rms error %.2e" % f_rel)
+    assert f_rel < 2e-2
+    assert_close_rms(f_got, f_ref, 1.5e-1, "train feature (bf16)")
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 3e-2 * max(1.0, abs(float(g["loss"])))
+    params = dict(enc.named_parameters())
+    worst = 1.0
+    for k in [k[7:] for k in g.files if k.startswith("grad64/") and not k.startswith("grad64/cls.")]:
+        truth = g["grad64/" + k].astype(np.float64)
+        if np.sqrt(np.mean(truth ** 2)) < 1e-5 or not k.endswith("conv.weight"):
+            continue
+        f = params[k].grad.detach().flatten()
+        mine = f[::max(1, f.numel() // 16384)].cpu().numpy().astype(np.float64)
+        cos = float(np.dot(mine, truth) / (np.linalg.norm(mine) * np.linalg.norm(truth)))
+        worst = min(worst, cos)
+        assert cos > 0.97, (k, cos)
+    print("bf16 training step: worst gradient cosine vs float64 reference %.4f" % worst)
+    assert sum(1 for p in enc.parameters() if p.grad is None) == int(g["dead_grad_count"])
+    sd = enc.state_dict()
+    for k in [k[3:] for k in g.files if k.startswith("bn/")]:
+        assert_close_rms(sd[k].cpu().numpy(), g["bn/" + k], 1.5e-1, "running stat " + k)
