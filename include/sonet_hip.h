@@ -365,6 +365,12 @@ int sonet_channel_affine_act_f32(float *y, const float *scale, const float *shif
  * ---------------------------------------------------------------------------------------------- */
 int sonet_chamfer_nn_f32(const float *q, const float *db, int32_t *nn, int B, int Nq, int Nd,
                          sonet_stream_t stream);
+/* Both directions of models/losses.py:255,262 from ONE sweep of the Na x Nb distance matrix: nn_ab[b][i] = nearest point of
+ * cloud b for a_i, nn_ba[b][j] = nearest point of cloud a for b_j (same arithmetic, ties -> lowest index: bit-identical to two
+ * sonet_chamfer_nn_f32 calls).  ws: sonet_chamfer_nn2_ws_size bytes (64-bit (distance, index) keys of the column minima). */
+size_t sonet_chamfer_nn2_ws_size(int B, int Na, int Nb);
+int sonet_chamfer_nn2_f32(const float *a, const float *b, int32_t *nn_ab, int32_t *nn_ba, void *ws, int B, int Na, int Nb,
+                          sonet_stream_t stream);
 
 #ifdef __cplusplus
 }

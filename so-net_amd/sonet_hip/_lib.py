@@ -80,6 +80,8 @@ SIGNATURES = {
     "sonet_pointwise_bwd_apply_bf16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_chamfer_nn2_ws_size": [_i, _i, _i],
+    "sonet_chamfer_nn2_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
 _RESTYPES = {
     "sonet_build_arch": ctypes.c_char_p,
@@ -92,6 +94,7 @@ _RESTYPES = {
     "sonet_pointresnet_bf16_pool_ws_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
+    "sonet_chamfer_nn2_ws_size": ctypes.c_size_t,
 }
 
 _lib = None

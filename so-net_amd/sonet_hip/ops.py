@@ -881,6 +881,25 @@ def chamfer_nn(q, db):
     return nn
 
 
+def chamfer_nn2(a, b):
+    """a B x 3 x Na, b B x 3 x Nb -> (nn_ab B x Na, nn_ba B x Nb) i32: both nearest-neighbour directions of the Chamfer loss from
+    one sweep of the distance matrix (``sonet_chamfer_nn2_f32``)."""
+    _chk(a, "a", torch.float32, 3)
+    _chk(b, "b", torch.float32, 3)
+    dev = _same_device(a, b)
+    B, _, Na = a.shape
+    Nb = b.shape[2]
+    if a.shape[1] != 3 or b.shape[1] != 3 or b.shape[0] != B:
+        raise SonetHipError("chamfer_nn2: clouds must be B x 3 x N")
+    lib = _lib.load()
+    nn_ab = torch.empty((B, Na), dtype=torch.int32, device=dev)
+    nn_ba = torch.empty((B, Nb), dtype=torch.int32, device=dev)
+    ws = torch.empty((lib.sonet_chamfer_nn2_ws_size(B, Na, Nb),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("chamfer_nn2"):
+        check(lib.sonet_chamfer_nn2_f32(ptr(a), ptr(b), ptr(nn_ab), ptr(nn_ba), ptr(ws), B, Na, Nb, stream_ptr()), "sonet_chamfer_nn2_f32")
+    return nn_ab, nn_ba
+
+
 def mfma_f16_sustained_rate(random_operands=True, iters=4000, device=None):
     """(TFLOP/s, shader GHz) a pure fp16 MFMA loop holds on the whole chip -- the measuring stick beside the nominal
     matrix peak (``sonet_diag_mfma_f16_rate``; with random operands the rate is power-limited, DESIGN.md finding 8)."""

@@ -420,3 +420,23 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert r.returncode != 0 and "only %d GPU" % n in (r.stdout + r.stderr)
+
+
+# ------------------------------------------------------------------------------------------ Chamfer: one sweep, both directions
+@pytest.mark.parametrize("B,Na,Nb", [(8, 1280, 5000), (3, 5000, 1280), (2, 1, 1), (2, 300, 300), (1, 2049, 4100), (2, 4097, 17)])
+def test_chamfer_nn2_equals_two_one_direction_searches(B, Na, Nb):
+    """Row and column arg-min from ONE sweep of the distance matrix == two sonet_chamfer_nn_f32 launches == the oracle's exact
+    search (bit-exact indices, ties -> lowest index; duplicated points force ties)."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(Na + Nb)
+    a = torch.rand(B, 3, Na, generator=g) * 2 - 1
+    b = torch.rand(B, 3, Nb, generator=g) * 2 - 1
+    if Na > 10 and Nb > 10:
+        a[:, :, 5] = a[:, :, 3]                     # exact ties in both directions
+        b[:, :, 7] = b[:, :, 2]
+    ab, ba = ops.chamfer_nn2(a.to(DEV), b.to(DEV))
+    np.testing.assert_array_equal(ab.cpu().numpy(), ops.chamfer_nn(a.to(DEV), b.to(DEV)).cpu().numpy())
+    np.testing.assert_array_equal(ba.cpu().numpy(), ops.chamfer_nn(b.to(DEV), a.to(DEV)).cpu().numpy())
+    np.testing.assert_array_equal(ab.cpu().numpy(), O.chamfer_nn(a.numpy(), b.numpy()))
+    np.testing.assert_array_equal(ba.cpu().numpy(), O.chamfer_nn(b.numpy(), a.numpy()))

@@ -70,5 +70,37 @@ def main():
             B, N, ms, B / ms * 1e3, ", ".join("%s %.2f" % (k, v["total_ms"]) for k, v in top)))
 
 
+def chamfer_roofline():
+    """configs[3]: 1280 predicted vs 5000 ground-truth points.  The search is VALU-bound: 8 exact f32 operations per pair for the
+    distance (no FMA: bit-exact neighbours) + 3 for the row minimum + 3 for the column check = 14 lane-operations per pair in the
+    single sweep; two one-direction launches need 2 x 11.  Roofline: 39.3 T lane-ops/s (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)."""
+    peak = 39.3e12
+    for B in (8, 64):
+        g = torch.Generator().manual_seed(B)
+        pred = (torch.rand(B, 3, 1280, generator=g) * 2 - 1).to(DEV)
+        gt = (torch.rand(B, 3, 5000, generator=g) * 2 - 1).to(DEV)
+        pairs = B * 1280 * 5000
+
+        def t(fn, it=30):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(it):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / it
+        ms2 = t(lambda: ops.chamfer_nn2(pred, gt))
+        ms1 = t(lambda: (ops.chamfer_nn(pred, gt), ops.chamfer_nn(gt, pred)))
+        print("chamfer B=%-3d 1280 x 5000: one sweep %.4f ms = %.2f T lane-ops/s (%.3f of the VALU roof) | two launches %.4f ms (%.3f)"
+              % (B, ms2, 14 * pairs / ms2 / 1e9, 14 * pairs / (ms2 * 1e-3) / peak, ms1, 22 * pairs / (ms1 * 1e-3) / peak), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "chamfer" in sys.argv[1:]:
+        chamfer_roofline()
+    else:
+        main()
+        chamfer_roofline()
