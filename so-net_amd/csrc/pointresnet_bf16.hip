@@ -24,6 +24,8 @@
 // otherwise).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -484,6 +486,297 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pointresnet_bf16_kernel(
     }
 }
 
+// ======================================================================================================================
+// Pool variant, second generation: TWO independent workgroups per CU, 4 waves x 32 points each (two waves per SIMD).
+// The 4-wave / 64-point kernel above leaves the matrix pipe idle whenever its one wave per SIMD does vector work between the
+// MFMA passes (activation packing: ~450 values per lane and tile; the per-node register max of the pool epilogue): 0.30 ms of
+// MFMA passes become 0.46-0.49 ms.  Tried first: (a) a second accumulator set with the previous group's epilogue sliced into
+// the MFMA shadow -- 137 register spills (the 256 architectural VGPRs hold the packed activations); (b) ONE workgroup of 8
+// waves x 32 points -- bit-identical, 233 registers, and no faster (0.483 ms): the per-group barrier keeps all eight waves in
+// the same phase, so they fight for the matrix pipe together and do their vector work together.  Two workgroups that share
+// nothing drift apart and fill each other's gaps.  To fit two sets of W buffers into the LDS a group is at most 32 slices:
+// layer 4's 20 K chunks x 3 tiles go by in two halves of 10 chunks (the accumulators carry over), 64 KiB of W per workgroup.
+// Price: every A fragment read from LDS feeds one MFMA instead of two, and the weight stream is pulled once per 128 points
+// instead of once per 256.  Same stream, arithmetic and roundings as the kernels above: bit-identical results.
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int P2_THREADS = 256, P2_WAVES = 4;
+constexpr int P2_BUF = 32;                                      // slices per LDS buffer
+constexpr int P2_SLOTS = 4;                                     // nodes of a 128-point tile pre-reduced in LDS
+constexpr int L4H_SL = 30;                                      // half a layer-4 group: 10 chunks x 3 tiles
+
+// KC0: first K chunk of this pass (acc is cleared when KC0 == 0), KCn chunks, MTn tiles, ONE 32-column tile.  Staging: this
+// wave moves slices idx * 4 + wave of the next group (NSL_NEXT slices, clamped: a surplus wave rewrites the last slice with
+// the same bytes), PER per K chunk while idx < NSTG_W.
+template <int KC0, int KCn, int MTn, int PER, int NSTG_W, int NSL_NEXT, bool STAGE, bool SWAP, typename BF>
+__device__ __forceinline__ void mfma_pass1(f32x16 (&acc)[MTn], const uint4 *lds_cur, uint4 *lds_nxt /*&buffer[0][lane]*/,
+                                           const __amdgpu_buffer_rsrc_t &rw, unsigned vow, unsigned gofs /*bytes of the next group's slice 0*/,
+                                           int wave, BF &&bfrag)
+{
+    static_assert(!STAGE || NSTG_W <= KCn * PER, "every staged slice needs a K chunk to ride on");
+    i32x4_t st[3][PER];
+    uint4 Af[2][MTn];
+#pragma unroll
+    for (int mt = 0; mt < MTn; ++mt) Af[0][mt] = lds_cur[mt * 64];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto slice_of = [&](int idx) { const int sl = idx * P2_WAVES + wave; return sl < NSL_NEXT ? sl : NSL_NEXT - 1; };
+    static_for<KCn>([&](auto kc_c) {
+        constexpr int kc = decltype(kc_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAGE) {
+            static_for<PER>([&](auto p_c) {
+                constexpr int iw = (kc - 2) * PER + decltype(p_c)::value;
+                if constexpr (kc >= 2 && iw < NSTG_W) lds_nxt[slice_of(iw) * 64] = __builtin_bit_cast(uint4, st[(kc - 2) % 3][decltype(p_c)::value]);
+            });
+            static_for<PER>([&](auto p_c) {
+                constexpr int il = kc * PER + decltype(p_c)::value;
+                if constexpr (il < NSTG_W) st[kc % 3][decltype(p_c)::value] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, gofs + (unsigned)slice_of(il) * 1024u, 0);
+            });
+        }
+        if constexpr (kc + 1 < KCn) {
+#pragma unroll
+            for (int mt = 0; mt < MTn; ++mt) Af[(kc + 1) & 1][mt] = lds_cur[((kc + 1) * MTn + mt) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 Bx;
+        bfrag(IC<KC0 + kc>{}, Bx);
+#pragma unroll
+        for (int mt = 0; mt < MTn; ++mt) {
+            const bf16x8 A = __builtin_bit_cast(bf16x8, Af[kc & 1][mt]);
+            if constexpr (SWAP) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bx, A, (KC0 + kc == 0) ? zero : acc[mt], 0, 0, 0);
+            else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bx, (KC0 + kc == 0) ? zero : acc[mt], 0, 0, 0);
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAGE) {
+        static_for<2>([&](auto d_c) {
+            constexpr int kc = KCn + decltype(d_c)::value;
+            static_for<PER>([&](auto p_c) {
+                constexpr int iw = (kc - 2) * PER + decltype(p_c)::value;
+                if constexpr (iw >= 0 && iw < NSTG_W) lds_nxt[slice_of(iw) * 64] = __builtin_bit_cast(uint4, st[(kc - 2) % 3][decltype(p_c)::value]);
+            });
+        });
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void pack_tiles1(const f32x16 (&acc)[T], const float2 *aff_tile0, unsigned (*P)[4])
+{
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 *ap = reinterpret_cast<const float4 *>(aff_tile0 + 32 * t + 16 * q);
+            const float4 c0 = ap[0], c1 = ap[1], c2 = ap[4], c3 = ap[5];
+            const float sc[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+            const float sh[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+            float va[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) va[e] = __fmaf_rn(acc[t][8 * q + e], sc[e], sh[e]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) P[2 * t + q][p] = fb_relu_pk(fb_cvt_pk_bf16(va[2 * p], va[2 * p + 1]));
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag1(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, make_uint4(p[0], p[1], p[2], p[3])); }
+
+__global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
+    const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g, int L, int tpc /*128-point tiles per cloud*/,
+    long long ntiles, const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0,
+    unsigned *__restrict__ pooled, unsigned *__restrict__ partial /*[ntiles][P2_SLOTS][384]*/, float *__restrict__ v0, int M)
+{
+    __shared__ uint4 wbuf[2][P2_BUF][64];                      // 2 x 32 KiB
+    __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL_BF];
+    __shared__ unsigned bins[P2_SLOTS][384];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned vow = (unsigned)lane * 16u;
+    const unsigned rowX = (unsigned)L * 4u;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(Wst), 0, NSLICE_BF * 1024, 0x00020000);
+    bool unit_lane = true;
+    for (int c = threadIdx.x; c < CH_TOTAL_BF; c += P2_THREADS) {
+        const float2 v = affine_g[c];
+        aff[c] = v;
+        if (c >= AFF_L4 && v.x != 1.0f) unit_lane = false;
+    }
+    for (int i = threadIdx.x; i < P2_SLOTS * 384; i += P2_THREADS) (&bins[0][0])[i] = FB_INIT;
+    for (int sl = wave; sl < G0_SL; sl += P2_WAVES)
+        wbuf[0][sl][lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)sl * 1024u, 0));
+    const bool l4_unit = __syncthreads_and(unit_lane) != 0;      // (also publishes aff, bins, group 0)
+    int nb = 0;
+
+    float xin[8];
+    int nid_n = -1, n0t_n = 0, nlt_n = 0, p0_n = 0;
+    auto load_x = [&](long long t) {
+        const long long b = t / tpc;
+        const int t0 = (int)(t - b * tpc) * 128, l0 = t0 + wave * 32;
+        const int ca = l0 + j;
+        const int cc = ca < L ? ca : (l0 < L ? l0 : 0);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + b * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowX), 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            xin[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (unsigned)(8 * h * L + cc) * 4u, (unsigned)e * rowX, 0));
+        const int32_t *idb = ids_sorted + b * (long long)L;
+        nid_n = ca < L ? idb[ca] : -1;
+        n0t_n = idb[t0 < L ? t0 : 0];
+        nlt_n = idb[t0 + 127 < L ? t0 + 127 : L - 1];
+        p0_n = pos0[b];
+    };
+    if ((long long)blockIdx.x < ntiles) load_x(blockIdx.x);
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long b = tile / tpc;
+        const int l0 = (int)(tile - b * tpc) * 128 + wave * 32;
+        const bool has_next = tile + gridDim.x < ntiles;
+        const int my_id = nid_n, n0t = __builtin_amdgcn_readfirstlane(n0t_n), nlt = __builtin_amdgcn_readfirstlane(nlt_n),
+                  p0t = __builtin_amdgcn_readfirstlane(p0_n);
+        unsigned P1[4][4], P2[8][4], P3[16][4];
+        {   // group 0: layer 1 + layer 2, staging layer 3's first group (32 slices: 8 per wave over the 4 chunks of layer 2)
+            unsigned X0[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) X0[p] = fb_cvt_pk_bf16(xin[2 * p], xin[2 * p + 1]);
+            const uint4 *cur = &wbuf[nb & 1][0][lane];
+            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            f32x16 a1[2];
+            mfma_pass1<0, 1, 2, 1, 0, 1, false, false>(a1, cur + OFF_L1 * 64, nxt, rw, vow, 0u, wave, [&](auto, bf16x8 &B) { B = frag1(X0); });
+            pack_tiles1<2>(a1, aff + AFF_L1 + 4 * h, P1);
+            f32x16 a2[4];
+            mfma_pass1<0, 4, 4, 2, 8, L3G_SL, true, false>(a2, cur + OFF_L2 * 64, nxt, rw, vow, (unsigned)OFF_L3 * 1024u, wave,
+                                                           [&](auto kc, bf16x8 &B) { B = frag1(P1[decltype(kc)::value]); });
+            pack_tiles1<4>(a2, aff + AFF_L2 + 4 * h, P2);
+            __syncthreads();
+            ++nb;
+        }
+        {   // group 1: layer 3 tiles 0-3, staging tiles 4-7
+            const uint4 *cur = &wbuf[nb & 1][0][lane];
+            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            f32x16 a3[4];
+            mfma_pass1<0, 8, 4, 1, 8, L3G_SL, true, false>(a3, cur, nxt, rw, vow, (unsigned)(OFF_L3 + L3G_SL) * 1024u, wave,
+                                                           [&](auto kc, bf16x8 &B) { B = frag1(P2[decltype(kc)::value]); });
+            pack_tiles1<4>(a3, aff + AFF_L3 + 4 * h, P3);
+            __syncthreads();
+            ++nb;
+        }
+        {   // group 2: layer 3 tiles 4-7, staging the first half of layer 4's first group (30 slices: 8 per wave, clamped)
+            const uint4 *cur = &wbuf[nb & 1][0][lane];
+            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            f32x16 a3[4];
+            mfma_pass1<0, 8, 4, 1, 8, L4H_SL, true, false>(a3, cur, nxt, rw, vow, (unsigned)OFF_L4 * 1024u, wave,
+                                                           [&](auto kc, bf16x8 &B) { B = frag1(P2[decltype(kc)::value]); });
+            pack_tiles1<4>(a3, aff + AFF_L3 + 32 * 4 + 4 * h, P3 + 8);
+            __syncthreads();
+            ++nb;
+        }
+        if (has_next) load_x(tile + gridDim.x);
+        const int nvalid = l0 < L ? ((L - l0) < 32 ? (L - l0) : 32) : 0;
+        for (int g = 0; g < 4; ++g) {
+            f32x16 a4[3];
+            auto b4 = [&](auto kc, bf16x8 &B) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < 4) B = frag1(P1[k]); else B = frag1(P3[k - 4]);
+            };
+            {   // K chunks 0-9 (act1 + the first 6 chunks of act3), staging chunks 10-19 of the same three tiles
+                const uint4 *cur = &wbuf[nb & 1][0][lane];
+                uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+                mfma_pass1<0, 10, 3, 1, 8, L4H_SL, true, true>(a4, cur, nxt, rw, vow, (unsigned)(OFF_L4 + g * L4G_SL + L4H_SL) * 1024u, wave, b4);
+                __syncthreads();
+                ++nb;
+            }
+            {   // K chunks 10-19, staging the next group's first half (or the next tile's group 0)
+                const uint4 *cur = &wbuf[nb & 1][0][lane];
+                uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+                if (g < 3) mfma_pass1<10, 10, 3, 1, 8, L4H_SL, true, true>(a4, cur, nxt, rw, vow, (unsigned)(OFF_L4 + (g + 1) * L4G_SL) * 1024u, wave, b4);
+                else if (has_next) mfma_pass1<10, 10, 3, 1, 5, G0_SL, true, true>(a4, cur, nxt, rw, vow, 0u, wave, b4);
+                else mfma_pass1<10, 10, 3, 1, 0, 1, false, true>(a4, cur, nxt, rw, vow, 0u, wave, b4);
+            }
+            // a4[mt][r] = Y[point (r&3) + 8 (r>>2) + 4 h][channel 96 g + 32 mt + j]
+            float bias4[3];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const float2 ss = aff[AFF_L4 + (g * 3 + mt) * 32 + j];
+                bias4[mt] = ss.y;
+                if (!l4_unit) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a4[mt][r] = __fmaf_rn(a4[mt][r], ss.x, ss.y);
+                    bias4[mt] = 0.f;
+                }
+            }
+            if (nvalid > 0) {
+                const int p0 = p0t - l0;
+                if (p0 >= 0 && p0 < 32) {                                   // features of original point copy 0
+                    const int hsel = (p0 >> 2) & 1, rsel = (p0 & 3) + 4 * (p0 >> 3);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r == rsel && h == hsel) {
+#pragma unroll
+                            for (int mt = 0; mt < 3; ++mt) v0[b * 384 + (g * 3 + mt) * 32 + j] = fb_round_bf16(a4[mt][r] + bias4[mt]);
+                        }
+                }
+                int s0 = 0;
+                while (s0 < nvalid) {
+                    const int node = __builtin_amdgcn_readlane(my_id, s0);
+                    const int e0 = s0 + __builtin_popcount((unsigned)__builtin_amdgcn_ballot_w64(my_id == node));
+                    float mx[3];
+                    if (s0 == 0 && e0 == 32) {
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) {
+                            float m = a4[mt][0];
+#pragma unroll
+                            for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(a4[mt][r]));
+                            mx[mt] = m;
+                        }
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) mx[mt] = -__builtin_inff();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int pr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const bool in = pr >= s0 && pr < e0;
+#pragma unroll
+                            for (int mt = 0; mt < 3; ++mt) {
+                                const float v = in ? a4[mt][r] : -__builtin_inff();
+                                asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));      // (ignores a NaN, as the reference's '>')
+                            }
+                        }
+                    }
+                    const int slot = node - n0t;
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) {
+                        float m = mx[mt];
+                        const float o = __shfl_xor(m, 32, 64);
+                        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+                        const unsigned key = fb_ord(__float_as_uint(fb_round_bf16(m + bias4[mt])));
+                        if (h == 0) {
+                            if (slot < P2_SLOTS) atomicMax(&bins[slot][(g * 3 + mt) * 32 + j], key);
+                            else atomicMax(pooled + ((long long)b * M + node) * 384 + (g * 3 + mt) * 32 + j, key);
+                        }
+                    }
+                    s0 = e0;
+                }
+            }
+            __syncthreads();
+            ++nb;
+            if (g == 3) {
+                int ns = nlt - n0t + 1;
+                ns = ns < P2_SLOTS ? ns : P2_SLOTS;
+                unsigned *dst = partial + tile * (long long)(P2_SLOTS * 384);
+                for (int i = threadIdx.x; i < ns * 384; i += P2_THREADS) {
+                    dst[i] = (&bins[0][0])[i];
+                    (&bins[0][0])[i] = FB_INIT;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pooled_bf16_init_kernel(unsigned *__restrict__ pooled, long long n) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < n) pooled[t] = FB_INIT;
@@ -495,7 +788,8 @@ __global__ __launch_bounds__(256) void pooled_bf16_init_kernel(unsigned *__restr
 __global__ __launch_bounds__(256) void pooled_bf16_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
                                                                   const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
                                                                   const int32_t *__restrict__ count, const float *__restrict__ v0,
-                                                                  float *__restrict__ out, int M, int L, int tpc, long long total)
+                                                                  float *__restrict__ out, int M, int L, int tpc, long long total,
+                                                                  int tile_pts /*points per tile*/, int slots /*LDS-reduced nodes per tile*/)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // over [B][M][384], c fastest (coalesced partial reads)
     if (t >= total) return;
@@ -507,10 +801,10 @@ __global__ __launch_bounds__(256) void pooled_bf16_decode_kernel(const unsigned 
     const int cnt = count[b * M + m];
     if (cnt > 0) {
         const int off = node_off[b * M + m];
-        for (int tl = off / 256; tl <= (off + cnt - 1) / 256; ++tl) {
-            const int slot = m - ids_sorted[b * L + tl * 256];
-            if (slot < FB_SLOTS) {
-                const unsigned k2 = partial[((b * tpc + tl) * FB_SLOTS + slot) * 384ll + c];
+        for (int tl = off / tile_pts; tl <= (off + cnt - 1) / tile_pts; ++tl) {
+            const int slot = m - ids_sorted[b * L + tl * tile_pts];
+            if (slot < slots) {
+                const unsigned k2 = partial[((b * tpc + tl) * slots + slot) * 384ll + c];
                 key = k2 > key ? k2 : key;
             }
         }
@@ -563,8 +857,8 @@ extern "C" int sonet_pointresnet_bf16(const float *x, int Cin0, const void *wstr
 extern "C" size_t sonet_pointresnet_bf16_pool_ws_size(int B, int L, int M)
 {
     if (B <= 0 || L <= 0 || M <= 0) return 0;
-    const long long ntiles = (long long)B * sonet::ceil_div(L, 256);
-    return (size_t)((long long)B * M * 384 + ntiles * FB_SLOTS * 384) * 4 + (size_t)B * 384 * 4;
+    const long long n256 = (long long)B * sonet::ceil_div(L, 256) * FB_SLOTS, n128 = (long long)B * sonet::ceil_div(L, 128) * P2_SLOTS;
+    return (size_t)((long long)B * M * 384 + (n256 > n128 ? n256 : n128) * 384) * 4 + (size_t)B * 384 * 4;
 }
 
 extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
@@ -577,23 +871,34 @@ extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, cons
     if ((double)Cin0 * L * 4.0 >= 2.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
     hipStream_t st = sonet::as_stream(stream);
     const long long npool = (long long)B * M * 384;
-    const int tpc = sonet::ceil_div(L, 256);
+    const char *e8 = getenv("SONET_BF16_POOL2");               // bench-only: 0 = the 4-wave / 64-point kernel (one workgroup per CU)
+    const bool two = !(e8 && atoi(e8) == 0);
+    const int tile_pts = two ? 128 : 256, slots = two ? P2_SLOTS : FB_SLOTS;
+    const int tpc = sonet::ceil_div(L, tile_pts);
     const long long ntiles = (long long)B * tpc;
     unsigned *pooled_ws = reinterpret_cast<unsigned *>(ws);
     unsigned *partial_ws = pooled_ws + npool;
-    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * FB_SLOTS * 384);
+    const long long n256 = (long long)B * sonet::ceil_div(L, 256) * FB_SLOTS, n128 = (long long)B * sonet::ceil_div(L, 128) * P2_SLOTS;
+    float *v0_ws = reinterpret_cast<float *>(partial_ws + (n256 > n128 ? n256 : n128) * 384);
     hipLaunchKernelGGL(pooled_bf16_init_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, npool);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const long long grid = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL(pointresnet_bf16_kernel<true>, dim3((unsigned)grid), dim3(FB_THREADS), 0, st,
-                       x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (uint16_t *)nullptr,
-                       L, tpc, ntiles, getenv("SONET_BF16_FUSED_ABLATE") ? atoi(getenv("SONET_BF16_FUSED_ABLATE")) : 0,
-                       ids_sorted, pos0, node_off, count, pooled_ws, partial_ws, v0_ws, M);
+    if (two) {
+        const long long grid = ntiles < 2ll * cus ? ntiles : 2ll * cus;      // persistent: two workgroups per CU
+        hipLaunchKernelGGL(pointresnet_bf16_pool2_kernel, dim3((unsigned)grid), dim3(P2_THREADS), 0, st,
+                           x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), L, tpc, ntiles,
+                           ids_sorted, pos0, pooled_ws, partial_ws, v0_ws, M);
+    } else {
+        const long long grid = ntiles < cus ? ntiles : cus;
+        hipLaunchKernelGGL(pointresnet_bf16_kernel<true>, dim3((unsigned)grid), dim3(FB_THREADS), 0, st,
+                           x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (uint16_t *)nullptr,
+                           L, tpc, ntiles, getenv("SONET_BF16_FUSED_ABLATE") ? atoi(getenv("SONET_BF16_FUSED_ABLATE")) : 0,
+                           ids_sorted, pos0, node_off, count, pooled_ws, partial_ws, v0_ws, M);
+    }
     hipLaunchKernelGGL(pooled_bf16_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
-                       ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);
+                       ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool, tile_pts, slots);
     return sonet::launched(what);
 }
