@@ -343,6 +343,11 @@ def main():
         golden_autoencoder(ref, "b2_n1024", B=2, N=1024, seed=401)
         golden_autoencoder(ref, "b2_n5000", B=2, N=5000, seed=402)            # BASELINE configs[3] size: 5000 gt vs 1280 predicted points
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "train5000":       # own mode: the configs[1] / configs[4] point count, ~1.5 min of CPU
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        golden_train_step(ref_harness.import_reference(), "b8_n5000", B=8, N=5000, seed=203)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = ref_harness.import_reference()

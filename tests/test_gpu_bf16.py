@@ -298,12 +298,63 @@ def test_bf16_layer_backward_vs_float64():
     assert all(v < 2e-2 for v in errs.values()), errs
 
 
-def test_classifier_training_step_bf16():
+@pytest.mark.parametrize("mode,tol", [("bf16", 1.5e-2), ("x3", 1e-4)])       # measured: 2e-3 .. 6e-3 and 3e-7 .. 1e-6
+def test_bf16_first_pointnet_backward_with_fixed_routing_vs_float64(mode, tol):
+    """The whole first PointNet in training mode (four bf16 layers with batch statistics, the skip concat, the last layer +
+    per-node arg-max pool as one autograd node with its SPARSE dgrad / wgrad) against float64 autograd of the same network
+    gathered at the SAME arg-max positions -- i.e. everything of the bf16 backward except the choice of winners, which a
+    reduced-precision forward is free to make differently (see the training-step test below)."""
+    from models import layers as Lm
+    from sonet_hip import ops, synth
+    B, L, M = 4, 1500, 16
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=11)
+    pr.to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 6, L, generator=g).to(torch.bfloat16).float()
+    ids = torch.randint(0, M, (B, L), generator=g, dtype=torch.int32)
+    wr = torch.randn(B, 384, M, generator=g)
+    with ops.precision(mode):
+        first, pooled, gi = pr.forward_pooled(x.to(DEV), ids.to(DEV), torch.ones(B, M, dtype=torch.int32, device=DEV), M)
+        (pooled * wr.to(DEV)).sum().backward()
+    assert first.dtype == (torch.bfloat16 if mode == "bf16" else torch.float32)
+    # float64 twin with the same routing
+    # The twin rounds where the bf16 path rounds in the FORWARD (weights as MFMA operands, the stored raw and activation
+    # tensors; straight-through for the gradient), so that both networks have the same ReLU pattern: sums like d loss / d beta
+    # cancel heavily under the sparse pooled gradient and a fraction f of differing masks shows up as ~sqrt(f) relative error
+    # (7-11 % against an unrounded float64 forward -- measured -- which says nothing about the backward arithmetic).
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in pr.named_parameters()}
+    rnd = (lambda t: t + (t.to(torch.bfloat16).double() - t).detach()) if mode == "bf16" else (lambda t: t)
+
+    def layer(h, i, bn=True):
+        raw = rnd(torch.einsum("oc,bcl->bol", rnd(P["layers.%d.conv.weight" % i][:, :, 0]), h) + P["layers.%d.conv.bias" % i].view(1, -1, 1))
+        if not bn:
+            return raw
+        mean, var = raw.mean(dim=(0, 2), keepdim=True), raw.var(dim=(0, 2), unbiased=False, keepdim=True)
+        return rnd(torch.relu((raw - mean) / torch.sqrt(var + 1e-5) * P["layers.%d.norm.weight" % i].view(1, -1, 1) + P["layers.%d.norm.bias" % i].view(1, -1, 1)))
+    skip = layer(x.double(), 0)
+    t = layer(layer(skip, 1), 2)
+    y = layer(torch.cat((skip, t), dim=1), 3, bn=False)
+    (y.gather(2, gi.cpu().long()) * wr.double()).sum().backward()
+    errs = {}
+    for k, v in pr.named_parameters():
+        r = P[k].grad
+        if r is None or float(r.pow(2).mean().sqrt()) < 1e-9:          # a bias in front of a BatchNorm has no gradient
+            continue
+        a = v.grad.detach().cpu().double()
+        errs[k] = float((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt())
+    print("%s first PointNet backward, fixed routing, rel-rms vs float64:" % mode, {k: "%.1e" % e for k, e in errs.items()})
+    # (the f32-class run of the same harness, x3, agrees to 1e-6)
+    assert len(errs) >= 10 and max(errs.values()) < tol, errs
+
+
+@pytest.mark.parametrize("fixture", ["train_step_b16_n512", "train_step_b8_n5000"])
+def test_classifier_training_step_bf16(fixture):
     """One training step of the classifier in bf16 storage (configs[1] shape family) vs the reference's float64 run of the same
     step: loss and feature at bf16 tolerance, gradients aligned with the float64 ones (cosine), running statistics updated."""
     from models import networks as NW
     from sonet_hip import ops, synth
-    g = golden("train_step_b16_n512")
+    g = golden(fixture)
     B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
     opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
                     activation="relu", normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="avg",
@@ -323,18 +374,22 @@ def test_classifier_training_step_bf16():
     assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad", "pooled_wgrad",
             "index_max_gather_bf16"} <= names, names
     # train-mode BatchNorm divides by batch statistics of bf16-rounded activations and the feature passes three max-pools whose
-    # winners may change: bound the rms error (3e-2; measured 2.0e-2) and the worst element (1.5e-1 of max(|ref|, rms))
+    # winners may change: bound the rms error (4e-2; measured 2.0e-2 at N=512, 3.1e-2 at N=5000) and the worst element
     f_got, f_ref = feat.detach().cpu().double().numpy(), g["feature"].astype(np.float64)
     f_rel = float(np.sqrt(np.mean((f_got - f_ref) ** 2)) / np.sqrt(np.mean(f_ref ** 2)))
     print("bf16 training forward: feature rel-rms error %.2e" % f_rel)
-    assert f_rel < 3e-2
-    assert_close_rms(f_got, f_ref, 1.5e-1, "train feature (bf16)")
+    assert f_rel < 4e-2
+    assert_close_rms(f_got, f_ref, 2e-1, "train feature (bf16)")
     assert abs(float(loss.detach()) - float(g["loss"])) <= 3e-2 * max(1.0, abs(float(g["loss"])))
     params = dict(enc.named_parameters())
-    # Gradients pass three arg-max pools; bf16 features tie often (8 significand bits) and a tie goes to the lowest index, so a
-    # share of the routing differs from the float64 run -- most visibly in the FIRST layers, whose gradient is the sum over all
-    # routed points.  Bar: every conv weight gradient points the same way (cosine > 0.8), the layers behind the pools agree
-    # closely (> 0.97), and the component-level test above pins each layer's backward at 1-2e-2 with no pool in between.
+    # Gradients pass three arg-max pools (per node over its points, over the K' neighbours, over the M nodes).  With 8
+    # significand bits, candidates within 2^-8 of the maximum tie or swap, and every swap re-routes that (cloud, channel)'s
+    # gradient to another column -- so the end-to-end gradient of EVERY layer (also the ones right behind the loss: measured
+    # cosine 0.83-0.88 on all of them, against 1e-3 rel-rms for the f32-class arithmetics) is a different, equally valid
+    # sub-gradient, not a noisy copy of the float64 one (0.73-0.81 at N=5000, where a node's pool has ~700 candidates).  Bar here:
+    # same direction (cosine > 0.6).  What pins the bf16 backward arithmetic itself are test_bf16_layer_backward_vs_float64 (1-2e-2
+    # per layer) and test_bf16_first_pointnet_backward_with_fixed_routing_vs_float64 (the whole first PointNet incl. the sparse
+    # pooled dgrad / wgrad, gathered at the same winners) above.
     cosines = {}
     for k in [k[7:] for k in g.files if k.startswith("grad64/") and not k.startswith("grad64/cls.")]:
         truth = g["grad64/" + k].astype(np.float64)
@@ -344,9 +399,8 @@ def test_classifier_training_step_bf16():
         mine = f[::max(1, f.numel() // 16384)].cpu().numpy().astype(np.float64)
         cosines[k] = float(np.dot(mine, truth) / (np.linalg.norm(mine) * np.linalg.norm(truth)))
     print("bf16 training step: gradient cosine vs the float64 reference:", {k: "%.3f" % v for k, v in cosines.items()})
-    assert min(cosines.values()) > 0.8, cosines
-    assert all(v > 0.97 for k, v in cosines.items() if k.startswith(("final_pointnet", "knnlayer"))), cosines
+    assert min(cosines.values()) > 0.6, cosines
     assert sum(1 for p in enc.parameters() if p.grad is None) == int(g["dead_grad_count"])
     sd = enc.state_dict()
     for k in [k[3:] for k in g.files if k.startswith("bn/")]:
-        assert_close_rms(sd[k].cpu().numpy(), g["bn/" + k], 1.5e-1, "running stat " + k)
+        assert_close_rms(sd[k].cpu().numpy(), g["bn/" + k], 2e-1, "running stat " + k)

@@ -233,7 +233,7 @@ def test_committed_golden_fixtures_regenerate_bit_identically_from_the_live_refe
     import glob
     import numpy as np
     env = dict(os.environ, SONET_GOLDEN_OUT=str(tmp_path))
-    for extra in ([], ["autoencoder"]):
+    for extra in ([], ["autoencoder"], ["train5000"]):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden.py")] + extra, env=env,
                            capture_output=True, text=True, timeout=800)
         assert p.returncode == 0, p.stderr[-3000:]
