@@ -374,9 +374,11 @@ def main():
                     ach = amount / (s_["mean_ms"] * 1e-3) / 1e9
                     k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
                     if name.startswith("som_assign"):
-                        # 64 nodes per 12-byte point: ~21 VALU operations per node-point pair (exact, un-contracted distance
-                        # + 3-deep selection) put this kernel on the vector-issue roof long before the HBM one
-                        lane_ops = 21.0 * B * N * 64
+                        # 64 nodes per 12-byte point: 13 VALU operations per node-point pair (8 for the exact, un-contracted
+                        # distance, 1 to pack the key, 4 for the 4-deep min / median chain) put this kernel on the vector-issue
+                        # roof long before the HBM one -- at B = 64 (320 k points, ~15 us of arithmetic) it is launch- and
+                        # atomics-bound, the vector roof shows at larger batches (tools/microbench.py som)
+                        lane_ops = 13.0 * B * N * 64
                         k["valu"] = {"achieved": round(lane_ops / (s_["mean_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_VALU_TLANEOPS,
                                      "unit": "T lane-ops/s", "frac": round(lane_ops / (s_["mean_ms"] * 1e-3) / 1e12 / PEAK_VALU_TLANEOPS, 4)}
             out.append(k)

@@ -16,6 +16,7 @@
 // nodes visited in ascending id with strict '<', so ties keep the lower id and slots come out in
 // ascending (distance, id) order -- the canonical order of torch.topk(sorted=True).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -69,6 +70,112 @@ __global__ __launch_bounds__(SA_THREADS) void som_assign_kernel(
             }
             bd[0] = c[0] ? d : bd[0];
             bi[0] = c[0] ? m : bi[0];
+        }
+        const size_t kN = (size_t)KSEL * N;
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) {
+            const size_t o = (size_t)b * kN + (size_t)s * N + n;
+            min32[o] = bi[s];
+            if (min64 != nullptr) min64[o] = bi[s];
+            atomicAdd(&cnt[bi[s]], 1u);
+            atomicAdd(&sums[bi[s]], (double)px);
+            atomicAdd(&sums[M + bi[s]], (double)py);
+            atomicAdd(&sums[2 * M + bi[s]], (double)pz);
+        }
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += SA_THREADS) {
+        const unsigned c = cnt[m];
+        if (c != 0u) {
+            atomicAdd(&count[(size_t)b * M + m], (int)c);
+            double *ws = sum_ws + (size_t)b * 3 * M;
+            unsafeAtomicAdd(&ws[m], sums[m]);
+            unsafeAtomicAdd(&ws[M + m], sums[M + m]);
+            unsafeAtomicAdd(&ws[2 * M + m], sums[2 * M + m]);
+        }
+    }
+}
+
+// ---- the same assignment, selection on packed keys ------------------------------------------------------------------------
+// The insertion list above costs ~13 vector operations per (point, node) pair on top of the 8 of the exact distance.  Here the
+// distance's bit pattern (d >= 0: it orders like the value) gives up its low IB bits to the node id, key = (bits(d) & ~mask) | m,
+// and the KSEL + 1 smallest keys are kept by an unsigned min / median-of-three chain: v_and_or + v_min + KSEL x v_med3 = 5
+// operations at k = 3, and the winners' ids are simply the keys' low bits -- no second pass, no distances kept.  Truncation can
+// only reorder two candidates whose distances agree in all the kept bits (within 2^IB ulp of each other): a lane sees that as
+// equal high parts among its KSEL + 1 smallest keys (the extra one guards the boundary of the list) and then -- like a lane
+// whose list reaches +inf / NaN, where the reference leaves id 0 -- redoes its point with the exact insertion list.  Bit-exact
+// with som_assign_kernel by construction; the slow branch runs for ~1e-4 of the points.
+template <int KSEL, int IB>
+__global__ __launch_bounds__(SA_THREADS) void som_assign_keys_kernel(
+    const float *__restrict__ x, const float *__restrict__ node, int N, int M,
+    int32_t *__restrict__ min32, int64_t *__restrict__ min64, int32_t *__restrict__ count,
+    double *__restrict__ sum_ws)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *nodes = reinterpret_cast<float4 *>(smem);
+    double *sums = reinterpret_cast<double *>(smem + (size_t)M * sizeof(float4));
+    unsigned *cnt = reinterpret_cast<unsigned *>(smem + (size_t)M * (sizeof(float4) + 3 * sizeof(double)));
+    constexpr unsigned IMASK = (1u << IB) - 1u;
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *nb = node + (size_t)b * 3 * M;
+    for (int m = tid; m < M; m += SA_THREADS) {
+        nodes[m] = make_float4(nb[m], nb[M + m], nb[2 * M + m], 0.f);
+        sums[m] = 0.0; sums[M + m] = 0.0; sums[2 * M + m] = 0.0;
+        cnt[m] = 0u;
+    }
+    __syncthreads();
+
+    const int n = blockIdx.x * SA_THREADS + tid;
+    if (n < N) {
+        const float px = xb[n], py = xb[N + n], pz = xb[2 * (size_t)N + n];
+        unsigned t[KSEL + 1];
+#pragma unroll
+        for (int s = 0; s <= KSEL; ++s) t[s] = 0xFFFFFFFFu;
+        const unsigned hi_mask = ~IMASK;
+        auto visit = [&](int m) {
+            unsigned key;                                                   // (bits(d) & ~IMASK) | m in one instruction
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(sqdist(px, py, pz, nodes[m]))), "v"(hi_mask), "s"((unsigned)m));   // (one scalar operand per VOP3)
+            // sorted insertion of key into t[0] <= t[1] <= ... : new t[s] = median(t[s-1], t[s], key), new t[0] = min(t[0], key)
+#pragma unroll
+            for (int s = KSEL; s >= 1; --s) {
+                unsigned md;                                                // (hipcc does not form v_med3_u32 from the selects)
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(md) : "v"(t[s - 1]), "v"(t[s]), "v"(key));
+                t[s] = md;
+            }
+            t[0] = key < t[0] ? key : t[0];
+        };
+        int m = 0;
+        for (; m + 8 <= M; m += 8) {                                       // (unrolled by hand: the asm statements keep the pragma from doing it)
+            visit(m); visit(m + 1); visit(m + 2); visit(m + 3); visit(m + 4); visit(m + 5); visit(m + 6); visit(m + 7);
+        }
+        for (; m < M; ++m) visit(m);
+        int bi[KSEL];
+        bool exact = t[KSEL - 1] >= 0x7F800000u;                            // the list reaches +inf / NaN: the reference keeps id 0 there
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) {
+            bi[s] = (int)(t[s] & IMASK);
+            exact = exact || ((t[s] & ~IMASK) == (t[s + 1] & ~IMASK));     // a pair the truncation may have ordered by id instead of by distance
+        }
+        if (exact) {
+            float bd[KSEL];
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) { bd[s] = __builtin_inff(); bi[s] = 0; }
+            for (int m = 0; m < M; ++m) {
+                const float d = sqdist(px, py, pz, nodes[m]);
+                bool c[KSEL];
+#pragma unroll
+                for (int s = 0; s < KSEL; ++s) c[s] = d < bd[s];
+#pragma unroll
+                for (int s = KSEL - 1; s >= 1; --s) {
+                    bd[s] = c[s - 1] ? bd[s - 1] : (c[s] ? d : bd[s]);
+                    bi[s] = c[s - 1] ? bi[s - 1] : (c[s] ? m : bi[s]);
+                }
+                bd[0] = c[0] ? d : bd[0];
+                bi[0] = c[0] ? m : bi[0];
+            }
         }
         const size_t kN = (size_t)KSEL * N;
 #pragma unroll
@@ -530,7 +637,11 @@ extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, in
         return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
     dim3 grid(sonet::ceil_div(N, SA_THREADS), B), block(SA_THREADS);
     const size_t lds = (size_t)M * (sizeof(float4) + 3 * sizeof(double) + sizeof(unsigned));
-#define SA_LAUNCH(KK) hipLaunchKernelGGL((som_assign_kernel<KK>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws)
+    const char *ek = getenv("SONET_SOM_KEYS");                  // bench / test switch: 0 = the insertion-list kernel
+    const bool keys = !(ek && atoi(ek) == 0);
+#define SA_LAUNCH(KK) do { if (keys && M <= 64) hipLaunchKernelGGL((som_assign_keys_kernel<KK, 6>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws); \
+                           else if (keys) hipLaunchKernelGGL((som_assign_keys_kernel<KK, 10>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws); \
+                           else hipLaunchKernelGGL((som_assign_kernel<KK>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws); } while (0)
     switch (k) { case 1: SA_LAUNCH(1); break; case 2: SA_LAUNCH(2); break; case 3: SA_LAUNCH(3); break; default: SA_LAUNCH(4); }
 #undef SA_LAUNCH
     return sonet::launched(what);
