@@ -37,6 +37,7 @@ constexpr int FB_THREADS = 256, FB_WAVES = 4;
 constexpr int G0_SL = 20, L3G_SL = 32, L4G_SL = 60;            // slices per group
 constexpr int OFF_L1 = 0, OFF_L2 = 4, OFF_L3 = G0_SL, OFF_L4 = G0_SL + 2 * L3G_SL;
 constexpr int NSLICE_BF = OFF_L4 + 4 * L4G_SL;                  // 324
+constexpr int NSLICE_PAD = 2;                                   // zero slices after the stream (the pool kernel stages 32-slice groups: the last half of layer 4 is 30)
 constexpr int BUF_SL = 60;
 constexpr int CH_TOTAL_BF = 64 + 128 + 256 + 384;
 constexpr int AFF_L1 = 0, AFF_L2 = 64, AFF_L3 = 192, AFF_L4 = 448;
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void pointresnet_bf16_pack_kernel(const float 
                                                                      int Cin0, uint4 *__restrict__ out)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= NSLICE_BF * 64) return;
+    if (t >= (NSLICE_BF + NSLICE_PAD) * 64) return;
+    if (t >= NSLICE_BF * 64) { out[t] = make_uint4(0u, 0u, 0u, 0u); return; }
     const int lane = t & 63, s = t >> 6;
     const int i = lane & 31, h = lane >> 5;
     const float *W = nullptr;
@@ -509,31 +511,46 @@ constexpr int P2_SLOTS = 4;                                     // nodes of a 12
 constexpr int L4H_SL = 30;                                      // half a layer-4 group: 10 chunks x 3 tiles
 
 // KC0: first K chunk of this pass (acc is cleared when KC0 == 0), KCn chunks, MTn tiles, ONE 32-column tile.  Staging: this
-// wave moves slices idx * 4 + wave of the next group (NSL_NEXT slices, clamped: a surplus wave rewrites the last slice with
-// the same bytes), PER per K chunk while idx < NSTG_W.
-template <int KC0, int KCn, int MTn, int PER, int NSTG_W, int NSL_NEXT, bool STAGE, bool SWAP, typename BF>
-__device__ __forceinline__ void mfma_pass1(f32x16 (&acc)[MTn], const uint4 *lds_cur, uint4 *lds_nxt /*&buffer[0][lane]*/,
-                                           const __amdgpu_buffer_rsrc_t &rw, unsigned vow, unsigned gofs /*bytes of the next group's slice 0*/,
-                                           int wave, BF &&bfrag)
+// wave moves the NSTG_W consecutive slices wave * NSTG_W ... of the next group, PER per K chunk.
+// The staged slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1-KiB slice per wave instruction, lane-linear,
+// which is the slice layout): no staging registers, no ds_write, and -- the point -- no wait in the middle of the pass: with
+// register staging the ds_write two chunks after its load stalled the wave for an L2 round trip eight times per pass (SQ
+// counters of the register-staged version: half of the wave cycles waiting).  hipcc does not see these loads; the caller waits
+// for them (s_waitcnt vmcnt(0)) right before the barrier that publishes the group.
+// Addressing: slices il and il + 1 ... of one wave are 1 KiB apart in the stream AND in LDS, and the instruction offset moves
+// both addresses, so four slices share one (M0, voffset) pair and every slice of a pass shares the scalar base `gsrc`: three
+// scalar registers and two vector registers per pass.  (The first version gave every slice its own 64-bit pointer and LDS
+// address; hipcc hoisted all 45 of them out of the tile loop into spilled SGPRs, and that build returned garbage whatever
+// waits and nops surrounded the DMA -- builds differing only by a debugging printf were right.  Not understood; this form has
+// no spilled operands.)
+template <int KC0, int KCn, int MTn, int PER, int NSTG_W, bool STAGE, bool SWAP, typename BF>
+__device__ __forceinline__ void mfma_pass1(f32x16 (&acc)[MTn], const uint4 *lds_cur, unsigned lds_nxt_addr /*LDS byte address of the next buffer*/,
+                                           const char *gsrc /*slice 0 of the next group in the weight stream*/, unsigned vow, int wave, BF &&bfrag)
 {
     static_assert(!STAGE || NSTG_W <= KCn * PER, "every staged slice needs a K chunk to ride on");
-    i32x4_t st[3][PER];
     uint4 Af[2][MTn];
 #pragma unroll
     for (int mt = 0; mt < MTn; ++mt) Af[0][mt] = lds_cur[mt * 64];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto slice_of = [&](int idx) { const int sl = idx * P2_WAVES + wave; return sl < NSL_NEXT ? sl : NSL_NEXT - 1; };
+    const unsigned wofs = (unsigned)wave * (unsigned)(NSTG_W * 1024);
+    const unsigned d_lo = lds_nxt_addr + wofs, d_hi = d_lo + 4096u;
+    const unsigned v_lo = vow + wofs, v_hi = v_lo + 4096u;
     static_for<KCn>([&](auto kc_c) {
         constexpr int kc = decltype(kc_c)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAGE) {
             static_for<PER>([&](auto p_c) {
-                constexpr int iw = (kc - 2) * PER + decltype(p_c)::value;
-                if constexpr (kc >= 2 && iw < NSTG_W) lds_nxt[slice_of(iw) * 64] = __builtin_bit_cast(uint4, st[(kc - 2) % 3][decltype(p_c)::value]);
-            });
-            static_for<PER>([&](auto p_c) {
                 constexpr int il = kc * PER + decltype(p_c)::value;
-                if constexpr (il < NSTG_W) st[kc % 3][decltype(p_c)::value] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, gofs + (unsigned)slice_of(il) * 1024u, 0);
+                if constexpr (il < NSTG_W) {
+                    // (locals: clang refuses captured variables as asm operands.)  M0 is the compiler's: saved and restored.
+                    // s_nop 4: should an operand arrive in an SGPR written by a VALU instruction (v_readlane of a spill), a
+                    // VMEM instruction reading it needs 5 wait states, and hipcc pads its own instructions, not inline asm.
+                    const char *g = gsrc;
+                    const unsigned d = il < 4 ? d_lo : d_hi, vo = il < 4 ? v_lo : v_hi;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(vo), "s"(g), "s"(d), "n"((il % 4) * 1024) : "memory");
+                }
             });
         }
         if constexpr (kc + 1 < KCn) {
@@ -551,15 +568,6 @@ __device__ __forceinline__ void mfma_pass1(f32x16 (&acc)[MTn], const uint4 *lds_
         }
     });
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STAGE) {
-        static_for<2>([&](auto d_c) {
-            constexpr int kc = KCn + decltype(d_c)::value;
-            static_for<PER>([&](auto p_c) {
-                constexpr int iw = (kc - 2) * PER + decltype(p_c)::value;
-                if constexpr (iw >= 0 && iw < NSTG_W) lds_nxt[slice_of(iw) * 64] = __builtin_bit_cast(uint4, st[(kc - 2) % 3][decltype(p_c)::value]);
-            });
-        });
-    }
 }
 
 template <int T>
@@ -590,9 +598,14 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
     long long ntiles, const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0,
     unsigned *__restrict__ pooled, unsigned *__restrict__ partial /*[ntiles][P2_SLOTS][384]*/, float *__restrict__ v0, int M)
 {
-    __shared__ uint4 wbuf[2][P2_BUF][64];                      // 2 x 32 KiB
-    __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL_BF];
-    __shared__ unsigned bins[P2_SLOTS][384];
+    // One LDS object so that the W buffers sit at its start: the LDS-DMA destination travels in M0, and the slices must stay
+    // below 64 KiB of the workgroup's LDS (with separate __shared__ arrays the compiler chose the order, and W buffer 1 ended
+    // past 64 KiB: its last slices landed on the affine table).
+    struct P2Lds { uint4 wbuf[2][P2_BUF][64]; float2 aff[CH_TOTAL_BF]; unsigned bins[P2_SLOTS][384]; };
+    __shared__ __attribute__((aligned(16))) P2Lds lds_;
+    auto &wbuf = lds_.wbuf;
+    auto &aff = lds_.aff;
+    auto &bins = lds_.bins;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -600,6 +613,8 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
     const unsigned vow = (unsigned)lane * 16u;
     const unsigned rowX = (unsigned)L * 4u;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(Wst), 0, NSLICE_BF * 1024, 0x00020000);
+    const char *wst = reinterpret_cast<const char *>(Wst);
+    const unsigned wbuf_lds = (unsigned)reinterpret_cast<size_t>(&wbuf[0][0][0]);      // LDS byte address of the W buffers (LDS-DMA target)
     bool unit_lane = true;
     for (int c = threadIdx.x; c < CH_TOTAL_BF; c += P2_THREADS) {
         const float2 v = affine_g[c];
@@ -639,39 +654,42 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
         const int my_id = nid_n, n0t = __builtin_amdgcn_readfirstlane(n0t_n), nlt = __builtin_amdgcn_readfirstlane(nlt_n),
                   p0t = __builtin_amdgcn_readfirstlane(p0_n);
         unsigned P1[4][4], P2[8][4], P3[16][4];
-        {   // group 0: layer 1 + layer 2, staging layer 3's first group (32 slices: 8 per wave over the 4 chunks of layer 2)
+        {   // group 0: layer 1 + layer 2, staging layer 3's first group (32 slices: 8 consecutive per wave over the 4 chunks of layer 2)
             unsigned X0[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) X0[p] = fb_cvt_pk_bf16(xin[2 * p], xin[2 * p + 1]);
             const uint4 *cur = &wbuf[nb & 1][0][lane];
-            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            const unsigned nxt = wbuf_lds + (unsigned)(((nb & 1) ^ 1) * P2_BUF) * 1024u;
             f32x16 a1[2];
-            mfma_pass1<0, 1, 2, 1, 0, 1, false, false>(a1, cur + OFF_L1 * 64, nxt, rw, vow, 0u, wave, [&](auto, bf16x8 &B) { B = frag1(X0); });
+            mfma_pass1<0, 1, 2, 1, 0, false, false>(a1, cur + OFF_L1 * 64, nxt, wst, vow, wave, [&](auto, bf16x8 &B) { B = frag1(X0); });
             pack_tiles1<2>(a1, aff + AFF_L1 + 4 * h, P1);
             f32x16 a2[4];
-            mfma_pass1<0, 4, 4, 2, 8, L3G_SL, true, false>(a2, cur + OFF_L2 * 64, nxt, rw, vow, (unsigned)OFF_L3 * 1024u, wave,
+            mfma_pass1<0, 4, 4, 2, 8, true, false>(a2, cur + OFF_L2 * 64, nxt, wst + OFF_L3 * 1024, vow, wave,
                                                            [&](auto kc, bf16x8 &B) { B = frag1(P1[decltype(kc)::value]); });
             pack_tiles1<4>(a2, aff + AFF_L2 + 4 * h, P2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA slices of the next group have landed
             __syncthreads();
             ++nb;
         }
         {   // group 1: layer 3 tiles 0-3, staging tiles 4-7
             const uint4 *cur = &wbuf[nb & 1][0][lane];
-            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            const unsigned nxt = wbuf_lds + (unsigned)(((nb & 1) ^ 1) * P2_BUF) * 1024u;
             f32x16 a3[4];
-            mfma_pass1<0, 8, 4, 1, 8, L3G_SL, true, false>(a3, cur, nxt, rw, vow, (unsigned)(OFF_L3 + L3G_SL) * 1024u, wave,
+            mfma_pass1<0, 8, 4, 1, 8, true, false>(a3, cur, nxt, wst + (OFF_L3 + L3G_SL) * 1024, vow, wave,
                                                            [&](auto kc, bf16x8 &B) { B = frag1(P2[decltype(kc)::value]); });
             pack_tiles1<4>(a3, aff + AFF_L3 + 4 * h, P3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA slices of the next group have landed
             __syncthreads();
             ++nb;
         }
-        {   // group 2: layer 3 tiles 4-7, staging the first half of layer 4's first group (30 slices: 8 per wave, clamped)
+        {   // group 2: layer 3 tiles 4-7, staging the first half of layer 4's first group (30 slices; 32 are moved, the last two belong to the next half)
             const uint4 *cur = &wbuf[nb & 1][0][lane];
-            uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
+            const unsigned nxt = wbuf_lds + (unsigned)(((nb & 1) ^ 1) * P2_BUF) * 1024u;
             f32x16 a3[4];
-            mfma_pass1<0, 8, 4, 1, 8, L4H_SL, true, false>(a3, cur, nxt, rw, vow, (unsigned)OFF_L4 * 1024u, wave,
+            mfma_pass1<0, 8, 4, 1, 8, true, false>(a3, cur, nxt, wst + OFF_L4 * 1024, vow, wave,
                                                            [&](auto kc, bf16x8 &B) { B = frag1(P2[decltype(kc)::value]); });
             pack_tiles1<4>(a3, aff + AFF_L3 + 32 * 4 + 4 * h, P3 + 8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA slices of the next group have landed
             __syncthreads();
             ++nb;
         }
@@ -685,17 +703,18 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
             };
             {   // K chunks 0-9 (act1 + the first 6 chunks of act3), staging chunks 10-19 of the same three tiles
                 const uint4 *cur = &wbuf[nb & 1][0][lane];
-                uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
-                mfma_pass1<0, 10, 3, 1, 8, L4H_SL, true, true>(a4, cur, nxt, rw, vow, (unsigned)(OFF_L4 + g * L4G_SL + L4H_SL) * 1024u, wave, b4);
+                const unsigned nxt = wbuf_lds + (unsigned)(((nb & 1) ^ 1) * P2_BUF) * 1024u;
+                mfma_pass1<0, 10, 3, 1, 8, true, true>(a4, cur, nxt, wst + (OFF_L4 + g * L4G_SL + L4H_SL) * 1024, vow, wave, b4);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 ++nb;
             }
             {   // K chunks 10-19, staging the next group's first half (or the next tile's group 0)
                 const uint4 *cur = &wbuf[nb & 1][0][lane];
-                uint4 *nxt = &wbuf[(nb & 1) ^ 1][0][lane];
-                if (g < 3) mfma_pass1<10, 10, 3, 1, 8, L4H_SL, true, true>(a4, cur, nxt, rw, vow, (unsigned)(OFF_L4 + (g + 1) * L4G_SL) * 1024u, wave, b4);
-                else if (has_next) mfma_pass1<10, 10, 3, 1, 5, G0_SL, true, true>(a4, cur, nxt, rw, vow, 0u, wave, b4);
-                else mfma_pass1<10, 10, 3, 1, 0, 1, false, true>(a4, cur, nxt, rw, vow, 0u, wave, b4);
+                const unsigned nxt = wbuf_lds + (unsigned)(((nb & 1) ^ 1) * P2_BUF) * 1024u;
+                if (g < 3) mfma_pass1<10, 10, 3, 1, 8, true, true>(a4, cur, nxt, wst + (OFF_L4 + (g + 1) * L4G_SL) * 1024, vow, wave, b4);
+                else if (has_next) mfma_pass1<10, 10, 3, 1, 5, true, true>(a4, cur, nxt, wst, vow, wave, b4);
+                else mfma_pass1<10, 10, 3, 1, 0, false, true>(a4, cur, nxt, wst, vow, wave, b4);
             }
             // a4[mt][r] = Y[point (r&3) + 8 (r>>2) + 4 h][channel 96 g + 32 mt + j]
             float bias4[3];
@@ -762,6 +781,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pointresnet_bf16_pool2_kernel(
                     s0 = e0;
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA slices of the next group have landed
             __syncthreads();
             ++nb;
             if (g == 3) {
@@ -817,7 +837,7 @@ __global__ __launch_bounds__(256) void pooled_bf16_decode_kernel(const unsigned 
 
 }  // namespace
 
-extern "C" size_t sonet_pointresnet_bf16_pack_size(void) { return (size_t)NSLICE_BF * 1024; }
+extern "C" size_t sonet_pointresnet_bf16_pack_size(void) { return (size_t)(NSLICE_BF + NSLICE_PAD) * 1024; }
 
 extern "C" int sonet_pointresnet_bf16_pack(const float *W1, const float *W2, const float *W3, const float *W4, int Cin0,
                                            void *stream_out, sonet_stream_t stream)
@@ -825,7 +845,7 @@ extern "C" int sonet_pointresnet_bf16_pack(const float *W1, const float *W2, con
     const char *what = "sonet_pointresnet_bf16_pack";
     SONET_REQUIRE(W1 && W2 && W3 && W4 && stream_out, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin0 >= 1 && Cin0 <= 16, "%s: Cin0=%d must be in [1, 16]", what, Cin0);
-    hipLaunchKernelGGL(pointresnet_bf16_pack_kernel, dim3(sonet::ceil_div(NSLICE_BF * 64, 256)), dim3(256), 0, sonet::as_stream(stream),
+    hipLaunchKernelGGL(pointresnet_bf16_pack_kernel, dim3(sonet::ceil_div((NSLICE_BF + NSLICE_PAD) * 64, 256)), dim3(256), 0, sonet::as_stream(stream),
                        W1, W2, W3, W4, Cin0, reinterpret_cast<uint4 *>(stream_out));
     return sonet::launched(what);
 }
@@ -887,7 +907,8 @@ extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, cons
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     if (two) {
-        const long long grid = ntiles < 2ll * cus ? ntiles : 2ll * cus;      // persistent: two workgroups per CU
+        long long grid = ntiles < 2ll * cus ? ntiles : 2ll * cus;            // persistent: two workgroups per CU
+        if (const char *eg = getenv("SONET_BF16_POOL2_GRID")) { const long long v = atoll(eg); if (v > 0 && v < grid) grid = v; }   // debugging
         hipLaunchKernelGGL(pointresnet_bf16_pool2_kernel, dim3((unsigned)grid), dim3(P2_THREADS), 0, st,
                            x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), L, tpc, ntiles,
                            ids_sorted, pos0, pooled_ws, partial_ws, v0_ws, M);

@@ -41,6 +41,19 @@ elif name == "fused_pool":
     wstream, affine = pr._fused_state()
     for _ in range(iters):
         ops.pointresnet_fused_pool(sg, wstream, affine, 64)
+elif name == "bf16_pool":
+    from models import layers as Lm
+    from sonet_hip import synth
+    pr = Lm.PointResNet(6, [64, 128, 256, 384], "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(pr.state_dict(), seed=7)
+    pr.to(DEV).eval()
+    inp = synth.make_inputs(B, 5000, seed=1, device=DEV)
+    a = ops.som_assign(inp["pc"], inp["node"], 3)
+    sg = ops.som_sort_group(inp["pc"], inp["sn"], a)
+    with ops.precision("bf16"):
+        wstream, affine = pr._fused_state()
+        for _ in range(iters):
+            ops.pointresnet_bf16_pool(sg, wstream, affine, 64)
 elif name == "index_max":
     data = torch.randn(B, 384, 15000, device=DEV)
     index = torch.randint(0, 64, (B, 15000), device=DEV, dtype=torch.int32)
