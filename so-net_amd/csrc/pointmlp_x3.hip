@@ -70,6 +70,16 @@ __device__ __forceinline__ void split16_pair(float x0, float x1, unsigned &h, un
     m = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
     l = __builtin_bit_cast(unsigned, hv * __builtin_bit_cast(f16x2_t, F16_2_M5_PK));
 }
+// the same values with the clamp written as one v_med3_f32 (what hipcc makes of fmin(fmax()) after a canonicalising v_max x, x:
+// a NaN input still leaves as -2047, the minimum of the three)
+__device__ __forceinline__ void split16_pair_med3(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    x0 = 32.f * __builtin_amdgcn_fmed3f(x0, -2047.f, 2047.f);
+    x1 = 32.f * __builtin_amdgcn_fmed3f(x1, -2047.f, 2047.f);
+    h = cvt_pk_f16(x0, x1);
+    const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+    m = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+    l = __builtin_bit_cast(unsigned, hv * __builtin_bit_cast(f16x2_t, F16_2_M5_PK));
+}
 // A side: (w0, w1) -> fp16(w), fp16(32 * (w - fp16(w)))
 __device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsigned &res) {
     w0 = __builtin_fminf(__builtin_fmaxf(w0, -65504.f), 65504.f);
@@ -79,10 +89,14 @@ __device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsig
     res = cvt_pk_f16(32.f * (w0 - (float)hv[0]), 32.f * (w1 - (float)hv[1]));
 }
 
-// Wp3[ct][kc][term][lane] (uint4 = 8 bf16 / fp16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7
+// bf16 flavour: Wp3[ct][kc][term][lane] (uint4 = 8 bf16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7, term = h, m, l.
+// fp16 flavour: Wp2[ct][kcp][term][lane], term 0 = fp16(w) (meets 32 xh and the scaled x residual), term 1 = fp16(32 (w - h))
+// (meets xh); kcp runs to KCP = KC rounded up to a multiple of H3_KPAD with ZERO chunks past KC: a (tile, chunk pair) is 4 KiB of
+// consecutive bytes -- one LDS-DMA base with four instruction offsets -- and a K tail needs no special case.
+constexpr int H3_KPAD = 8;
 template <bool F16>
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
-                                                       int Cin, int Cout, int KC, long long total, unsigned *__restrict__ trailer)
+                                                       int Cin, int Cout, int KC /*fp16: KCP*/, long long total, unsigned *__restrict__ trailer)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
     if (t >= total) return;                                              // (total is a multiple of 64: whole waves leave)
@@ -100,8 +114,6 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
         const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
         range_track(wr, w0, w1);
         if constexpr (F16) {
-            // A side: slice 0 = fp16(w) (meets 32 xh and the scaled x residual), slice 2 = fp16(32 * (w - h)) (meets xh);
-            // slice 1 is unused by the fp16 kernel (the packed size is shared with the bf16 flavour)
             unsigned hh, res;
             split16_w(w0, w1, hh, res);
             h[p] = hh; m[p] = 0u; l[p] = res;
@@ -109,10 +121,16 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
             split3_pair(w0, w1, h[p], m[p], l[p]);
         }
     }
-    uint4 *dst = Wp3 + (r * 3) * 64 + lane;
-    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
-    dst[64] = make_uint4(m[0], m[1], m[2], m[3]);
-    dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
+    if constexpr (F16) {
+        uint4 *dst = Wp3 + (r * 2) * 64 + lane;
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[64] = make_uint4(l[0], l[1], l[2], l[3]);
+    } else {
+        uint4 *dst = Wp3 + (r * 3) * 64 + lane;
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[64] = make_uint4(m[0], m[1], m[2], m[3]);
+        dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| of the layer (range log, word 1 of a launch)
 }
 
@@ -122,7 +140,8 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
     const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
-    unsigned *__restrict__ rlog /*optional (fp16 flavour): range-log slot, word 0 = max |x| bits, word 1 = max |w| bits*/)
+    unsigned *__restrict__ rlog /*optional (fp16 flavour): range-log slot, word 0 = max |x| bits, word 1 = max |w| bits*/,
+    int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/)
 {
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(Wp3), 0, (int)((unsigned)CT * (unsigned)KC * 3072u), 0x00020000);
+        const_cast<uint4 *>(Wp3), 0, (int)((unsigned)CT * (unsigned)KCP * (unsigned)(NTW * 1024)), 0x00020000);
     const unsigned vox = (unsigned)(8 * h * L + lc) * 4u;      // lane byte offset inside a 16-channel chunk
     // x1 through a gather index (the neighbour gather of KNNModule, models/layers.py:313-350, done by the operand load):
     // an index outside [0, L1) reads zeros (lane offset past the panel: the descriptor's bounds check)
@@ -195,17 +214,17 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-        // slice sl of a stage: chunk i = sl / (NTW*MT), cout tile mt = (sl / NTW) % MT, term = sl % NTW (fp16: packed slices 0 and 2)
+        // slice sl of a stage: chunk i = sl / (NTW*MT), cout tile mt = (sl / NTW) % MT, term = sl % NTW
         auto stage_load = [&](i32x4_t (&w)[NS], int st) {
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 int sl = wave + t * X3_WAVES;
                 sl = sl < NSL ? sl : NSL - 1;
                 const int i = sl / (NTW * MT), rem = sl - i * (NTW * MT);
-                const int mt = rem / NTW, term = (rem - mt * NTW) * (F16 ? 2 : 1);
+                const int mt = rem / NTW, term = rem - mt * NTW;
                 int kc = st * S + i;
                 kc = kc < KC ? kc : KC - 1;
-                w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(((ct0 + mt) * KC + kc) * 3 + term) * 1024u, 0);
+                w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (unsigned)(((ct0 + mt) * KCP + kc) * NTW + term) * 1024u, 0);
             }
         };
         auto stage_write = [&](const i32x4_t (&w)[NS], int slot) {
@@ -305,8 +324,223 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             // (lanes of padded columns re-read a valid column, a wave past the last group re-reads group 0: real values only)
             range_publish(rlog, wave_umax(range_amax_bits(xr)), lane);
             if (blockIdx.x == 0 && threadIdx.x == 0)
-                atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wp3 + (long long)CT * KC * 3 * 64)[0]);
+                atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wp3 + (long long)CT * KCP * NTW * 64)[0]);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp16-split layer, second generation ("h3r").  Same arithmetic, operand order and outputs as pointmlp_x3_kernel<.., true>
+// (bit-identical: every accumulator sees the same MFMAs in the same order); a different pipeline:
+//   * W goes global -> LDS by LDS-DMA into a ring of H3R_SLOTS stages, each stage = S = 2 K chunks x MT = 4 output tiles
+//     x 2 terms = 16 KiB; a wave moves ONE (tile, chunk pair) per stage = 4 KiB of consecutive pack bytes: one scalar base, one M0,
+//     four instruction offsets.  Three stages are in flight (the first-generation kernel staged through registers with one stage
+//     of look-ahead: at the node-level shapes -- 4096 ... 36864 columns -- every 6-18 MFMAs waited for an L2 round trip).
+//   * X rows are prefetched two stages ahead (f32, raw buffer loads), split into the fp16 terms for chunk i + 1 while the 12 MFMAs
+//     of chunk i run; A fragments are read one chunk ahead.
+//   * one barrier per stage (24 MFMAs per wave), 64 KiB of LDS + the affine table: two workgroups per CU.
+// The DMA requests are invisible to hipcc's s_waitcnt bookkeeping: each iteration issues a CONSTANT number of memory
+// operations (stage indices are clamped, not skipped), so "the DMA of stage st has landed" is vmcnt(H3R_WAIT) at every stage.
+#ifndef H3R_ABL
+#define H3R_ABL 0                                              // timing ablations (tools/build_variant.sh): never set in the product
+#endif
+constexpr int H3R_MT = 4, H3R_S = 2, H3R_SLOTS = 4, H3R_SLOT_SL = H3R_S * H3R_MT * 2;
+constexpr int H3R_WAIT = 2 * 4 + 2 * H3R_S * 8;               // the DMAs of two later stages + the X loads of two stages
+
+__global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
+    const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp2,
+    const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
+    int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
+    const int32_t *__restrict__ gidx, int L1, unsigned *__restrict__ rlog, int KCP, int nslab, int ncol /*column groups of 128*/)
+{
+    constexpr int MT = H3R_MT, S = H3R_S;
+    // Workgroup -> (column group, output slab), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with
+    // its own L2; the `nslab` workgroups that read the SAME X columns get consecutive slots of ONE XCD, so the panel comes from HBM
+    // once and from that L2 nslab - 1 times (x-major grids re-read it from HBM / MALL per slab: the node-level layers ran at the
+    // bandwidth of that re-read, not at anything the pipeline could fix).  Grid = ceil(ncol / 8) * 8 * nslab.
+    const int wg_xcd = blockIdx.x & 7, wg_local = blockIdx.x >> 3;
+    const int wg_col = (wg_local / nslab) * 8 + wg_xcd, wg_slab = wg_local - (wg_local / nslab) * nslab;
+    if (wg_col >= ncol) return;
+    struct Lds { uint4 wsm[H3R_SLOTS][H3R_SLOT_SL][64]; float2 affine[1024]; };      // W ring first: LDS-DMA addresses below 64 KiB
+    __shared__ __attribute__((aligned(16))) Lds lds;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    long long q = (long long)wg_col * X3_WAVES + wave;
+    const bool wave_valid = q < ngroups;
+    q = wave_valid ? q : 0;
+    const long long b = q / gpc;
+    const int l0 = (int)(q - b * gpc) * 32;
+    const bool pv = wave_valid && (l0 + j < L);
+    const int lc = (l0 + j < L) ? l0 + j : l0;
+
+    const unsigned rowB = (unsigned)L * 4u, rowB1 = (unsigned)L1 * 4u;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x1 + b * (long long)C1 * L1), 0, (int)((unsigned)C1 * rowB1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x2 ? x2 + b * (long long)C2 * L : x1), 0, (int)((unsigned)(x2 ? C2 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
+    const unsigned vox = (unsigned)(8 * h * L + lc) * 4u;
+    unsigned vox1 = vox;
+    if (gidx) {
+        const int src = gidx[b * L + lc];
+        vox1 = (unsigned)src < (unsigned)L1 ? (unsigned)(8 * h * L1 + src) * 4u : 0x7FFFFF00u;
+    }
+    const unsigned voy = (unsigned)(4 * h * L + lc) * 4u;
+    const unsigned vow = (unsigned)lane * 16u;
+
+    const int KC1 = C2 > 0 ? (C1 >> 4) : KC;
+    const int nstage = (KC + S - 1) / S;
+
+    auto load_b = [&](float (&raw)[S][8], int st) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int kc = st * S + i;                          // (a chunk past KC reads past both panels: zeros)
+            const bool second = kc >= KC1;
+            const unsigned rb = second ? rowB : rowB1;
+            const unsigned row0 = (unsigned)(16 * (second ? kc - KC1 : kc)) * rb;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned so = row0 + (unsigned)t * rb;
+                raw[i][t] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
+                                                              : __builtin_amdgcn_raw_buffer_load_b32(r1, vox1, so, 0));
+            }
+        }
+    };
+
+    const int ct_begin = wg_slab * ct_per_y;
+    const int ct_end = min(CT, ct_begin + ct_per_y);
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
+        lds.affine[o - ct_begin * 32] = make_float2(scale[o] * 0.03125f, shift[o]);       // accumulators hold 32 W.x
+
+    // this wave's DMA unit of a stage: output tile `wave`, both chunks, both terms = bytes [wave * 4 KiB, +4 KiB) of the slot
+    const unsigned wsm_lds = (unsigned)reinterpret_cast<size_t>(&lds.wsm[0][0][0]);
+    const unsigned dma_dst_w = wsm_lds + (unsigned)wave * 4096u;
+    const uint4 *lds_w = &lds.wsm[0][0][lane];
+
+    RangeAcc xr = {0, 0u};
+    for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+        const char *gw = reinterpret_cast<const char *>(Wp2) + ((size_t)(ct0 + wave) * KCP) * 2048u;
+        auto dma = [&](int st) {                               // stage st (clamped) -> slot st % H3R_SLOTS
+            const int sc = st < nstage ? st : nstage - 1;
+            const char *g = gw + (size_t)sc * (S * 2048);
+            const unsigned d = dma_dst_w + (unsigned)(st & (H3R_SLOTS - 1)) * (unsigned)(H3R_SLOT_SL * 1024), vo = vow;
+            unsigned keep;
+            // (s_nop 4: an operand may arrive in an SGPR written by a VALU instruction -- v_readlane of a spill, v_readfirstlane --,
+            // and a VMEM instruction reading such an SGPR needs 5 wait states that hipcc does not add inside inline asm)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(vo), "s"(g), "s"(d) : "memory");
+        };
+        // slot layout = pack layout of the four tiles side by side: [mt][i][term] -> slice (mt * S + i) * 2 + term
+        // (the range maxima are tracked unconditionally -- two v_max3 per value pair in the MFMA shadow; a branch here would cut
+        // the scheduling region that interleaves the split with the MFMAs -- and published by slab 0 only)
+        auto split = [&](const float (&raw)[8], unsigned (&bh)[4], unsigned (&bm)[4], unsigned (&bl)[4]) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) range_track(xr, raw[2 * p], raw[2 * p + 1]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) split16_pair_med3(raw[2 * p], raw[2 * p + 1], bh[p], bm[p], bl[p]);
+        };
+        // one MFMA, then VALU_PER of the split's vector instructions in its shadow (a wave issues in order: twelve MFMAs in a row
+        // followed by the split leave the matrix pipe idle for the ~200 cycles of the split; hipcc emits exactly that by itself)
+        auto interleave = [&]() {
+#pragma unroll
+            for (int k = 0; k < 3 * MT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        };
+        auto read_a = [&](uint4 (&Ar)[MT], uint4 (&Ah)[MT], int slot, int i) {
+            const uint4 *base = lds_w + (size_t)slot * (H3R_SLOT_SL * 64);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                Ar[mt] = base[((mt * S + i) * 2 + 1) * 64];
+                Ah[mt] = base[((mt * S + i) * 2 + 0) * 64];
+            }
+        };
+        auto mfmas = [&](const uint4 (&Ar)[MT], const uint4 (&Ah)[MT], const unsigned (&bh)[4], const unsigned (&bm)[4], const unsigned (&bl)[4]) {
+            const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));     // 32 xh
+            const f16x8 Bm = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));     // 32 * residual
+            const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[mt]), Bl, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bm, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bh, acc[mt], 0, 0, 0);
+        };
+
+        float xa[S][8], xb[S][8], xc[S][8];
+        unsigned bh[2][4], bm[2][4], bl[2][4];
+        __syncthreads();                                        // every wave is done with the previous tile group's slots (and the affine table is written)
+        dma(0); dma(1); dma(2);
+        load_b(xa, 0);
+        load_b(xb, nstage > 1 ? 1 : 0);
+        split(xa[0], bh[0], bm[0], bl[0]);
+        // stage st: X in xcur (chunk 0 already split into set 0), xnxt = stage st + 1, xfar receives stage st + 2
+        // (a third stage of X look-ahead measured 5-10 % SLOWER: r02y)
+#define H3R_STAGE(st, xcur, xnxt, xfar)                                                                      \
+        {                                                                                                    \
+            if (!(H3R_ABL & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(H3R_WAIT) : "memory");   /* this wave's unit of stage st has landed */ \
+            __builtin_amdgcn_s_barrier(); }                                                                  \
+            if (!(H3R_ABL & 2)) dma((st) + 3);                  /* into the slot of stage st - 1 */          \
+            if (!(H3R_ABL & 1)) load_b(xfar, (st) + 2 < nstage ? (st) + 2 : nstage - 1);                      \
+            const int slot = (st) & (H3R_SLOTS - 1);                                                         \
+            uint4 Ar0[MT], Ah0[MT], Ar1[MT], Ah1[MT];                                                        \
+            read_a(Ar0, Ah0, slot, 0);                                                                       \
+            read_a(Ar1, Ah1, slot, 1);                                                                       \
+            mfmas(Ar0, Ah0, bh[0], bm[0], bl[0]);                                                            \
+            split(xcur[1], bh[1], bm[1], bl[1]);                                                             \
+            interleave();                                                                                    \
+            mfmas(Ar1, Ah1, bh[1], bm[1], bl[1]);                                                            \
+            split(xnxt[0], bh[0], bm[0], bl[0]);                                                             \
+            interleave();                                                                                    \
+        }
+        int st = 0;
+        for (; st + 3 <= nstage; st += 3) {
+            H3R_STAGE(st, xa, xb, xc)
+            H3R_STAGE(st + 1, xb, xc, xa)
+            H3R_STAGE(st + 2, xc, xa, xb)
+        }
+        if (st < nstage) {
+            H3R_STAGE(st, xa, xb, xc)
+            if (st + 1 < nstage) H3R_STAGE(st + 1, xb, xc, xa)
+        }
+#undef H3R_STAGE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-loads of the tail: nothing may land after the next group starts
+
+        if (pv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = lds.affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                }
+            }
+        }
+    }
+    if (rlog != nullptr && ct_begin == 0) {
+        range_publish(rlog, wave_umax(range_amax_bits(xr)), lane);
+        if (wg_col == 0 && threadIdx.x == 0)
+            atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wp2 + (long long)CT * KCP * 2 * 64)[0]);
     }
 }
 
@@ -318,16 +552,19 @@ extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
     if (Cin <= 0 || Cout <= 0) return 0;
     // 3 KiB per (cout tile, K chunk) + a 64-byte trailer: word 0 = bits of max |w| (written by the pack kernels, read by the
     // fp16-flavour kernel for the range log)
-    return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 3 * 64 * 16 + 64;     // bytes
+    // (bf16 flavour: 3 slices per chunk; fp16 flavour: 2 slices per chunk of the K range rounded up to H3_KPAD chunks)
+    const size_t kc = (size_t)sonet::ceil_div(Cin, 16), kcp = (size_t)sonet::ceil_div(Cin, 16 * H3_KPAD) * H3_KPAD;
+    const size_t per_tile = kc * 3 > kcp * 2 ? kc * 3 : kcp * 2;
+    return (size_t)sonet::ceil_div(Cout, 32) * per_tile * 1024 + 64;     // bytes
 }
 
 static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
 {
     SONET_REQUIRE(W && Wp3, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
-    const int KC = sonet::ceil_div(Cin, 16);
+    const int KC = f16 ? sonet::ceil_div(Cin, 16 * H3_KPAD) * H3_KPAD : sonet::ceil_div(Cin, 16);
     const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
-    unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(Wp3) + total * 3);
+    unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(Wp3) + total * (f16 ? 2 : 3));
     if (hipMemsetAsync(trailer, 0, 64, sonet::as_stream(stream)) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
     if (f16) hipLaunchKernelGGL(x3_pack_kernel<true>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
                                 W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total, trailer);
@@ -359,12 +596,49 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     if (Cout % 32 != 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d must be a multiple of 32", what, Cout);
     const int Cin = C1 + C2;
     const int CT = Cout / 32, KC = sonet::ceil_div(Cin, 16);
+    const int KCP = f16 ? sonet::ceil_div(Cin, 16 * H3_KPAD) * H3_KPAD : KC;
     const int gpc = sonet::ceil_div(L, 32);
     const long long ngroups = (long long)B * gpc;
-    if ((double)C1 * L1 * 4.0 >= 2.0e9 || (double)(C1 > C2 ? C1 : C2) * L * 4.0 >= 4.0e9 || (double)Cout * L * 4.0 >= 4.0e9 || (double)CT * KC * 3072.0 >= 4.0e9)
+    if ((double)C1 * L1 * 4.0 >= 2.0e9 || (double)(C1 > C2 ? C1 : C2) * L * 4.0 >= 4.0e9 || (double)Cout * L * 4.0 >= 4.0e9 || (double)CT * KCP * 3072.0 >= 2.0e9)
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
     const long long nwg_x = sonet::ceil_div64(ngroups, (long long)X3_WAVES);
     if (nwg_x > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+    hipStream_t st = sonet::as_stream(stream);
+    const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
+    unsigned *rlog = f16 ? sonet::range_log() : nullptr;
+    const char *eg = getenv("SONET_POINTMLP_H3R");          // bench-only: 0 = the first-generation pipeline
+    // second-generation pipeline where it measures faster (profiles/r02y_pointmlp_h3r.log): inputs that stay in the 256 MB MALL
+    // across the CT / 4 passes over X.  At the point-level sizes (64 x 15000 columns) each pass re-reads X from HBM, and the first
+    // generation's 6-tile groups (two passes for 384 channels instead of three) win by 15-20 %.
+    const bool h3r_fits = (double)Cin * (double)B * (double)L * 4.0 <= 128.0e6 && (long long)B * L >= 256;
+    if (f16 && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : h3r_fits)) {
+        // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
+        // x (groups per workgroup); ties go to the larger d (shorter workgroups)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const int groups = CT / H3R_MT;
+        const long long slots = 2ll * cus;
+        int best = 0;
+        long long best_cost = 0;
+        for (int d = 1; d <= groups; ++d) {
+            if (groups % d != 0 || CT / d > 32) continue;
+            const long long cost = sonet::ceil_div64(nwg_x * d, slots) * (groups / d);
+            if (best == 0 || cost <= best_cost) { best = d; best_cost = cost; }
+        }
+        if (const char *e = getenv("SONET_POINTMLP_YSPLIT")) {
+            const int want = atoi(e);
+            if (want >= 1 && groups % want == 0 && CT / want <= 32) best = want;
+        }
+        if (best == 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
+        const long long nwg = sonet::ceil_div64(nwg_x, 8) * 8 * best;
+        if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+        hipLaunchKernelGGL(pointmlp_h3r_kernel, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
+                           x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x);
+        return sonet::launched(what);
+    }
     int MT = 1, S = 1;
     if (CT % 6 == 0) MT = 6;
     else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
@@ -388,10 +662,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
-    hipStream_t st = sonet::as_stream(stream);
-    const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
-    unsigned *rlog = f16 ? sonet::range_log() : nullptr;
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
