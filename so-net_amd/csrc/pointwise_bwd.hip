@@ -735,65 +735,107 @@ extern "C" int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *po
 
 // ---- small-batch fully connected layer (classifier / decoder heads in eval mode) --------------------------------------
 // y[b][o] = act((sum_k x[b][k] * W[o][k]) * scale[o] + shift[o]),  x [B][Cin], W [Cout][Cin] (nn.Linear layout), exact f32
-// fma chain in k order.  MyLinear (models/layers.py:123-166) on a B x C feature: three of these (1024 -> 512 -> 256 -> 40)
-// replace ~12 aten launches (GEMM + bias, batch-norm transform, clamp) that cost 110 us of a 1.4 ms step.
+// fma chains.  MyLinear (models/layers.py:123-166) on a B x C feature: three of these (1024 -> 512 -> 256 -> 40)
+// replace ~12 aten launches (GEMM + bias, batch-norm transform, clamp).
 namespace {
-// One workgroup = FC_OC output channels (4, 2 or 1: the launcher keeps >= ~256 workgroups in flight) x 64 rows; thread (r, kq) owns row r and a quarter of the k range: its x values are
-// one contiguous segment read with independent 16-byte loads (all in flight at once: the layer is latency-, not
-// bandwidth-bound), the FC_OC weight rows sit in LDS (broadcast reads); the four quarters meet in LDS in a fixed order.
-template <int FC_OC>
+// The layer is a latency problem (67 MFLOP at B = 64, three of them in a row): the work is cut into many small workgroups and
+// every memory request of a thread is in flight before its first fma.  One workgroup = FC_ROWS = 16 rows x FC_OC = 8 outputs;
+// thread (row, ks) owns every 16th float4 of its row (the 16 ks lanes of a row read 256 consecutive bytes), its 8 weight rows
+// sit in LDS in the order the lanes walk k (ws[k % 4][k / 4][8]: the 16 lanes of an LDS read touch consecutive 32-byte slots);
+// the 16 k slices of a row meet in LDS and are summed in a fixed order.  1024 -> 512 at B = 64: 256 workgroups.
+// (Round 1: 64 rows x 2-4 outputs per workgroup, every lane reading its own row -- 64 cache lines per load instruction -- and
+// each workgroup pulling all of x: 22 us.  A version that staged x through LDS in chunks, 64 workgroups: 29-34 us, one wave per
+// SIMD waiting for each chunk.)
+constexpr int FC_ROWS = 16, FC_OC = 8, FC_KS = 16, FC_MAXJ = 16;   // FC_MAXJ float4 per thread: Cin <= 4096
 __global__ __launch_bounds__(256) void linear_act_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                           const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ y, int B, int Cin, int Cout)
+                                                          float *__restrict__ y, int B, int Cin, int Cout, int nj /*float4 per thread*/)
 {
-    extern __shared__ float fc_lds[];                             // ws[FC_OC][Cin] | part[4][64][FC_OC]
+    extern __shared__ __attribute__((aligned(16))) float fc_lds[];   // ws[4][K4][8] | part[16][16][8]
+    const int K4 = nj * FC_KS;                                    // padded Cin / 4
     float *ws = fc_lds;
-    float *part = fc_lds + FC_OC * Cin;
-    const int r = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const int o0 = blockIdx.x * FC_OC, row = blockIdx.y * 64 + r;
-    for (int i = threadIdx.x; i < FC_OC * Cin; i += 256) {
-        const int oo = i / Cin, kk = i - oo * Cin;
-        ws[i] = o0 + oo < Cout ? W[(size_t)(o0 + oo) * Cin + kk] : 0.f;
+    float *part = ws + (size_t)4 * K4 * FC_OC;
+    const int ks = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int o0 = blockIdx.x * FC_OC, row = blockIdx.y * FC_ROWS + rr;
+    const bool vec = (Cin & 3) == 0;
+    // x first: the requests travel while the weights are staged
+    float4 xv[FC_MAXJ];
+#pragma unroll
+    for (int j = 0; j < FC_MAXJ; ++j) {
+        xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = (j * FC_KS + ks) * 4;
+        if (j < nj && row < B && k < Cin) {
+            const float *src = x + (size_t)row * Cin + k;
+            if (vec) xv[j] = *reinterpret_cast<const float4 *>(src);
+            else {
+                xv[j].x = src[0];
+                if (k + 1 < Cin) xv[j].y = src[1];
+                if (k + 2 < Cin) xv[j].z = src[2];
+                if (k + 3 < Cin) xv[j].w = src[3];
+            }
+        }
     }
-    __syncthreads();
-    const int Kq = ((Cin + 3) / 4 + 3) & ~3;                      // quarter length, multiple of 4
-    const int k_beg = kq * Kq, k_end = min(Cin, k_beg + Kq);
-    float acc[FC_OC];
+    // weights: float4 along k, eight requests per thread in flight at a time; zero past Cin / Cout
+    for (int i0 = 0; i0 < FC_OC * K4; i0 += 8 * 256) {
+        float4 wv[8];
 #pragma unroll
-    for (int q = 0; q < FC_OC; ++q) acc[q] = 0.f;
-    if (row < B) {
-        const float *xr = x + (size_t)row * Cin;
-        int k = k_beg;
-        if ((Cin & 3) == 0) {
-#pragma unroll 4
-            for (; k + 4 <= k_end; k += 4) {
-                const float4 xv = *reinterpret_cast<const float4 *>(xr + k);
-#pragma unroll
-                for (int q = 0; q < FC_OC; ++q) {
-                    const float *w = ws + q * Cin + k;
-                    acc[q] = __fmaf_rn(xv.w, w[3], __fmaf_rn(xv.z, w[2], __fmaf_rn(xv.y, w[1], __fmaf_rn(xv.x, w[0], acc[q]))));
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + (int)threadIdx.x, q = i / K4, k = (i - q * K4) * 4;
+            wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < FC_OC * K4 && o0 + q < Cout && k < Cin) {
+                const float *src = W + (size_t)(o0 + q) * Cin + k;
+                if (vec) wv[u] = *reinterpret_cast<const float4 *>(src);
+                else {
+                    wv[u].x = src[0];
+                    if (k + 1 < Cin) wv[u].y = src[1];
+                    if (k + 2 < Cin) wv[u].z = src[2];
+                    if (k + 3 < Cin) wv[u].w = src[3];
                 }
             }
         }
-        for (; k < k_end; ++k) {
-            const float xv = xr[k];
 #pragma unroll
-            for (int q = 0; q < FC_OC; ++q) acc[q] = __fmaf_rn(xv, ws[q * Cin + k], acc[q]);
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + (int)threadIdx.x, q = i / K4, k4 = i - q * K4;
+            if (i < FC_OC * K4) {
+                ws[(0 * K4 + k4) * FC_OC + q] = wv[u].x;
+                ws[(1 * K4 + k4) * FC_OC + q] = wv[u].y;
+                ws[(2 * K4 + k4) * FC_OC + q] = wv[u].z;
+                ws[(3 * K4 + k4) * FC_OC + q] = wv[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    float acc[FC_OC];
+#pragma unroll
+    for (int q = 0; q < FC_OC; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FC_MAXJ; ++j) {
+        if (j < nj) {
+            const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+            const float4 *wp = reinterpret_cast<const float4 *>(ws + (size_t)(j * FC_KS + ks) * FC_OC);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 w0 = wp[(size_t)e * K4 * 2], w1 = wp[(size_t)e * K4 * 2 + 1];
+                acc[0] = __fmaf_rn(xe[e], w0.x, acc[0]); acc[1] = __fmaf_rn(xe[e], w0.y, acc[1]);
+                acc[2] = __fmaf_rn(xe[e], w0.z, acc[2]); acc[3] = __fmaf_rn(xe[e], w0.w, acc[3]);
+                acc[4] = __fmaf_rn(xe[e], w1.x, acc[4]); acc[5] = __fmaf_rn(xe[e], w1.y, acc[5]);
+                acc[6] = __fmaf_rn(xe[e], w1.z, acc[6]); acc[7] = __fmaf_rn(xe[e], w1.w, acc[7]);
+            }
         }
     }
 #pragma unroll
-    for (int q = 0; q < FC_OC; ++q) part[(kq * 64 + r) * FC_OC + q] = acc[q];
+    for (int q = 0; q < FC_OC; ++q) part[(rr * FC_KS + ks) * FC_OC + q] = acc[q];
     __syncthreads();
-    if (kq == 0 && row < B) {
+    if (threadIdx.x < FC_ROWS * FC_OC) {
+        const int r2 = threadIdx.x >> 3, q = threadIdx.x & 7;
+        const int o = o0 + q, row2 = blockIdx.y * FC_ROWS + r2;
+        if (o < Cout && row2 < B) {
+            float sum = 0.f;
 #pragma unroll
-        for (int q = 0; q < FC_OC; ++q) {
-            const int o = o0 + q;
-            if (o >= Cout) continue;
-            const float sum = (part[(0 * 64 + r) * FC_OC + q] + part[(1 * 64 + r) * FC_OC + q]) +
-                              (part[(2 * 64 + r) * FC_OC + q] + part[(3 * 64 + r) * FC_OC + q]);
+            for (int t = 0; t < FC_KS; ++t) sum += part[(r2 * FC_KS + t) * FC_OC + q];
             float v = __fmaf_rn(sum, scale[o], shift[o]);
             if (relu) v = (v < 0.f) ? 0.f : v;
-            y[(size_t)row * Cout + o] = v;
+            y[(size_t)row2 * Cout + o] = v;
         }
     }
 }
@@ -805,16 +847,19 @@ extern "C" int sonet_linear_act_f32(const float *x, const float *W, const float 
     const char *what = "sonet_linear_act_f32";
     SONET_REQUIRE(x && W && scale && shift && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0, "%s: non-positive size", what);
-    if (sonet::ceil_div(B, 64) > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d too large", what, B);
-    const int rows = sonet::ceil_div(B, 64);
-    int oc = 4;                                                   // fewer channels per workgroup while the grid would not fill the chip
-    while (oc > 1 && (long long)sonet::ceil_div(Cout, oc) * rows < 256) oc >>= 1;
-    const size_t lds = ((size_t)oc * Cin + 4 * 64 * oc) * sizeof(float);
-    if (lds > 64 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d too large (max 3840)", what, Cin);
-    dim3 grid(sonet::ceil_div(Cout, oc), rows), block(256);
+    const int rows = sonet::ceil_div(B, FC_ROWS);
+    if (rows > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d too large", what, B);
+    const int nj = sonet::ceil_div(Cin, 4 * FC_KS);
+    if (nj > FC_MAXJ) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d too large (max %d)", what, Cin, 4 * FC_KS * FC_MAXJ);
+    const size_t lds = ((size_t)4 * nj * FC_KS * FC_OC + FC_ROWS * FC_KS * FC_OC) * sizeof(float);
+    dim3 grid(sonet::ceil_div(Cout, FC_OC), rows), block(256);
     hipStream_t st = sonet::as_stream(stream);
-    if (oc == 4)      hipLaunchKernelGGL(linear_act_kernel<4>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
-    else if (oc == 2) hipLaunchKernelGGL(linear_act_kernel<2>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
-    else              hipLaunchKernelGGL(linear_act_kernel<1>, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout);
+    static bool raised = false;                                   // (dynamic LDS above 64 KiB has to be asked for: Cin > 1792)
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+            return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", what);
+        raised = true;
+    }
+    hipLaunchKernelGGL(linear_act_kernel, grid, block, lds, st, x, W, scale, shift, relu, y, B, Cin, Cout, nj);
     return sonet::launched(what);
 }
