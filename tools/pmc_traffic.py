@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WIDE_READERS = ("index_max",)
 NAMES = [("pointresnet_bf16_pool2_kernel", "pointresnet_bf16_pool_L15000"), ("pointresnet_fused_kernel", "pointresnet_fused_pool_L15000"), ("index_max_kernel", "index_max_gather"),
-         ("som_assign_kernel", "som_assign"), ("som_sort_group_kernel", "som_sort_group"), ("som_group_kernel", "som_group")]
+         ("som_assign_keys_kernel", "som_assign"), ("som_assign_kernel", "som_assign"), ("som_sort_group_kernel", "som_sort_group"), ("som_group_kernel", "som_group")]
 
 
 def load(counter):
