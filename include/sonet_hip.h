@@ -306,6 +306,15 @@ int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float
 int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
                                   const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
 
+/* out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_{i<NL} wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]);  z [B][C][M] = the
+ * layer applied to the M node features once (sonet_pointmlp_h3_f32 with unit scale), gidx [B][L] i32 (out of range: 0),
+ * lead [B][NL][L] the per-column channels (NL <= 4: the 3 de-centred coordinates), wl [C][NL] their weight columns, exact f32
+ * fmas in channel order.  KNNModule layer 1 (models/layers.py:313-350: cat(de-centred coordinates, gathered features) -> 1x1
+ * conv) without the K-fold redundant MFMAs over gathered columns. */
+int sonet_node_gather_lead_affine_act_f32(const float *z, const int32_t *gidx, const float *lead, const float *wl,
+                                          const float *scale, const float *shift, int relu, float *out,
+                                          int B, int C, int L, int M, int NL, sonet_stream_t stream);
+
 /* Small-batch fully connected layer: y[b][o] = act((sum_k x[b][k] W[o][k]) * scale[o] + shift[o]); x [B][Cin], W [Cout][Cin]
  * (nn.Linear layout), exact f32 fma chain.  MyLinear = Linear + BatchNorm1d(eval) + ReLU (models/layers.py:123-166) with the
  * bias and the running statistics folded into (scale, shift): the classifier head of models/networks.py:202-227. */

@@ -118,6 +118,78 @@ __global__ __launch_bounds__(256) void node_add_affine_act_kernel(float *__restr
     }
 }
 
+// out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_i wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]):  a layer over GATHERED node
+// features plus a few per-column channels (KNNModule layer 1: 384 gathered + 3 de-centred coordinate channels over K * M
+// columns, models/layers.py:313-350) is linear in the features, so W_f . x is computed ONCE per node (z, M columns instead of
+// K * M: one ninth of the MFMAs at K = 9) and gathered here; the NL <= 4 lead channels are exact f32 fmas in channel order.
+// One workgroup per (cloud, 8 channels): gidx / lead are read once per 8 output rows, the 8 node rows sit in LDS.
+constexpr int NGL_CH = 8, NGL_THREADS = 128;
+__global__ __launch_bounds__(NGL_THREADS) void node_gather_lead_kernel(const float *__restrict__ z, const int32_t *__restrict__ gidx,
+                                                                        const float *__restrict__ lead, const float *__restrict__ wl,
+                                                                        const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                                        float *__restrict__ out, int C, int L, int M, int NL)
+{
+    extern __shared__ float zs[];                                 // [NGL_CH][M] | coef[NGL_CH][6] (w0..w3, scale, shift)
+    float *coef = zs + NGL_CH * M;
+    const int cb = blockIdx.x * NGL_CH;
+    const long long b = blockIdx.y;
+    const int nch = min(NGL_CH, C - cb);
+    for (int i = threadIdx.x; i < nch * M; i += NGL_THREADS) zs[i] = z[((long long)b * C + cb) * M + i];
+    if (threadIdx.x < nch) {
+        const int c = cb + threadIdx.x;
+        for (int i = 0; i < 4; ++i) coef[threadIdx.x * 6 + i] = i < NL ? wl[c * NL + i] : 0.f;
+        coef[threadIdx.x * 6 + 4] = scale[c];
+        coef[threadIdx.x * 6 + 5] = shift[c];
+    }
+    __syncthreads();
+    const int32_t *g = gidx + b * L;
+    const float *ld = lead + b * (long long)NL * L;
+    float *ob = out + ((long long)b * C + cb) * L;
+    const int L4 = (L + 3) >> 2;
+    const bool vec = (L & 3) == 0;
+    // a thread owns a quad of columns: node ids and lead channels are read once and serve the 8 channel rows
+    for (int q = threadIdx.x; q < L4; q += NGL_THREADS) {
+        const int l = q * 4;
+        int m[4];
+        float d[4][4];
+        if (vec) {
+            const int4 mv = *reinterpret_cast<const int4 *>(g + l);
+            m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 dv = i < NL ? *reinterpret_cast<const float4 *>(ld + (long long)i * L + l) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[i][0] = dv.x; d[i][1] = dv.y; d[i][2] = dv.z; d[i][3] = dv.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int le = l + e < L ? l + e : L - 1;
+                m[e] = g[le];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i][e] = i < NL ? ld[(long long)i * L + le] : 0.f;
+            }
+        }
+        for (int c = 0; c < nch; ++c) {
+            const float *cf = coef + c * 6;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = (unsigned)m[e] < (unsigned)M ? zs[c * M + m[e]] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a = __fmaf_rn(cf[i], d[i][e], a);      // (absent lead channels: + 0 * 0, exact)
+                a = __fmaf_rn(a, cf[4], cf[5]);
+                v[e] = (relu && a < 0.f) ? 0.f : a;
+            }
+            float *o = ob + (long long)c * L + l;
+            if (vec) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (l + e < L) o[e] = v[e];
+            }
+        }
+    }
+}
+
 // per-channel coefficient kernels (C threads): replace a dozen C-element aten launches per layer
 __global__ __launch_bounds__(256) void bn_fwd_coeffs_kernel(const float *__restrict__ mean, const float *__restrict__ var,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -443,6 +515,18 @@ extern "C" int sonet_node_add_affine_act_f32(float *t, const float *z, const int
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(node_add_affine_act_kernel, dim3((unsigned)rows, gy), dim3(256), (size_t)M * sizeof(float),
                        sonet::as_stream(stream), t, z, min_idx_i32, scale, shift, relu, C, L, M);
+    return sonet::launched(what);
+}
+
+extern "C" int sonet_node_gather_lead_affine_act_f32(const float *z, const int32_t *gidx, const float *lead, const float *wl,
+                                                     const float *scale, const float *shift, int relu, float *out,
+                                                     int B, int C, int L, int M, int NL, sonet_stream_t stream)
+{
+    const char *what = "sonet_node_gather_lead_affine_act_f32";
+    SONET_REQUIRE(z && gidx && scale && shift && out && (NL == 0 || (lead && wl)), "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && M > 0 && M <= 1024 && NL >= 0 && NL <= 4, "%s: bad size B=%d C=%d L=%d M=%d NL=%d", what, B, C, L, M, NL);
+    hipLaunchKernelGGL(node_gather_lead_kernel, dim3((unsigned)sonet::ceil_div(C, NGL_CH), (unsigned)B), dim3(NGL_THREADS), (size_t)NGL_CH * (M + 6) * sizeof(float),
+                       sonet::as_stream(stream), z, gidx, lead, wl, scale, shift, relu, out, C, L, M, NL);
     return sonet::launched(what);
 }
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sonet_pointmlp_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_gather": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_index_max_gather_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_node_gather_lead_affine_act_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],

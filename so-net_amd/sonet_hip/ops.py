@@ -232,6 +232,25 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     return t
 
 
+def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
+    """act((z[:, :, gidx] + wl . lead) * scale + shift): z B x C x M (the layer on the M node features), gidx B x L i32 (out of
+    range -> 0), lead B x NL x L (NL <= 4 per-column channels), wl C x NL.  -> B x C x L f32."""
+    _chk(z, "z", torch.float32, 3)
+    _chk(gidx, "gidx", torch.int32, 2)
+    _chk(lead, "lead", torch.float32, 3)
+    _chk(wl, "wl", torch.float32, 2)
+    dev = _same_device(z, gidx, lead, wl, scale, shift)
+    B, C, M = z.shape
+    L, NL = gidx.shape[1], lead.shape[1]
+    if gidx.shape[0] != B or lead.shape[0] != B or lead.shape[2] != L or tuple(wl.shape) != (C, NL) or scale.numel() != C or shift.numel() != C:
+        raise SonetHipError("node_gather_lead_affine_act: z B x C x M, gidx B x L, lead B x NL x L, wl C x NL, scale / shift C")
+    out = torch.empty((B, C, L), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("node_gather_lead_%dx%d_L%d" % (NL, C, L)):
+        check(_lib.load().sonet_node_gather_lead_affine_act_f32(ptr(z), ptr(gidx), ptr(lead), ptr(wl), ptr(scale), ptr(shift), int(bool(relu)),
+                                                                ptr(out), B, C, L, M, NL, stream_ptr()), "sonet_node_gather_lead_affine_act_f32")
+    return out
+
+
 def knn_self(node, K):
     """node B x 3 x M f32 -> B x M x K i64: the K nearest nodes of every node (itself first)."""
     _chk(node, "node", torch.float32, 3)
@@ -312,6 +331,8 @@ FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
 # no-grad node-level stage (KNNModule + final PointNet) without the gathered tensor and without concats: the neighbour
 # gather happens in the first layer's operand loads, narrow leading panels go last through a rotated weight pack (h3 only)
 GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
+# KNNModule layer 1 as (layer on the M node features) + gather + coordinate channels instead of a layer over K * M gathered columns
+NODE_LINEAR_SPLIT = _os.environ.get("SONET_NODE_LINEAR_SPLIT", "1") != "0"
 
 
 # ---- operand-range guard of the fp16-split ("h3") arithmetic ------------------------------------------------------------------

@@ -473,3 +473,48 @@ def test_pointmlp_h3_second_generation_is_bit_identical(B, C1, C2, Cout, L, L1, 
     ref = torch.relu(torch.einsum("oc,bcl->bol", w.double(), xin) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1))
     err = (out["1"].double() - ref).abs()
     assert float(err.max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,M,L,NL", [(3, 512, 64, 576, 3), (2, 37, 10, 33, 3), (1, 8, 5, 7, 0), (2, 64, 100, 1000, 4)])
+def test_node_gather_lead_affine_act_vs_torch(B, C, M, L, NL):
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B * C + L)
+    z = torch.randn(B, C, M, generator=g)
+    gidx = torch.randint(-1, M + 1, (B, L), generator=g, dtype=torch.int32)
+    lead = torch.randn(B, NL, L, generator=g)
+    wl = torch.randn(C, NL, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ok = (gidx >= 0) & (gidx < M)
+    zg = torch.gather(z.double(), 2, gidx.clamp(0, M - 1).long().unsqueeze(1).expand(B, C, L)) * ok.unsqueeze(1)
+    ref = torch.relu((zg + torch.einsum("ci,bil->bcl", wl.double(), lead.double())) * sc.double().view(1, -1, 1) + sh.double().view(1, -1, 1))
+    got = ops.node_gather_lead_affine_act(cu(z), cu(gidx), cu(lead), cu(wl), cu(sc), cu(sh), True).cpu().double()
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+def test_knn_module_linear_split_matches_gathered_layer():
+    """KNNModule layer 1 as (layer on the node features) + gather + coordinate channels == the layer over the gathered columns,
+    within the split arithmetic's own noise; the encoder forward meets the oracle on both (the golden tests run the default)."""
+    from models import layers as Lm
+    from sonet_hip import ops, synth
+    B, M, K, C = 4, 64, 9, 384
+    knn = Lm.KNNModule(3 + C, (512, 512), "relu", "batch", 0.1, None, 1)
+    synth.fill_state_dict_(knn.state_dict(), seed=3)
+    knn.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    coord, x = cu(torch.rand(B, 3, M, generator=g) * 2 - 1), cu(torch.randn(B, C, M, generator=g))
+    knn_I = ops.knn_self(coord, K)
+    out = {}
+    old = ops.NODE_LINEAR_SPLIT
+    try:
+        for flag in (True, False):
+            ops.NODE_LINEAR_SPLIT = flag
+            with torch.no_grad(), ops.kernel_timing() as rec:
+                out[flag] = knn(coord, x, knn_I, K, "center")[1]
+            names = [n for n, _, _ in rec.records]
+            assert any(n.startswith("node_gather_lead") for n in names) == flag, names
+    finally:
+        ops.NODE_LINEAR_SPLIT = old
+    err = (out[True] - out[False]).abs().max()
+    assert float(err) <= 1e-5 * max(1.0, float(out[False].abs().max()))
