@@ -306,6 +306,13 @@ int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float
 int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
                                   const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
 
+/* Weight gradient of a point-wise layer: dw[o][c] = sum_b sum_l g[b][o][l] * x[b][c][l]  (g [B][Cout][L], x [B][Cin][L], dw
+ * [Cout][Cin], f32) -- what autograd computes for the nn.Conv1d / nn.Conv2d(1x1) weights of models/layers.py:282-296.  Both
+ * operands are split into three bf16 pieces, six products kept (f32-class, f32 range), f32 accumulation on the matrix cores;
+ * partial 128 x 128 blocks over column slices are summed in a fixed order (deterministic).  ws = sonet_wgrad_x3_ws_size bytes. */
+size_t sonet_wgrad_x3_ws_size(int B, int Cout, int Cin, int L);
+int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
+
 /* out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_{i<NL} wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]);  z [B][C][M] = the
  * layer applied to the M node features once (sonet_pointmlp_h3_f32 with unit scale), gidx [B][L] i32 (out of range: 0),
  * lead [B][NL][L] the per-column channels (NL <= 4: the 3 de-centred coordinates), wl [C][NL] their weight columns, exact f32

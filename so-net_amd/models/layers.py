@@ -122,14 +122,22 @@ def _dgrad(g_raw, pack):
 
 
 def _wgrad(g_raw, x):
-    """sum over clouds of g_raw[b] . x[b]^T  (Cout x Ci, f32).  One batched GEMM (hipBLASLt; K = L is the long axis); bf16
-    operands accumulate and come out in f32 (a bf16 per-cloud partial would cost three of the eight significand bits)."""
+    """sum over clouds of g_raw[b] . x[b]^T  (Cout x Ci, f32).  f32-class modes: ``sonet_wgrad_x3_f32`` (both operands split
+    into three bf16 pieces on the matrix cores, partial blocks summed in a fixed order); exact-f32 mode and tiny problems: one
+    batched hipBLASLt GEMM (K = L is the long axis); bf16 operands accumulate and come out in f32 (a bf16 per-cloud partial
+    would cost three of the eight significand bits)."""
     if g_raw.dtype == torch.bfloat16:
         xt = x.transpose(1, 2)
         try:
             return torch.bmm(g_raw, xt, out_dtype=torch.float32).sum(0)
         except (TypeError, RuntimeError):
             return torch.bmm(g_raw.float(), xt.float()).sum(0)
+    if (_ops.WGRAD_KERNEL and _ops.POINTMLP_PRECISION in ("h3", "x3") and g_raw.is_cuda and g_raw.dtype == torch.float32
+            and x.dtype == torch.float32 and g_raw.shape[0] * g_raw.shape[2] >= 4096 and g_raw.shape[1] * x.shape[1] >= 256 * 128):
+        # split-operand MFMA kernel, deterministic; measured against the library GEMM + sum (profiles/r02za_wgrad.log): 256x128 at
+        # 64 x 15000 columns 450 vs 533 us, the node-level shapes 55-142 vs 83-182 us; narrow gradients (64x6, 128x64) stay on
+        # hipBLASLt (150 vs 50, 195 vs 170 us: too few rows per column slice to keep the loads busy)
+        return _ops.wgrad_x3(g_raw.contiguous(), x.contiguous())
     return torch.bmm(g_raw, x.transpose(1, 2)).sum(0)
 
 

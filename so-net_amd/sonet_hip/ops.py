@@ -232,6 +232,25 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     return t
 
 
+def wgrad_x3(g, x):
+    """sum_b g[b] . x[b]^T: g B x Cout x L, x B x Cin x L (f32) -> Cout x Cin f32, bf16 x 3 split of both operands on the matrix cores."""
+    _chk(g, "g", torch.float32, 3)
+    _chk(x, "x", torch.float32, 3)
+    dev = _same_device(g, x)
+    B, Cout, L = g.shape
+    if x.shape[0] != B or x.shape[2] != L:
+        raise SonetHipError("wgrad_x3: g B x Cout x L and x B x Cin x L")
+    Cin = x.shape[1]
+    lib = _lib.load()
+    dw = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    if g.numel() == 0 or x.numel() == 0:
+        return dw.zero_()
+    ws = torch.empty((lib.sonet_wgrad_x3_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("wgradx3_%dx%d_L%d" % (Cout, Cin, L)):
+        check(lib.sonet_wgrad_x3_f32(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_x3_f32")
+    return dw
+
+
 def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
     """act((z[:, :, gidx] + wl . lead) * scale + shift): z B x C x M (the layer on the M node features), gidx B x L i32 (out of
     range -> 0), lead B x NL x L (NL <= 4 per-column channels), wl C x NL.  -> B x C x L f32."""
@@ -333,6 +352,7 @@ FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
 GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
 # KNNModule layer 1 as (layer on the M node features) + gather + coordinate channels instead of a layer over K * M gathered columns
 NODE_LINEAR_SPLIT = _os.environ.get("SONET_NODE_LINEAR_SPLIT", "1") != "0"
+WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 
 # ---- operand-range guard of the fp16-split ("h3") arithmetic ------------------------------------------------------------------

@@ -518,3 +518,24 @@ def test_knn_module_linear_split_matches_gathered_layer():
         ops.NODE_LINEAR_SPLIT = old
     err = (out[True] - out[False]).abs().max()
     assert float(err) <= 1e-5 * max(1.0, float(out[False].abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cout,Cin,L", [(3, 256, 128, 1500), (2, 64, 6, 777), (4, 128, 64, 64), (1, 512, 387, 1000), (2, 1024, 768, 130),
+                                         (5, 96, 33, 1), (2, 256, 320, 4099)])
+def test_wgrad_x3_vs_float64(B, Cout, Cin, L):
+    """sonet_wgrad_x3_f32 == sum_b g[b] x[b]^T in float64 at f32-class accuracy (operands of very different scale: gradients
+    ~1e-4, activations ~1), ragged L, channel counts that are no multiple of the 32-row tile, several column slices; and
+    bitwise reproducible (fixed summation order)."""
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(Cout + Cin + L)
+    g = cu(torch.randn(B, Cout, L, generator=gen) * 1e-4 * (1 + 10 * torch.rand(1, Cout, 1, generator=gen)))
+    x = cu(torch.randn(B, Cin, L, generator=gen) * (0.1 + torch.rand(1, Cin, 1, generator=gen)))
+    ref = torch.einsum("bol,bcl->oc", g.double(), x.double())
+    got = ops.wgrad_x3(g, x)
+    assert tuple(got.shape) == (Cout, Cin)
+    scale = float(torch.einsum("bol,bcl->oc", g.double().abs(), x.double().abs()).max())       # the sum's own conditioning
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * scale
+    assert torch.equal(got, ops.wgrad_x3(g, x))
+    f32 = torch.bmm(g, x.transpose(1, 2)).sum(0)
+    assert float((got.double() - ref).abs().max()) <= 4.0 * float((f32.double() - ref).abs().max()) + 1e-7 * scale
