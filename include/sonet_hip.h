@@ -306,6 +306,18 @@ int sonet_pointwise_bwd_apply_f32(const float *gy, const float *raw, const float
 int sonet_node_add_affine_act_f32(float *t, const float *z, const int32_t *min_idx_i32, const float *scale,
                                   const float *shift, int relu, int B, int C, int L, int M, sonet_stream_t stream);
 
+/* sonet_pointmlp_h3_f32 / sonet_pointmlp_x3_f32 that also return mean[c] and the biased variance var[c] of y over (B, L) --
+ * BatchNorm's batch statistics (models/layers.py:60-70) -- from the kernel's epilogue instead of a second pass over y: per-workgroup
+ * (sum, sum of squares) partials in f64 (rows reduced over a wave's 32 columns in f32), summed in a fixed order.
+ * stats_ws: sonet_pointmlp_stats_ws_size(B, Cout, L) bytes. */
+size_t sonet_pointmlp_stats_ws_size(int B, int Cout, int L);
+int sonet_pointmlp_h3_stats_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                float *mean, float *var, sonet_stream_t stream);
+int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                float *mean, float *var, sonet_stream_t stream);
+
 /* Weight gradient of a point-wise layer: dw[o][c] = sum_b sum_l g[b][o][l] * x[b][c][l]  (g [B][Cout][L], x [B][Cin][L], dw
  * [Cout][Cin], f32) -- what autograd computes for the nn.Conv1d / nn.Conv2d(1x1) weights of models/layers.py:282-296.  Both
  * operands are split into three bf16 pieces, six products kept (f32-class, f32 range), f32 accumulation on the matrix cores;

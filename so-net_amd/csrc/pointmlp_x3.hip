@@ -134,6 +134,44 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| of the layer (range log, word 1 of a launch)
 }
 
+// sum over the 32 lanes of a half wave, result in every lane (all lanes must be active): xor-1, xor-2 inside a quad, mirror inside
+// 8 and 16 lanes (DPP modifiers of the add), then the other row of 16 through ds_swizzle (no LDS memory is touched)
+__device__ __forceinline__ float row32_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                     // lane ^ 16
+    return v;
+}
+
+// mean / biased variance from the per-workgroup partial sums of the statistics epilogue: 4 channels x 64 slices per workgroup, fixed
+// order (deterministic)
+__global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const double *__restrict__ partial, int nwg, int C, double inv_n,
+                                                                     float *__restrict__ mean, float *__restrict__ var)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int k = ln; k < nwg; k += 64) {
+            const double *p = partial + ((size_t)k * C + c) * 2;
+            s1 += p[0];
+            s2 += p[1];
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    if (ln == 0 && c < C) {
+        const double m = s1 * inv_n;
+        double v = s2 * inv_n - m * m;
+        if (v < 0.0) v = 0.0;
+        mean[c] = (float)m;
+        var[c] = (float)v;
+    }
+}
+
 template <int MT, int S, bool F16>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
@@ -141,13 +179,15 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
     const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
     unsigned *__restrict__ rlog /*optional (fp16 flavour): range-log slot, word 0 = max |x| bits, word 1 = max |w| bits*/,
-    int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/)
+    int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/,
+    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum and sum of squares of the stored output over this workgroup's columns*/)
 {
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
     constexpr int NS = (NSL + X3_WAVES - 1) / X3_WAVES;
     __shared__ uint4 wsm[2][NS * X3_WAVES][64];
     __shared__ float2 affine[1024];
+    __shared__ float2 red[X3_WAVES][MT * 32];                   // (statistics epilogue) per wave: (sum, sum of squares) of a row over its 32 columns
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,7 +343,37 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         if (st < nstage) X3_STAGE(st, b0, b1, 0)
 #undef X3_STAGE
 
-        if (pv) {
+        if (stats_partial != nullptr) {
+            // Training forward: BatchNorm's batch statistics (models/layers.py:60-70) of the output come out of this epilogue instead of
+            // a second pass over the tensor.  A row's 32 columns sit in the 32 lanes of a half wave: four DPP adds + one swizzle per
+            // quantity, all lanes active (a padded column stores to an out-of-range offset -- dropped by the descriptor -- and adds 0).
+            const unsigned voy_s = pv ? voy : 0x7FFFFF00u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy_s, so_tile + (unsigned)orow * rowB, 0);
+                    const float sv = pv ? v : 0.f;
+                    const float s1 = row32_sum(sv), s2 = row32_sum(sv * sv);
+                    if (j == 0) red[wave][mt * 32 + orow + 4 * h] = make_float2(s1, s2);
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < MT * 32; t += X3_THREADS) {
+                const double a = ((double)red[0][t].x + (double)red[1][t].x) + ((double)red[2][t].x + (double)red[3][t].x);
+                const double q = ((double)red[0][t].y + (double)red[1][t].y) + ((double)red[2][t].y + (double)red[3][t].y);
+                double *dst = stats_partial + ((size_t)blockIdx.x * Cout + (size_t)ct0 * 32 + t) * 2;
+                dst[0] = a;
+                dst[1] = q;
+            }
+            __syncthreads();                                    // (red is reused by the next tile group)
+        } else if (pv) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
@@ -585,7 +655,8 @@ extern "C" int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Co
 
 static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, const float *x2, int C2, const void *Wp3,
                        const float *scale, const float *shift, int relu, float *y,
-                       int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0)
+                       int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
+                       double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -611,7 +682,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     // across the CT / 4 passes over X.  At the point-level sizes (64 x 15000 columns) each pass re-reads X from HBM, and the first
     // generation's 6-tile groups (two passes for 384 channels instead of three) win by 15-20 %.
     const bool h3r_fits = (double)Cin * (double)B * (double)L * 4.0 <= 128.0e6 && (long long)B * L >= 256;
-    if (f16 && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : h3r_fits)) {
+    if (f16 && !stats_ws && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : h3r_fits)) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
         int dev = 0, cus = 256;
@@ -662,7 +733,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
@@ -675,7 +746,36 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     }
 #undef X3_LAUNCH
 #undef X3_ARGS
+    if (stats_ws)
+        hipLaunchKernelGGL(stats_partial_finalize_kernel, dim3((unsigned)sonet::ceil_div(Cout, 4)), dim3(256), 0, st, stats_ws, (int)nwg_x, Cout,
+                           1.0 / ((double)B * L), mean, var);
     return sonet::launched(what);
+}
+
+extern "C" size_t sonet_pointmlp_stats_ws_size(int B, int Cout, int L)
+{
+    if (B <= 0 || Cout <= 0 || L <= 0) return 0;
+    return (size_t)sonet::ceil_div64((long long)B * sonet::ceil_div(L, 32), X3_WAVES) * Cout * 2 * sizeof(double);
+}
+
+/* sonet_pointmlp_{h3,x3}_f32 that also return the per-channel mean and biased variance of y over (B, L) -- BatchNorm's batch
+ * statistics (models/layers.py:60-70) -- from the kernel's epilogue.  stats_ws: sonet_pointmlp_stats_ws_size bytes. */
+extern "C" int sonet_pointmlp_h3_stats_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                           const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                           float *mean, float *var, sonet_stream_t stream)
+{
+    SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_h3_stats_f32: NULL pointer");
+    return x3_run_impl("sonet_pointmlp_h3_stats_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                       reinterpret_cast<double *>(stats_ws), mean, var);
+}
+
+extern "C" int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                           const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                           float *mean, float *var, sonet_stream_t stream)
+{
+    SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_x3_stats_f32: NULL pointer");
+    return x3_run_impl("sonet_pointmlp_x3_stats_f32", false, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                       reinterpret_cast<double *>(stats_ws), mean, var);
 }
 
 extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,

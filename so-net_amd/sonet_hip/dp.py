@@ -147,6 +147,10 @@ class GradientAllReducer:
             for i in members:
                 self._bucket_of[i] = b
         self._flat = torch.zeros(off, dtype=ref.dtype, device=ref.device)
+        # views of the flat buffer shaped like the parameters, per bucket: gradients go in and out with ONE multi-tensor copy per
+        # bucket (a copy per parameter was 110 four-microsecond launches per training step)
+        self._views = [[self._flat[self._slices[i][0]:self._slices[i][0] + self._slices[i][1]].view_as(self.params[i]) for i in members]
+                       for _, _, members in self.buckets]
         if self.overlap and (world_size() > 1 or self.always_reduce):
             for i in live:
                 self._hooks.append(self.params[i].register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -169,13 +173,12 @@ class GradientAllReducer:
                 # this bucket is a partial sum -- reduce() redoes the exchange from the accumulated .grad tensors
                 self._dirty = True
                 return
-            off, n = self._slices[i]
-            self._flat[off:off + n].copy_(p.grad.reshape(-1))
             self._pending[b] -= 1
             # launch every complete bucket up to the first incomplete one, in index order: a rank whose autograd graph
             # finishes bucket 2 before bucket 1 still issues the collectives in the order every other rank does
             while self._next_launch < len(self.buckets) and self._pending[self._next_launch] == 0:
-                bo, bn, _ = self.buckets[self._next_launch]
+                bo, bn, members = self.buckets[self._next_launch]
+                _copy_all(self._views[self._next_launch], [self.params[j].grad for j in members])
                 self._work[self._next_launch] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
                 self._next_launch += 1
         return hook
@@ -234,24 +237,32 @@ class GradientAllReducer:
                 self._work[b].wait()
         else:
             for i in self._live:
-                g = self.params[i].grad
-                if g is None:
+                if self.params[i].grad is None:
                     raise RuntimeError("parameter %d had a gradient on the first step but has none now" % i)
-                off, n = self._slices[i]
-                self._flat[off:off + n].copy_(g.reshape(-1))
+            for b, (_, _, members) in enumerate(self.buckets):
+                _copy_all(self._views[b], [self.params[j].grad for j in members])
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         if ev is not None:
             ev[1].record()
             self._exposed_events.append(ev)
         self._flat.div_(w)
-        for i in self._live:
-            g = self.params[i].grad
-            off, n = self._slices[i]
-            g.copy_(self._flat[off:off + n].view_as(g))
+        for b, (_, _, members) in enumerate(self.buckets):
+            _copy_all([self.params[j].grad for j in members], self._views[b])
         self._work_done = list(self._work)                            # (what the hooks launched during this step: tests look at it)
         if self._armed:
             self._arm()                                               # next backward
         return self._flat.numel() * self._flat.element_size()
+
+
+def _copy_all(dst, src):
+    """dst[k].copy_(src[k]) for all k in one multi-tensor launch where torch has it."""
+    if not dst:
+        return
+    try:
+        torch._foreach_copy_(dst, src)
+    except (AttributeError, RuntimeError):
+        for d, s_ in zip(dst, src):
+            d.copy_(s_)
 
 
 def all_reduce_max(value, device):

@@ -651,6 +651,41 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     return y
 
 
+STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)
+
+
+def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
+    """pointmlp(...) plus the per-channel (mean, biased var) of its output over (B, L), from the kernel's epilogue.  h3 / x3 packs
+    (f32 storage) only; -> (y, mean, var)."""
+    h3 = wp.dtype == torch.int8
+    if not (h3 or wp.dtype == torch.uint8):
+        raise SonetHipError("pointmlp_stats: an h3 or x3 pack")
+    _chk(x1, "x", torch.float32, 3)
+    B, C1, L = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2", torch.float32, 3)
+        if x2.shape[0] != B or x2.shape[2] != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.shape[1]
+    dev = _same_device(x1, x2, wp, scale, shift)
+    lib = _lib.load()
+    if wp.numel() != lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout):
+        raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C1 + C2, Cout))
+    y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    mean = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    var = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.sonet_pointmlp_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
+    name = "pointmlp%s_stats_%dx%d_L%d" % ("h3" if h3 else "x3", C1 + C2, Cout, L)
+    if h3:
+        _range_arm(name)
+    fn = lib.sonet_pointmlp_h3_stats_f32 if h3 else lib.sonet_pointmlp_x3_stats_f32
+    with torch.cuda.device(dev), _timed(name):
+        check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
+                 stream_ptr()), "sonet_pointmlp_stats")
+    return y, mean, var
+
+
 def pointresnet_pack(w1, w2, w3, w4):
     """Pack the four [Cout][Cin] f32 weights of the first PointNet into the fused kernel's weight stream."""
     for i, w in enumerate((w1, w2, w3, w4)):

@@ -539,3 +539,29 @@ def test_wgrad_x3_vs_float64(B, Cout, Cin, L):
     assert torch.equal(got, ops.wgrad_x3(g, x))
     f32 = torch.bmm(g, x.transpose(1, 2)).sum(0)
     assert float((got.double() - ref).abs().max()) <= 4.0 * float((f32.double() - ref).abs().max()) + 1e-7 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["h3", "x3"])
+@pytest.mark.parametrize("B,C1,C2,Cout,L", [(3, 64, 0, 128, 1500), (2, 6, 0, 64, 777), (2, 256, 64, 384, 300), (5, 128, 0, 256, 33)])
+def test_pointmlp_statistics_epilogue(mode, B, C1, C2, Cout, L):
+    """The layer kernel's statistics epilogue: same output as the plain launch bit for bit, mean / biased variance equal to the
+    separate pass (f64 sums over every element) to 1e-6 of the channel's scale -- with a large common offset (mean^2 >> var)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    w = cu(torch.randn(Cout, C1 + C2, generator=g) / (C1 + C2) ** 0.5)
+    x1 = cu(torch.randn(B, C1, L, generator=g))
+    x2 = cu(torch.randn(B, C2, L, generator=g)) if C2 else None
+    scale = cu(torch.ones(Cout))
+    shift = cu(torch.randn(Cout, generator=g) * 3.0)                       # the conv bias: a common offset per channel
+    wp = ops.pointmlp_pack(w, mode)
+    y0 = ops.pointmlp(x1, wp, scale, shift, False, Cout, x2=x2)
+    m0, v0 = ops.channel_stats(y0)
+    y1, m1, v1 = ops.pointmlp_stats(x1, wp, scale, shift, False, Cout, x2=x2)
+    assert torch.equal(y0, y1)
+    ref = y0.double()
+    mref, vref = ref.mean(dim=(0, 2)), ref.var(dim=(0, 2), unbiased=False)
+    sc = (mref.abs() + vref.sqrt()).clamp_min(1e-3)
+    assert float(((m1.double().cpu() - mref.cpu()).abs() / sc.cpu()).max()) < 1e-6
+    assert float(((v1.double().cpu() - vref.cpu()).abs() / (sc.cpu() ** 2)).max()) < 2e-6
+    assert float(((m0.double() - m1.double()).abs() / sc).max()) < 1e-6
