@@ -794,6 +794,8 @@ __global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__
 // partial (slot = m - first node of the tile), combined with the rare straight-to-memory fallback in `pooled`
 // (tiles spanning more than SEG_SLOTS nodes).  Nodes that never beat -1000 (empty, or all values <= -1000) take the
 // features of original point copy 0, as gather index 0 does in the reference (models/networks.py:185).
+// (A workgroup per cloud x 64 channels x 64 nodes with an LDS transpose -- coalesced stores instead of 4-byte values 256 bytes
+// apart -- measured 43.6 vs 20.8 us: sixteen dependent count / offset / key chains per thread instead of one.  r02zc.)
 __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
                                                              const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
                                                              const int32_t *__restrict__ count, const float *__restrict__ v0,
