@@ -395,7 +395,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("B%d_N%d" % (B, N), {})
+            allt = json.load(open(tpath))
+            traffic = dict(allt.get("B%d_N%d" % (B, N), {}))
+            if ops.POINTMLP_PRECISION == "bf16":
+                traffic.update(allt.get("B%d_N%d_bf16" % (B, N), {}))
         except Exception:
             traffic = {}
     for k in kernels:

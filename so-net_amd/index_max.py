@@ -42,6 +42,8 @@ def forward_cpu(data, index, K):
 
 
 def forward_multi_thread_cpu(data, index, K, thread_num):
+    """Reference signature (index_max.cpp:73-112).  ``thread_num`` is validated and otherwise has no meaning here: the staged
+    tensors run through the one GPU kernel, there are no host worker threads to size."""
     if int(thread_num) < 1:
         raise SonetHipError("thread_num must be >= 1")
     return _staged(data, index, K)
