@@ -318,6 +318,12 @@ int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float *x2, int C2
                                 const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
                                 float *mean, float *var, sonet_stream_t stream);
 
+/* bf16 twin: statistics of the STORED bf16 values (what the normalise pass and the backward read). */
+size_t sonet_pointmlp_bf16_stats_ws_size(int B, int Cout, int L);
+int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                              const float *scale, const float *shift, int relu, uint16_t *y,
+                              int B, int Cout, int L, void *stats_ws, float *mean, float *var, sonet_stream_t stream);
+
 /* Weight gradient of a point-wise layer: dw[o][c] = sum_b sum_l g[b][o][l] * x[b][c][l]  (g [B][Cout][L], x [B][Cin][L], dw
  * [Cout][Cin], f32) -- what autograd computes for the nn.Conv1d / nn.Conv2d(1x1) weights of models/layers.py:282-296.  Both
  * operands are split into three bf16 pieces, six products kept (f32-class, f32 range), f32 accumulation on the matrix cores;

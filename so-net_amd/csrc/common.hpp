@@ -37,7 +37,23 @@ uint32_t *range_log();
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
 
+// statistics epilogue of the layer kernels: mean / biased variance from per-workgroup (sum, sum of squares) partials
+// [nwg][C][2] (f64), fixed order.  Defined in pointmlp_x3.hip.
+int launch_stats_finalize(const double *partial, int nwg, int C, double inv_n, float *mean, float *var, hipStream_t st);
+
 }  // namespace sonet
+
+// sum over the 32 lanes of a half wave, result in every lane (all lanes must be active): xor-1, xor-2 inside a quad, mirror inside
+// 8 and 16 lanes (DPP modifiers of the add), then the other row of 16 through ds_swizzle (no LDS memory is touched)
+__device__ __forceinline__ float row32_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                     // lane ^ 16
+    return v;
+}
+
 
 // Bijective XCD-aware remap of a 1-D block id: consecutive *virtual* ids land on the same XCD
 // (and so share its L2).  Pure speed choice -- correctness never depends on placement.

@@ -64,12 +64,14 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     const uint16_t *__restrict__ x1, int C1, const uint16_t *__restrict__ x2, int C2, const uint4 *__restrict__ Wp,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
     int Cout, int L, int gpc /*64-column groups per cloud*/, long long ngroups, int CT, int KC, int ct_per_y,
-    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/)
+    const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
+    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum / sum of squares of the STORED (bf16) output over this workgroup's columns*/)
 {
     constexpr int NSL = S * MT;                              // 1 KiB W slices per stage
     constexpr int NS = (NSL + BF_WAVES - 1) / BF_WAVES;
     __shared__ uint4 wsm[2][NS * BF_WAVES][64];
     __shared__ float2 affine[1024];
+    __shared__ float2 red[BF_WAVES][MT * 32];                   // (statistics epilogue)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -209,7 +211,43 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
         if (st < nstage) BF_STAGE(st, b0, b1, 0)
 #undef BF_STAGE
 
-        if (pva) {
+        if (stats_partial != nullptr) {
+            // training forward: batch statistics of the STORED values (what the normalise pass and the backward read) from this
+            // epilogue -- see pointmlp_x3.hip; all lanes active, padded columns store out of range and add 0
+            const unsigned voya_s = pva ? voya : 0x7FFFFF00u, voyb_s = pvb ? voyb : 0x7FFFFF00u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
+                    if (relu) { va = (va < 0.f) ? 0.f : va; vb = (vb < 0.f) ? 0.f : vb; }
+                    const unsigned pk = cvt_pk_bf16(va, vb);
+                    const unsigned so = so_tile + (unsigned)orow * rowB;
+                    if constexpr (PAIRED) {
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pk, ry, voya_s, so, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b16((short)(pk & 0xFFFFu), ry, voya_s, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((short)(pk >> 16), ry, voyb_s, so, 0);
+                    }
+                    const float ra = pva ? __uint_as_float(pk << 16) : 0.f, rb = pvb ? __uint_as_float(pk & 0xFFFF0000u) : 0.f;
+                    const float s1 = row32_sum(ra + rb), s2 = row32_sum(__fmaf_rn(ra, ra, rb * rb));
+                    if (j == 0) red[wave][mt * 32 + orow + 4 * h] = make_float2(s1, s2);
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < MT * 32; t += BF_THREADS) {
+                const double a = ((double)red[0][t].x + (double)red[1][t].x) + ((double)red[2][t].x + (double)red[3][t].x);
+                const double qq = ((double)red[0][t].y + (double)red[1][t].y) + ((double)red[2][t].y + (double)red[3][t].y);
+                double *dst = stats_partial + ((size_t)blockIdx.x * Cout + (size_t)ct0 * 32 + t) * 2;
+                dst[0] = a;
+                dst[1] = qq;
+            }
+            __syncthreads();
+        } else if (pva) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
@@ -420,7 +458,8 @@ extern "C" int sonet_pointmlp_bf16_pack(const float *W, void *Wp, int Cin, int C
 
 static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
                          const float *scale, const float *shift, int relu, uint16_t *y,
-                         int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0)
+                         int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
+                         double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -476,7 +515,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         // the experiment and as the skeleton of the fused bf16 kernel (pointresnet_bf16.hip), where X never comes from HBM.
         const char *e = getenv("SONET_BF16_XREG");
         const bool want = e && atoi(e) >= 1, force = e && atoi(e) == 2;
-        if (want && paired && xmt > 0 && CT % xmt == 0 && Cout <= 1024 && (nwg_x >= 512 || force) && (getenv("SONET_BF16_MT") == nullptr || force)) {
+        if (want && !stats_ws && paired && xmt > 0 && CT % xmt == 0 && Cout <= 1024 && (nwg_x >= 512 || force) && (getenv("SONET_BF16_MT") == nullptr || force)) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) {
                 int v = 0;
@@ -500,7 +539,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         }
     }
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
-#define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1
+#define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, true>), BF_ARGS); } \
                            else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
@@ -515,7 +554,25 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     }
 #undef BF_LAUNCH
 #undef BF_ARGS
+    if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
     return sonet::launched(what);
+}
+
+extern "C" size_t sonet_pointmlp_bf16_stats_ws_size(int B, int Cout, int L)
+{
+    if (B <= 0 || Cout <= 0 || L <= 0) return 0;
+    return (size_t)sonet::ceil_div64((long long)B * sonet::ceil_div(L, 64), BF_WAVES) * Cout * 2 * sizeof(double);
+}
+
+/* sonet_pointmlp_bf16 that also returns mean / biased variance of the stored (bf16) output over (B, L): BatchNorm's batch statistics
+ * (models/layers.py:60-70) from the kernel's epilogue.  stats_ws: sonet_pointmlp_bf16_stats_ws_size bytes. */
+extern "C" int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                         const float *scale, const float *shift, int relu, uint16_t *y,
+                                         int B, int Cout, int L, void *stats_ws, float *mean, float *var, sonet_stream_t stream)
+{
+    SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_bf16_stats: NULL pointer");
+    return bf16_run_impl("sonet_pointmlp_bf16_stats", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                         reinterpret_cast<double *>(stats_ws), mean, var);
 }
 
 extern "C" int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,

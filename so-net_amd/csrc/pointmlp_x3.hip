@@ -134,17 +134,6 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| of the layer (range log, word 1 of a launch)
 }
 
-// sum over the 32 lanes of a half wave, result in every lane (all lanes must be active): xor-1, xor-2 inside a quad, mirror inside
-// 8 and 16 lanes (DPP modifiers of the add), then the other row of 16 through ds_swizzle (no LDS memory is touched)
-__device__ __forceinline__ float row32_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                     // lane ^ 16
-    return v;
-}
-
 // mean / biased variance from the per-workgroup partial sums of the statistics epilogue: 4 channels x 64 slices per workgroup, fixed
 // order (deterministic)
 __global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const double *__restrict__ partial, int nwg, int C, double inv_n,
@@ -617,6 +606,13 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 
 }  // namespace
 
+// (shared with pointmlp_bf16.hip)
+int sonet::launch_stats_finalize(const double *partial, int nwg, int C, double inv_n, float *mean, float *var, hipStream_t st)
+{
+    hipLaunchKernelGGL(stats_partial_finalize_kernel, dim3((unsigned)sonet::ceil_div(C, 4)), dim3(256), 0, st, partial, nwg, C, inv_n, mean, var);
+    return 0;
+}
+
 extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0) return 0;
@@ -746,9 +742,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     }
 #undef X3_LAUNCH
 #undef X3_ARGS
-    if (stats_ws)
-        hipLaunchKernelGGL(stats_partial_finalize_kernel, dim3((unsigned)sonet::ceil_div(Cout, 4)), dim3(256), 0, st, stats_ws, (int)nwg_x, Cout,
-                           1.0 / ((double)B * L), mean, var);
+    if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
     return sonet::launched(what);
 }
 

@@ -161,8 +161,9 @@ class _PointwiseFn(torch.autograd.Function):
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, scale, y if relu else x1.new_empty(0),
                                   ones, zeros)
         else:
-            if (_ops.STATS_EPILOGUE and wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32 and Cout % 32 == 0
-                    and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)):
+            if (_ops.STATS_EPILOGUE and Cout % 32 == 0 and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)
+                    and ((wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32)
+                         or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16))):
                 # batch statistics out of the layer kernel's epilogue (one pass over raw less; big tensors: the small node-level
                 # ones keep the second-generation kernel, which has no statistics epilogue)
                 raw, mean, var = _ops.pointmlp_stats(x1, wp, ones, bias, False, Cout, x2=x2)

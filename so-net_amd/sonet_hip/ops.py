@@ -658,23 +658,32 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
     """pointmlp(...) plus the per-channel (mean, biased var) of its output over (B, L), from the kernel's epilogue.  h3 / x3 packs
     (f32 storage) only; -> (y, mean, var)."""
     h3 = wp.dtype == torch.int8
-    if not (h3 or wp.dtype == torch.uint8):
-        raise SonetHipError("pointmlp_stats: an h3 or x3 pack")
-    _chk(x1, "x", torch.float32, 3)
+    bf16 = wp.dtype == torch.int16
+    if not (h3 or bf16 or wp.dtype == torch.uint8):
+        raise SonetHipError("pointmlp_stats: an h3, x3 or bf16 pack")
+    xdt = torch.bfloat16 if bf16 else torch.float32
+    _chk(x1, "x", xdt, 3)
     B, C1, L = x1.shape
     C2 = 0
     if x2 is not None:
-        _chk(x2, "x2", torch.float32, 3)
+        _chk(x2, "x2", xdt, 3)
         if x2.shape[0] != B or x2.shape[2] != L:
             raise SonetHipError("x2 must be B x C2 x L")
         C2 = x2.shape[1]
     dev = _same_device(x1, x2, wp, scale, shift)
     lib = _lib.load()
-    if wp.numel() != lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout):
+    want = lib.sonet_pointmlp_bf16_pack_size(C1 + C2, Cout) // 2 if bf16 else lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout)
+    if wp.numel() != want:
         raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C1 + C2, Cout))
-    y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    y = torch.empty((B, Cout, L), dtype=xdt, device=dev)
     mean = torch.empty((Cout,), dtype=torch.float32, device=dev)
     var = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    if bf16:
+        ws = torch.empty((lib.sonet_pointmlp_bf16_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
+            check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
+        return y, mean, var
     ws = torch.empty((lib.sonet_pointmlp_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
     name = "pointmlp%s_stats_%dx%d_L%d" % ("h3" if h3 else "x3", C1 + C2, Cout, L)
     if h3:

@@ -404,3 +404,26 @@ def test_classifier_training_step_bf16(fixture):
     sd = enc.state_dict()
     for k in [k[3:] for k in g.files if k.startswith("bn/")]:
         assert_close_rms(sd[k].cpu().numpy(), g["bn/" + k], 2e-1, "running stat " + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C1,C2,Cout,L", [(3, 64, 0, 128, 1500), (2, 6, 0, 64, 777), (2, 256, 64, 384, 300), (4, 128, 0, 256, 64)])
+def test_pointmlp_bf16_statistics_epilogue(B, C1, C2, Cout, L):
+    """bf16 layer kernel's statistics epilogue: output bit-identical to the plain launch; mean / biased variance of the STORED bf16
+    values equal to the separate pass (f64 sums) to 1e-6 of the channel's scale (odd L: the 2-byte access variant)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    w = (torch.randn(Cout, C1 + C2, generator=g) / (C1 + C2) ** 0.5).to(DEV)
+    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16).to(DEV) if C2 else None
+    scale = torch.ones(Cout, device=DEV)
+    shift = (torch.randn(Cout, generator=g) * 3.0).to(DEV)
+    wp = ops.pointmlp_pack(w, "bf16")
+    y0 = ops.pointmlp(x1, wp, scale, shift, False, Cout, x2=x2)
+    y1, m1, v1 = ops.pointmlp_stats(x1, wp, scale, shift, False, Cout, x2=x2)
+    assert torch.equal(y0, y1)
+    ref = y0.double()
+    mref, vref = ref.mean(dim=(0, 2)), ref.var(dim=(0, 2), unbiased=False)
+    sc = (mref.abs() + vref.sqrt()).clamp_min(1e-3)
+    assert float(((m1.double() - mref).abs() / sc).max()) < 1e-6
+    assert float(((v1.double() - vref).abs() / sc ** 2).max()) < 2e-6
