@@ -318,6 +318,14 @@ int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float *x2, int C2
                                 const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
                                 float *mean, float *var, sonet_stream_t stream);
 
+/* sonet_pointmlp_h3_f32 with a per-node addend gathered in the epilogue: y = act((W . cat(x1, x2) + zadd[b][o][zidx[b][l]]) * scale
+ * + shift), zadd [B][Cout][ZM] f32, zidx [B][L] i32 (out of range: + 0).  The first Segmenter layer (models/networks.py:296-326,
+ * models/segmenter.py:90-109): its per-node and per-cloud input channels are multiplied once per node (zadd) instead of once per
+ * point copy; replaces sonet_pointmlp_h3_f32 + sonet_node_add_affine_act_f32 (one pass over the 1024-channel tensor less). */
+int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                  const float *shift, int relu, float *y, int B, int Cout, int L,
+                                  const float *zadd, const int32_t *zidx, int ZM, sonet_stream_t stream);
+
 /* bf16 twin: statistics of the STORED bf16 values (what the normalise pass and the backward read). */
 size_t sonet_pointmlp_bf16_stats_ws_size(int B, int Cout, int L);
 int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
     unsigned *__restrict__ rlog /*optional (fp16 flavour): range-log slot, word 0 = max |x| bits, word 1 = max |w| bits*/,
     int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/,
-    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum and sum of squares of the stored output over this workgroup's columns*/)
+    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum and sum of squares of the stored output over this workgroup's columns*/,
+    const float *__restrict__ zadd /*optional [B][Cout][ZM]: y = act((W x + zadd[b][o][zidx[b][l]]) * scale + shift)*/,
+    const int32_t *__restrict__ zidx /*[B][L], out of range: + 0*/, int ZM)
 {
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
@@ -362,6 +364,28 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 dst[1] = q;
             }
             __syncthreads();                                    // (red is reused by the next tile group)
+        } else if (pv && zadd != nullptr) {
+            // a per-node addend gathered in the epilogue: the layer's input concatenates per-column channels (the GEMM above) with
+            // channels that are constant per node -- their block of W . x is computed once per node by another launch (z) and added
+            // here, before the folded BatchNorm and the ReLU (segmenter layer 1, models/networks.py:296-326)
+            const int zm = zidx[b * L + lc];
+            const bool zok = (unsigned)zm < (unsigned)ZM;
+            const float *zb = zadd + ((size_t)b * Cout) * ZM + (zok ? zm : 0);
+            const float unscale = F16 ? 32.f : 1.f;                // (fp16 flavour: the affine table holds scale / 32)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    const float zv = zok ? zb[(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
+                    float v = __fmaf_rn(acc[mt][r], ss.x, __fmaf_rn(zv, ss.x * unscale, ss.y));
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                }
+            }
         } else if (pv) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -411,7 +435,8 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp2,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
-    const int32_t *__restrict__ gidx, int L1, unsigned *__restrict__ rlog, int KCP, int nslab, int ncol /*column groups of 128*/)
+    const int32_t *__restrict__ gidx, int L1, unsigned *__restrict__ rlog, int KCP, int nslab, int ncol /*column groups of 128*/,
+    const float *__restrict__ zadd /*optional per-node addend, as in pointmlp_x3_kernel*/, const int32_t *__restrict__ zidx, int ZM)
 {
     constexpr int MT = H3R_MT, S = H3R_S;
     // Workgroup -> (column group, output slab), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with
@@ -580,7 +605,25 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 #undef H3R_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-loads of the tail: nothing may land after the next group starts
 
-        if (pv) {
+        if (pv && zadd != nullptr) {                           // per-node addend gathered here (see pointmlp_x3_kernel)
+            const int zm = zidx[b * L + lc];
+            const bool zok = (unsigned)zm < (unsigned)ZM;
+            const float *zb = zadd + ((size_t)b * Cout) * ZM + (zok ? zm : 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = lds.affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    const float zv = zok ? zb[(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
+                    float v = __fmaf_rn(acc[mt][r], ss.x, __fmaf_rn(zv, ss.x * 32.f, ss.y));
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                }
+            }
+        } else if (pv) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
@@ -652,7 +695,8 @@ extern "C" int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Co
 static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, const float *x2, int C2, const void *Wp3,
                        const float *scale, const float *shift, int relu, float *y,
                        int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
-                       double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr)
+                       double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr,
+                       const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -674,11 +718,14 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
     unsigned *rlog = f16 ? sonet::range_log() : nullptr;
     const char *eg = getenv("SONET_POINTMLP_H3R");          // bench-only: 0 = the first-generation pipeline
-    // second-generation pipeline where it measures faster (profiles/r02y_pointmlp_h3r.log): inputs that stay in the 256 MB MALL
-    // across the CT / 4 passes over X.  At the point-level sizes (64 x 15000 columns) each pass re-reads X from HBM, and the first
-    // generation's 6-tile groups (two passes for 384 channels instead of three) win by 15-20 %.
+    // second-generation pipeline where it measures faster (profiles/r02y_pointmlp_h3r.log, r02zd): inputs that stay in the 256 MB
+    // MALL across the CT / 4 passes over X, and point-level inputs whenever the first generation would also run 4-tile groups (CT
+    // not a multiple of 6: 1024 -> 512 at 64 x 3072 columns 0.62 vs 0.78 ms).  With 6-tile groups (two passes for 384 channels
+    // instead of three) the first generation wins by 15-20 % at 64 x 15000 columns.
     const bool h3r_fits = (double)Cin * (double)B * (double)L * 4.0 <= 128.0e6 && (long long)B * L >= 256;
-    if (f16 && !stats_ws && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : h3r_fits)) {
+    const bool h3r_pick = h3r_fits || (CT % 6 != 0 && (long long)B * L >= 256);
+    // (the per-node addend form measured better on the first generation: 0.86 vs 0.98 ms for 393 -> 1024 at 64 x 3072 columns)
+    if (f16 && !stats_ws && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : (h3r_pick && !zadd))) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
         int dev = 0, cus = 256;
@@ -703,16 +750,20 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         const long long nwg = sonet::ceil_div64(nwg_x, 8) * 8 * best;
         if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
         hipLaunchKernelGGL(pointmlp_h3r_kernel, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
-                           x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x);
+                           x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x,
+                           zadd, zidx, ZM);
         return sonet::launched(what);
     }
     int MT = 1, S = 1;
+    // (8 tiles per group -- half the passes over a point-level input panel -- needs 290 registers: one wave per SIMD, and measured
+    // slower than 4 everywhere it applies: 1024 -> 512 at 64 x 3072 columns 0.69 vs 0.77 ms but 128 -> 256 at 64 x 15000 and the
+    // segmenter's first layer lose 20-70 %.  Opt-in: SONET_POINTMLP_MT=8.)
     if (CT % 6 == 0) MT = 6;
     else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
     else if (CT % 2 == 0) MT = 2;
     if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
         const int want = atoi(e);
-        if ((want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
+        if ((want == 8 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
     }
     if (const char *e = getenv("SONET_POINTMLP_S")) {
         const int want = atoi(e);
@@ -729,12 +780,14 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, false>), X3_ARGS); } } while (0)
+    if (MT == 8) S = 1;
     switch (MT) {
+        case 8: X3_LAUNCH(8); break;
         case 6: X3_LAUNCH(6); break;
         case 4: X3_LAUNCH(4); break;
         case 2: X3_LAUNCH(2); break;
@@ -744,6 +797,17 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
 #undef X3_ARGS
     if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
     return sonet::launched(what);
+}
+
+/* y = act((W . cat(x1, x2) + zadd[b][o][zidx[b][l]]) * scale + shift): the fp16-split layer with a per-node addend gathered in the
+ * epilogue (zadd [B][Cout][ZM], zidx [B][L] i32, out of range: + 0). */
+extern "C" int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                             const float *shift, int relu, float *y, int B, int Cout, int L,
+                                             const float *zadd, const int32_t *zidx, int ZM, sonet_stream_t stream)
+{
+    SONET_REQUIRE(zadd && zidx && ZM > 0, "sonet_pointmlp_h3_nodeadd_f32: NULL pointer or ZM <= 0");
+    return x3_run_impl("sonet_pointmlp_h3_nodeadd_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                       nullptr, nullptr, nullptr, zadd, zidx, ZM);
 }
 
 extern "C" size_t sonet_pointmlp_stats_ws_size(int B, int Cout, int L)

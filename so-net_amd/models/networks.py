@@ -378,13 +378,18 @@ class Segmenter(nn.Module):
         Cout = lyr.conv.out_channels
         ones, zeros = _ops.const_vec(Cout, 1.0, x.device), _ops.const_vec(Cout, 0.0, x.device)
         small = [x_decentered, torch.cat([x] * k, dim=2)] + ([torch.cat([sn] * k, dim=2)] if self.opt.surface_normal else [])
-        t = _ops.pointmlp(first_pn_out.contiguous(), wp_point, ones, zeros, False, Cout, x2=torch.cat(small, dim=1).contiguous())
         node_in = [som_node, masked_max] + ([knn_feature_1] if self.opt.som_k >= 2 else []) + [final_pn_out]
         onehot = torch.zeros(B, 16, dtype=torch.float32, device=x.device)
         onehot.scatter_(1, label.unsqueeze(1), 1)
         zg = torch.cat([onehot, feature], dim=1) @ w_glob.t()                       # B x Cout: per-cloud block
-        z = _ops.pointmlp(torch.cat(node_in, dim=1).contiguous(), wp_node, ones, zeros, False, Cout) + zg.unsqueeze(2)
-        h = _ops.node_add_affine_act_(t, z.contiguous(), min_idx_i32, scale, shift, lyr.activation == 'relu')
+        z = (_ops.pointmlp(torch.cat(node_in, dim=1).contiguous(), wp_node, ones, zeros, False, Cout) + zg.unsqueeze(2)).contiguous()
+        x2 = torch.cat(small, dim=1).contiguous()
+        if wp_point.dtype == torch.int8 and _ops.POINTMLP_PRECISION == "h3":
+            # the per-node block is gathered and added in the per-point launch's epilogue (one pass over B x 1024 x kN less)
+            h = _ops.pointmlp_nodeadd(first_pn_out.contiguous(), wp_point, scale, shift, lyr.activation == 'relu', Cout, z, min_idx_i32, x2=x2)
+        else:
+            t = _ops.pointmlp(first_pn_out.contiguous(), wp_point, ones, zeros, False, Cout, x2=x2)
+            h = _ops.node_add_affine_act_(t, z, min_idx_i32, scale, shift, lyr.activation == 'relu')
         return self._tail(self.layer3(self.layer2(h)), k)
 
     def _tail(self, h, k):

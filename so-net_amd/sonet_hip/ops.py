@@ -651,6 +651,34 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     return y
 
 
+def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
+    """act((W . cat(x1, x2) + z[:, :, zidx]) * scale + shift) in one launch: z B x Cout x M f32 (the per-node block of the layer's
+    pre-activation), zidx B x L i32 (out of range: + 0).  h3 packs only."""
+    if wp.dtype != torch.int8:
+        raise SonetHipError("pointmlp_nodeadd: an h3 pack")
+    _chk(x1, "x", torch.float32, 3)
+    _chk(z, "z", torch.float32, 3)
+    _chk(zidx, "zidx", torch.int32, 2)
+    B, C1, L = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2", torch.float32, 3)
+        if x2.shape[0] != B or x2.shape[2] != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.shape[1]
+    dev = _same_device(x1, x2, wp, scale, shift, z, zidx)
+    lib = _lib.load()
+    if wp.numel() != lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout) or tuple(z.shape[:2]) != (B, Cout) or tuple(zidx.shape) != (B, L):
+        raise SonetHipError("pointmlp_nodeadd: pack for Cin=%d Cout=%d, z B x Cout x M, zidx B x L" % (C1 + C2, Cout))
+    y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    name = "pointmlph3_nodeadd_%dx%d_L%d" % (C1 + C2, Cout, L)
+    _range_arm(name)
+    with torch.cuda.device(dev), _timed(name):
+        check(lib.sonet_pointmlp_h3_nodeadd_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                ptr(z), ptr(zidx), z.shape[2], stream_ptr()), "sonet_pointmlp_h3_nodeadd_f32")
+    return y
+
+
 STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)
 
 

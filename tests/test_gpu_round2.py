@@ -565,3 +565,29 @@ def test_pointmlp_statistics_epilogue(mode, B, C1, C2, Cout, L):
     assert float(((m1.double().cpu() - mref.cpu()).abs() / sc.cpu()).max()) < 1e-6
     assert float(((v1.double().cpu() - vref.cpu()).abs() / (sc.cpu() ** 2)).max()) < 2e-6
     assert float(((m0.double() - m1.double()).abs() / sc).max()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C1,C2,Cout,L,M", [(3, 384, 9, 1024, 700, 64), (2, 64, 0, 256, 33, 5), (2, 128, 6, 512, 3072, 64)])
+def test_pointmlp_nodeadd_epilogue(B, C1, C2, Cout, L, M):
+    """Layer with a per-node addend gathered in the epilogue == the plain layer (unit scale) + sonet_node_add_affine_act_f32, to the
+    rounding of the intermediate tensor; and == float64."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    w = cu(torch.randn(Cout, C1 + C2, generator=g) / (C1 + C2) ** 0.5)
+    x1 = cu(torch.randn(B, C1, L, generator=g))
+    x2 = cu(torch.randn(B, C2, L, generator=g)) if C2 else None
+    z = cu(torch.randn(B, Cout, M, generator=g))
+    idx = cu(torch.randint(-1, M + 1, (B, L), generator=g, dtype=torch.int32))
+    scale, shift = cu(torch.rand(Cout, generator=g) + 0.5), cu(torch.randn(Cout, generator=g))
+    wp = ops.pointmlp_pack(w, "h3")
+    got = ops.pointmlp_nodeadd(x1, wp, scale, shift, True, Cout, z, idx, x2=x2)
+    t = ops.pointmlp(x1, wp, torch.ones_like(scale), torch.zeros_like(shift), False, Cout, x2=x2)
+    two = ops.node_add_affine_act_(t, z, idx, scale, shift, True)
+    xin = torch.cat([x1, x2], 1).double() if x2 is not None else x1.double()
+    ok = (idx >= 0) & (idx < M)
+    zg = torch.gather(z.double(), 2, idx.clamp(0, M - 1).long().unsqueeze(1).expand(B, Cout, L)) * ok.unsqueeze(1)
+    ref = torch.relu((torch.einsum("oc,bcl->bol", w.double(), xin) + zg) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1))
+    bound = 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((got.double() - ref).abs().max()) <= bound
+    assert float((got - two).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
