@@ -756,14 +756,14 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     }
     int MT = 1, S = 1;
     // (8 tiles per group -- half the passes over a point-level input panel -- needs 290 registers: one wave per SIMD, and measured
-    // slower than 4 everywhere it applies: 1024 -> 512 at 64 x 3072 columns 0.69 vs 0.77 ms but 128 -> 256 at 64 x 15000 and the
-    // segmenter's first layer lose 20-70 %.  Opt-in: SONET_POINTMLP_MT=8.)
+    // slower than 4 where it matters: 1024 -> 512 at 64 x 3072 columns 0.69 vs 0.77 ms but 128 -> 256 at 64 x 15000 and the
+    // segmenter's first layer lose 20-70 %.  Not instantiated.)
     if (CT % 6 == 0) MT = 6;
     else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
     else if (CT % 2 == 0) MT = 2;
     if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
         const int want = atoi(e);
-        if ((want == 8 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
+        if ((want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
     }
     if (const char *e = getenv("SONET_POINTMLP_S")) {
         const int want = atoi(e);
@@ -785,9 +785,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, false>), X3_ARGS); } } while (0)
-    if (MT == 8) S = 1;
     switch (MT) {
-        case 8: X3_LAUNCH(8); break;
         case 6: X3_LAUNCH(6); break;
         case 4: X3_LAUNCH(4); break;
         case 2: X3_LAUNCH(2); break;
