@@ -482,6 +482,9 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     if (CT % 4 == 0) MT = 4;
     else if (CT % 6 == 0) MT = 6;
     else if (CT % 2 == 0) MT = 2;
+    // node-level launches (a few thousand columns): with 4 tiles per group 515 -> 768 at 64 x 64 columns is 16 x 6 = 96 workgroups of
+    // three groups each on 256 CUs; two tiles per group doubles the workgroups that can run side by side
+    if (MT == 4 && nwg_x * (CT / 4) < 256 && CT % 2 == 0) MT = 2;
     if (const char *e = getenv("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
         const int want = atoi(e);
         if ((want == 12 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
@@ -491,9 +494,12 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         if (want == 1 || want == 2) S = want;
     }
     if (KC == 1) S = 1;
-    int ysplit = 1;
-    while (nwg_x * ysplit < 512 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;      // small launches: spread the output channels too
-    while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    // output-channel slabs: small launches spread the channels over workgroups too -- the smallest divisor d of the CT / MT groups
+    // that gives >= 512 workgroups (and <= 32 tiles per slab), else the largest (round 2a: powers of two only, which left 768
+    // channels = 6 groups at d = 2)
+    int ysplit = CT / MT;
+    for (int d = CT / MT; d >= 1; --d)
+        if ((CT / MT) % d == 0 && nwg_x * d >= 512 && CT / d <= 32) ysplit = d;
     if (const char *e = getenv("SONET_BF16_YSPLIT")) {
         const int want = atoi(e);
         if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;
