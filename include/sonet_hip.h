@@ -348,6 +348,10 @@ int sonet_node_gather_lead_affine_act_f32(const float *z, const int32_t *gidx, c
                                           const float *scale, const float *shift, int relu, float *out,
                                           int B, int C, int L, int M, int NL, sonet_stream_t stream);
 
+int sonet_node_gather_lead_affine_act_bf16(const uint16_t *z, const int32_t *gidx, const float *lead, const float *wl,
+                                           const float *scale, const float *shift, int relu, uint16_t *out,
+                                           int B, int C, int L, int M, int NL, sonet_stream_t stream);   /* z, out: bfloat16 bits */
+
 /* Small-batch fully connected layer: y[b][o] = act((sum_k x[b][k] W[o][k]) * scale[o] + shift[o]); x [B][Cin], W [Cout][Cin]
  * (nn.Linear layout), exact f32 fma chain.  MyLinear = Linear + BatchNorm1d(eval) + ReLU (models/layers.py:123-166) with the
  * bias and the running statistics folded into (scale, shift): the classifier head of models/networks.py:202-227. */

@@ -124,17 +124,34 @@ __global__ __launch_bounds__(256) void node_add_affine_act_kernel(float *__restr
 // K * M: one ninth of the MFMAs at K = 9) and gathered here; the NL <= 4 lead channels are exact f32 fmas in channel order.
 // One workgroup per (cloud, 8 channels): gidx / lead are read once per 8 output rows, the 8 node rows sit in LDS.
 constexpr int NGL_CH = 8, NGL_THREADS = 128;
-__global__ __launch_bounds__(NGL_THREADS) void node_gather_lead_kernel(const float *__restrict__ z, const int32_t *__restrict__ gidx,
+__device__ __forceinline__ float ngl_ld(const float *p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ngl_ld(const uint16_t *p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ __forceinline__ void ngl_st4(float *o, const float (&v)[4]) { *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void ngl_st4(uint16_t *o, const float (&v)[4]) {                 // bfloat16, round to nearest even
+    unsigned a, b;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(v[0]), "v"(v[1]));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(b) : "v"(v[2]), "v"(v[3]));
+    *reinterpret_cast<uint2 *>(o) = make_uint2(a, b);
+}
+__device__ __forceinline__ void ngl_st1(float *o, float v) { *o = v; }
+__device__ __forceinline__ void ngl_st1(uint16_t *o, float v) {
+    unsigned a;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(v), "v"(v));
+    *o = (uint16_t)(a & 0xFFFFu);
+}
+// T: storage type of z and out (float, or uint16_t = bfloat16 bits: values widened, arithmetic in f32, one rounding on the store)
+template <typename T>
+__global__ __launch_bounds__(NGL_THREADS) void node_gather_lead_kernel(const T *__restrict__ z, const int32_t *__restrict__ gidx,
                                                                         const float *__restrict__ lead, const float *__restrict__ wl,
                                                                         const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                                                                        float *__restrict__ out, int C, int L, int M, int NL)
+                                                                        T *__restrict__ out, int C, int L, int M, int NL)
 {
     extern __shared__ float zs[];                                 // [NGL_CH][M] | coef[NGL_CH][6] (w0..w3, scale, shift)
     float *coef = zs + NGL_CH * M;
     const int cb = blockIdx.x * NGL_CH;
     const long long b = blockIdx.y;
     const int nch = min(NGL_CH, C - cb);
-    for (int i = threadIdx.x; i < nch * M; i += NGL_THREADS) zs[i] = z[((long long)b * C + cb) * M + i];
+    for (int i = threadIdx.x; i < nch * M; i += NGL_THREADS) zs[i] = ngl_ld(z, (size_t)((long long)b * C + cb) * M + i);
     if (threadIdx.x < nch) {
         const int c = cb + threadIdx.x;
         for (int i = 0; i < 4; ++i) coef[threadIdx.x * 6 + i] = i < NL ? wl[c * NL + i] : 0.f;
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(NGL_THREADS) void node_gather_lead_kernel(const flo
     __syncthreads();
     const int32_t *g = gidx + b * L;
     const float *ld = lead + b * (long long)NL * L;
-    float *ob = out + ((long long)b * C + cb) * L;
+    T *ob = out + ((long long)b * C + cb) * L;
     const int L4 = (L + 3) >> 2;
     const bool vec = (L & 3) == 0;
     // a thread owns a quad of columns: node ids and lead channels are read once and serve the 8 channel rows
@@ -180,11 +197,11 @@ __global__ __launch_bounds__(NGL_THREADS) void node_gather_lead_kernel(const flo
                 a = __fmaf_rn(a, cf[4], cf[5]);
                 v[e] = (relu && a < 0.f) ? 0.f : a;
             }
-            float *o = ob + (long long)c * L + l;
-            if (vec) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            T *o = ob + (long long)c * L + l;
+            if (vec) ngl_st4(o, v);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (l + e < L) o[e] = v[e];
+                for (int e = 0; e < 4; ++e) if (l + e < L) ngl_st1(o + e, v[e]);
             }
         }
     }
@@ -525,7 +542,20 @@ extern "C" int sonet_node_gather_lead_affine_act_f32(const float *z, const int32
     const char *what = "sonet_node_gather_lead_affine_act_f32";
     SONET_REQUIRE(z && gidx && scale && shift && out && (NL == 0 || (lead && wl)), "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && M > 0 && M <= 1024 && NL >= 0 && NL <= 4, "%s: bad size B=%d C=%d L=%d M=%d NL=%d", what, B, C, L, M, NL);
-    hipLaunchKernelGGL(node_gather_lead_kernel, dim3((unsigned)sonet::ceil_div(C, NGL_CH), (unsigned)B), dim3(NGL_THREADS), (size_t)NGL_CH * (M + 6) * sizeof(float),
+    hipLaunchKernelGGL(node_gather_lead_kernel<float>, dim3((unsigned)sonet::ceil_div(C, NGL_CH), (unsigned)B), dim3(NGL_THREADS), (size_t)NGL_CH * (M + 6) * sizeof(float),
+                       sonet::as_stream(stream), z, gidx, lead, wl, scale, shift, relu, out, C, L, M, NL);
+    return sonet::launched(what);
+}
+
+/* bf16 storage of z and out (bfloat16 bit patterns); lead, wl, scale, shift f32 */
+extern "C" int sonet_node_gather_lead_affine_act_bf16(const uint16_t *z, const int32_t *gidx, const float *lead, const float *wl,
+                                                      const float *scale, const float *shift, int relu, uint16_t *out,
+                                                      int B, int C, int L, int M, int NL, sonet_stream_t stream)
+{
+    const char *what = "sonet_node_gather_lead_affine_act_bf16";
+    SONET_REQUIRE(z && gidx && scale && shift && out && (NL == 0 || (lead && wl)), "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && B <= 65535 && C > 0 && L > 0 && M > 0 && M <= 1024 && NL >= 0 && NL <= 4, "%s: bad size B=%d C=%d L=%d M=%d NL=%d", what, B, C, L, M, NL);
+    hipLaunchKernelGGL(node_gather_lead_kernel<uint16_t>, dim3((unsigned)sonet::ceil_div(C, NGL_CH), (unsigned)B), dim3(NGL_THREADS), (size_t)NGL_CH * (M + 6) * sizeof(float),
                        sonet::as_stream(stream), z, gidx, lead, wl, scale, shift, relu, out, C, L, M, NL);
     return sonet::launched(what);
 }

@@ -337,14 +337,15 @@ class _FusedPointwise(nn.Module):
         return self._wpr
 
     def _packed_split(self, lead):
-        """(h3 pack of W[:, lead:], W[:, :lead] as a contiguous Cout x lead f32 matrix): the layer is linear, so a caller whose
-        input is cat(a, gather(b)) applies the wide block to b ONCE per node and adds the narrow block per column."""
+        """(h3 or bf16 pack of W[:, lead:], W[:, :lead] as a contiguous Cout x lead f32 matrix): the layer is linear, so a caller
+        whose input is cat(a, gather(b)) applies the wide block to b ONCE per node and adds the narrow block per column."""
         w = self.conv.weight
-        key = (w._version, w.data_ptr(), w.device, lead)
+        mode = "bf16" if _ops.POINTMLP_PRECISION == "bf16" else "h3"
+        key = (w._version, w.data_ptr(), w.device, lead, mode)
         if getattr(self, '_wps_key', None) != key:
             with torch.no_grad():
                 w2 = self._weight2d().detach().float()
-                self._wps = (_ops.pointmlp_pack(w2[:, lead:].contiguous(), "h3"), w2[:, :lead].contiguous())
+                self._wps = (_ops.pointmlp_pack(w2[:, lead:].contiguous(), mode), w2[:, :lead].contiguous())
             self._wps_key = key
         return self._wps
 
@@ -638,13 +639,14 @@ class KNNModule(nn.Module):
             l1, l2 = self.layers
             s1, t1 = l1._eval_affine()
             sdt = torch.bfloat16 if _ops.POINTMLP_PRECISION == "bf16" else torch.float32
-            if _ops.NODE_LINEAR_SPLIT and sdt == torch.float32 and _ops.x3_supported(x.shape[1], 0, l1.conv.out_channels):
+            if _ops.NODE_LINEAR_SPLIT and _ops.x3_supported(x.shape[1], 0, l1.conv.out_channels):
                 # W . cat(dec, x[:, gidx]) = (W_x . x)[:, gidx] + W_dec . dec: the 384-channel block once per node (M columns, not
                 # K * M), the three coordinate channels as exact f32 fmas in the gather kernel
                 wpf, wl = l1._packed_split(3)
                 C1o = l1.conv.out_channels
-                z = _ops.pointmlp(x.contiguous(), wpf, _ops.const_vec(C1o, 1.0, x.device), _ops.const_vec(C1o, 0.0, x.device), False, C1o)
-                h = _ops.node_gather_lead_affine_act(z, gidx, dec, wl, s1, t1, l1.activation == 'relu')
+                # (bf16 mode: z and h in bf16 storage -- z is rounded once more than in the gathered-layer form, inside the bf16 bound)
+                z = _ops.pointmlp(x.to(sdt).contiguous(), wpf, _ops.const_vec(C1o, 1.0, x.device), _ops.const_vec(C1o, 0.0, x.device), False, C1o)
+                h = _ops.node_gather_lead_affine_act(z, gidx, dec.float(), wl, s1, t1, l1.activation == 'relu')
             else:
                 h = _ops.pointmlp(x.to(sdt).contiguous(), l1._packed_rotated(3), s1, t1, l1.activation == 'relu', l1.conv.out_channels,
                                   x2=dec.to(sdt), gidx=gidx)              # B x C1 x (K*M), k-major columns

@@ -254,7 +254,9 @@ def wgrad_x3(g, x):
 def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
     """act((z[:, :, gidx] + wl . lead) * scale + shift): z B x C x M (the layer on the M node features), gidx B x L i32 (out of
     range -> 0), lead B x NL x L (NL <= 4 per-column channels), wl C x NL.  -> B x C x L f32."""
-    _chk(z, "z", torch.float32, 3)
+    _chk(z, "z", dim=3)
+    if z.dtype not in (torch.float32, torch.bfloat16):
+        raise SonetHipError("node_gather_lead_affine_act: z float32 or bfloat16")
     _chk(gidx, "gidx", torch.int32, 2)
     _chk(lead, "lead", torch.float32, 3)
     _chk(wl, "wl", torch.float32, 2)
@@ -263,10 +265,12 @@ def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
     L, NL = gidx.shape[1], lead.shape[1]
     if gidx.shape[0] != B or lead.shape[0] != B or lead.shape[2] != L or tuple(wl.shape) != (C, NL) or scale.numel() != C or shift.numel() != C:
         raise SonetHipError("node_gather_lead_affine_act: z B x C x M, gidx B x L, lead B x NL x L, wl C x NL, scale / shift C")
-    out = torch.empty((B, C, L), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("node_gather_lead_%dx%d_L%d" % (NL, C, L)):
-        check(_lib.load().sonet_node_gather_lead_affine_act_f32(ptr(z), ptr(gidx), ptr(lead), ptr(wl), ptr(scale), ptr(shift), int(bool(relu)),
-                                                                ptr(out), B, C, L, M, NL, stream_ptr()), "sonet_node_gather_lead_affine_act_f32")
+    out = torch.empty((B, C, L), dtype=z.dtype, device=dev)
+    lib = _lib.load()
+    fn = lib.sonet_node_gather_lead_affine_act_f32 if z.dtype == torch.float32 else lib.sonet_node_gather_lead_affine_act_bf16
+    with torch.cuda.device(dev), _timed("node_gather_lead%s_%dx%d_L%d" % ("" if z.dtype == torch.float32 else "bf16", NL, C, L)):
+        check(fn(ptr(z), ptr(gidx), ptr(lead), ptr(wl), ptr(scale), ptr(shift), int(bool(relu)), ptr(out), B, C, L, M, NL, stream_ptr()),
+              "sonet_node_gather_lead_affine_act")
     return out
 
 
