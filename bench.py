@@ -143,7 +143,7 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
         return "mfma", 2.0 * (6 * 64 + 64 * 128 + 128 * 256 + 320 * 384) * B * L
     if name.startswith("pointmlp"):
         dims, L = name.split("_", 1)[1].split("_L")
-        cin, cout = dims.split("x")
+        cin, cout = dims.split("_")[-1].split("x")              # (pointmlph3_nodeadd_393x1024_L3072: a variant tag in front of the dims)
         return "mfma", 2.0 * int(cin) * int(cout) * B * int(L.split("_")[0])     # ("_kmax9": the max over k is in the epilogue)
     return "hbm", None
 

@@ -436,7 +436,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
     const int32_t *__restrict__ gidx, int L1, unsigned *__restrict__ rlog, int KCP, int nslab, int ncol /*column groups of 128*/,
-    const float *__restrict__ zadd /*optional per-node addend, as in pointmlp_x3_kernel*/, const int32_t *__restrict__ zidx, int ZM)
+    const float *__restrict__ zadd /*optional per-node addend, as in pointmlp_x3_kernel*/, const int32_t *__restrict__ zidx, int ZM,
+    unsigned *__restrict__ kmax /*optional [B][Cout][KM] ordered keys: the output is max-reduced over the columns l with the same l % KM
+                                  (KNNModule: k-major columns, max over the K neighbour planes) and y is not written*/, int KM)
 {
     constexpr int MT = H3R_MT, S = H3R_S;
     // Workgroup -> (column group, output slab), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with
@@ -605,7 +607,28 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 #undef H3R_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-loads of the tail: nothing may land after the next group starts
 
-        if (pv && zadd != nullptr) {                           // per-node addend gathered here (see pointmlp_x3_kernel)
+        if (kmax != nullptr) {
+            // max over the neighbour planes in the epilogue: column l of a k-major tensor belongs to node l % KM; a 32-column tile of
+            // one plane is 32 consecutive nodes, so a store instruction's 32 lanes hit 32 consecutive keys of one channel row -- an
+            // atomic per element costs what the store would, and B x C x K*M never exists (torch.max(dim=3) of models/layers.py:350).
+            // Keys: order-preserving integers (sign flipped for positives, all bits for negatives), memset 0 = below everything.
+            if (pv) {
+                unsigned *kb = kmax + (size_t)b * Cout * KM + (lc % KM);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float2 *aff = lds.affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int orow = (r & 3) + 8 * (r >> 2);
+                        const float2 ss = aff[orow];
+                        float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                        if (relu) v = (v < 0.f) ? 0.f : v;
+                        const unsigned u = __float_as_uint(v);
+                        atomicMax(kb + (size_t)((ct0 + mt) * 32 + orow + 4 * h) * KM, (u & 0x80000000u) ? ~u : (u | 0x80000000u));
+                    }
+                }
+            }
+        } else if (pv && zadd != nullptr) {                    // per-node addend gathered here (see pointmlp_x3_kernel)
             const int zm = zidx[b * L + lc];
             const bool zok = (unsigned)zm < (unsigned)ZM;
             const float *zb = zadd + ((size_t)b * Cout) * ZM + (zok ? zm : 0);
@@ -696,11 +719,11 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                        const float *scale, const float *shift, int relu, float *y,
                        int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
                        double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr,
-                       const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0)
+                       const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0, unsigned *kmax = nullptr, int KM = 0)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
-    SONET_REQUIRE(x1 && Wp3 && scale && shift && y, "%s: NULL pointer", what);
+    SONET_REQUIRE(x1 && Wp3 && scale && shift && (y || kmax), "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
     SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
@@ -725,7 +748,8 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const bool h3r_fits = (double)Cin * (double)B * (double)L * 4.0 <= 128.0e6 && (long long)B * L >= 256;
     const bool h3r_pick = h3r_fits || (CT % 6 != 0 && (long long)B * L >= 256);
     // (the per-node addend form measured better on the first generation: 0.86 vs 0.98 ms for 393 -> 1024 at 64 x 3072 columns)
-    if (f16 && !stats_ws && CT % H3R_MT == 0 && (eg ? atoi(eg) != 0 : (h3r_pick && !zadd))) {
+    if (kmax && !(f16 && CT % H3R_MT == 0)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the max-reduced form needs Cout %% 128 == 0", what);
+    if (f16 && !stats_ws && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
         int dev = 0, cus = 256;
@@ -751,7 +775,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
         hipLaunchKernelGGL(pointmlp_h3r_kernel, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
                            x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x,
-                           zadd, zidx, ZM);
+                           zadd, zidx, ZM, kmax, KM);
         return sonet::launched(what);
     }
     int MT = 1, S = 1;
@@ -806,6 +830,35 @@ extern "C" int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const floa
     SONET_REQUIRE(zadd && zidx && ZM > 0, "sonet_pointmlp_h3_nodeadd_f32: NULL pointer or ZM <= 0");
     return x3_run_impl("sonet_pointmlp_h3_nodeadd_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
                        nullptr, nullptr, nullptr, zadd, zidx, ZM);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void kmax_decode_kernel(const unsigned *__restrict__ keys, float *__restrict__ out, long long n)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const unsigned k = keys[t];
+    out[t] = k == 0u ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+}  // namespace
+
+/* out[b][o][m] = max over the columns l with l % M == m of act((W . cat(x1, x2)) * scale + shift)[b][o][l]: the layer followed by
+ * the max over the K neighbour planes of a k-major B x Cout x (K * M) tensor (KNNModule, models/layers.py:340-350) without
+ * materialising it.  keys_ws: B * Cout * M * 4 bytes.  fp16-split arithmetic, Cout % 128 == 0. */
+extern "C" int sonet_pointmlp_h3_kmax_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                          const float *shift, int relu, float *out, void *keys_ws, int B, int Cout, int L, int M,
+                                          sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_h3_kmax_f32";
+    SONET_REQUIRE(out && keys_ws && M > 0 && L % M == 0, "%s: NULL pointer or L %% M != 0", what);
+    const size_t n = (size_t)B * Cout * M;
+    if (hipMemsetAsync(keys_ws, 0, n * 4, sonet::as_stream(stream)) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
+    const int rc = x3_run_impl(what, true, x1, C1, x2, C2, Wp3, scale, shift, relu, nullptr, B, Cout, L, stream, nullptr, 0,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, reinterpret_cast<unsigned *>(keys_ws), M);
+    if (rc != SONET_OK) return rc;
+    hipLaunchKernelGGL(kmax_decode_kernel, dim3((unsigned)sonet::ceil_div64((long long)n, 256)), dim3(256), 0, sonet::as_stream(stream),
+                       reinterpret_cast<const unsigned *>(keys_ws), out, (long long)n);
+    return sonet::launched(what);
 }
 
 extern "C" size_t sonet_pointmlp_stats_ws_size(int B, int Cout, int L)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sonet_pointmlp_bf16_stats_ws_size": [_i, _i, _i],
     "sonet_pointmlp_bf16_stats": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pointmlp_h3_nodeadd_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "sonet_pointmlp_h3_kmax_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_wgrad_x3_ws_size": [_i, _i, _i, _i],
     "sonet_wgrad_x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],

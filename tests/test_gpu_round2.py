@@ -591,3 +591,20 @@ def test_pointmlp_nodeadd_epilogue(B, C1, C2, Cout, L, M):
     bound = 1e-5 * max(1.0, float(ref.abs().max()))
     assert float((got.double() - ref).abs().max()) <= bound
     assert float((got - two).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,Cout,M,K", [(3, 512, 512, 64, 9), (2, 64, 128, 5, 3), (1, 128, 256, 100, 16)])
+def test_pointmlp_kmax_epilogue(B, C, Cout, M, K):
+    """Layer + max over the K planes of its k-major output from the epilogue == planes_max(pointmlp(...)) bit for bit (max is exact,
+    the layer kernel is the same), incl. negative outputs (no ReLU)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C + Cout + M)
+    w = cu(torch.randn(Cout, C, generator=g) / C ** 0.5)
+    x = cu(torch.randn(B, C, K * M, generator=g))
+    scale, shift = cu(torch.rand(Cout, generator=g) + 0.5), cu(torch.randn(Cout, generator=g))
+    wp = ops.pointmlp_pack(w, "h3")
+    for relu in (True, False):
+        ref = ops.planes_max(ops.pointmlp(x, wp, scale, shift, relu, Cout), K)
+        got = ops.pointmlp_kmax(x, wp, scale, shift, relu, Cout, M)
+        assert torch.equal(got, ref)
