@@ -623,7 +623,8 @@ def test_encoder_other_configs_fast_path_vs_exact_path(node_num, sn, k, N):
 def test_linear_act_vs_torch():
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(13)
-    for B, Cin, Cout, relu in [(64, 1024, 512, True), (8, 512, 256, True), (3, 256, 40, False), (70, 33, 5, True)]:
+    for B, Cin, Cout, relu in [(64, 1024, 512, True), (8, 512, 256, True), (3, 256, 40, False), (70, 33, 5, True), (5, 2500, 48, True),
+                               (2, 4096, 8, False), (17, 1026, 9, True)]:
         x, W = torch.randn(B, Cin, generator=gen), torch.randn(Cout, Cin, generator=gen) * 0.05
         sc, sh = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
         ref = (x.double() @ W.double().t()) * sc.double() + sh.double()
