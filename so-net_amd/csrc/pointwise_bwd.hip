@@ -666,29 +666,26 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
                 __syncthreads();
             }
         }
-        // one wave per column (no two waves touch the same accumulators, entries of a column in sorted order: deterministic);
-        // its lanes cover the input channels, two entries in flight to overlap the W-row loads (L2 latency)
-        const int wv = tid >> 6, ln = tid & 63, nwv = nth >> 6;
-        for (int col = wv; col < PD_TL; col += nwv) {
-            int lo = 0, hi = n;                                  // first entry with column >= col / > col
-            for (int a = 0, z = n; a < z;) { const int mid = (a + z) >> 1; if ((int)(keys[mid] >> 20) < col) a = mid + 1; else z = mid; lo = a; }
-            for (int a = lo, z = n; a < z;) { const int mid = (a + z) >> 1; if ((int)(keys[mid] >> 20) <= col) a = mid + 1; else z = mid; hi = a; }
-            if (lo >= n || (int)(keys[lo] >> 20) != col) continue;
-            if (hi < lo) hi = lo;
-            float *ac = acc + col * ld;
-            int e = lo;
-            for (; e + 2 <= hi; e += 2) {
-                const float g0 = vals[e], g1 = vals[e + 1];
-                const float *w0 = W + (size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin, *w1 = W + (size_t)((int)(keys[e + 1] & 0xFFFFFu) / M) * Cin;
-                for (int i = ln; i < Cin; i += 64) {
-                    const float a0 = w0[i], a1 = w1[i];
-                    ac[i] = __fmaf_rn(g1, a1, __fmaf_rn(g0, a0, ac[i]));
+        // Accumulate: thread i owns input channel i of every column of the tile and walks the entries in sorted (column, id) order, so
+        // the order of the fma chain of an accumulator is fixed (deterministic) and no two threads touch the same one.  The W rows of
+        // 16 entries (coalesced: the workgroup reads a whole row per entry, L2-resident) are requested before their first fma.
+        // (Round 1 gave every COLUMN to a wave: 7 columns per wave in sequence, each with two binary searches in LDS and a
+        // dependent W-row load per entry -- 50 us per workgroup for ~50 entries, 0.97 ms per training step.)
+        for (int i = tid; i < Cin; i += nth) {
+            for (int e0 = 0; e0 < n; e0 += 16) {
+                float wv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int e = e0 + q < n ? e0 + q : n - 1;
+                    wv[q] = W[(size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin + i];
                 }
-            }
-            if (e < hi) {
-                const float g0 = vals[e];
-                const float *w0 = W + (size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin;
-                for (int i = ln; i < Cin; i += 64) ac[i] = __fmaf_rn(g0, w0[i], ac[i]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (e0 + q < n) {
+                        float *ac = acc + (int)(keys[e0 + q] >> 20) * ld + i;
+                        *ac = __fmaf_rn(vals[e0 + q], wv[q], *ac);
+                    }
+                }
             }
         }
     }
