@@ -619,11 +619,12 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
                                                            int E, int M, int Cin, int C1, int L, int ntile,
                                                            TO *__restrict__ gx1, TO *__restrict__ gx2)
 {
-    extern __shared__ float sm_f[];              // acc[PD_TL][Cin + 1] | keys[PD_SORT] | vals[PD_SORT]
+    extern __shared__ float sm_f[];              // acc[PD_TL][Cin + 1] | keys[PD_SORT] | vals[PD_SORT] | wrow[PD_SORT]
     const int ld = Cin + 1;
     float *acc = sm_f;
     uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld);
     float *vals = reinterpret_cast<float *>(keys + PD_SORT);
+    int *wrow = reinterpret_cast<int *>(vals + PD_SORT);
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
     for (int i = tid; i < PD_TL * ld; i += nth) acc[i] = 0.f;
     const int beg = tile_off[(size_t)b * (ntile + 1) + tile], end = tile_off[(size_t)b * (ntile + 1) + tile + 1];
@@ -671,18 +672,26 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
         // 16 entries (coalesced: the workgroup reads a whole row per entry, L2-resident) are requested before their first fma.
         // (Round 1 gave every COLUMN to a wave: 7 columns per wave in sequence, each with two binary searches in LDS and a
         // dependent W-row load per entry -- 50 us per workgroup for ~50 entries, 0.97 ms per training step.)
+        // (per entry, once: the W row offset and the accumulator row offset -- the division by M per (entry, thread) was half of the
+        // kernel's instructions)
+        for (int e = tid; e < n; e += nth) {
+            const uint32_t kk = keys[e];
+            wrow[e] = ((int)(kk & 0xFFFFFu) / M) * Cin;
+            keys[e] = (kk >> 20) * (uint32_t)ld;
+        }
+        __syncthreads();
         for (int i = tid; i < Cin; i += nth) {
             for (int e0 = 0; e0 < n; e0 += 16) {
                 float wv[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int e = e0 + q < n ? e0 + q : n - 1;
-                    wv[q] = W[(size_t)((int)(keys[e] & 0xFFFFFu) / M) * Cin + i];
+                    wv[q] = W[(size_t)wrow[e] + i];
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     if (e0 + q < n) {
-                        float *ac = acc + (int)(keys[e0 + q] >> 20) * ld + i;
+                        float *ac = acc + keys[e0 + q] + i;
                         *ac = __fmaf_rn(vals[e0 + q], wv[q], *ac);
                     }
                 }
@@ -691,6 +700,18 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
     }
     __syncthreads();
     const int l0 = tile * PD_TL;
+    if (sizeof(TO) == 2 && (L & 1) == 0) {
+        // bf16 output, even L: two columns per thread, one 4-byte store (2-byte stores of single elements: 0.80 ms of the bf16 step)
+        for (int idx = tid; idx < Cin * (PD_TL / 2); idx += nth) {
+            const int i = idx / (PD_TL / 2), col = (idx - i * (PD_TL / 2)) * 2;
+            if (l0 + col >= L) continue;                        // (L even: col + 1 is inside too)
+            unsigned r;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(acc[col * ld + i]), "v"(acc[(col + 1) * ld + i]));
+            TO *dst = i < C1 ? gx1 + ((size_t)b * C1 + i) * L + l0 + col : gx2 + ((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col;
+            *reinterpret_cast<unsigned *>(dst) = r;
+        }
+        return;
+    }
     for (int idx = tid; idx < Cin * PD_TL; idx += nth) {        // coalesced: consecutive threads along the columns of one channel
         const int i = idx / PD_TL, col = idx - i * PD_TL;
         if (l0 + col >= L) continue;
@@ -818,7 +839,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
     const int Cin = C1 + C2, E = C * M, ntile = sonet::ceil_div(L, PD_TL);
     if ((long long)C * M >= (1 << 20) || B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C*M=%d entries per cloud (max 2^20)", what, E);
-    const size_t lds2 = ((size_t)PD_TL * (Cin + 1) + 2 * PD_SORT) * 4;
+    const size_t lds2 = ((size_t)PD_TL * (Cin + 1) + 3 * PD_SORT) * 4;
     if (lds2 > 160 * 1024 || (size_t)(2 * ntile + 1) * 4 > 64 * 1024)
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d or L=%d too large for the LDS tile", what, Cin, L);
     uint32_t *ent_key = reinterpret_cast<uint32_t *>(ws);
