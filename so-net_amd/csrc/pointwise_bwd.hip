@@ -574,7 +574,7 @@ namespace {
 constexpr int PD_TL = 32;                      // columns per tile (41 KB of LDS at 320 channels: 3 workgroups per CU)
 constexpr int PD_SORT = 1024;                  // entries per tile sorted in LDS (more: chunks in arrival order)
 
-__global__ __launch_bounds__(256) void pooled_bucket_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g,
+__global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g,
                                                             int E, int L, int ntile, int32_t *__restrict__ tile_off,
                                                             uint32_t *__restrict__ ent_key, float *__restrict__ ent_val)
 {
@@ -582,9 +582,9 @@ __global__ __launch_bounds__(256) void pooled_bucket_kernel(const int32_t *__res
     int *cnt = sm_i, *off = sm_i + ntile;
     const int b = blockIdx.x;
     const int32_t *pb = pos + (size_t)b * E;
-    for (int t = threadIdx.x; t < ntile; t += 256) cnt[t] = 0;
+    for (int t = threadIdx.x; t < ntile; t += 1024) cnt[t] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
         if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_TL], 1);
     }
@@ -595,8 +595,8 @@ __global__ __launch_bounds__(256) void pooled_bucket_kernel(const int32_t *__res
         off[ntile] = acc;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t <= ntile; t += 256) tile_off[(size_t)b * (ntile + 1) + t] = off[t];
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int t = threadIdx.x; t <= ntile; t += 1024) tile_off[(size_t)b * (ntile + 1) + t] = off[t];
+    for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
         if ((unsigned)l >= (unsigned)L) continue;
         const int t = l / PD_TL;
@@ -846,7 +846,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
     int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
     hipStream_t st = sonet::as_stream(stream);
-    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(256), (size_t)(2 * ntile + 1) * 4, st, pos, g_pooled, E, L, ntile, tile_off, ent_key, ent_val);
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * ntile + 1) * 4, st, pos, g_pooled, E, L, ntile, tile_off, ent_key, ent_val);
     hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B), dim3(320), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1, L, ntile, gx1,
                        gx2 ? gx2 : gx1);
     return sonet::launched(what);
