@@ -438,7 +438,8 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const int32_t *__restrict__ gidx, int L1, unsigned *__restrict__ rlog, int KCP, int nslab, int ncol /*column groups of 128*/,
     const float *__restrict__ zadd /*optional per-node addend, as in pointmlp_x3_kernel*/, const int32_t *__restrict__ zidx, int ZM,
     unsigned *__restrict__ kmax /*optional [B][Cout][KM] ordered keys: the output is max-reduced over the columns l with the same l % KM
-                                  (KNNModule: k-major columns, max over the K neighbour planes) and y is not written*/, int KM)
+                                  (KNNModule: k-major columns, max over the K neighbour planes) and y is not written*/, int KM,
+    double *__restrict__ stats_partial /*optional [ncol][Cout][2]: statistics epilogue, as in pointmlp_x3_kernel*/)
 {
     constexpr int MT = H3R_MT, S = H3R_S;
     // Workgroup -> (column group, output slab), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const int wg_xcd = blockIdx.x & 7, wg_local = blockIdx.x >> 3;
     const int wg_col = (wg_local / nslab) * 8 + wg_xcd, wg_slab = wg_local - (wg_local / nslab) * nslab;
     if (wg_col >= ncol) return;
-    struct Lds { uint4 wsm[H3R_SLOTS][H3R_SLOT_SL][64]; float2 affine[1024]; };      // W ring first: LDS-DMA addresses below 64 KiB
+    struct Lds { uint4 wsm[H3R_SLOTS][H3R_SLOT_SL][64]; float2 affine[1024]; float2 red[X3_WAVES][H3R_MT * 32]; };   // W ring first: LDS-DMA addresses below 64 KiB
     __shared__ __attribute__((aligned(16))) Lds lds;
 
     const int lane = threadIdx.x & 63;
@@ -607,7 +608,34 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 #undef H3R_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-loads of the tail: nothing may land after the next group starts
 
-        if (kmax != nullptr) {
+        if (stats_partial != nullptr) {                        // BatchNorm batch statistics from the epilogue (see pointmlp_x3_kernel)
+            const unsigned voy_s = pv ? voy : 0x7FFFFF00u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = lds.affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy_s, so_tile + (unsigned)orow * rowB, 0);
+                    const float sv = pv ? v : 0.f;
+                    const float s1 = row32_sum(sv), s2 = row32_sum(sv * sv);
+                    if (j == 0) lds.red[wave][mt * 32 + orow + 4 * h] = make_float2(s1, s2);
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < MT * 32; t += X3_THREADS) {
+                const double a = ((double)lds.red[0][t].x + (double)lds.red[1][t].x) + ((double)lds.red[2][t].x + (double)lds.red[3][t].x);
+                const double qq = ((double)lds.red[0][t].y + (double)lds.red[1][t].y) + ((double)lds.red[2][t].y + (double)lds.red[3][t].y);
+                double *dst = stats_partial + ((size_t)wg_col * Cout + (size_t)ct0 * 32 + t) * 2;
+                dst[0] = a;
+                dst[1] = qq;
+            }
+            __syncthreads();
+        } else if (kmax != nullptr) {
             // max over the neighbour planes in the epilogue: column l of a k-major tensor belongs to node l % KM; a 32-column tile of
             // one plane is 32 consecutive nodes, so a store instruction's 32 lanes hit 32 consecutive keys of one channel row -- an
             // atomic per element costs what the store would, and B x C x K*M never exists (torch.max(dim=3) of models/layers.py:350).
@@ -746,10 +774,11 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     // not a multiple of 6: 1024 -> 512 at 64 x 3072 columns 0.62 vs 0.78 ms).  With 6-tile groups (two passes for 384 channels
     // instead of three) the first generation wins by 15-20 % at 64 x 15000 columns.
     const bool h3r_fits = (double)Cin * (double)B * (double)L * 4.0 <= 128.0e6 && (long long)B * L >= 256;
-    const bool h3r_pick = h3r_fits || (CT % 6 != 0 && (long long)B * L >= 256);
+    // (... and a long K loop: 128 -> 256 at 64 x 15000 columns -- 8 chunks, then 1 GB of output -- stays 15 % faster on the first generation)
+    const bool h3r_pick = h3r_fits || (CT % 6 != 0 && Cin >= 512 && (long long)B * L >= 256);
     // (the per-node addend form measured better on the first generation: 0.86 vs 0.98 ms for 393 -> 1024 at 64 x 3072 columns)
     if (kmax && !(f16 && CT % H3R_MT == 0)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the max-reduced form needs Cout %% 128 == 0", what);
-    if (f16 && !stats_ws && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
+    if (f16 && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
         int dev = 0, cus = 256;
@@ -775,7 +804,8 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
         hipLaunchKernelGGL(pointmlp_h3r_kernel, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
                            x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x,
-                           zadd, zidx, ZM, kmax, KM);
+                           zadd, zidx, ZM, kmax, KM, stats_ws);
+        if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
         return sonet::launched(what);
     }
     int MT = 1, S = 1;
