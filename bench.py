@@ -56,6 +56,8 @@ def parse():
                     help="forward = the BASELINE metric (default); train = forward+backward+gradient all-reduce+Adam "
                          "(BASELINE configs[4], reported under its own metric name)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent batches in flight: P HIP graphs replayed round-robin on P streams (1 = one stream; forward mode)")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-other-precisions", action="store_true", help="skip the x3 / exact-f32 throughput keys")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the timed batch (rank 0)")
@@ -281,26 +283,64 @@ def main():
     # The step is shape-static: replay it as ONE HIP graph (sonet_hip/graph.py).  `value` is timed on the
     # replays; the per-kernel durations for the roofline come from a second, eagerly launched region of
     # the same K steps with HIP events around every C-ABI launch (events cannot be read inside a graph).
+    #
+    # Batches of a serving / evaluation loop are independent, and most of the step outside the fused first PointNet is short,
+    # latency-bound launches that leave CUs idle: with P graphs replayed round-robin on P HIP streams (each with its own batch and
+    # its own workspaces) the SOM stage and the node-level stage of one batch run on the CUs the other batch's kernels do not fill.
+    # Same kernels, same results (checked below: a replay among others == the replay alone); `single_stream` keeps the P = 1 figure.
     use_graph = not args.no_graph
+    P = max(1, args.in_flight) if use_graph else 1
+    fwd = lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False))      # noqa: E731
     with torch.no_grad():
         if use_graph:
             from sonet_hip.graph import GraphedForward
-            graphed = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False)),
-                                     (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"]), warmup=max(1, args.warmup))
-            run = lambda: graphed(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])   # noqa: E731
+            inps = [inp] + [synth.make_inputs(B, N, seed=100 + rank + 1000 * q, device=dev) for q in range(1, P)]
+            graphs = [GraphedForward(fwd, (i_["pc"], i_["sn"], i_["node"], i_["node_knn_I"]), warmup=max(1, args.warmup)) for i_ in inps]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+            graphed = graphs[0]
+
+            def run_many(n, first=0):
+                o = None
+                for s_ in range(n):
+                    q = (first + s_) % P
+                    with torch.cuda.stream(streams[q]):
+                        i_ = inps[q]
+                        o = graphs[q](i_["pc"], i_["sn"], i_["node"], i_["node_knn_I"])
+                return o
         else:
-            run = step
-        for _ in range(args.warmup):
-            run()
+            run_many = lambda n, first=0: [step() for _ in range(n)][-1]            # noqa: E731
+        run_many(args.warmup)
         dp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = run()
+        out = run_many(args.steps)
         dp.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert torch.isfinite(out).all()
+        single = None
+        overlap_ok = None
+        if use_graph and P > 1:
+            # the same K steps on ONE stream (graph 0 only), and: a replay among the others == the replay alone, bit for bit.
+            # (A graph is only ever replayed on ITS stream: the same executable graph launched on two streams at once is undefined --
+            # on this runtime a "write access to a read-only page" fault.)
+            run_many(2 * P)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                for _ in range(args.steps):
+                    graphs[0](inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            single = {"clouds_per_s": round(B * args.steps / dt1, 1), "ms_per_step": round(dt1 * 1e3 / args.steps, 4)}
+            alone = graphs[0].static_output.clone()
+            torch.cuda.synchronize()
+            run_many(P, first=1)                              # ends with graph 0, after the other P - 1 were launched
+            torch.cuda.synchronize()
+            overlap_ok = bool(torch.equal(graphs[0].static_output, alone))
+            if not overlap_ok:
+                raise SystemExit("bench.py: a graph replayed among %d others differs from the same graph replayed alone" % (P - 1))
+            out = graphs[0].static_output
         # instrumented eager region (same K steps) for the per-kernel figures
         for _ in range(2):
             step()
@@ -325,6 +365,12 @@ def main():
             finally:
                 ops.FUSE_POOL = True
         # the replayed forward's operand-range log (fp16-split arithmetic): a violation would mean clamped features
+        # (the graphs of a device share its range log: graph 0 is replayed alone right before the log is read)
+        if use_graph:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(streams[0]):
+                graphs[0](inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+            torch.cuda.synchronize()
         range_bad = graphed.range_violations() if use_graph else []
         if range_bad:
             raise SystemExit("bench.py: h3 operand range violated on the synthetic batch: %s" % (range_bad[:3],))
@@ -346,7 +392,7 @@ def main():
                         g2(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t2
-                other[mode] = {"clouds_per_s": round(B * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4)}
+                other[mode] = {"clouds_per_s": round(B * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4), "in_flight": 1}
                 del g2
     elapsed = dp.all_reduce_max(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
@@ -431,7 +477,9 @@ def main():
                                "k=3, som_k=9, surface normals" % N,
                    "batch_per_gpu": B, "global_batch": B * world, "points": N,
                    "parallelism": "dp%d: batch shards, no data-path collective" % world},
-        "launch_mode": "hip-graph replay" if use_graph else "eager",
+        "launch_mode": ("hip-graph replay, %d independent batches in flight on %d streams" % (P, P) if use_graph and P > 1
+                        else "hip-graph replay" if use_graph else "eager"),
+        "in_flight": P, "single_stream": single, "replay_among_others_equals_replay_alone": overlap_ok,
         "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,
         "range_guard": {"enabled": bool(ops.RANGE_GUARD), "violations": len(range_bad)},
         "eager_instrumented_ms_per_step": round(eager_ms, 4),

@@ -17,6 +17,21 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+int zero_words(void *p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), n);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 static thread_local uint32_t *g_range_log = nullptr;
 uint32_t *range_log() { return g_range_log; }
 

@@ -37,6 +37,12 @@ uint32_t *range_log();
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
 
+// Zero `bytes` (a multiple of 4, 4-byte aligned) of device memory with a KERNEL instead of hipMemsetAsync.  The forward of a batch is
+// captured into a HIP graph and several such graphs are replayed concurrently on different streams (bench.py --in-flight); with
+// memset NODES in the graphs that combination faulted intermittently ("write access to a read-only page") on this runtime.
+// Defined in api.hip.
+int zero_words(void *p, size_t bytes, hipStream_t st);
+
 // statistics epilogue of the layer kernels: mean / biased variance from per-workgroup (sum, sum of squares) partials
 // [nwg][C][2] (f64), fixed order.  Defined in pointmlp_x3.hip.
 int launch_stats_finalize(const double *partial, int nwg, int C, double inv_n, float *mean, float *var, hipStream_t st);

@@ -598,8 +598,8 @@ extern "C" int sonet_som_sort_group_f32(const float *x, const float *sn, const i
     const long long kN = (long long)k * N;
     // (One 1024-thread workgroup per cloud doing the whole sort in LDS -- no global cursor, no memset, one launch -- measured
     //  SLOWER: 50 vs 39 us at B = 64; 64 workgroups and 15000 LDS atomics on 64 counters each.  Not kept.)
-    if (hipMemsetAsync(cursor_ws, 0, (size_t)B * M * sizeof(int32_t), st) != hipSuccess)
-        return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    if (sonet::zero_words(cursor_ws, (size_t)B * M * sizeof(int32_t), st) != 0)       // (a kernel, not a memset node: common.hpp)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: zero fill failed", what);
     dim3 grid((unsigned)sonet::ceil_div64(kN, SG_THREADS * SG_PER_THREAD), B), block(SG_THREADS);
     hipLaunchKernelGGL(som_sort_group_kernel, grid, block, (size_t)M * (3 * sizeof(float) + 3 * sizeof(int)), st,
                        x, sn, min_idx_i32, count, sum_ws, N, M, k, som_node, row_max, x_aug_sorted, ids_sorted, pos0, cursor_ws, node_off);
@@ -635,9 +635,9 @@ extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, in
     hipStream_t st = sonet::as_stream(stream);
     const size_t sum_bytes = (size_t)B * 3 * M * sizeof(double), cnt_bytes = (size_t)B * M * sizeof(int32_t);
     const bool adjacent = reinterpret_cast<char *>(sum_ws) + sum_bytes == reinterpret_cast<char *>(count);   // one clear launch then
-    if (adjacent ? hipMemsetAsync(sum_ws, 0, sum_bytes + cnt_bytes, st) != hipSuccess
-                 : (hipMemsetAsync(count, 0, cnt_bytes, st) != hipSuccess || hipMemsetAsync(sum_ws, 0, sum_bytes, st) != hipSuccess))
-        return sonet::fail(SONET_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    if (adjacent ? sonet::zero_words(sum_ws, sum_bytes + cnt_bytes, st) != 0
+                 : (sonet::zero_words(count, cnt_bytes, st) != 0 || sonet::zero_words(sum_ws, sum_bytes, st) != 0))
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: zero fill failed", what);
     dim3 grid(sonet::ceil_div(N, SA_THREADS), B), block(SA_THREADS);
     const size_t lds = (size_t)M * (sizeof(float4) + 3 * sizeof(double) + sizeof(unsigned));
     const char *ek = getenv("SONET_SOM_KEYS");                  // bench / test switch: 0 = the insertion-list kernel

@@ -608,3 +608,47 @@ def test_pointmlp_kmax_epilogue(B, C, Cout, M, K):
         ref = ops.planes_max(ops.pointmlp(x, wp, scale, shift, relu, Cout), K)
         got = ops.pointmlp_kmax(x, wp, scale, shift, relu, Cout, M)
         assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_two_graphed_forwards_in_flight_on_two_streams():
+    """bench.py's default launch mode: independent batches captured into separate HIP graphs and replayed round-robin on separate
+    streams.  Every replay must equal the same graph replayed alone, also after eager allocations in between (with hipMemsetAsync
+    NODES in the graphs this faulted intermittently on ROCm 7.2 -- the forward now clears its workspaces with a kernel)."""
+    from models import networks as NW
+    from sonet_hip import synth
+    from sonet_hip.graph import GraphedForward
+    import bench
+    dev = torch.device(DEV)
+    B, N, P = 8, 2000, 2
+    opt = bench.make_opt(dev, B, N)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    synth.fill_state_dict_(enc.state_dict(), 0)
+    synth.fill_state_dict_(cls.state_dict(), 1)
+    enc.to(dev).eval()
+    cls.to(dev).eval()
+    inps = [synth.make_inputs(B, N, seed=7 + q, device=dev) for q in range(P)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    with torch.no_grad():
+        graphs = [GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False)),
+                                 (i["pc"], i["sn"], i["node"], i["node_knn_I"]), warmup=2) for i in inps]
+
+        def rep(q):
+            with torch.cuda.stream(streams[q]):
+                i = inps[q]
+                return graphs[q](i["pc"], i["sn"], i["node"], i["node_knn_I"])
+        alone = []
+        for q in range(P):
+            rep(q)
+            torch.cuda.synchronize()
+            alone.append(graphs[q].static_output.clone())
+        for rnd in range(6):
+            for s in range(8):
+                rep((rnd + s) % P)
+            torch.cuda.synchronize()
+            for q in range(P):
+                assert torch.equal(graphs[q].static_output, alone[q]), (rnd, q)
+            junk = [torch.isfinite(graphs[q].static_output).all().item() for q in range(P)]      # eager allocations between the rounds
+            assert all(junk)
+        eager = cls(enc(inps[1]["pc"], inps[1]["sn"], inps[1]["node"], inps[1]["node_knn_I"], is_train=False))
+        assert torch.equal(eager, alone[1])
