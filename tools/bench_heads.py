@@ -56,6 +56,31 @@ def main():
             ms, top = timeit(lambda: NW.segmentation_forward(enc, seg, inp["pc"], inp["sn"], label, inp["node"], inp["node_knn_I"]))
         print("segmenter  B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   top: %s" % (
             B, N, ms, B / ms * 1e3, ", ".join("%s %.2f" % (k, v["total_ms"]) for k, v in top)))
+        if (B, N) == (64, 1024):
+            # the same forward as three HIP graphs in flight on three streams (independent batches, as bench.py --in-flight 3)
+            from sonet_hip.graph import GraphedForward
+            P, K = 3, 30
+            with torch.no_grad():
+                inps = [synth.make_inputs(B, N, seed=3 + q, device=DEV) for q in range(P)]
+                graphs = [GraphedForward(lambda pc, sn, node, knn: NW.segmentation_forward(enc, seg, pc, sn, label, node, knn),
+                                         (i["pc"], i["sn"], i["node"], i["node_knn_I"]), warmup=2) for i in inps]
+                streams = [torch.cuda.Stream(device=DEV) for _ in range(P)]
+
+                def many(n):
+                    for s_ in range(n):
+                        with torch.cuda.stream(streams[s_ % P]):
+                            i = inps[s_ % P]
+                            graphs[s_ % P](i["pc"], i["sn"], i["node"], i["node_knn_I"])
+                many(2 * P)
+                torch.cuda.synchronize()
+                best = float("inf")
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    many(K)
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / K)
+            print("segmenter  B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   (3 HIP graphs in flight on 3 streams)" % (B, N, best * 1e3, B / best))
+            del graphs
     for B, N in ((8, 5000), (64, 5000)):
         opt = opt_for(B, N, classes=40)
         enc, dec, crit = NW.Encoder(opt), NW.Decoder(opt), LS.ChamferLoss(opt)
