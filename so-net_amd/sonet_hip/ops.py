@@ -711,6 +711,49 @@ def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
     return y
 
 
+# backward: the weight gradient of a layer does not depend on its input gradient -- the two run on two HIP streams
+BWD_SIDE_STREAM = _os.environ.get("SONET_BWD_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+class side_stream:
+    """``with ops.side_stream(device) as s: <launches>`` -- the launches go to a per-device side stream that first waits for everything
+    queued on the current stream; ``s.join()`` (after the block) makes the current stream wait for them.  Tensors ALLOCATED inside the
+    block and used afterwards must be passed to ``s.keep(t)`` (record_stream: the caching allocator then knows the consumer stream).
+    Disabled (everything on the current stream) when BWD_SIDE_STREAM is off, on CPU, or while a HIP graph is being captured."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.on = (BWD_SIDE_STREAM and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing())
+        self.main = self.side = self._ctx = None
+
+    def __enter__(self):
+        if self.on:
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self.side = _side_streams.get(idx)
+            if self.side is None:
+                self.side = _side_streams[idx] = torch.cuda.Stream(device=self.device)
+            self.main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def keep(self, t):
+        if self.on and t is not None:
+            t.record_stream(self.main)
+        return t
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)
 
 
