@@ -59,7 +59,7 @@ def main():
         if (B, N) == (64, 1024):
             # the same forward as three HIP graphs in flight on three streams (independent batches, as bench.py --in-flight 3)
             from sonet_hip.graph import GraphedForward
-            P, K = 3, 30
+            P, K = int(os.environ.get("SONET_HEADS_INFLIGHT", "3")), 30
             with torch.no_grad():
                 inps = [synth.make_inputs(B, N, seed=3 + q, device=DEV) for q in range(P)]
                 graphs = [GraphedForward(lambda pc, sn, node, knn: NW.segmentation_forward(enc, seg, pc, sn, label, node, knn),
@@ -79,7 +79,7 @@ def main():
                     many(K)
                     torch.cuda.synchronize()
                     best = min(best, (time.perf_counter() - t0) / K)
-            print("segmenter  B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   (3 HIP graphs in flight on 3 streams)" % (B, N, best * 1e3, B / best))
+            print("segmenter  B=%-3d N=%-5d : %8.3f ms/step  %9.0f clouds/s   (%d HIP graphs in flight on %d streams)" % (B, N, best * 1e3, B / best, P, P))
             del graphs
     for B, N in ((8, 5000), (64, 5000)):
         opt = opt_for(B, N, classes=40)
