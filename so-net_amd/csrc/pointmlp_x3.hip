@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const doubl
     }
 }
 
-template <int MT, int S, bool F16>
+// ZADD: the per-node addend form with its gathers issued BEFORE the K loop (64 registers; instantiated for MT = 4 only).
+template <int MT, int S, bool F16, bool ZADD = false>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
@@ -244,6 +245,19 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        // (ZADD) this group's 16 * MT node values per lane are requested now and used in the epilogue: gathered there they cost the
+        // segmenter's first layer 0.28 ms of exposed L2 latency (0.85 vs 0.57 ms for the plain layer)
+        float zreg[ZADD ? MT : 1][16];
+        if constexpr (ZADD) {
+            const int zm = zidx[b * L + lc];
+            const bool zok = pv && (unsigned)zm < (unsigned)ZM;
+            const float *zb = zadd + ((size_t)b * Cout) * ZM + (zok ? zm : 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zreg[mt][r] = zok ? zb[(size_t)((ct0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ZM] : 0.f;
+        }
 
         // slice sl of a stage: chunk i = sl / (NTW*MT), cout tile mt = (sl / NTW) % MT, term = sl % NTW
         auto stage_load = [&](i32x4_t (&w)[NS], int st) {
@@ -380,7 +394,9 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int orow = (r & 3) + 8 * (r >> 2);
                     const float2 ss = aff[orow];
-                    const float zv = zok ? zb[(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
+                    float zv;
+                    if constexpr (ZADD) zv = zreg[mt][r];
+                    else zv = zok ? zb[(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
                     float v = __fmaf_rn(acc[mt][r], ss.x, __fmaf_rn(zv, ss.x * unscale, ss.y));
                     if (relu) v = (v < 0.f) ? 0.f : v;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
@@ -839,6 +855,16 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, false>), X3_ARGS); } } while (0)
+    if (zadd && f16 && CT % 4 == 0 && !stats_ws && nwg_x >= 512 && !getenv("SONET_POINTMLP_MT")) {      // (small launches: more slabs instead)
+        // per-node addend: 4-tile groups with the gathers in flight during the K loop
+        dim3 gz((unsigned)nwg_x, (unsigned)sonet::ceil_div(CT, 32));      // (slabs of <= 32 tiles: the affine table; a workgroup walks its groups)
+        const int cpy = CT / (int)gz.y;
+        if (CT % (int)gz.y == 0 && cpy % 4 == 0 && cpy <= 32) {
+            hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, true>), gz, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups,
+                               CT, KC, cpy, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM);
+            return sonet::launched(what);
+        }
+    }
     switch (MT) {
         case 6: X3_LAUNCH(6); break;
         case 4: X3_LAUNCH(4); break;
