@@ -44,8 +44,8 @@ PEAK_H3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)         # (a step is ~1 ms: the whole default run stays well under a minute)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (BASELINE configs[4]: 512 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
