@@ -1,73 +1,80 @@
-// pointresnet_fused.hip -- the whole first PointNet of the encoder as ONE kernel (eval mode).
+// pointresnet_fused.hip -- the whole first PointNet of the encoder as ONE kernel (eval mode), third generation.
 //
 // Replaces the four EquivariantLayer launches of PointResNet.forward (models/layers.py:419-432, built at
-// models/networks.py:82-83 as 6 -> 64 -> 128 -> 256 -> [64 + 256] -> 384 with BN + ReLU on the first
-// three layers) when BatchNorm runs on its running statistics.  Per 32-point tile a wave keeps every
-// intermediate activation in registers; HBM sees only the 6-channel input and the 384-channel output
-// (the unfused path writes and re-reads 64 + 128 + 256 channels per point: 3.6 KB / point).
+// models/networks.py:82-83 as 6 -> 64 -> 128 -> 256 -> [64 + 256] -> 384 with BN + ReLU on the first three layers)
+// when BatchNorm runs on its running statistics.  HBM sees only the 6-channel input and the 384-channel output (or,
+// pool variant, only the per-node maxima: models/networks.py:175-185).
 //
 // Arithmetic: fp32 operands split into fp16 pieces, three v_mfma_f32_32x32x16_f16 per product set with fp32
-// accumulation (see "operand split" below; the layer-wise kernels of pointmlp_x3.hip use six bf16 terms).
+// accumulation ("operand split" below).  Per accumulator the MFMA sequence (K chunk order, term order l, m, h) is the
+// one of the second-generation kernel, so the results are bit-identical to it.
 //
-// Register chaining.  v_mfma_f32_32x32x16_f16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
-// in register r of lane l and consumes B[k = 8*(l>>5) + e][col = l&31], e = 0..7.  Registers 8q .. 8q+7 of
-// an output tile therefore ARE the B operand of a 16-channel chunk of the next layer (after the affine +
-// ReLU and the split), provided the next layer's weights are packed with the matching channel order
-//     k = 8h + e   <->   channel 32*t + 16*q + (e&3) + 8*(e>>2) + 4*h          ("chained" packing)
-// No shuffle, no LDS round trip, no transposition between layers.
+// Work decomposition (what changed).  The second generation gave every wave its own 32 points and ALL channels: each
+// 1-KiB weight fragment read from LDS fed one MFMA per wave, every wave re-split layer 4's input in each of its passes
+// (4.9 VALU + 0.92 LDS instructions per MFMA), and a barrier every 36 MFMAs published the shared weight ring.  Here a
+// workgroup = 4 waves owns 64 consecutive points (two 32-column MFMA tiles c = 0, 1) and the waves split the OUTPUT
+// CHANNELS of layers 2-4:
+//   layer 1 (6 -> 64):    every wave computes it for all 64 points (12 MFMAs, 2 % redundant work) and keeps the result;
+//   layer 2 (64 -> 128):  wave w computes output tile w;             its input is the wave's own layer-1 result;
+//   layer 3 (128 -> 256): wave w computes output tiles 2w, 2w+1;     its input is layer 2 of all waves, through LDS;
+//   layer 4 (320 -> 384): wave w computes output tiles 3w .. 3w+2;   input: own layer 1 + layer 3 of all waves (LDS).
+// Activations are handed over PRE-SPLIT: when a wave's accumulators are complete they are turned once (BatchNorm affine +
+// ReLU + split: a "job" of 36 VALU instructions per 8 values) into the fp16 pieces (32 xh, fp16(32 xm)) that ARE the B
+// operand of the next layer, written to LDS in fragment layout (one ds_write_b128 per piece) and read back by every
+// wave with ds_read_b128: 4 KiB of B per K chunk feed 18 MFMAs (0.22 KiB per MFMA instead of 0.67-0.92).
+// Weights never touch LDS: every wave streams ONLY its own output tiles' fragments (a quarter of the stream, packed
+// wave-major in consumption order) from L2 straight into registers, two steps ahead of their use, and every fragment
+// feeds both column tiles.  Two barriers per 64-point tile (layer-2 and layer-3 hand-over) instead of 27 per 128.
 //
-// Weights.  All four layers are packed (pointresnet_pack_kernel) into ONE linear stream of 1-KiB slices
-// (64 lanes x 8 fp16) in exactly the order the MFMAs consume them, so W staging is a linear copy (LDS-DMA):
-// the 4 waves of a workgroup stream the stage after next (NSTG slices) into the LDS ring and read their A fragments
-// back at (ring slot) + compile-time offsets.  One barrier per 36 MFMAs (24 slices).
-//   L1: 2 tiles x 1 chunk, L2: 4 x 4, L3: 8 x 8  (tile-major),  L4: 2 passes x 20 chunks x 6 tiles; two slices each.
-// Workgroups are persistent (one per CU) and walk the 128-point tiles; the weight stream simply restarts.
+// Software pipeline.  The short dependent front of a tile (x -> layer 1 -> job -> layer 2 -> job -> LDS) would leave the
+// matrix pipe idle, so the front of tile i+1 is computed INSIDE layer 4 of tile i (its 36 MFMAs and 12 jobs fill VALU
+// slots behind layer 4's MFMAs); the jobs of layer 3 ride behind the first four steps of layer 4 (which read the wave's
+// own layer-1 registers, not LDS).  Per tile and wave: barrier, layer 3 (96 MFMAs), layer 4 steps 0-3 + layer-3 jobs,
+// barrier, layer 4 steps 4-19 + front of the next tile, epilogue.
+//
+// Register chaining.  v_mfma_f32_32x32x16_f16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r
+// of lane l and consumes B[k = 8*(l>>5) + e][col = l&31], e = 0..7.  Registers 8q .. 8q+7 of an output tile therefore
+// ARE the B operand of a 16-channel chunk of the next layer, provided the next layer's weights are packed with the
+// matching channel order     k = 8h + e   <->   channel 32*t + 16*q + (e&3) + 8*(e>>2) + 4*h     ("chained" packing).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int PF_THREADS = 256, PF_WAVES = 4;
+constexpr int TPTS = 64;                                       // points per workgroup tile (two column tiles)
 constexpr int T0 = 2, T1 = 4, T2 = 8, T3 = 12;               // output tiles (x32 channels) of the four layers
 constexpr int KC2 = 2 * T0, KC3 = 2 * T1, KC4 = 2 * T0 + 2 * T2;   // 16-channel K chunks per layer
-constexpr int MT4 = 6, NPASS = T3 / MT4;                      // layer-4 cout tiles per accumulator pass
-constexpr int NSTG = 24;                                       // slices per LDS stage (2 slices feed 3 MFMAs)
-constexpr int NTERM = 2;                                       // W slices per (cout tile, K chunk): h and l (see the operand split)
-constexpr int GS = 4;                                          // cout tiles processed together in layers 2 and 3
-constexpr int SL1 = 8 /* 4 used + 4 pad: keeps every step aligned */, SL2 = T1 * KC2 * NTERM, SL3 = T2 * KC3 * NTERM;
-constexpr int OFF1 = 0, OFF2 = SL1, OFF3 = SL1 + SL2;
-constexpr int PRE = ((SL1 + SL2 + SL3 + NSTG - 1) / NSTG) * NSTG;                 // layer 4 starts on a stage boundary
-static_assert(OFF2 % (NTERM * GS) == 0 && OFF3 % (NTERM * GS) == 0 && NSTG % (NTERM * GS) == 0 && NSTG % (NTERM * MT4) == 0 && T1 % GS == 0 && T2 % GS == 0,
-              "a step (one K chunk x a group of tiles) must never straddle a stage boundary");
-constexpr int SL4 = KC4 * MT4 * NTERM;                         // slices per layer-4 pass
-constexpr int NSLICE = PRE + NPASS * SL4;
-constexpr int NSTAGE = NSLICE / NSTG;
-static_assert(SL4 % NSTG == 0 && NSLICE % NSTG == 0 && PRE == SL1 + SL2 + SL3, "whole stages, no padding stage");
-constexpr int NSW = NSTG / PF_WAVES;                           // slices staged per wave
-static_assert(NSTG % PF_WAVES == 0, "");
+constexpr int W2T = T1 / PF_WAVES, W3T = T2 / PF_WAVES, W4T = T3 / PF_WAVES;   // output tiles per wave: 1, 2, 3
+static_assert(W2T == 1 && W3T == 2 && W4T == 3, "the step code below is written for this split");
+constexpr int NTERM = 2;                                       // W slices per (cout tile, K chunk): h and l
+// the weight stream: [layer 1: 4 slices, shared][wave 0: L2 8, L3 32, L4 120][wave 1 ...] ...
+constexpr int NS_L1 = T0 * NTERM, NS_L2 = KC2 * W2T * NTERM, NS_L3 = KC3 * W3T * NTERM, NS_L4 = KC4 * W4T * NTERM;
+constexpr int NS_WAVE = NS_L2 + NS_L3 + NS_L4;
+constexpr int NSLICE = NS_L1 + PF_WAVES * NS_WAVE;
 constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
+constexpr int LB1 = 0, LB2 = 32 * T0, LB3 = 32 * (T0 + T1), LB4 = 32 * (T0 + T1 + T2);
+constexpr int C4 = 32 * T3;                                    // 384 output channels
 
 // ---- fp32 -> 3 x fp16 operand split ------------------------------------------------------------------
 // x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; 32 * (a*b) is taken as
 //     ah * (32 bh)  +  ah * fp16(32 bm)  +  fp16(32 am) * bh
 // i.e. THREE fp16 MFMAs with fp32 accumulation (the dropped am*bm and the rounding of the scaled residuals are
-// <= 2^-22 relative).  The factor 32 keeps the residuals out of the fp16 subnormals (|x| > 4e-3 stays normal; below
-// that the absolute error is < 1e-9); it is carried by the ACCUMULATOR (every power-of-two scaling is exact) and
-// taken out again by the layer's affine (scale / 32), so the first two terms share ONE weight operand: the stream
-// holds two slices per (cout tile, K chunk), ah and fp16(32 am), for three MFMAs -- a third less LDS-DMA, LDS read
-// and L2 traffic than one slice per MFMA, for bit-identical results.  Measured on the reference fixtures: whole first
-// PointNet within 2.9e-6 * max(|ref|, rms) -- the same as the six-term 3 x bf16 split it replaces, at half the
-// matrix work (any five of the six bf16 terms: 3-4e-5, outside the 1e-5 bound).  Operand range: |x| <= 2047
-// (32 x must fit fp16); the split clamps.
-// Naming: term h = (ah, 32 bh), m = (ah, 32 bm), l = (32 am, bh); the B side keeps them as b.h, b.m, b.l.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// <= 2^-22 relative).  The factor 32 keeps the residuals out of the fp16 subnormals; it is carried by the ACCUMULATOR
+// (every power-of-two scaling is exact) and taken out again by the layer's affine, so the first two terms share ONE
+// weight operand: the stream holds two slices per (cout tile, K chunk), ah and fp16(32 am), for three MFMAs.
+// Operand range: |x| <= 2047 (32 x must fit fp16); the split clamps and the range log reports it.
+// Naming: B side pieces h = 32 bh, m = fp16(32 bm), l = bh = h * 2^-5 (derived when used, never stored);
+// terms in accumulation order: (A.l, B.l), (A.h, B.m), (A.h, B.h).
 constexpr float F16_MAX = 2047.0f;                             // 32 * 2047 = 65504, the largest fp16
+constexpr float F16_MAX32 = 65504.0f;
 constexpr float ACC_UNSCALE = 0.03125f;                        // accumulators hold 32 * (W . x)
 constexpr unsigned F16_2_M5_PK = 0x28002800u;                  // packed fp16 (2^-5, 2^-5)
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {        // one v_cvt_pk_f16_f32 (round to nearest even)
@@ -81,84 +88,66 @@ __device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, r);
 }
 __device__ __forceinline__ float clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -F16_MAX), F16_MAX); }
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    h = cvt_pk_f16(32.f * x0, 32.f * x1);                                  // 32 xh
-    m = cvt_pk_f16(32.f * x0 - f16_lo(h), 32.f * x1 - f16_hi(h));          // 32 (x - xh), exact before the rounding
-    l = pk_mul_f16(h, F16_2_M5_PK);                                        // xh
+__device__ __forceinline__ f16x8 as_f16x8(u32x4_t v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ u32x4_t piece_l(u32x4_t h) {        // xh = (32 xh) * 2^-5 (exact)
+    u32x4_t r;
+    r[0] = pk_mul_f16(h[0], F16_2_M5_PK); r[1] = pk_mul_f16(h[1], F16_2_M5_PK);
+    r[2] = pk_mul_f16(h[2], F16_2_M5_PK); r[3] = pk_mul_f16(h[3], F16_2_M5_PK);
+    return r;
 }
-
-struct B3 { f16x8 h, m, l; };
-template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v)[8]);
-__device__ __forceinline__ B3 split_chunk(const float (&v)[8]) {             // clamped, no affine (the network input)
-    unsigned bh[4], bm[4], bl[4];
+// the network input (clamped, no affine): 8 channel values of one point -> (h, m)
+__device__ __forceinline__ void split_input(const float (&v)[8], u32x4_t &h, u32x4_t &m) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) split3_pair(clamp_f16(v[2 * p]), clamp_f16(v[2 * p + 1]), bh[p], bm[p], bl[p]);
-    B3 b;
-    b.h = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-    b.m = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
-    b.l = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-    return b;
-}
-
-template <int ABL> __device__ __forceinline__ B3 split_chunk_abl(const float (&v)[8]) {
-    if constexpr (ABL & 2) {
-        B3 b;
-        const unsigned u = __float_as_uint(v[0]);
-        b.h = __builtin_bit_cast(f16x8, make_uint4(u, u, u, u)); b.m = b.h; b.l = b.h;
-        return b;
-    } else {
-        return split_chunk(v);
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = clamp_f16(v[2 * p]), x1 = clamp_f16(v[2 * p + 1]);
+        const unsigned hh = cvt_pk_f16(32.f * x0, 32.f * x1);                         // 32 xh
+        h[p] = hh;
+        m[p] = cvt_pk_f16(32.f * x0 - f16_lo(hh), 32.f * x1 - f16_hi(hh));            // 32 (x - xh), exact before the rounding
     }
 }
 
-// The same split fused with the producing layer's BatchNorm affine + ReLU, one VALU instruction at a time, so that
-// the fused kernel can place a few of them behind each MFMA (a clump of dependent VALU between two MFMAs stalls the
-// matrix pipe: tools/mfma_bf16_issue.hip).  (volatile asm: instruction selection floats pure VALU ops across
-// sched_barrier and clumps them.)  The activations stay raw in their registers; an in-place affine pass after each
-// layer cost ~4k cycles per tile in serialised LDS reads of the coefficients.
-struct SplitState { float x[8], r[8]; float2 sc[8]; unsigned h[4], m[4], l[4]; int rm; };   // rm: running max of the post-affine values (range log)
+// ---- a "job": BatchNorm affine + ReLU + split of 8 accumulator values (registers 8Q..8Q+7 of an output tile) ----
+// One VALU instruction at a time (volatile asm: instruction selection floats pure VALU ops across sched_barrier and
+// clumps them; a clump of dependent VALU between two MFMAs stalls the matrix pipe), so that the steps can place a few
+// of them behind each MFMA.  The accumulators hold 32 W.x and the coefficients are (scale, 32 shift): the affine
+// delivers 32 x directly (bit-identical to 32 * fl(acc * scale/32 + shift): power-of-two scalings commute with the
+// rounding), ReLU and the fp16 range clamp are one v_med3 against 32 * 2047.
 __device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
-// ReLU and the fp16 range clamp in one instruction (a NaN does not survive it; the exact-f32 mode keeps NaNs)
-__device__ __forceinline__ float pin_relu_clamp(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX)); return r; }
+__device__ __forceinline__ float pin_relu_clamp32(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX32)); return r; }
 __device__ __forceinline__ unsigned pin_cvt(float lo, float hi) { unsigned r; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
-__device__ __forceinline__ float pin_mul32(float a) { float r; asm volatile("v_mul_f32 %0, 0x42000000, %1" : "=v"(r) : "v"(a)); return r; }
-// 32*x - (fp16 half of pk = 32 xh) = 32 * (x - xh), exact
+// x32 - (fp16 half of pk = 32 xh) = 32 * (x - xh), exact
 __device__ __forceinline__ float pin_res_lo(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
 __device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(-1.0f), "v"(x32)); return r; }
-// range log: max over the post-affine, pre-clamp activations as signed-int-ordered bits (positive side; what ReLU keeps)
+// range log: max over the post-affine, pre-clamp activations (x 32) as signed-int-ordered bits (positive side: what ReLU keeps)
 __device__ __forceinline__ int pin_max3_i32(int m, float a, float b) { int r; asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ unsigned pin_scale_dn(unsigned pk) { unsigned r; asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(pk), "v"(F16_2_M5_PK)); return r; }
-// Op I of 48 = two groups of 24 (two value pairs each, neighbours independent): affine x4, range max x2, relu+clamp x4,
-// 32x x4, 32xh x2, residual x4, 32xm x2, xh = 32xh * 2^-5 x2.
-constexpr int SPLIT_OPS = 48;
-template <int ABL, int I> __device__ __forceinline__ void split_op(SplitState &s) {
-    if constexpr (ABL & 2) {
-        if constexpr (I == 0) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) s.h[p] = s.m[p] = s.l[p] = __float_as_uint(s.x[0]);
-        }
-    } else if constexpr (I >= 0 && I < SPLIT_OPS) {
-        constexpr int g = I / 24, k = I % 24;
-        if constexpr (k < 4) { constexpr int e = 4 * g + k; s.x[e] = pin_fma(s.x[e], s.sc[e].x, s.sc[e].y); }
-        else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); s.rm = pin_max3_i32(s.rm, s.x[e], s.x[e + 1]); }
-        else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; s.x[e] = pin_relu_clamp(s.x[e]); }
-        else if constexpr (k < 14) { constexpr int e = 4 * g + (k - 10); s.r[e] = pin_mul32(s.x[e]); }
-        else if constexpr (k < 16) { constexpr int P = 2 * g + (k - 14); s.h[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        else if constexpr (k < 20) { constexpr int e = 4 * g + (k - 16); s.r[e] = (e & 1) ? pin_res_hi(s.h[e >> 1], s.r[e]) : pin_res_lo(s.h[e >> 1], s.r[e]); }
-        else if constexpr (k < 22) { constexpr int P = 2 * g + (k - 20); s.m[P] = pin_cvt(s.r[2 * P], s.r[2 * P + 1]); }
-        else { constexpr int P = 2 * g + (k - 22); s.l[P] = pin_scale_dn(s.h[P]); }
-    }
+
+struct JobSc { float2 sc[8]; };                                // (scale, 32 shift) of the job's 8 channels
+struct JobOut { u32x4_t h, m; };
+struct JobX { float x[8]; };                                   // the 8 values in flight
+constexpr int JOB_OPS = 36;
+// op I of 36 = two groups of 18 (values 4g..4g+3, neighbours independent): affine x4, range max x2, relu+clamp x4,
+// 32xh x2 (cvt), residual x4, 32xm x2 (cvt).
+template <int Q, int I> __device__ __forceinline__ void job_op(const f32x16 &a, JobX &v, const JobSc &s, JobOut &o, int &rm) {
+    static_assert(I >= 0 && I < JOB_OPS, "");
+    constexpr int g = I / 18, k = I % 18, R = 8 * Q;
+    if constexpr (k < 4) { constexpr int e = 4 * g + k; v.x[e] = pin_fma(a[R + e], s.sc[e].x, s.sc[e].y); }
+    else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); rm = pin_max3_i32(rm, v.x[e], v.x[e + 1]); }
+    else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; v.x[e] = pin_relu_clamp32(v.x[e]); }
+    else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); o.h[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
+    else if constexpr (k < 16) { constexpr int e = 4 * g + (k - 12); v.x[e] = (e & 1) ? pin_res_hi(o.h[e >> 1], v.x[e]) : pin_res_lo(o.h[e >> 1], v.x[e]); }
+    else { constexpr int P = 2 * g + (k - 16); o.m[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
 }
-template <int ABL, int I> __device__ __forceinline__ void split_all(SplitState &s) {     // back to back (layer transitions)
-    if constexpr (I < SPLIT_OPS) { split_op<ABL, I>(s); split_all<ABL, I + 1>(s); }
+template <int Q, int I0, int I1> __device__ __forceinline__ void job_ops(const f32x16 &a, JobX &v, const JobSc &s, JobOut &o, int &rm) {
+    if constexpr (I0 < I1 && I0 < JOB_OPS) { job_op<Q, I0>(a, v, s, o, rm); job_ops<Q, I0 + 1, I1>(a, v, s, o, rm); }
 }
-__device__ __forceinline__ B3 split_result(const SplitState &s) {
-    B3 b;
-    b.h = __builtin_bit_cast(f16x8, make_uint4(s.h[0], s.h[1], s.h[2], s.h[3]));
-    b.m = __builtin_bit_cast(f16x8, make_uint4(s.m[0], s.m[1], s.m[2], s.m[3]));
-    b.l = __builtin_bit_cast(f16x8, make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]));
-    return b;
+
+// compile-time loop: f(integral_constant<int, i>) for i in [I0, I1)
+template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
 }
+template <int V> using IC = std::integral_constant<int, V>;
+#define SFOR(var, N) static_for<0, (N)>([&](auto var##_c_) __attribute__((always_inline)) { constexpr int var = decltype(var##_c_)::value;
+#define SEND });
 
 // ---- weight stream packing -------------------------------------------------------------------------
 // slice s of the stream -> (layer, cout tile, K chunk, split term); one thread per (slice, lane).
@@ -173,74 +162,42 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
     const int i = lane & 31, h = lane >> 5;
     const float *W = nullptr;
     int Cin = 0, ct = 0, kc = 0, term = 0;
-    bool chained = true, valid = true;
-    // consumption order: per layer, tile-group major, then K chunk, then tile within the group, then split term
-    if (s < OFF2) {                       // L1: 2 tiles x 1 chunk, standard channel order (input comes from memory)
-        const int u = s - OFF1; term = u % NTERM; kc = 0; ct = u / NTERM; W = W1; Cin = Cin0; chained = false; valid = u < T0 * NTERM;
-    } else if (s < OFF3) {
-        const int u = s - OFF2; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC2;
-        ct = (u / (NTERM * GS * KC2)) * GS + mt; W = W2; Cin = 32 * T0;
-    } else if (s < OFF3 + SL3) {
-        const int u = s - OFF3; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC3;
-        ct = (u / (NTERM * GS * KC3)) * GS + mt; W = W3; Cin = 32 * T1;
-    } else if (s < PRE) {
-        valid = false;                    // padding up to an even number of stages
-    } else {                              // L4: pass-major, then chunk-major, MT4 tiles per chunk
-        const int u = (s - PRE) % SL4, pass = (s - PRE) / SL4;
-        term = u % NTERM; ct = pass * MT4 + (u / NTERM) % MT4; kc = u / (NTERM * MT4); W = W4; Cin = 32 * (T0 + T2);
-    }
-    unsigned w[4] = {0, 0, 0, 0};
-    if (valid) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float v[2];
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                const int e = 2 * p + z;
-                const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
-                v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
-            }
-            range_track(wr, v[0], v[1]);
-            // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
-            const unsigned hh = cvt_pk_f16(v[0], v[1]);
-            const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
-            w[p] = term == 0 ? hh : ll;
+    bool chained = true;
+    if (s < NS_L1) {                      // L1: 2 tiles x 1 chunk, standard channel order (the input comes from memory)
+        term = s % NTERM; ct = s / NTERM; kc = 0; W = W1; Cin = Cin0; chained = false;
+    } else {                              // per wave: consumption order = K chunk, then the wave's tiles, then the split term
+        const int w = (s - NS_L1) / NS_WAVE, r = (s - NS_L1) % NS_WAVE;
+        if (r < NS_L2) {
+            term = r % NTERM; kc = r / (NTERM * W2T); ct = w * W2T + (r / NTERM) % W2T; W = W2; Cin = 32 * T0;
+        } else if (r < NS_L2 + NS_L3) {
+            const int u = r - NS_L2; term = u % NTERM; kc = u / (NTERM * W3T); ct = w * W3T + (u / NTERM) % W3T; W = W3; Cin = 32 * T1;
+        } else {
+            const int u = r - NS_L2 - NS_L3; term = u % NTERM; kc = u / (NTERM * W4T); ct = w * W4T + (u / NTERM) % W4T; W = W4; Cin = 32 * (T0 + T2);
         }
     }
-    out[(long long)s * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    unsigned w4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float v[2];
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            const int e = 2 * p + z;
+            const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
+            v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
+        }
+        range_track(wr, v[0], v[1]);
+        // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
+        const unsigned hh = cvt_pk_f16(v[0], v[1]);
+        const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
+        w4[p] = term == 0 ? hh : ll;
+    }
+    out[(long long)s * 64 + lane] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| over the four layers (range log, word 1)
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------
-// LDS ring of NSLOT = 3 stages of W (36 KiB each), filled by LDS-DMA.  While stage n is consumed, stage n+1 is
-// resident and published (the last step of a stage reads the A fragments of the next stage's first step from it)
-// and stage n+2 is landing in the slot stage n-1 occupied.  Boundary(n), run by every wave at the first step of
-// stage n:   s_waitcnt vmcnt(0) (this wave's pieces of stage n+1 have landed);  barrier;  issue stage n+2.
-// (A 4-slot ring with vmcnt(9), two stages of landing time, measured no faster.)
-// With one wave per SIMD nothing else hides those latencies.
-//
-// SONET_NSLOT = 4: the same ring with one more slot and NO per-stage barrier.  Each wave publishes a progress counter
-// in LDS at its boundary(n) (prog[wave] = n + 1: "my pieces of the stages <= n + 1 have landed and I have finished
-// reading the stages <= n - 1") and, in the LAST step of stage n, waits until every counter is >= n + 1 before it
-// touches stage n + 1 (its first fragments are read there) -- which is also what boundary(n + 1) needs to refill the
-// slot of stage n - 1 with stage n + 3.  A wave may therefore run up to (a stage minus a step) ahead of the slowest
-// one instead of meeting it 27 times per tile; the real barrier stays only where the pool bins are flushed.
-#ifndef SONET_NSLOT
-#define SONET_NSLOT 3
-#endif
-constexpr int NSLOT = SONET_NSLOT;
-#ifndef SONET_RING_BARRIER
-constexpr bool FLAGS = NSLOT == 4;
-constexpr bool DEEP = false;
-#else
-constexpr bool FLAGS = false;                                  // experiment: 4 slots, per-stage barrier, stage n + 3 issued at
-constexpr bool DEEP = NSLOT == 4;                              // boundary(n) and waited for with vmcnt(9): two stages to land
-#endif
-
-struct AF { f16x8 h[MT4], l[MT4]; };                          // A fragments of one step (up to MT4 tiles x 2 slices)
-
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
-constexpr int SEG_SLOTS = NSLOT == 4 ? 12 : 16;                              // nodes of a 128-point tile pre-reduced in LDS (the rest: global atomics)
+constexpr int SEG_SLOTS = 4;                                  // nodes of a 64-point tile pre-reduced in LDS (the rest: global atomics)
 constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
 
 __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
@@ -254,29 +211,31 @@ constexpr int PROF_N = 32;
 __device__ long long g_prof[1024 * PROF_N];
 #define PROF_DECL long long prof_[PROF_N] = {}; const long long prof_rt0_ = (long long)__builtin_amdgcn_s_memrealtime(); long long prof_t_ = __builtin_readcyclecounter();
 #define PROF_MARK(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
-#define PROF_T0 long long pt_ = __builtin_readcyclecounter();
-#define PROF_T1(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - pt_; pt_ = n_; }
 #define PROF_DUMP prof_[31] = (long long)__builtin_amdgcn_s_memrealtime() - prof_rt0_; /* 100 MHz constant clock */ if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
-#define PROF_T0
-#define PROF_T1(i)
 #define PROF_DUMP
 #endif
 
-template <int ABL, bool SEGMAX>   // ABL: bench-only ablation: 1 = no stores, 2 = no operand split, 4 = no W streaming / barriers
+#define PF_SB __builtin_amdgcn_sched_barrier(0);
+
+// A fragments of one step: up to 3 output tiles x (h, l)
+struct AF { f16x8 h[W4T], l[W4T]; };
+
+template <bool SEGMAX>
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
-    const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
-    float *__restrict__ y, int L, int tpc /*128-point tiles per cloud*/, long long ntiles,
+    const float *__restrict__ x, int Cin0, const u32x4_t *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
+    float *__restrict__ y, int L, int tpc /*64-point tiles per cloud*/, long long ntiles,
     const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0, unsigned *__restrict__ pooled, float *__restrict__ v0, int M,
-    unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][32*MT4] keys of the tile's first SEG_SLOTS nodes*/,
+    unsigned *__restrict__ partial /*[ntiles][SEG_SLOTS][384] keys of the tile's first SEG_SLOTS nodes*/,
     unsigned *__restrict__ rlog /*optional range-log slot: [0] max |x in|, [1] max |w|, [2] max post-affine input of layers 2-4 (bits)*/)
 {
-    __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? 32 * MT4 : 1];
-    __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 24 KiB
+    // activations in B-fragment layout: [16-channel chunk][column tile][piece h, m][lane] x 16 bytes
+    __shared__ u32x4_t act2s[KC3][2][2][64];                   // layer-2 output, 32 KiB
+    __shared__ u32x4_t act3s[2 * T2][2][2][64];                // layer-3 output, 64 KiB
     __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
-    __shared__ __attribute__((aligned(16))) unsigned prog[PF_WAVES];   // FLAGS: per-wave progress counters
+    __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? C4 : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -284,505 +243,465 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     bool l4_unit_lane = true;                                   // layer 4 has no BatchNorm in the reference: scale == 1
     for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) {
         const float2 v = affine_g[c];
-        aff[c] = make_float2(v.x * ACC_UNSCALE, v.y);          // the accumulators carry a factor 32 (exact either way)
-        if (c >= 32 * (T0 + T1 + T2) && v.x != 1.0f) l4_unit_lane = false;
+        // layers 1-3: the split wants 32 x = acc * scale + 32 shift (the accumulators carry a factor 32);
+        // layer 4: y = acc * scale / 32 + shift
+        aff[c] = c < LB4 ? make_float2(v.x, 32.f * v.y) : make_float2(v.x * ACC_UNSCALE, v.y);
+        if (c >= LB4 && v.x != 1.0f) l4_unit_lane = false;
+    }
+    if constexpr (SEGMAX) {
+        for (int i = threadIdx.x; i < SEG_SLOTS * C4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
     }
     const bool l4_unit = __syncthreads_and(l4_unit_lane) != 0;   // then max(x + b) = max(x) + b exactly: bias after the pool
     PROF_DECL
 
-    const unsigned vow = (unsigned)lane * 16u;
     const unsigned rowB = (unsigned)L * 4u;
-
-    // The W stream goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1 KiB slice per wave instruction,
-    // lane-linear, which is exactly the slice layout): no staging VGPRs and no ds_write pass.  hipcc does not see
-    // these loads; their completion is counted by hand (vmcnt(0) before the barrier that publishes the stage).
-    const unsigned wsm_lds = (unsigned)reinterpret_cast<size_t>(&wsm[0][0]);
-    const char *dma_g = nullptr;                                // this wave's NSW slices of the stage being streamed
-    unsigned dma_dst = 0;
-    auto dma_setup = [&](int n, int slot) {                     // stream stage n (wraps: the stream restarts per tile)
-        const int sn = n % NSTAGE;
-        dma_g = reinterpret_cast<const char *>(Wst) + (size_t)(sn * NSTG + wave * NSW) * 1024u;
-        dma_dst = wsm_lds + (unsigned)(slot * NSTG + wave * NSW) * 1024u;
-    };
-    // pieces t and t+1 (t even) of the wave's NSW = 6: they share an M0 / base pair, the instruction offset moves both
-    // the global and the LDS address.  (M0 is written in the statement that uses it and not restored: nothing else
-    // in this kernel reads it.  Saving/restoring it and re-deriving the base per piece cost ~9 scalar instructions
-    // per piece, ~60 cycles in front of the next MFMA, 27 stage boundaries per tile.)
-    auto dma_pair = [&](int t, bool two) {                      // t, two: literals at every call site
-        const char *g = dma_g + (t / 4) * 4096;
-        const unsigned d = dma_dst + (unsigned)(t / 4) * 4096u;
-        const int o = (t % 4) * 1024;
-        if (two) {
-            if (o == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(vow), "s"(g), "s"(d) : "memory");
-            else        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(vow), "s"(g), "s"(d) : "memory");
-        } else {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vow), "s"(g), "s"(d) : "memory");
-        }
-    };
-    auto stage_dma = [&](int n, int slot) {
-        dma_setup(n, slot);
-        dma_pair(0, true); dma_pair(2, true); dma_pair(4, true);
-    };
-    // ring state (wave-uniform scalars)
-    int n_cur = 0;                                              // stage being consumed
-    int slot_cur = 0, slot_nxt = 1, slot_fill = DEEP ? 3 : 2;
-    stage_dma(0, 0);
-    stage_dma(1, 1);
-    if constexpr (DEEP) stage_dma(2, 2);
-    if (FLAGS && threadIdx.x < PF_WAVES) prog[threadIdx.x] = 1u;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                            // stages 0 and 1 are published (stage 0 is read cold)
-    const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
-    const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
-    bool first_boundary = true;
-    int pend_n = 0;
-    // SEGMAX: partial-maxima block whose LDS bins are still to be stored.  The very first flush is a dry run (all
-    // INIT) into the block that the same lanes rewrite one pass later, which keeps the flush free of branches.
-    unsigned *pend = partial + (blockIdx.x * (long long)NPASS * SEG_SLOTS) * (32 * MT4);
-    // The bins of a pass are stored at the first stage boundary AFTER it, between the barrier (all lanes have
-    // published) and the next W loads: the stores are older than those loads, so the vmcnt wait that the next
-    // boundary needs anyway covers them a whole stage later.  Stored right after the epilogue they (or atomics)
-    // put a memory round trip in front of the next ds_write (vmcnt(0)): measured 0.2 ms per launch.
-    auto flush_bins = [&]() {                                   // branch-free on the common path (<= 4 nodes per tile)
-#pragma unroll
-        for (int i = 0; i < 4 * 32 * MT4 / PF_THREADS; ++i) {          // branch-free on the common path (<= 4 nodes per tile)
-            const int e = i * PF_THREADS + threadIdx.x;
-            unsigned *bp = &bins[0][0] + e;
-            pend[e] = *bp;
-            *bp = SEG_INIT;
-        }
-        for (int e = 4 * 32 * MT4 + threadIdx.x; e < pend_n; e += PF_THREADS) {   // only the slots this tile's nodes occupy
-            unsigned *bp = &bins[0][0] + e;
-            pend[e] = *bp;
-            *bp = SEG_INIT;
-        }
-    };
-
-    // Boundary of the stage that the CURRENT step opens, in two halves so that the step can put its own `h` fragment
-    // reads between them (LDS executes a wave's operations in order: behind the nine ds_write_b128 they would
-    // return ~120 cycles later).
-    auto boundary_sync = [&](bool flush) {                      // `flush` is a literal at every call site
-        if constexpr (ABL & 4) return;
-        if constexpr (FLAGS) {
-            PROF_T0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage n + 1 have landed
-            PROF_T1(28)
-            if (!first_boundary) n_cur += 1;
-            if (lane == 0) *(volatile __attribute__((address_space(3))) unsigned *)(&prog[wave]) = (unsigned)n_cur + 1u;
-            if constexpr (SEGMAX && !(ABL & 8)) { if (flush) __syncthreads(); }   // every wave's bin atomics of the pass are in
-            slot_cur = n_cur & 3; slot_nxt = (n_cur + 1) & 3; slot_fill = (n_cur + 2) & 3;
-        } else {
-            if constexpr (!(ABL & 128)) {
-                PROF_T0
-                if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the pieces issued TWO boundaries ago
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage issued one boundary ago have landed
-                PROF_T1(28)
-#ifdef SONET_LITE_BARRIER
-                // experiment: no lgkmcnt(0) in front of the barrier.  The only LDS operations in flight here are the
-                // fragment reads of the step that opens the stage (slots nobody refills now); the bins need the full fence.
-                if (flush) __syncthreads(); else asm volatile("s_barrier" ::: "memory");
+    // this wave's part of the weight stream (lane-linear 16-byte fragments), read through buffer descriptors: the lane
+    // offset is ONE VGPR, every slice offset a scalar / immediate (with flat pointers hipcc hoists a 64-bit VGPR address
+    // per fragment out of the tile loop: 300+ registers)
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4_t *>(Wst), 0, NS_L1 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4_t *>(Wst) + (size_t)(NS_L1 + wave * NS_WAVE) * 64, 0, NS_WAVE * 1024, 0x00020000);
+    const unsigned vow = (unsigned)lane * 16u;
+#define PF_WLOAD(rsrc, slice) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vow, (unsigned)(slice) * 1024u, 0))
+#ifdef SONET_ABL_NOW                                            // experiment: the main steps keep their first fragments (no weight traffic)
+#define PF_WLOAD_MAIN(rsrc, slice) f_keep_
 #else
-                __syncthreads();
+#define PF_WLOAD_MAIN(rsrc, slice) PF_WLOAD(rsrc, slice)
 #endif
-                PROF_T1(29)
-            }
-            if (!first_boundary) {                              // rotate: the stage just finished becomes the fill slot
-                n_cur += 1;
-                if constexpr (DEEP) { slot_cur = n_cur & 3; slot_nxt = (n_cur + 1) & 3; slot_fill = (n_cur + 3) & 3; }
-                else { const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t; }
-            }
-        }
-        first_boundary = false;
-        lds_cur = &wsm[slot_cur * NSTG][lane];
-        lds_nxt = &wsm[slot_nxt * NSTG][lane];
-    };
-    auto boundary_fill = [&](bool flush) {                      // the step itself issues the NSW slices (dma_one) between its MFMAs
-        if constexpr (ABL & 4) return;
-        if constexpr (SEGMAX && !(ABL & 8)) { if (flush) flush_bins(); }
-        dma_setup(n_cur + (DEEP ? 3 : 2), slot_fill);           // lands during this stage, published at the next boundary
-    };
-    // FLAGS: last step of stage n -- nobody is more than (a stage minus this step) behind.  `pg` was read at the top of
-    // the step, so the common case costs a min and a scalar compare.
-    // explicit LDS address space: through a generic pointer the re-read becomes a FLAT load, and one FLAT operation
-    // in the loop turns every counted lgkmcnt wait of the MFMA steps into lgkmcnt(0)
-    typedef volatile __attribute__((address_space(3))) u32x4_t *prog_vec_p;
-    auto prog_wait = [&](u32x4_t pg) {
-        const unsigned need = (unsigned)n_cur + 1u;
-        PROF_T0
-#ifdef SONET_SPIN_LIMIT
-        int spins = 0;                                          // experiments only: abort instead of hanging the GPU
-#endif
-        for (;;) {
-            const unsigned a = pg.x < pg.y ? pg.x : pg.y, c = pg.z < pg.w ? pg.z : pg.w;
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)(a < c ? a : c)) >= need) break;
-#ifdef SONET_SPIN_LIMIT
-            if (++spins > SONET_SPIN_LIMIT) __builtin_trap();
-#endif
-            __builtin_amdgcn_s_sleep(1);
-            pg = *(prog_vec_p)(&prog[0]);
-        }
-        PROF_T1(30)
-        asm volatile("" ::: "memory");                          // the stage's fragment reads stay behind the check
-    };
-#define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
-#define PF_SB __builtin_amdgcn_sched_barrier(0);
-    // PF_SWAP (layer 4 of the pool variant): X as the A operand, W as B -> the accumulator tile comes out transposed
-    // (rows = points, columns = channels); the per-lane register contents of both operands are the same either way.
-#define PF_MF(accarr, tbase, NT, fa, fb, u)                                                          \
-    if constexpr ((u) < (NT)) {                                                                      \
-        if constexpr (PF_SWAP) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa[u], accarr[(tbase) + (u)], 0, 0, 0); \
-        else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, accarr[(tbase) + (u)], 0, 0, 0); \
-    }
-    // first term of an accumulator's first K chunk: C = 0 as an inline constant (no v_mov zero-fill of 416 registers per tile)
-#define PF_MFZ(accarr, tbase, NT, fa, fb, u)                                                         \
-    if constexpr ((u) < (NT)) {                                                                      \
-        const f32x16 cz_ = PF_ZERO ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : accarr[(tbase) + (u)]; \
-        if constexpr (PF_SWAP) accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa[u], cz_, 0, 0, 0); \
-        else accarr[(tbase) + (u)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb, cz_, 0, 0, 0); \
-    }
-    // VALU slot behind MFMA number q = TERM * NT + u of the step: the 44 affine+split ops of the next step's B chunk
-    // start after the first two MFMAs (the coefficient reads need that long) -- 3 per MFMA at 6 tiles (16 slots), 5 at 4.
-#define PF_SLOT(HAVE, NT, TERM, u)                                                                   \
-    if constexpr (HAVE) {                                                                            \
-        constexpr int skip_ = 2, q_ = (TERM) * (NT) + (u) - skip_;                                   \
-        constexpr int ops_ = (SPLIT_OPS + 3 * (NT) - skip_ - 1) / (3 * (NT) - skip_);                \
-        if constexpr (q_ >= 0) {                                                                     \
-            split_op<ABL, ops_ * q_>(sp_); split_op<ABL, ops_ * q_ + 1>(sp_); split_op<ABL, ops_ * q_ + 2>(sp_); \
-            if constexpr (ops_ > 3) { split_op<ABL, ops_ * q_ + 3>(sp_); split_op<ABL, ops_ * q_ + 4>(sp_); } \
-            static_assert(ops_ <= 5, "slot width");                                                  \
-        }                                                                                            \
-    }
-#define PF_DMA_AFTER(NT, u)                                                                          \
-    if constexpr (so_ == 0 && !(ABL & 4) && !(ABL & 64)) {                                            \
-        static_assert(NSW == 6, "three statements: pieces 01 23 45");                               \
-        if constexpr ((NT) >= 3) {                                                                   \
-            if constexpr ((u) == 0) dma_pair(0, true);                                               \
-            if constexpr ((u) == 1) dma_pair(2, true);                                               \
-            if constexpr ((u) == 2) dma_pair(4, true);                                               \
-        } else {                                                                                     \
-            if constexpr ((u) == 0) { dma_pair(0, true); dma_pair(2, true); }                        \
-            if constexpr ((u) == 1) dma_pair(4, true);                                               \
-        }                                                                                            \
-    }
-#define PF_TA1(accarr, tbase, NT, fa, fb, HAVE, u) if constexpr ((u) < (NT)) { PF_MFZ(accarr, tbase, NT, fa, fb, u) PF_DMA_AFTER(NT, u) PF_SLOT(HAVE, NT, 0, u) PF_SB }
-#define PF_TERM_A(accarr, tbase, NT, fa, fb, HAVE)                                                   \
-    PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 0) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 1) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 2)  \
-    PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 3) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 4) PF_TA1(accarr, tbase, NT, fa, fb, HAVE, 5)
-#define PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, u) if constexpr ((u) < (NT)) { PF_MF(accarr, tbase, NT, fa, fb, u) PF_SLOT(HAVE, NT, ti, u) PF_SB }
-#define PF_TERM_V(accarr, tbase, NT, fa, fb, HAVE, ti)                                               \
-    PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 0) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 1) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 2) \
-    PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 3) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 4) PF_TV1(accarr, tbase, NT, fa, fb, HAVE, ti, 5)
-    // One step = one K chunk (16 channels) x NT cout tiles = 3 NT MFMAs: the three product terms l, m, h TERM-major
-    // across the tiles (consecutive MFMAs never share an accumulator).  It is scheduled by hand (sched_barrier after
-    // every MFMA), because with one wave per SIMD nothing else hides a latency:
-    //  - on entry af.l / af.h already hold this step's fragments (read by the step before; COLD steps -- first of a
-    //    tile / of a layer-4 pass -- read them first thing, from the ring slot that is about to become current);
-    //  - a step that opens a stage waits for its own LDS-DMA slices, takes the barrier, and issues the NSW slices of
-    //    the stage after next between the MFMAs of the first term;
-    //  - `h` feeds the second and third term; the freed `l` registers take the NEXT step's `l` after the second term
-    //    (from the next ring slot when that step opens a stage: published one barrier earlier), `h` likewise after
-    //    the third (it lands under the next step's first term): no second fragment set, <= 12 LDS reads in flight;
-    //  - the next step's B chunk gets its affine + ReLU + split a few VALU instructions behind each MFMA
-    //    (tools/mfma_bf16_issue.hip: <= 4 dependent VALU per MFMA ride in its shadow, 8 halve the rate).
-#define PF_STEP(accarr, tbase, NT, sidx, NTN, SIDXN, bcur, HAVE, CHUNKCODE, bnext, COLD, FLUSH, ZERO)   \
-    {                                                                                                \
-        constexpr bool PF_SWAP = SEGMAX && ((sidx) >= PRE);                                          \
-        constexpr bool PF_ZERO = (ZERO);                                                             \
-        constexpr int so_ = (sidx) % NSTG, son_ = (SIDXN) % NSTG;                                    \
-        SplitState sp_;                                                                              \
-        if (COLD) {                                                                                  \
-            const uint4 *cb_ = (so_ != 0 || first_boundary) ? lds_cur : lds_nxt;                     \
-            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.l[u_] = PF_LDA(cb_, so_ + NTERM * u_ + 1); \
-            _Pragma("unroll") for (int u_ = 0; u_ < NT; ++u_) af.h[u_] = PF_LDA(cb_, so_ + NTERM * u_);     \
-        }                                                                                            \
-        if (so_ == 0) { boundary_sync(FLUSH); boundary_fill(FLUSH); }                                \
-        const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;                                            \
-        u32x4_t pg_ = {0u, 0u, 0u, 0u};                                                                \
-        if constexpr (FLAGS && son_ == 0 && !(ABL & 4)) pg_ = *(prog_vec_p)(&prog[0]); \
-        { CHUNKCODE }                                                                                \
-        PF_SB                                                                                        \
-        PF_TERM_A(accarr, tbase, NT, af.l, bcur.l, HAVE)                                             \
-        PF_SB                                                                                        \
-        PF_TERM_V(accarr, tbase, NT, af.h, bcur.m, HAVE, 1)                                          \
-        if constexpr (FLAGS && son_ == 0 && !(ABL & 4)) prog_wait(pg_);                              \
-        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.l[u_] = PF_LDA(nb_, son_ + NTERM * u_ + 1); \
-        PF_SB                                                                                        \
-        PF_TERM_V(accarr, tbase, NT, af.h, bcur.h, HAVE, 2)                                          \
-        _Pragma("unroll") for (int u_ = 0; u_ < NTN; ++u_) af.h[u_] = PF_LDA(nb_, son_ + NTERM * u_); \
-        PF_SB                                                                                        \
-        if constexpr (HAVE) { bnext = split_result(sp_); rmax_ = sp_.rm; }                           \
-    }
-    // raw values of K chunk kc of an activation array (registers 8q..8q+7 of tile kc>>1) + their 8 (scale, shift)
-    // pairs: element e is channel 32t + 16q + (e&3) + 8(e>>2) + 4h of the producing layer (base LB in `aff`)
-#define PF_CHUNK_AFF(sp, arr, kc, LB)                                                                \
-    {                                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) sp.x[e] = arr[(kc) >> 1][8 * ((kc) & 1) + e];   \
-        const float4 *ap_ = reinterpret_cast<const float4 *>(&aff[(LB) + 32 * ((kc) >> 1) + 16 * ((kc) & 1) + 4 * h]); \
-        const float4 c0_ = ap_[0], c1_ = ap_[1], c2_ = ap_[4], c3_ = ap_[5];                          \
-        sp.sc[0] = make_float2(c0_.x, c0_.y); sp.sc[1] = make_float2(c0_.z, c0_.w);                  \
-        sp.sc[2] = make_float2(c1_.x, c1_.y); sp.sc[3] = make_float2(c1_.z, c1_.w);                  \
-        sp.sc[4] = make_float2(c2_.x, c2_.y); sp.sc[5] = make_float2(c2_.z, c2_.w);                  \
-        sp.sc[6] = make_float2(c3_.x, c3_.y); sp.sc[7] = make_float2(c3_.z, c3_.w);                  \
-        sp.rm = rmax_;                                                                               \
-    }
-    constexpr int NMID = KC2 * (T1 / GS) + KC3 * (T2 / GS);    // steps of layers 2 and 3 (4 + 16)
-    // slice index / tile group of middle step i (layer 2 first, then layer 3)
-#define MID_SIDX(i) ((i) < KC2 * (T1 / GS) ? OFF2 + (i) * NTERM * GS : OFF3 + ((i) - KC2 * (T1 / GS)) * NTERM * GS)
+    constexpr int WO2 = 0, WO3 = NS_L2, WO4 = NS_L2 + NS_L3;     // slice offsets of layers 2-4 in the wave's stream
+    u32x4_t *const act2w = &act2s[0][0][0][lane];               // + ((chunk * 2 + c) * 2 + piece) * 64
+    u32x4_t *const act3w = &act3s[0][0][0][lane];
+#define PF_ACT(base, chunk, c, piece) (base)[(((chunk) * 2 + (c)) * 2 + (piece)) * 64]
 
-    AF af;
-    PROF_MARK(0)                                                // kernel prologue
-    // inputs of a tile, read one tile ahead (in front of the previous tile's last epilogue): read at the top of the
-    // tile, the x / node-id loads put an HBM round trip (~3k cycles per tile) in front of layer 1
-    float xin_n[8];
-    int nid_n = -1, n0_n = 0, nlast_n = 0, pos0_n = 0;
-    auto prefetch_tile = [&](long long t) {
-        if (t >= ntiles) return;
+    // ---- the main steps: global step g = 0..7 layer 3 (K chunk g, tiles 2w, 2w+1), g = 8..27 layer 4 (K chunk g - 8,
+    // tiles 3w..3w+2).  A fragments live in a two-deep buffer af[g & 1]; the `l` half of a buffer is refilled with the
+    // fragments of step g + 2 as soon as the first term of step g has issued, the `h` half after the third term.
+    AF af[2];
+    auto load_l = [&](auto gc, AF &f) __attribute__((always_inline)) {      // `l` fragments of global step g (wraps: next tile)
+        constexpr int g = decltype(gc)::value % (KC3 + KC4);
+        const f16x8 f_keep_ = f.l[0]; (void)f_keep_;
+        if constexpr (g < KC3) { SFOR(u, W3T) f.l[u] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * u + 1); SEND }
+        else { SFOR(u, W4T) f.l[u] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * u + 1); SEND }
+    };
+    auto load_h = [&](auto gc, AF &f) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value % (KC3 + KC4);
+        const f16x8 f_keep_ = f.h[0]; (void)f_keep_;
+        if constexpr (g < KC3) { SFOR(u, W3T) f.h[u] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * u); SEND }
+        else { SFOR(u, W4T) f.h[u] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * u); SEND }
+    };
+#define PF_MFMA(ACCE, A_, B_, ZEROC, SWAPC)                                                              \
+    {                                                                                                    \
+        if constexpr (ZEROC) {                                                                           \
+            const f32x16 cz_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+            if constexpr (SWAPC) ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(B_, A_, cz_, 0, 0, 0);    \
+            else ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, cz_, 0, 0, 0);                    \
+        } else {                                                                                         \
+            if constexpr (SWAPC) ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(B_, A_, ACCE, 0, 0, 0);   \
+            else ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACCE, 0, 0, 0);                   \
+        }                                                                                                \
+    }
+    // One STEP = a 16-channel K chunk x NT output tiles x 2 column tiles = 6 NT MFMAs, hand-scheduled (sched_barrier
+    // after every MFMA: with one wave per SIMD nothing else hides a latency).  Term order (A.l, B.l), (A.h, B.m),
+    // (A.h, B.h) per accumulator; SLOT(q) places VALU / LDS work behind MFMA q; G = global step (fragment refills).
+#define PF_STEP(NT, G, FR, ACC, BH0, BM0, BL0, BH1, BM1, BL1, ZERO, SWAP, SLOT)                          \
+    {                                                                                                    \
+        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
+        PF_SB                                                                                            \
+        SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
+            PF_MFMA(ACC(u, c), FR.l[u], bl_[c], (ZERO), (SWAP))                                          \
+            SLOT(q)                                                                                      \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        if constexpr ((G) >= 0) load_l(IC<((G) >= 0 ? (G) + 2 : 0)>{}, FR);                              \
+        PF_SB                                                                                            \
+        SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
+            PF_MFMA(ACC(u, c), FR.h[u], bm_[c], false, (SWAP))                                           \
+            SLOT(2 * (NT) + q)                                                                           \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
+            PF_MFMA(ACC(u, c), FR.h[u], bh_[c], false, (SWAP))                                           \
+            SLOT(4 * (NT) + q)                                                                           \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        if constexpr ((G) >= 0) load_h(IC<((G) >= 0 ? (G) + 2 : 0)>{}, FR);                              \
+        PF_SB                                                                                            \
+    }
+    // (scale, 32 shift) of the 8 channels of a job: channels CH + (e&3) + 8(e>>2), CH = layer base + 32 tile + 16 Q + 4 h
+#define PF_LOAD_SC(scv, CH)                                                                              \
+    {                                                                                                    \
+        const float4 *ap_ = reinterpret_cast<const float4 *>(&aff[(CH)]);                                \
+        const float4 c0_ = ap_[0], c1_ = ap_[1], c2_ = ap_[4], c3_ = ap_[5];                             \
+        scv.sc[0] = make_float2(c0_.x, c0_.y); scv.sc[1] = make_float2(c0_.z, c0_.w);                    \
+        scv.sc[2] = make_float2(c1_.x, c1_.y); scv.sc[3] = make_float2(c1_.z, c1_.w);                    \
+        scv.sc[4] = make_float2(c2_.x, c2_.y); scv.sc[5] = make_float2(c2_.z, c2_.w);                    \
+        scv.sc[6] = make_float2(c3_.x, c3_.y); scv.sc[7] = make_float2(c3_.z, c3_.w);                    \
+    }
+    // ops [I0, I1) of the 72 of a job PAIR (both column tiles of one (tile, half Q): same coefficients)
+#define PF_JOB2(Q, I0, I1, A0, A1, OUT0, OUT1)                                                           \
+    {                                                                                                    \
+        if constexpr ((I0) < JOB_OPS) job_ops<Q, (I0), ((I1) < JOB_OPS ? (I1) : JOB_OPS)>(A0, jx_, sc_, OUT0, rmax_); \
+        if constexpr ((I1) > JOB_OPS) job_ops<Q, ((I0) > JOB_OPS ? (I0) - JOB_OPS : 0), (I1) - JOB_OPS>(A1, jx_, sc_, OUT1, rmax_); \
+    }
+    // ... placed OPS at a time behind the MFMAs of a step, from the third on (the coefficient reads need that long)
+#ifdef SONET_ABL_NOJOB
+#define PF_JOBS_ON false
+#else
+#define PF_JOBS_ON true
+#endif
+#define PF_SLOT2(q, OPS, Q, A0, A1, OUT0, OUT1)                                                          \
+    {                                                                                                    \
+        if constexpr (PF_JOBS_ON && (q) >= 2 && (OPS) * ((q) - 2) < 2 * JOB_OPS) {                                     \
+            constexpr int i0_ = (OPS) * ((q) - 2);                                                       \
+            PF_JOB2(Q, i0_, i0_ + (OPS), A0, A1, OUT0, OUT1)                                             \
+        }                                                                                                \
+    }
+
+    // ---- the front of a tile: x -> layer 1 (all 64 points, every wave) -> layer 2 (this wave's tile) -> LDS ----
+    float xin[2][8];
+    u32x4_t xh[2], xm[2], xl[2];
+    AF fl1;                                                     // layer 1's 4 fragments (h, l of 2 tiles)
+    f16x8 fl2h, fl2l;                                           // layer 2: one tile, one chunk
+    f32x16 acc1[T0][2], acc2[2];
+    JobOut a1n[T0][2][2];                                       // layer-1 output of the NEXT tile [tile][half][column tile]
+    JobOut a2o[2][2];                                           // this wave's layer-2 tile [half][column tile]
+    int rmax_ = 0;                                              // range log: running max of the post-affine inputs of layers 2-4 (x 32)
+    unsigned xin_r = 0u;                                        // ... and of |network input|, as ordered bit patterns
+    auto front_load_x = [&](long long t) __attribute__((always_inline)) {
+        t = t < ntiles ? t : ntiles - 1;                        // past the end: recompute the last tile's front (never consumed)
         const long long bb = t / tpc;
-        const int t0 = (int)(t - bb * tpc) * 128;
-        const int ll0 = t0 + wave * 32;
-        const bool pvv = ll0 + j < L;
-        const int lcc = pvv ? ll0 + j : (ll0 < L ? ll0 : 0);
+        const int t0 = (int)(t - bb * tpc) * TPTS;
         const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(x + bb * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowB), 0x00020000);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            xin_n[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
-        if constexpr (SEGMAX) {
-            const int32_t *idb = ids_sorted + bb * (long long)L;
-            nid_n = pvv ? idb[ll0 + j] : -1;
-            n0_n = idb[t0];                                                        // first / last node of the workgroup's tile
-            nlast_n = idb[(t0 + 127 < L ? t0 + 127 : L - 1)];
-            pos0_n = pos0[bb];
+        for (int c = 0; c < 2; ++c) {
+            const int ll0 = t0 + 32 * c;
+            const int lcc = ll0 + j < L ? ll0 + j : (ll0 < L ? ll0 : 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)                          // rows >= Cin0 are out of range of the descriptor: 0
+                xin[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
         }
     };
-    prefetch_tile(blockIdx.x);
-    // range log: running max of the post-affine inputs of layers 2-4 (ONE word for the three layers: the kernel sits at
-    // the 512-register limit) and of |network input|, both as ordered bit patterns
-    int rmax_ = 0;
-    unsigned xin_r = 0u;
+    auto front_load_w1 = [&]() __attribute__((always_inline)) {
+        SFOR(u, T0) fl1.h[u] = PF_WLOAD(rw1, NTERM * u); fl1.l[u] = PF_WLOAD(rw1, NTERM * u + 1); SEND
+    };
+    auto front_split_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned a0 = __float_as_uint(xin[c][2 * p]) & 0x7FFFFFFFu, a1 = __float_as_uint(xin[c][2 * p + 1]) & 0x7FFFFFFFu;
+                xin_r = max(max(xin_r, a0), a1);
+            }
+            split_input(xin[c], xh[c], xm[c]);
+            xl[c] = piece_l(xh[c]);
+        }
+    };
+#define ACC1(u, c) acc1[u][c]
+#define NOSLOT(q)
+    auto front_l1 = [&]() __attribute__((always_inline)) {      // 12 MFMAs
+        PF_STEP(T0, -1, fl1, ACC1, xh[0], xm[0], xl[0], xh[1], xm[1], xl[1], true, false, NOSLOT)
+    };
+    auto front_load_w2 = [&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value;
+        fl2h = PF_WLOAD(rww, WO2 + kc * NTERM); fl2l = PF_WLOAD(rww, WO2 + kc * NTERM + 1);
+    };
+    auto front_l2 = [&](auto kcc) __attribute__((always_inline)) {    // 6 MFMAs: chunk kc of layer 2, this wave's tile
+        constexpr int kc = decltype(kcc)::value, t = kc >> 1, q = kc & 1;
+        const f16x8 b0l = as_f16x8(piece_l(a1n[t][q][0].h)), b1l = as_f16x8(piece_l(a1n[t][q][1].h));
+        PF_SB
+        PF_MFMA(acc2[0], fl2l, b0l, (kc == 0), false) PF_SB
+        PF_MFMA(acc2[1], fl2l, b1l, (kc == 0), false) PF_SB
+        PF_MFMA(acc2[0], fl2h, as_f16x8(a1n[t][q][0].m), false, false) PF_SB
+        PF_MFMA(acc2[1], fl2h, as_f16x8(a1n[t][q][1].m), false, false) PF_SB
+        PF_MFMA(acc2[0], fl2h, as_f16x8(a1n[t][q][0].h), false, false) PF_SB
+        PF_MFMA(acc2[1], fl2h, as_f16x8(a1n[t][q][1].h), false, false) PF_SB
+    };
+    auto front_store_a2 = [&]() __attribute__((always_inline)) {  // this wave's layer-2 tile = chunks 2w, 2w+1 of layer 3's input
+        SFOR(q, 2) SFOR(c, 2)
+            PF_ACT(act2w, 2 * wave + q, c, 0) = a2o[q][c].h; PF_ACT(act2w, 2 * wave + q, c, 1) = a2o[q][c].m;
+        SEND SEND
+    };
+    auto front_exposed = [&](long long t) __attribute__((always_inline)) {   // the whole front back to back (first tile of a workgroup)
+        front_load_x(t);
+        front_load_w1();
+        front_split_x();
+        front_l1();
+        SFOR(ck, KC2)
+            JobSc sc_; JobX jx_;
+            PF_LOAD_SC(sc_, LB1 + 32 * (ck >> 1) + 16 * (ck & 1) + 4 * h)
+            PF_JOB2((ck & 1), 0, 2 * JOB_OPS, acc1[ck >> 1][0], acc1[ck >> 1][1], a1n[ck >> 1][ck & 1][0], a1n[ck >> 1][ck & 1][1])
+        SEND
+        SFOR(kc, KC2)
+            front_load_w2(IC<kc>{});
+            front_l2(IC<kc>{});
+        SEND
+        SFOR(q, 2)
+            JobSc sc_; JobX jx_;
+            PF_LOAD_SC(sc_, LB2 + 32 * wave + 16 * q + 4 * h)
+            PF_JOB2(q, 0, 2 * JOB_OPS, acc2[0], acc2[1], a2o[q][0], a2o[q][1])
+        SEND
+        front_store_a2();
+    };
+
+    PROF_MARK(0)                                                // kernel prologue
+    front_exposed(blockIdx.x);
+    // fragments of the first two main steps
+#ifdef SONET_ABL_NOW
+    SFOR(u, W4T) af[0].l[u] = PF_WLOAD(rww, WO4 + 2 * u + 1); af[0].h[u] = PF_WLOAD(rww, WO4 + 2 * u); af[1].l[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u + 1); af[1].h[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u); SEND
+#else
+    load_l(IC<0>{}, af[0]); load_h(IC<0>{}, af[0]);
+    load_l(IC<1>{}, af[1]); load_h(IC<1>{}, af[1]);
+#endif
+    PROF_MARK(1)                                                // first front
+
+    int pend_n = 0;
+    unsigned *pend = partial;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long b = tile / tpc;
-        const int l0 = (int)(tile - b * tpc) * 128 + wave * 32;
-        const bool pv = l0 + j < L;
-        const int lc = pv ? l0 + j : (l0 < L ? l0 : 0);
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
-
-        // per-node max-pool bookkeeping of this wave's 32 (node-sorted) points
-        int nid = -1, n0 = 0, jpos0 = -1, nslots = 0;
+        const int t0 = (int)(tile - b * tpc) * TPTS;             // first point of the tile (same 64 points for all four waves)
+        bool pv[2]; int lc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int l0 = t0 + 32 * c;
+            pv[c] = l0 + j < L;
+            lc[c] = pv[c] ? l0 + j : (l0 < L ? l0 : 0);
+        }
+        // per-node max-pool bookkeeping of the tile's 2 x 32 (node-sorted) points (used by the epilogue, a tile later)
+        int nid[2] = {-1, -1}, n0 = 0, nslots = 0, jpos0[2] = {-1, -1};
         if constexpr (SEGMAX) {
-            nid = nid_n;
-            n0 = n0_n;
-            nslots = nlast_n - n0_n + 1 < SEG_SLOTS ? nlast_n - n0_n + 1 : SEG_SLOTS;
-            const int p0 = pos0_n - l0;
-            jpos0 = (p0 >= 0 && p0 < 32) ? p0 : -1;
-            if (tile == blockIdx.x)                                               // first tile of this workgroup: clear the bins
-            {
-                for (int i = threadIdx.x; i < SEG_SLOTS * 32 * MT4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
-                if constexpr (FLAGS) __syncthreads();                             // (the 3-slot ring meets at its first boundary)
+            const int32_t *idb = ids_sorted + b * (long long)L;
+            nid[0] = pv[0] ? idb[t0 + j] : -1;
+            nid[1] = pv[1] ? idb[t0 + 32 + j] : -1;
+            n0 = idb[t0];
+            const int nlast = idb[(t0 + TPTS - 1 < L ? t0 + TPTS - 1 : L - 1)];
+            nslots = nlast - n0 + 1 < SEG_SLOTS ? nlast - n0 + 1 : SEG_SLOTS;
+            const int p0 = pos0[b];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int pp = p0 - (t0 + 32 * c);
+                jpos0[c] = (pp >= 0 && pp < 32) ? pp : -1;
             }
         }
-        float xin[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xin[e] = xin_n[e];
-        f32x16 act1[T0], act2[T1], act3[T2];                   // written by the first MFMA of their first K chunk (C = 0)
-        B3 bq[2];
-        B3 bsave[KC3];                                          // layer 3: the split chunks of act2, made once for both tile groups
-        PROF_MARK(1)                                            // tile prologue (ids, x loads issued, accumulators zeroed)
-        // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned a0 = __float_as_uint(xin[2 * p]) & 0x7FFFFFFFu, a1 = __float_as_uint(xin[2 * p + 1]) & 0x7FFFFFFFu;
-            xin_r = max(max(xin_r, a0), a1);
-        }
-        bq[0] = split_chunk_abl<ABL>(xin);
-        PF_STEP(act1, 0, T0, OFF1, GS, OFF2, bq[0], false, , bq[1], true, false, true)
-        {                                                       // layer transition: nothing to overlap with
-            SplitState sp_;
-            PF_CHUNK_AFF(sp_, act1, 0, 0)
-            split_all<ABL, 0>(sp_);
-            bq[1] = split_result(sp_);
-            rmax_ = sp_.rm;
-        }
-        PROF_MARK(6)                                            // layer 1
-        // ---- layers 2 and 3: middle steps i = 0 .. NMID-1, set parity (i + 1) & 1 ----
-#define PF_MID_CHUNK if constexpr (last_of_l3) PF_CHUNK_AFF(sp_, act1, 0, 0) else if constexpr (l2) PF_CHUNK_AFF(sp_, act1, (l2 ? kcn : 0), 0) else PF_CHUNK_AFF(sp_, act2, (l2 ? 0 : kcn), 32 * T0)
-#define PF_MID(I_)                                                          \
-        {                                                                   \
-            constexpr int i = (I_);                                         \
-            constexpr int sidx = MID_SIDX(i); \
-            constexpr int cur = (i + 1) & 1, nxt = i & 1; \
-            constexpr bool l2 = i < KC2 * (T1 / GS); \
-            constexpr int grp = l2 ? i / KC2 : (i - KC2 * (T1 / GS)) / KC3; \
-            constexpr bool last_of_l2 = (i == KC2 * (T1 / GS) - 1), last_of_l3 = (i == NMID - 1); \
-            constexpr int kcn = l2 ? (i + 1) % KC2 : (i + 1 - KC2 * (T1 / GS)) % KC3; \
-            constexpr int ntn = last_of_l3 ? 0 : GS;                         /* layer 4 starts cold */ \
-            if constexpr (l2) { PF_STEP(act2, grp * GS, GS, sidx, ntn, sidx + NTERM * GS, bq[cur], !last_of_l2, PF_MID_CHUNK, bq[nxt], false, false, (i % KC2 == 0)) } \
-            else if constexpr (grp == 0) {                                  /* layer 3, tiles 0-3: keep each split chunk */ \
-                constexpr int kc3 = i - KC2 * (T1 / GS);                    \
-                bsave[kc3] = bq[cur];                                       \
-                PF_STEP(act3, 0, GS, sidx, ntn, sidx + NTERM * GS, bq[cur], (kc3 + 1 < KC3), PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
-            } else {                                                        /* tiles 4-7 reuse them: no split work at all */ \
-                constexpr int kc3 = i - KC2 * (T1 / GS) - KC3;              \
-                PF_STEP(act3, GS, GS, sidx, ntn, sidx + NTERM * GS, bsave[kc3], last_of_l3, PF_MID_CHUNK, bq[nxt], false, false, (kc3 == 0)) \
-            } \
-            if constexpr (last_of_l2) {                                     /* layer transition */ \
-                SplitState sp2_; \
-                PF_CHUNK_AFF(sp2_, act2, 0, 32 * T0) \
-                split_all<ABL, 0>(sp2_); \
-                bq[nxt] = split_result(sp2_); \
-                rmax_ = sp2_.rm; \
-            } \
-        }
-        static_assert(NMID == 20 && T2 == 2 * GS, "expand PF_MID to NMID steps; layer 3 = two groups");
-        PF_MID(0) PROF_MARK(8) PF_MID(1) PROF_MARK(9) PF_MID(2) PROF_MARK(10) PF_MID(3) PROF_MARK(11) PF_MID(4) PROF_MARK(12) PF_MID(5) PROF_MARK(13) PF_MID(6) PROF_MARK(14) PF_MID(7) PROF_MARK(15) PF_MID(8) PROF_MARK(16) PF_MID(9) PROF_MARK(17) PF_MID(10) PROF_MARK(18) PF_MID(11) PROF_MARK(19) PF_MID(12) PROF_MARK(20) PF_MID(13) PROF_MARK(21) PF_MID(14) PROF_MARK(22) PF_MID(15) PROF_MARK(23) PF_MID(16) PROF_MARK(24) PF_MID(17) PROF_MARK(25) PF_MID(18) PROF_MARK(26) PF_MID(19) PROF_MARK(27)
-#undef PF_MID
-#undef PF_MID_CHUNK
-        PROF_MARK(2)                                            // layers 1-3
-        // ---- layer 4: NPASS passes x KC4 steps of MT4 tiles; set parity of step kc is (NMID + 1 + kc) & 1 ----
-        for (int pass = 0; pass < NPASS; ++pass) {
-            f32x16 acc[MT4];
-#define PF_L4_CHUNK if constexpr (kn < KC2) PF_CHUNK_AFF(sp_, act1, (kn < KC2 ? kn : 0), 0) else PF_CHUNK_AFF(sp_, act3, (kn < KC2 ? 0 : kn - KC2), 32 * (T0 + T1))
-#define PF_L4(K_)                                                           \
-            {                                                               \
-                constexpr int kc = (K_);                                    \
-                constexpr int sidx = PRE + kc * MT4 * NTERM; \
-                constexpr int cur = (NMID + 1 + kc) & 1, nxt = cur ^ 1; \
-                constexpr int kn = (kc + 1) % KC4; \
-                PF_STEP(acc, 0, MT4, sidx, (kc + 1 < KC4 ? MT4 : 0), sidx + NTERM * MT4, bq[cur], true, PF_L4_CHUNK, bq[nxt], (kc == 0), (kc == 0), (kc == 0)) \
+        // the layer-1 output of THIS tile (made by the front a tile ago) moves out of the front's registers
+        JobOut a1[T0][2][2];
+        SFOR(t, T0) SFOR(q, 2) SFOR(c, 2) a1[t][q][c] = a1n[t][q][c]; SEND SEND SEND
+
+        __syncthreads();                                        // #1: layer 2 of this tile is in LDS; everyone is done with the previous tile
+        if constexpr (SEGMAX) {                                 // the previous tile's maxima: LDS bins -> its partial block
+            for (int e = threadIdx.x; e < pend_n; e += PF_THREADS) {
+                unsigned *bp = &bins[0][0] + e;
+                pend[e] = *bp;
+                *bp = SEG_INIT;
             }
-            static_assert(KC4 == 20, "expand PF_L4 to KC4 steps");
-            PF_L4(0) PF_L4(1) PF_L4(2) PF_L4(3) PF_L4(4) PF_L4(5) PF_L4(6) PF_L4(7) PF_L4(8) PF_L4(9) PF_L4(10) PF_L4(11) PF_L4(12) PF_L4(13) PF_L4(14) PF_L4(15) PF_L4(16) PF_L4(17) PF_L4(18) PF_L4(19)
-#undef PF_L4
-#undef PF_L4_CHUNK
-            if (pass == NPASS - 1) prefetch_tile(tile + gridDim.x);
-            PROF_MARK(3)                                        // layer-4 pass (MFMA stream)
-            if constexpr (SEGMAX) {
-                // ---- per-node max-pool of this pass's 192 channels (replaces index_max + masked gather,
-                //      models/networks.py:180-185, for the no-grad path: only the VALUES are needed) ----
-                // Layer 4 of this variant runs with the MFMA operands swapped (PF_MF ... SWAP): the accumulators are
-                // TRANSPOSED, acc[mt][r] = Y[point prow(r)][channel 32 mt + j] with prow(r) = (r&3) + 8 (r>>2) + 4 h, so the
-                // maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a 5-step
-                // cross-lane reduction of every register (80 DPP ops per tile); the two half-waves (16 points each)
-                // meet in the LDS atomic.
-                // 1) affine in place (one coefficient pair per lane and tile); features of original copy 0
-                float bias4[MT4];
+        }
+        PROF_MARK(2)                                            // tile prologue + barrier 1
+        // ---- layer 3: 8 steps, tiles 2w, 2w+1, B = layer 2 from LDS ----
+        f32x16 acc3[W3T][2];
+#define ACC3(u, c) acc3[u][c]
+        u32x4_t bh[2], bm[2], bl[2];                            // B pieces of the current step
+        bh[0] = PF_ACT(act2w, 0, 0, 0); bm[0] = PF_ACT(act2w, 0, 0, 1); bh[1] = PF_ACT(act2w, 0, 1, 0); bm[1] = PF_ACT(act2w, 0, 1, 1);
+        bl[0] = piece_l(bh[0]); bl[1] = piece_l(bh[1]);
+        SFOR(kc, KC3)
+            u32x4_t nh[2], nm[2], nl[2];                        // next step's B chunk, read now
+            if constexpr (kc + 1 < KC3) {
+#ifdef SONET_ABL_NOB
+                nh[0] = bh[0]; nm[0] = bm[0]; nh[1] = bh[1]; nm[1] = bm[1];
+#else
+                nh[0] = PF_ACT(act2w, kc + 1, 0, 0); nm[0] = PF_ACT(act2w, kc + 1, 0, 1); nh[1] = PF_ACT(act2w, kc + 1, 1, 0); nm[1] = PF_ACT(act2w, kc + 1, 1, 1);
+#endif
+            } else {                                            // layer 4 starts with the wave's own layer-1 chunk 0
+                nh[0] = a1[0][0][0].h; nm[0] = a1[0][0][0].m; nh[1] = a1[0][0][1].h; nm[1] = a1[0][0][1].m;
+            }
+#define SLOT_L3(q) { if constexpr ((q) == 8) nl[0] = piece_l(nh[0]); if constexpr ((q) == 9) nl[1] = piece_l(nh[1]); }
+            PF_STEP(W3T, kc, af[kc & 1], ACC3, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), false, SLOT_L3)
+#undef SLOT_L3
+            bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1];
+        SEND
+        PROF_MARK(3)                                            // layer 3
+        // ---- layer 4: 20 steps, tiles 3w..3w+2; chunks 0-3 = own layer-1 output, 4-19 = layer 3 from LDS ----
+        f32x16 acc[W4T][2];
+#define ACC4(u, c) acc[u][c]
+        // steps 0-3: the 8 jobs of layer 3 (step s: tile s>>1, half s&1, both column tiles), stored when complete
+        SFOR(kc, KC2)
+            constexpr int ju = kc >> 1, jq = kc & 1;
+            JobSc sc_; JobX jx_;
+            JobOut a3o[2];                                      // the job pair's outputs on their way to LDS
+            PF_LOAD_SC(sc_, LB3 + 32 * (W3T * wave + ju) + 16 * jq + 4 * h)
+            u32x4_t nh[2], nm[2], nl[2];
+            if constexpr (kc + 1 < KC2) {
+                constexpr int tn = (kc + 1) >> 1, qn = (kc + 1) & 1;
+                nh[0] = a1[tn][qn][0].h; nm[0] = a1[tn][qn][0].m; nh[1] = a1[tn][qn][1].h; nm[1] = a1[tn][qn][1].m;
+            }
+#define SLOT_L4A(q) { PF_SLOT2(q, 6, jq, acc3[ju][0], acc3[ju][1], a3o[0], a3o[1]) \
+                      if constexpr (kc + 1 < KC2) { if constexpr ((q) == 14) nl[0] = piece_l(nh[0]); if constexpr ((q) == 15) nl[1] = piece_l(nh[1]); } }
+            PF_STEP(W4T, KC3 + kc, af[kc & 1], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), SEGMAX, SLOT_L4A)
+#undef SLOT_L4A
+            SFOR(c, 2)
+                PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 0) = a3o[c].h; PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 1) = a3o[c].m;
+            SEND
+            if constexpr (kc + 1 < KC2) { bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1]; }
+        SEND
+        PROF_MARK(4)                                            // layer 4, steps 0-3 (+ layer-3 jobs)
+        __syncthreads();                                        // #2: layer 3 of this tile is in LDS
+        PROF_MARK(5)
+        bh[0] = PF_ACT(act3w, 0, 0, 0); bm[0] = PF_ACT(act3w, 0, 0, 1); bh[1] = PF_ACT(act3w, 0, 1, 0); bm[1] = PF_ACT(act3w, 0, 1, 1);
+        bl[0] = piece_l(bh[0]); bl[1] = piece_l(bh[1]);
+        // steps 4-19 carry the front of the NEXT tile of this workgroup:
+        //   step 4: x loads + layer-1 fragments;  6: split x;  7: layer 1 (12 MFMAs);  8-11: its 8 jobs (a pair per step);
+        //   12-15: layer 2, one chunk per step (6 MFMAs, fragments read a step ahead);  16-17: its 4 jobs;  18: stores to LDS.
+        SFOR(s, KC4 - KC2)
+            constexpr int kc = KC2 + s;
+            u32x4_t nh[2], nm[2], nl[2];
+            if constexpr (kc + 1 < KC4) {
+#ifdef SONET_ABL_NOB
+                nh[0] = bh[0]; nm[0] = bm[0]; nh[1] = bh[1]; nm[1] = bm[1];
+#else
+                nh[0] = PF_ACT(act3w, kc + 1 - KC2, 0, 0); nm[0] = PF_ACT(act3w, kc + 1 - KC2, 0, 1);
+                nh[1] = PF_ACT(act3w, kc + 1 - KC2, 1, 0); nm[1] = PF_ACT(act3w, kc + 1 - KC2, 1, 1);
+#endif
+            }
+            constexpr bool j1 = kc >= 8 && kc < 12, j2 = kc >= 16 && kc < 18;      // a layer-1 / layer-2 job pair rides on this step
+            constexpr int ck1 = j1 ? kc - 8 : 0, q2 = j2 ? kc - 16 : 0;
+            JobSc sc_; JobX jx_;
+            if constexpr (kc == 4) { front_load_x(tile + gridDim.x); front_load_w1(); }
+            if constexpr (kc == 6) front_split_x();
+            if constexpr (j1) PF_LOAD_SC(sc_, LB1 + 32 * (ck1 >> 1) + 16 * (ck1 & 1) + 4 * h)
+            if constexpr (j2) PF_LOAD_SC(sc_, LB2 + 32 * wave + 16 * q2 + 4 * h)
+#define SLOT_L4B(q) { \
+                if constexpr (kc + 1 < KC4) { if constexpr ((q) == 0) nl[0] = piece_l(nh[0]); if constexpr ((q) == 1) nl[1] = piece_l(nh[1]); } \
+                if constexpr (j1) PF_SLOT2(q, 6, (ck1 & 1), acc1[ck1 >> 1][0], acc1[ck1 >> 1][1], a1n[ck1 >> 1][ck1 & 1][0], a1n[ck1 >> 1][ck1 & 1][1]) \
+                if constexpr (j2) PF_SLOT2(q, 6, q2, acc2[0], acc2[1], a2o[q2][0], a2o[q2][1]) \
+            }
+            PF_STEP(W4T, KC3 + kc, af[kc & 1], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], false, SEGMAX, SLOT_L4B)
+#undef SLOT_L4B
+            if constexpr (kc == 7) front_l1();
+            if constexpr (kc >= 12 && kc < 16) front_l2(IC<(kc >= 12 && kc < 16 ? kc - 12 : 0)>{});
+            if constexpr (kc >= 11 && kc < 15) front_load_w2(IC<(kc >= 11 && kc < 15 ? kc - 11 : 0)>{});   // (after the chunk before it has been consumed)
+            if constexpr (kc == 18) front_store_a2();
+            if constexpr (kc + 1 < KC4) { bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1]; }
+        SEND
+        PROF_MARK(6)                                            // layer 4, steps 4-19 (+ front of the next tile)
+        // ---- epilogue: this wave's 96 channels x 64 points ----
+        if constexpr (SEGMAX) {
+            // per-node max-pool (replaces index_max + masked gather, models/networks.py:180-185, for the no-grad path:
+            // only the VALUES are needed).  Layer 4 of this variant runs with the MFMA operands swapped: the accumulators
+            // are TRANSPOSED, acc[mt][c][r] = Y[point 32c + prow(r)][channel 96w + 32mt + j], prow(r) = (r&3) + 8(r>>2) + 4h,
+            // so the maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a cross-lane
+            // reduction of every register; the two half-waves (16 points each) meet in the LDS atomic.
+            float bias4[W4T];
 #pragma unroll
-                for (int mt = 0; mt < MT4; ++mt) {
-                    const float2 ss = aff[32 * (T0 + T1 + T2) + (pass * MT4 + mt) * 32 + j];
-                    bias4[mt] = ss.y;
-                    if (!l4_unit) {
+            for (int mt = 0; mt < W4T; ++mt) {
+                const float2 ss = aff[LB4 + (W4T * wave + mt) * 32 + j];
+                bias4[mt] = ss.y;
+                if (!l4_unit) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mt][r] = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                    }
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][c][r] = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
                 }
-                if (jpos0 >= 0) {                                                 // wave-uniform: one wave per cloud
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (jpos0[c] >= 0) {                                              // wave-uniform: features of original copy 0
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0) {
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0[c]) {
 #pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = l4_unit ? __fmaf_rn(acc[mt][r], ACC_UNSCALE, bias4[mt]) : acc[mt][r];
+                            for (int mt = 0; mt < W4T; ++mt) v0[b * C4 + (W4T * wave + mt) * 32 + j] = l4_unit ? __fmaf_rn(acc[mt][c][r], ACC_UNSCALE, bias4[mt]) : acc[mt][c][r];
                         }
                 }
-                // 2) per node present in this wave (usually 1, 2 at a node boundary; ids are sorted, so a node's points
-                //    are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's '>'
-                //    does), published by integer atomicMax on orderable keys -- to the LDS bins of the workgroup's
-                //    first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
-                if constexpr (!(ABL & 16)) {
-                unsigned remaining = (unsigned)__ballot(pv);                      // lanes 0..31 <-> the wave's 32 points
-                const int nvalid = __builtin_popcount(remaining);
+                // per node present in this column tile (usually 1, 2 at a node boundary; ids are sorted, so a node's
+                // points are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's
+                // '>' does), published by integer atomicMax on orderable keys -- to the LDS bins of the tile's
+                // first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
+                unsigned remaining = (unsigned)__ballot(pv[c]);                   // lanes 0..31 <-> the column tile's 32 points
                 while (remaining != 0u) {
                     const int s0 = __builtin_ctz(remaining);
-                    const int node = __builtin_amdgcn_readlane(nid, s0);
-                    const unsigned segmask = (unsigned)__ballot(pv && nid == node);
+                    const int node = __builtin_amdgcn_readlane(nid[c], s0);
+                    const unsigned segmask = (unsigned)__ballot(pv[c] && nid[c] == node);
                     remaining &= ~segmask;
                     const int e0 = s0 + __builtin_popcount(segmask);
                     const bool whole = (s0 == 0 && e0 == 32);
                     const int slot = node - n0;
-                    float mx[MT4];
+                    float mx[W4T];
                     if (whole) {
 #pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt) {
-                            float m = acc[mt][0];
+                        for (int mt = 0; mt < W4T; ++mt) {
+                            float m = acc[mt][c][0];
 #pragma unroll
-                            for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][r]));
+                            for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][c][r]));
                             mx[mt] = m;
                         }
                     } else {
 #pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = -__builtin_inff();
+                        for (int mt = 0; mt < W4T; ++mt) mx[mt] = -__builtin_inff();
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
                             const bool in = prow >= s0 && prow < e0;
 #pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) {
-                                const float v = in ? acc[mt][r] : -__builtin_inff();
+                            for (int mt = 0; mt < W4T; ++mt) {
+                                const float v = in ? acc[mt][c][r] : -__builtin_inff();
                                 asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));
                             }
                         }
                     }
-                    (void)nvalid;
                     if (l4_unit) {                                                // fl(x / 32 + b) is monotone in x: after the max
 #pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
+                        for (int mt = 0; mt < W4T; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
                     }
-                    if constexpr (!(ABL & 32)) {
-                        // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
-                        // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
-                        if (slot < SEG_SLOTS) {
+                    // two explicit paths: a generic pointer here would make FLAT atomics (and FLAT operations count on
+                    // both vmcnt and lgkmcnt)
+                    if (slot < SEG_SLOTS) {
 #pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) atomicMax(&bins[slot][32 * mt + j], ord_f32(__float_as_uint(mx[mt])));
-                        } else {
-                            unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * (32 * MT4);
-#pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
-                        }
+                        for (int mt = 0; mt < W4T; ++mt) atomicMax(&bins[slot][(W4T * wave + mt) * 32 + j], ord_f32(__float_as_uint(mx[mt])));
                     } else {
+                        unsigned *gdst = pooled + ((long long)b * M + node) * C4 + (W4T * wave) * 32;
 #pragma unroll
-                        for (int mt = 0; mt < MT4; ++mt) asm volatile("" ::"v"(mx[mt]));
+                        for (int mt = 0; mt < W4T; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
                     }
                 }
-                }
-                if constexpr (!(ABL & 8)) pend_n = nslots * (32 * MT4);
-                if constexpr (!(ABL & 8))
-                    pend = partial + ((tile * NPASS + pass) * SEG_SLOTS) * (long long)(32 * MT4);   // stored at the next boundary
-            } else if (pv) {
+            }
+            pend_n = nslots * C4;
+            pend = partial + (tile * SEG_SLOTS) * (long long)C4;                   // stored after the next barrier 1
+        } else {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                y + b * (long long)C4 * L, 0, (int)((unsigned)C4 * rowB), 0x00020000);
 #pragma unroll
-                for (int mt = 0; mt < MT4; ++mt) {
-                    const int ct = pass * MT4 + mt;
+            for (int c = 0; c < 2; ++c) {
+                if (!pv[c]) continue;
+#pragma unroll
+                for (int mt = 0; mt < W4T; ++mt) {
+                    const int ct = W4T * wave + mt;
                     const unsigned so_tile = (unsigned)(ct * 32) * rowB;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int orow = (r & 3) + 8 * (r >> 2);
-                        const float2 ss = aff[32 * (T0 + T1 + T2) + ct * 32 + orow + 4 * h];
-                        const float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                        if constexpr (ABL & 1) { asm volatile("" ::"v"(v)); } else
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (unsigned)(4 * h * L + lc) * 4u,
+                        const float2 ss = aff[LB4 + ct * 32 + orow + 4 * h];
+                        const float v = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (unsigned)(4 * h * L + lc[c]) * 4u,
                                                               so_tile + (unsigned)orow * rowB, 0);
                     }
                 }
             }
-            PROF_MARK(4)                                        // epilogue (pool or stores)
         }
+        PROF_MARK(7)                                            // epilogue (pool or stores)
     }
-    if constexpr (SEGMAX && !(ABL & 8)) {
+    if constexpr (SEGMAX) {
         __syncthreads();
-        if (blockIdx.x < ntiles) flush_bins();
+        for (int e = threadIdx.x; e < pend_n; e += PF_THREADS) pend[e] = (&bins[0][0])[e];
     }
     if (rlog != nullptr) {
         range_publish(rlog, wave_umax(xin_r), lane);
-        range_publish(rlog + 2, wave_umax((unsigned)rmax_), lane);
+        // the jobs logged 32 x: take the factor out of the exponent (a NaN / inf stays far above the fp16 range)
+        unsigned rb = wave_umax((unsigned)(rmax_ > 0 ? rmax_ : 0));
+        rb = rb > (5u << 23) ? rb - (5u << 23) : 0u;
+        range_publish(rlog + 2, rb, lane);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wst + (long long)NSLICE * 64)[0]);
     }
-    PROF_MARK(5)
+    PROF_MARK(8)
     PROF_DUMP
-#undef PF_STEP
-#undef PF_TERM
-#undef PF_LDA
-#undef PF_SPLIT_PAIR
-#undef PF_CHUNK_AFF
-#undef MID_SIDX
 }
 
 __global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__ pooled, long long n) {
@@ -794,8 +713,6 @@ __global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__
 // partial (slot = m - first node of the tile), combined with the rare straight-to-memory fallback in `pooled`
 // (tiles spanning more than SEG_SLOTS nodes).  Nodes that never beat -1000 (empty, or all values <= -1000) take the
 // features of original point copy 0, as gather index 0 does in the reference (models/networks.py:185).
-// (A workgroup per cloud x 64 channels x 64 nodes with an LDS transpose -- coalesced stores instead of 4-byte values 256 bytes
-// apart -- measured 43.6 vs 20.8 us: sixteen dependent count / offset / key chains per thread instead of one.  r02zc.)
 __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
                                                              const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
                                                              const int32_t *__restrict__ count, const float *__restrict__ v0,
@@ -803,28 +720,35 @@ __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__re
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // over [B][M][384], c fastest (coalesced partial reads)
     if (t >= total) return;
-    const int C = 32 * T3;
-    const int c = (int)(t % C);
-    const long long bm = t / C;
+    const int c = (int)(t % C4);
+    const long long bm = t / C4;
     const int m = (int)(bm % M);
     const long long b = bm / M;
     unsigned key = pooled[t];
     const int cnt = count[b * M + m];
     if (cnt > 0) {
         const int off = node_off[b * M + m];
-        const int pass = c / (32 * MT4), cl = c - pass * (32 * MT4);
-        for (int tl = off / 128; tl <= (off + cnt - 1) / 128; ++tl) {
-            const int slot = m - ids_sorted[b * L + tl * 128];
+        for (int tl = off / TPTS; tl <= (off + cnt - 1) / TPTS; ++tl) {
+            const int slot = m - ids_sorted[b * L + tl * TPTS];
             if (slot < SEG_SLOTS) {
-                const unsigned k2 = partial[((((b * tpc + tl) * NPASS + pass) * SEG_SLOTS) + slot) * (long long)(32 * MT4) + cl];
+                const unsigned k2 = partial[((b * tpc + tl) * SEG_SLOTS + slot) * (long long)C4 + c];
                 key = k2 > key ? k2 : key;
             }
         }
     }
     float v;
     if (key > SEG_INIT) v = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
-    else v = v0[b * C + c];
-    out[(b * C + c) * M + m] = v;
+    else v = v0[b * C4 + c];
+    out[(b * C4 + c) * M + m] = v;
+}
+
+int cu_count() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus;
 }
 
 }  // namespace
@@ -850,31 +774,22 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     const char *what = "sonet_pointresnet_fused_f32";
     SONET_REQUIRE(x && wstream && affine && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d Cin0=%d", what, B, L, Cin0);
-    if ((double)(32 * T3) * L * 4.0 >= 4.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
-    const int tpc = sonet::ceil_div(L, 128);
+    if ((double)C4 * L * 4.0 >= 4.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
+    const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // bench-only (tools/fused_variants.py)
+    const int cus = cu_count();
     const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
-    int abl = 0;
-    if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
-#define PF_LAUNCH(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream), \
-                       x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles, \
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log())
-    switch (abl) { case 1: PF_LAUNCH(1); break; case 2: PF_LAUNCH(2); break; case 4: PF_LAUNCH(4); break; case 7: PF_LAUNCH(7); break; default: PF_LAUNCH(0); }
-#undef PF_LAUNCH
+    hipLaunchKernelGGL((pointresnet_fused_kernel<false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
+                       x, Cin0, reinterpret_cast<const u32x4_t *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log());
     return sonet::launched(what);
 }
 
 extern "C" size_t sonet_pointresnet_pool_ws_size(int B, int L, int M)
 {
     if (B <= 0 || L <= 0 || M <= 0) return 0;
-    const long long ntiles = (long long)B * sonet::ceil_div(L, 128);
-    return (size_t)((long long)B * M * (32 * T3) + ntiles * NPASS * SEG_SLOTS * (32 * MT4)) * 4 + (size_t)B * (32 * T3) * 4;
+    const long long ntiles = (long long)B * sonet::ceil_div(L, TPTS);
+    return (size_t)((long long)B * M * C4 + ntiles * SEG_SLOTS * C4) * 4 + (size_t)B * C4 * 4;
 }
 
 extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
@@ -885,28 +800,18 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
     SONET_REQUIRE(x_sorted && wstream && affine && ids_sorted && pos0 && node_off && count && ws && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && M > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d M=%d Cin0=%d", what, B, L, M, Cin0);
     hipStream_t st = sonet::as_stream(stream);
-    const long long npool = (long long)B * M * (32 * T3);
-    const int tpc = sonet::ceil_div(L, 128);
+    const long long npool = (long long)B * M * C4;
+    const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
     unsigned *pooled_ws = reinterpret_cast<unsigned *>(ws);
     unsigned *partial_ws = pooled_ws + npool;
-    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * NPASS * SEG_SLOTS * (32 * MT4));
+    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * SEG_SLOTS * C4);
     hipLaunchKernelGGL(pooled_init_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, npool);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // bench-only
+    const int cus = cu_count();
     const long long grid = ntiles < cus ? ntiles : cus;
-    int abl = 0;
-    if (const char *e = getenv("SONET_FUSED_ABLATE")) abl = atoi(e);       // bench-only (tools/microbench.py)
-#define PF_LAUNCH_POOL(AA) hipLaunchKernelGGL((pointresnet_fused_kernel<AA, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st, \
-                       x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr, \
-                       L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log())
-    switch (abl) { case 64: PF_LAUNCH_POOL(64); break; case 128: PF_LAUNCH_POOL(128); break; case 4: PF_LAUNCH_POOL(4); break; case 2: PF_LAUNCH_POOL(2); break; case 8: PF_LAUNCH_POOL(8); break; case 16: PF_LAUNCH_POOL(16); break; case 32: PF_LAUNCH_POOL(32); break;
-                   case 56: PF_LAUNCH_POOL(56); break; default: PF_LAUNCH_POOL(0); }
-#undef PF_LAUNCH_POOL
+    hipLaunchKernelGGL((pointresnet_fused_kernel<true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st,
+                       x_sorted, Cin0, reinterpret_cast<const u32x4_t *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
+                       L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log());
     hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
                        ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);
     return sonet::launched(what);

@@ -39,23 +39,22 @@ NP = 32
 buf = np.zeros(1024 * NP, dtype=np.int64)
 assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
 p = buf.reshape(1024, NP).astype(np.float64)
-tiles = B * ((15000 + 127) // 128) / float(min(256, int(os.environ.get("SONET_FUSED_MAXCU", "256"))))
-names = ["kernel prologue", "tile prologue", "(unused)", "layer-4 MFMA passes", "epilogue", "tail", "layer 1", "(unused)"] + ["mid step %d" % i for i in range(20)]
-ideal = [0, 0, 0, 2 * 360 * 32, 0, 0, 2 * 3 * 32, 0] + [12 * 32] * 20
-tot = p[:, :28].sum(1).mean()                      # slots 28.. are sub-totals of the phases above
-print("mode %s: %.0f cycles per wave (%.3f ms at 2.39 GHz), %.1f tiles per workgroup" % (mode, tot, tot / 2.39e6, tiles))
-names += ["(inside the above) boundary: s_waitcnt vmcnt", "(inside) boundary: s_barrier", "(inside) progress-flag wait", "(s_memrealtime ticks, not cycles)"]
-ideal += [0, 0, 0, 0]
+tiles = B * ((15000 + 63) // 64) / 256.0
+# phase slots of the third-generation kernel (PROF_MARK in pointresnet_fused.hip); MFMA-only ideal = 32 cycles per MFMA
+names = ["kernel prologue", "first front (exposed)", "tile prologue + barrier 1", "layer 3 (96 MFMAs)", "layer 4 steps 0-3 + layer-3 jobs (72)",
+         "barrier 2", "layer 4 steps 4-19 + next front (324)", "epilogue", "tail"]
+ideal = [0, 0, 0, 96 * 32, 72 * 32, 0, 324 * 32, 0, 0]
+tot = p[:, :9].sum(1).mean()
+print("mode %s: %.0f cycles per wave, %.2f tiles per workgroup, MFMA-only ideal per tile %d" % (mode, tot, tiles, sum(ideal)))
 for i, n in enumerate(names):
     per_tile = p[:, i].mean() / tiles
-    print("  %-22s %9.0f cycles/tile  (%4.1f%%)%s" % (n, per_tile, 100 * p[:, i].mean() / tot,
+    print("  %-42s %9.0f cycles/tile  (%4.1f%%)%s" % (n, per_tile, 100 * p[:, i].mean() / tot,
           "   MFMA-only ideal %d -> %.0f%%" % (ideal[i], 100 * ideal[i] / per_tile) if ideal[i] else ""))
-# per-wave view: a systematic imbalance shows up as one wave with less wait and more busy time than the others
 pw = p.reshape(-1, 4, NP)
-print("  per wave (cycles/tile):   total   l4-passes  epilogue  tile-prologue  layer1  vmcnt-wait  barrier-wait  flag-wait")
+print("  per wave (cycles/tile):   total  barrier1    layer3   l4a   barrier2    l4b  epilogue")
 for w in range(4):
     m = pw[:, w, :].mean(0) / tiles
-    print("    wave %d               %8.0f %9.0f %9.0f %12.0f %8.0f %10.0f %12.0f %10.0f" % (w, pw[:, w, :28].sum(1).mean() / tiles, m[3], m[4], m[1], m[6], m[28], m[29], m[30]))
+    print("    wave %d               %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f" % (w, pw[:, w, :9].sum(1).mean() / tiles, m[2], m[3], m[4], m[5], m[6], m[7]))
 rt = p[:, 31].mean()                                            # s_memrealtime ticks (100 MHz) per wave
-cyc = p[:, :28].sum(1).mean()
+cyc = p[:, :9].sum(1).mean()
 print("  shader clock while the kernel runs: %.0f cycles in %.1f us = %.3f GHz" % (cyc, rt / 100.0, cyc / (rt * 10.0) if rt else 0.0))
