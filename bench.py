@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-other-precisions", action="store_true", help="skip the x3 / exact-f32 throughput keys")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the timed batch (rank 0)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other BASELINE.json configs (training step bf16 / f32-class, segmenter, autoencoder + Chamfer) under `other_configs`")
+    ap.add_argument("--other-steps", type=int, default=30, help="timed steps per window of each `other_configs` entry")
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of K steps of the headline (the first one is `value`)")
     return ap.parse_args()
 
 
@@ -107,12 +111,16 @@ def parity_check(args, enc, cls, inp, out, enc_sd, cls_sd, n_clouds=4):
         bound = tol * np.maximum(np.abs(b), np.sqrt(np.mean(b ** 2)))
         return float((np.abs(a - b) / bound).max())
 
+    # node ids of EVERY cloud of the timed batch against the C restatement of BatchSOM.query_topk (util/som.py:237-269)
+    all_idx = enc.min_idx.cpu().numpy()
+    ids_ok = bool(np.array_equal(all_idx, O.som_query_topk(inp["pc"].cpu(), inp["node"].cpu(), 3)[0]))
     res = {"clouds": P, "of_the_timed_batch": True, "min_idx_bit_exact": bool(np.array_equal(got_idx, ref["min_idx"])),
+           "node_ids_bit_exact_all_clouds": {"clouds": args.batch, "ok": bool(ids_ok)},
            "feature_err_over_bound": round(worst(feat[:P], ref["feature"]), 4),
            "score_err_over_bound": round(worst(out[:P], ref_score), 4),
            "replay_equals_eager": bool(torch.equal(out, score_eager)),
            "bound": "%g * max(|ref|, rms(ref))" % tol, "oracle": "oracle/cpu_oracle.py"}
-    res["ok"] = bool(res["min_idx_bit_exact"] and res["feature_err_over_bound"] <= 1.0 and res["score_err_over_bound"] <= 1.0)
+    res["ok"] = bool(res["min_idx_bit_exact"] and ids_ok and res["feature_err_over_bound"] <= 1.0 and res["score_err_over_bound"] <= 1.0)
     if not res["ok"]:
         raise SystemExit("bench.py: the timed batch does NOT match the oracle: %s" % json.dumps(res))
     return res
@@ -188,6 +196,255 @@ def cpu_baseline(args, enc_sd, cls_sd):
                                                        "the reference's own compiled" if use_ref else "restated", cores, reps, ncpu)}
 
 
+def rank_evidence(world, rank, dev, my_clouds_per_s):
+    """Every rank reports the physical device it ran on (UUID, PCI bus id) and its own clouds/s; rank 0 puts the list on the
+    line and FAILS the run when two ranks sat on the same device -- an N-GPU number cannot come from fewer than N GPUs."""
+    pr = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_device": dev.index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+          "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+          "clouds_per_s": round(my_clouds_per_s, 1)}
+    if world > 1:
+        allr = [None] * world
+        torch.distributed.all_gather_object(allr, me)
+    else:
+        allr = [me]
+    ids = [(r_["uuid"], r_["pci"]) for r_ in allr]
+    distinct = len(set(ids))
+    if distinct != world:
+        raise SystemExit("bench.py: %d ranks ran on %d distinct device(s): %s" % (world, distinct, ids))
+    rates = [r_["clouds_per_s"] for r_ in allr]
+    return {"world": world, "distinct_devices": distinct, "per_rank_clouds_per_s": {"min": min(rates), "max": max(rates)}, "devices": allr}
+
+
+def _kernel_top(rec, steps, B, N, n=5):
+    """Top kernels of an instrumented region (ops.kernel_timing) + the roofline of the dominant one that has an
+    algorithmic figure (same convention as the headline's `roofline`)."""
+    summ = rec.summary()
+    tot = sum(v["total_ms"] for v in summ.values()) or 1.0
+    top, roof = [], None
+    for name, s_ in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+        e = {"name": name, "ms_per_step": round(s_["total_ms"] / steps, 4), "share": round(s_["total_ms"] / tot, 3)}
+        try:
+            bound, amount = algorithmic(name, B, N)
+        except Exception:
+            bound, amount = None, None
+        if amount and roof is None:
+            if bound == "mfma":
+                peak = (PEAK_H3_TFLOPS if name.startswith(("pointresnet_fused", "pointmlph3", "pointmlpws")) else PEAK_X3_TFLOPS if name.startswith("pointmlpx3")
+                        else PEAK_BF16_MFMA_TFLOPS if name.startswith(("pointresnet_bf16", "pointmlpbf16")) else PEAK_F32_MFMA_TFLOPS)
+                ach = amount / (s_["mean_ms"] * 1e-3) / 1e12
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "mean_ms": round(s_["mean_ms"], 5)}
+            else:
+                ach = amount / (s_["mean_ms"] * 1e-3) / 1e9
+                roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                        "mean_ms": round(s_["mean_ms"], 5)}
+        if len(top) < n:
+            top.append(e)
+    return top, roof
+
+
+def _encoder_parity(enc, inp, P=2, tol=1e-5, **kw):
+    """The encoder stage of a timed batch against the oracle on its first P clouds (node ids bit-exact, feature within tol)."""
+    import numpy as np
+    from oracle import cpu_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+    ref = O.encoder_forward(sd, inp["pc"][:P].cpu(), inp["sn"][:P].cpu(), inp["node"][:P].cpu(), inp["node_knn_I"][:P].cpu(),
+                            use_ref_index_max=O.ref_module() is not None, **kw)
+    b = ref["feature"].double().numpy()
+    a = enc.feature[:P].detach().cpu().double().numpy()
+    bound = tol * np.maximum(np.abs(b), np.sqrt(np.mean(b ** 2)))
+    res = {"clouds": P, "min_idx_bit_exact": bool(np.array_equal(enc.min_idx[:P].cpu().numpy(), ref["min_idx"])),
+           "feature_err_over_bound": round(float((np.abs(a - b) / bound).max()), 4), "bound": "%g * max(|ref|, rms(ref))" % tol,
+           "oracle": "oracle/cpu_oracle.py encoder_forward"}
+    res["ok"] = bool(res["min_idx_bit_exact"] and res["feature_err_over_bound"] <= 1.0)
+    return res
+
+
+def _windows(fn, steps, n=3):
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / steps)
+    return ts
+
+
+def other_configs(args, dev):
+    """The other BASELINE.json configs on one GPU, after the headline (same process, inputs resident, >= 30 timed steps per
+    window, three windows, the median reported): configs[1] the 5000-point classifier TRAINING step in bf16 and in the f32-class
+    arithmetic (models/classifier.py:78-99), configs[2] the part segmenter at 1024 points (models/segmenter.py:79-109),
+    configs[3] the autoencoder forward with the Chamfer loss (models/autoencoder.py:66-103).  Each entry carries the roofline of
+    its dominant kernel and an oracle check of its timed batch.  A failing entry is reported, never hidden."""
+    from argparse import Namespace
+    from models import networks as NW, losses as LS
+    from sonet_hip import dp, ops, synth
+    from sonet_hip.graph import GraphedForward
+    K = max(1, args.other_steps)
+    out = {}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:                                   # noqa: BLE001 -- the headline must still be printed
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+
+    def train(precision):
+        B, N = args.batch, args.points
+        with ops.precision(precision):
+            opt = make_opt(dev, B, N)
+            enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+            synth.fill_state_dict_(enc.state_dict(), 0)
+            synth.fill_state_dict_(cls.state_dict(), 1)
+            enc.to(dev).train()
+            cls.to(dev).train()
+            inp = synth.make_inputs(B, N, seed=100, device=dev)
+            dp.init_distributed(force=True)                       # a one-rank RCCL group: the same bucketed exchange as the 8-GPU job
+            dp.broadcast_parameters([enc, cls])
+            opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
+            opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
+            reducer = dp.GradientAllReducer([enc, cls], always_reduce=True)
+            state = {}
+
+            def step():
+                feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                score = cls(feat, 0)
+                enc.zero_grad(set_to_none=True)
+                cls.zero_grad(set_to_none=True)
+                loss = torch.nn.functional.cross_entropy(score, inp["label"])
+                loss.backward()
+                state["nbytes"] = reducer.reduce()
+                opt_e.step()
+                opt_c.step()
+                state["loss"] = loss
+            # the batch that is about to be timed, eval forward with the initial weights, against the oracle (gates `ok`)
+            enc.eval()
+            with torch.no_grad():
+                enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+            par = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
+            enc.train()
+            for _ in range(5):
+                step()
+            ts = _windows(step, K)
+            exposed_us = reducer.exposed_ms(last=K) * 1e3
+            assert torch.isfinite(state["loss"])
+            with ops.kernel_timing() as rec:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+            top, roof = _kernel_top(rec, 3, B, N)
+            reducer.remove_hooks()
+            # the model that was just trained, in eval mode, against the oracle with the SAME (updated) weights
+            enc.eval()
+            with torch.no_grad():
+                enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+            after = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
+            par["after_the_timed_steps"] = {"min_idx_bit_exact": after["min_idx_bit_exact"], "feature_err_over_bound": after["feature_err_over_bound"],
+                                            "what": "the same check with the weights and BatchNorm running statistics the timed Adam steps left behind "
+                                                    "(random labels, %d steps): reported, not gated -- the bound is the reference fixtures' bound" % (5 + 3 * K + 3)}
+            med = sorted(ts)[len(ts) // 2]
+            return {"workload": "ModelNet40 classifier TRAINING step (forward + backward + gradient all-reduce + Adam), %d x %d pts" % (B, N),
+                    "arithmetic": precision, "clouds_per_s": round(B / med, 1), "ms_per_step": round(med * 1e3, 4),
+                    "ms_per_step_windows": [round(t * 1e3, 4) for t in ts], "steps_per_window": K,
+                    "allreduce": {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
+                                  "bytes_per_step": state["nbytes"], "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1)},
+                    "top_kernels": top, "roofline": roof,
+                    "loss_after": round(float(state["loss"]), 5),
+                    "parity_checked": dict(par, what="eval forward of the timed batch with the weights the timed steps start from vs the oracle; "
+                                                "training gradients are pinned by tests/golden/train_step_* (tests/test_gpu_parity.py, tests/test_gpu_bf16.py)")}
+
+    def heads_opt(B, N, **kw):
+        d = dict(gpu_id=dev.index or 0, device=dev, batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024, activation="relu",
+                 normalization="batch", dropout=0.6, node_num=64, k=3, som_k=9, som_k_type="avg", bn_momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=50, output_fc_pc_num=256, output_conv_pc_num=1024)
+        d.update(kw)
+        return Namespace(**d)
+
+    def graphed(fwd, inp, B, N, workload, parity):
+        with torch.no_grad():
+            g = GraphedForward(fwd, (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"]), warmup=3)
+            call = lambda: g(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])     # noqa: E731
+            for _ in range(3):
+                call()
+            ts = _windows(call, K)
+            bad = g.range_violations()
+            for _ in range(2):
+                fwd(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+            torch.cuda.synchronize()
+            with ops.kernel_timing() as rec:
+                for _ in range(3):
+                    fwd(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+                torch.cuda.synchronize()
+        top, roof = _kernel_top(rec, 3, B, N)
+        med = sorted(ts)[len(ts) // 2]
+        return {"workload": workload, "arithmetic": ops.POINTMLP_PRECISION, "launch_mode": "hip-graph replay, one stream",
+                "clouds_per_s": round(B / med, 1), "ms_per_step": round(med * 1e3, 4), "ms_per_step_windows": [round(t * 1e3, 4) for t in ts],
+                "steps_per_window": K, "range_guard_violations": len(bad), "top_kernels": top, "roofline": roof, "parity_checked": parity()}
+
+    def segmenter():
+        B, N = args.batch, 1024
+        opt = heads_opt(B, N, som_k_type="center")
+        enc, seg = NW.Encoder(opt), NW.Segmenter(opt)
+        synth.fill_state_dict_(enc.state_dict(), 1)
+        synth.fill_state_dict_(seg.state_dict(), 2)
+        enc.to(dev).eval()
+        seg.to(dev).eval()
+        inp = synth.make_inputs(B, N, seed=3, device=dev)
+        label = torch.randint(0, 16, (B,), device=dev)
+        fwd = lambda pc, sn, node, knn: NW.segmentation_forward(enc, seg, pc, sn, label, node, knn)     # noqa: E731
+
+        def parity():
+            r = _encoder_parity(enc, inp, 2, som_k_type="center")
+            r["what"] = ("encoder stage of the timed batch vs the oracle; the per-point head (node_gather back-broadcast + 3356-channel "
+                         "layer) is pinned by tests/golden/segmenter_b2_n{256,1024} written from the live reference")
+            return r
+        return graphed(fwd, inp, B, N, "ShapeNetPart segmenter forward (encoder + per-point head, eval), %d x %d pts, 50 parts" % (B, N), parity)
+
+    def autoencoder():
+        import numpy as np
+        from oracle import cpu_oracle as O
+        B, N = args.batch, args.points
+        opt = heads_opt(B, N, classes=40)
+        enc, dec, crit = NW.Encoder(opt), NW.Decoder(opt), LS.ChamferLoss(opt)
+        synth.fill_state_dict_(enc.state_dict(), 1)
+        synth.fill_state_dict_(dec.state_dict(), 2)
+        enc.to(dev).eval()
+        dec.to(dev).eval()
+        inp = synth.make_inputs(B, N, seed=3, device=dev)
+        keep = {}
+
+        def fwd(pc, sn, node, knn):
+            pred = dec(enc(pc, sn, node, knn, False, None))
+            keep["pred"], keep["conv"] = pred, dec.conv_pc4
+            return crit(pred, pc) + crit(dec.conv_pc4, pc)
+
+        def parity():
+            r = _encoder_parity(enc, inp, 2)
+            with torch.no_grad():
+                pred = dec(enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], False, None))
+                got = float(crit(pred[:2], inp["pc"][:2]))
+            f, b, _ = O.chamfer_loss(pred[:2].cpu().numpy(), inp["pc"][:2].cpu().numpy())
+            rel = abs(got - (f + b)) / max(abs(f + b), 1e-30)
+            r.update(chamfer_loss={"got": got, "oracle": f + b, "rel_err": float(rel), "ok": bool(rel <= 1e-5),
+                                   "what": "Chamfer loss of the decoder output for 2 clouds vs oracle chamfer_loss (models/losses.py:237-290 restated; "
+                                           "exact brute-force 1-NN stands in for faiss: parity unpinned at that boundary)"})
+            r["ok"] = bool(r["ok"] and rel <= 1e-5)
+            return r
+        return graphed(fwd, inp, B, N, "autoencoder forward (encoder + decoder + two-resolution Chamfer loss, eval), %d x %d pts vs %d + %d predicted"
+                       % (B, N, 256 + 1024, 1024), parity)
+
+    guarded("configs[1] train bf16", lambda: train("bf16"))
+    guarded("configs[1] train h3", lambda: train("h3"))
+    guarded("configs[2] segmenter", segmenter)
+    guarded("configs[3] autoencoder", autoencoder)
+    return out
+
+
 def train_bench(args, enc, cls, inp, world, rank, dev):
     """Data-parallel training step (models/classifier.py:78-99 + the bucketed RCCL gradient all-reduce of sonet_hip/dp.py)."""
     from sonet_hip import dp
@@ -222,9 +479,11 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         loss, nbytes = step()
     dp.barrier()
     torch.cuda.synchronize()
-    elapsed = dp.all_reduce_max(time.perf_counter() - t0, dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = dp.all_reduce_max(my_elapsed, dev)
     assert torch.isfinite(loss)
     exposed_us = reducer.exposed_ms(last=args.steps) * 1e3
+    ranks = rank_evidence(world, rank, dev, args.batch * args.steps / my_elapsed)
     if rank != 0:
         return
     B, N = args.batch, args.points
@@ -239,7 +498,9 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
                                   % (world, nbytes, max(1, len(reducer.buckets)))},
-        "allreduce": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None, "bytes_per_step": nbytes,
+        "ranks": ranks,
+        "allreduce": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                      "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1, "bytes_per_step": nbytes,
                       "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1),
                       "what": "GPU time between the last backward kernel and the arrival of the last bucket (HIP events around the waits)"},
         "range_guard": {"enabled": bool(ops.RANGE_GUARD), "arithmetic_at_end": ops.POINTMLP_PRECISION}})
@@ -318,6 +579,16 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert torch.isfinite(out).all()
+        # further windows of the same K steps (`value` is the FIRST window, as the contract says; the spread is on the line)
+        window_s = [elapsed]
+        for _ in range(max(0, args.windows - 1)):
+            dp.barrier()
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            run_many(args.steps)
+            dp.barrier()
+            torch.cuda.synchronize()
+            window_s.append(time.perf_counter() - tw)
         single = None
         overlap_ok = None
         if use_graph and P > 1:
@@ -394,9 +665,12 @@ def main():
                     dt = time.perf_counter() - t2
                 other[mode] = {"clouds_per_s": round(B * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4), "in_flight": 1}
                 del g2
+    my_elapsed = elapsed
     elapsed = dp.all_reduce_max(elapsed, dev)
+    window_s = [dp.all_reduce_max(w_, dev) for w_ in window_s]
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
+    ranks = rank_evidence(world, rank, dev, B * args.steps / my_elapsed)
 
     if rank != 0:
         return
@@ -479,6 +753,11 @@ def main():
                    "parallelism": "dp%d: batch shards, no data-path collective" % world},
         "launch_mode": ("hip-graph replay, %d independent batches in flight on %d streams" % (P, P) if use_graph and P > 1
                         else "hip-graph replay" if use_graph else "eager"),
+        "windows": {"steps_each": args.steps, "clouds_per_s": [round(world * B * args.steps / w_, 1) for w_ in window_s],
+                    "min": round(world * B * args.steps / max(window_s), 1),
+                    "median": round(world * B * args.steps / sorted(window_s)[len(window_s) // 2], 1),
+                    "what": "whole-job clouds/s of every timed window (max over ranks each); `value` is the first"},
+        "ranks": ranks,
         "in_flight": P, "single_stream": single, "replay_among_others_equals_replay_alone": overlap_ok,
         "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,
         "range_guard": {"enabled": bool(ops.RANGE_GUARD), "violations": len(range_bad)},
@@ -490,6 +769,11 @@ def main():
     }
     if not args.no_parity_check:
         line["parity_checked"] = parity_check(args, enc, cls, inp, out, enc_cpu, cls_cpu)
+    if world == 1 and not args.no_other_configs:
+        if use_graph:
+            del graphs, graphed
+        torch.cuda.empty_cache()
+        line["other_configs"] = other_configs(args, dev)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
     return line

@@ -259,10 +259,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // offset is ONE VGPR, every slice offset a scalar / immediate (with flat pointers hipcc hoists a 64-bit VGPR address
     // per fragment out of the tile loop: 300+ registers)
     const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4_t *>(Wst), 0, NS_L1 * 1024, 0x00020000);
+#ifdef SONET_ABL_SAMEW                                          // experiment: every wave reads wave 0's stream (L1 hits)
+    const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4_t *>(Wst) + (size_t)NS_L1 * 64, 0, NS_WAVE * 1024, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u32x4_t *>(Wst) + (size_t)(NS_L1 + wave * NS_WAVE) * 64, 0, NS_WAVE * 1024, 0x00020000);
+#endif
     const unsigned vow = (unsigned)lane * 16u;
-#define PF_WLOAD(rsrc, slice) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vow, (unsigned)(slice) * 1024u, 0))
+#ifndef SONET_WAUX
+#define SONET_WAUX 0
+#endif
+#define PF_WLOAD(rsrc, slice) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vow, (unsigned)(slice) * 1024u, SONET_WAUX))
 #ifdef SONET_ABL_NOW                                            // experiment: the main steps keep their first fragments (no weight traffic)
 #define PF_WLOAD_MAIN(rsrc, slice) f_keep_
 #else
@@ -274,20 +281,26 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #define PF_ACT(base, chunk, c, piece) (base)[(((chunk) * 2 + (c)) * 2 + (piece)) * 64]
 
     // ---- the main steps: global step g = 0..7 layer 3 (K chunk g, tiles 2w, 2w+1), g = 8..27 layer 4 (K chunk g - 8,
-    // tiles 3w..3w+2).  A fragments live in a two-deep buffer af[g & 1]; the `l` half of a buffer is refilled with the
-    // fragments of step g + 2 as soon as the first term of step g has issued, the `h` half after the third term.
-    AF af[2];
-    auto load_l = [&](auto gc, AF &f) __attribute__((always_inline)) {      // `l` fragments of global step g (wraps: next tile)
-        constexpr int g = decltype(gc)::value % (KC3 + KC4);
+    // tiles 3w..3w+2).  A fragments live in a ring af[g % AFD]; step g starts by requesting the fragments of step g + AFD - 1
+    // into the buffer step g - 1 has just read (with 4 waves pulling 6 KiB each per step the texture path is ~2/3 busy: a
+    // request issued one step ahead arrives late).
+#ifndef SONET_AFD
+#define SONET_AFD 4
+#endif
+    constexpr int AFD = SONET_AFD;                               // fragment buffers; step g reads af[g % AFD], refilled AFD - 1 steps ahead
+    static_assert((KC3 + KC4) % AFD == 0, "the buffer of a step must not depend on the tile");
+    AF af[AFD];
+    // fragment i of global step g (wraps: next tile): i < NT the `l` slices, then the `h` slices
+    auto load_frag = [&](auto gc, auto ic, AF &f) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value % (KC3 + KC4), i = decltype(ic)::value;
         const f16x8 f_keep_ = f.l[0]; (void)f_keep_;
-        if constexpr (g < KC3) { SFOR(u, W3T) f.l[u] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * u + 1); SEND }
-        else { SFOR(u, W4T) f.l[u] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * u + 1); SEND }
-    };
-    auto load_h = [&](auto gc, AF &f) __attribute__((always_inline)) {
-        constexpr int g = decltype(gc)::value % (KC3 + KC4);
-        const f16x8 f_keep_ = f.h[0]; (void)f_keep_;
-        if constexpr (g < KC3) { SFOR(u, W3T) f.h[u] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * u); SEND }
-        else { SFOR(u, W4T) f.h[u] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * u); SEND }
+        if constexpr (g < KC3) {
+            if constexpr (i < W3T) f.l[i] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * i + 1);
+            else if constexpr (i < 2 * W3T) f.h[i - W3T] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * (i - W3T));
+        } else {
+            if constexpr (i < W4T) f.l[i] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * i + 1);
+            else if constexpr (i < 2 * W4T) f.h[i - W4T] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * (i - W4T));
+        }
     };
 #define PF_MFMA(ACCE, A_, B_, ZEROC, SWAPC)                                                              \
     {                                                                                                    \
@@ -303,28 +316,38 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     // One STEP = a 16-channel K chunk x NT output tiles x 2 column tiles = 6 NT MFMAs, hand-scheduled (sched_barrier
     // after every MFMA: with one wave per SIMD nothing else hides a latency).  Term order (A.l, B.l), (A.h, B.m),
     // (A.h, B.h) per accumulator; SLOT(q) places VALU / LDS work behind MFMA q; G = global step (fragment refills).
+#define PF_REQ(G, NT, qq)                                        /* 6 NT MFMAs, up to 6 fragments: one behind every NT-th */ \
+    {                                                                                                    \
+        if constexpr ((G) >= 0 && (qq) % (NT) == 0) {                                                    \
+            constexpr int gn_ = ((G) >= 0 ? (G) : 0) + AFD - 1;                                          \
+            load_frag(IC<gn_>{}, IC<(qq) / (NT)>{}, af[gn_ % AFD]);                                      \
+        }                                                                                                \
+    }
 #define PF_STEP(NT, G, FR, ACC, BH0, BM0, BL0, BH1, BM1, BL1, ZERO, SWAP, SLOT)                          \
     {                                                                                                    \
         const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
+        /* ONE weight request behind every NT-th MFMA (the fragments of step G + AFD - 1, into the buffer the previous step */ \
+        /* read): a wave issues in order, and a burst of requests holds its MFMAs back while the texture unit takes them    */ \
         PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
             PF_MFMA(ACC(u, c), FR.l[u], bl_[c], (ZERO), (SWAP))                                          \
+            PF_REQ((G), (NT), q)                                                                               \
             SLOT(q)                                                                                      \
             PF_SB                                                                                        \
         SEND                                                                                             \
-        if constexpr ((G) >= 0) load_l(IC<((G) >= 0 ? (G) + 2 : 0)>{}, FR);                              \
         PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
             PF_MFMA(ACC(u, c), FR.h[u], bm_[c], false, (SWAP))                                           \
+            PF_REQ((G), (NT), 2 * (NT) + q)                                                                    \
             SLOT(2 * (NT) + q)                                                                           \
             PF_SB                                                                                        \
         SEND                                                                                             \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
             PF_MFMA(ACC(u, c), FR.h[u], bh_[c], false, (SWAP))                                           \
+            PF_REQ((G), (NT), 4 * (NT) + q)                                                                    \
             SLOT(4 * (NT) + q)                                                                           \
             PF_SB                                                                                        \
         SEND                                                                                             \
-        if constexpr ((G) >= 0) load_h(IC<((G) >= 0 ? (G) + 2 : 0)>{}, FR);                              \
         PF_SB                                                                                            \
     }
     // (scale, 32 shift) of the 8 channels of a job: channels CH + (e&3) + 8(e>>2), CH = layer base + 32 tile + 16 Q + 4 h
@@ -450,8 +473,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #ifdef SONET_ABL_NOW
     SFOR(u, W4T) af[0].l[u] = PF_WLOAD(rww, WO4 + 2 * u + 1); af[0].h[u] = PF_WLOAD(rww, WO4 + 2 * u); af[1].l[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u + 1); af[1].h[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u); SEND
 #else
-    load_l(IC<0>{}, af[0]); load_h(IC<0>{}, af[0]);
-    load_l(IC<1>{}, af[1]); load_h(IC<1>{}, af[1]);
+    SFOR(g, AFD - 1) SFOR(i, 2 * W4T) load_frag(IC<g>{}, IC<i>{}, af[g]); SEND SEND
 #endif
     PROF_MARK(1)                                                // first front
 
@@ -514,7 +536,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 nh[0] = a1[0][0][0].h; nm[0] = a1[0][0][0].m; nh[1] = a1[0][0][1].h; nm[1] = a1[0][0][1].m;
             }
 #define SLOT_L3(q) { if constexpr ((q) == 8) nl[0] = piece_l(nh[0]); if constexpr ((q) == 9) nl[1] = piece_l(nh[1]); }
-            PF_STEP(W3T, kc, af[kc & 1], ACC3, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), false, SLOT_L3)
+            PF_STEP(W3T, kc, af[kc % AFD], ACC3, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), false, SLOT_L3)
 #undef SLOT_L3
             bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1];
         SEND
@@ -535,7 +557,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             }
 #define SLOT_L4A(q) { PF_SLOT2(q, 6, jq, acc3[ju][0], acc3[ju][1], a3o[0], a3o[1]) \
                       if constexpr (kc + 1 < KC2) { if constexpr ((q) == 14) nl[0] = piece_l(nh[0]); if constexpr ((q) == 15) nl[1] = piece_l(nh[1]); } }
-            PF_STEP(W4T, KC3 + kc, af[kc & 1], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), SEGMAX, SLOT_L4A)
+            PF_STEP(W4T, KC3 + kc, af[kc % AFD], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), SEGMAX, SLOT_L4A)
 #undef SLOT_L4A
             SFOR(c, 2)
                 PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 0) = a3o[c].h; PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 1) = a3o[c].m;
@@ -573,7 +595,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 if constexpr (j1) PF_SLOT2(q, 6, (ck1 & 1), acc1[ck1 >> 1][0], acc1[ck1 >> 1][1], a1n[ck1 >> 1][ck1 & 1][0], a1n[ck1 >> 1][ck1 & 1][1]) \
                 if constexpr (j2) PF_SLOT2(q, 6, q2, acc2[0], acc2[1], a2o[q2][0], a2o[q2][1]) \
             }
-            PF_STEP(W4T, KC3 + kc, af[kc & 1], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], false, SEGMAX, SLOT_L4B)
+            PF_STEP(W4T, KC3 + kc, af[kc % AFD], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], false, SEGMAX, SLOT_L4B)
 #undef SLOT_L4B
             if constexpr (kc == 7) front_l1();
             if constexpr (kc >= 12 && kc < 16) front_l2(IC<(kc >= 12 && kc < 16 ? kc - 12 : 0)>{});
@@ -748,6 +770,9 @@ int cu_count() {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
+#ifdef SONET_MAXCU_ENV                                          // experiment builds only (tools/build_variant.sh): cap the persistent grid
+    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }
+#endif
     return cus;
 }
 

@@ -39,7 +39,7 @@ NP = 32
 buf = np.zeros(1024 * NP, dtype=np.int64)
 assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
 p = buf.reshape(1024, NP).astype(np.float64)
-tiles = B * ((15000 + 63) // 64) / 256.0
+tiles = B * ((15000 + 63) // 64) / float(min(256, int(os.environ.get("SONET_FUSED_MAXCU", "256"))))
 # phase slots of the third-generation kernel (PROF_MARK in pointresnet_fused.hip); MFMA-only ideal = 32 cycles per MFMA
 names = ["kernel prologue", "first front (exposed)", "tile prologue + barrier 1", "layer 3 (96 MFMAs)", "layer 4 steps 0-3 + layer-3 jobs (72)",
          "barrier 2", "layer 4 steps 4-19 + next front (324)", "epilogue", "tail"]

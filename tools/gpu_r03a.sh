@@ -1,9 +1,14 @@
 #!/bin/bash
-# round-3 GPU call: third-generation fused kernel vs the second generation (bit identity + time), ablations, phase counters,
-# the GPU suite and the forward bench
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03b; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03h; mkdir -p $O; cd $R
 export TMPDIR=/tmp
-echo "== variants"; ITERS=25 timeout 900 python tools/fused_variants.py gen2 gen3 now nob nojob nowb nowbj 2>&1 | grep -v amdgpu.ids | tee $O/variants.log | tail -30
-echo "== phases"; VARIANT=gen3prof timeout 300 python tools/fused_phases.py pool 2>&1 | grep -v amdgpu.ids | tee $O/phases_pool.log | tail -30
-echo "== pytest"; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log
-echo "== bench"; timeout 600 python bench.py --steps 50 --warmup 10 2> $O/bench.err | tail -1 > $O/bench_forward.json; head -c 1500 $O/bench_forward.json; echo
+echo "== bench"; ( time timeout 900 python bench.py 2> $O/bench.err | tail -1 > $O/bench_forward.json ) 2>&1 | grep real; tail -5 $O/bench.err; python - <<'PY'
+import json
+l=json.load(open('gpurun_out/r03h/bench_forward.json'))
+print({k:l[k] for k in ('value','ms_per_step','windows','single_stream')})
+print(l['ranks'])
+print(l['roofline'])
+print(l['parity_checked'])
+for k,v in l.get('other_configs',{}).items(): print(k, json.dumps(v)[:1500])
+print(l.get('cpu_baseline'))
+PY
+echo "== pytest bench"; timeout 900 python -m pytest tests/test_gpu_bench_line.py -x -q -m gpu 2>&1 | tail -15
