@@ -330,10 +330,23 @@ class _FusedPointwise(nn.Module):
         w = self.conv.weight
         return w.reshape(w.shape[0], w.shape[1])
 
+    def _h3_ok(self):
+        """Weight side of the h3 range guard (sonet_hip.ops.h3_weight_ok), cached per weight version."""
+        w = self.conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        if getattr(self, '_h3ok_key', None) != key:
+            self._h3ok = _ops.h3_weight_ok(self._weight2d()) if w.is_cuda else True
+            self._h3ok_key = key
+            if not self._h3ok:
+                _ops.h3_ratio_warn("a point-wise layer's weight (%d x %d)" % (w.shape[0], w.shape[1]))
+        return self._h3ok
+
     def _packed(self, C1=None, C2=0):
         """Packed weight for the current arithmetic mode (``sonet_hip.ops.POINTMLP_PRECISION``)."""
         w = self.conv.weight
         mode = _ops.POINTMLP_PRECISION
+        if mode == "h3" and not self._h3_ok():
+            mode = "x3"
         if mode in ("x3", "h3", "bf16") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
             mode = "f32"
         key = (w._version, w.data_ptr(), w.device, mode)
@@ -372,6 +385,7 @@ class _FusedPointwise(nn.Module):
     def _direct_ok(self, x):
         """Eval-mode, no-grad, h3 / bf16: the caller may launch the kernel itself with this layer's pack and folded affine."""
         return (_ops.GATHER_NODE_STAGE and _ops.POINTMLP_PRECISION in ("h3", "bf16") and not torch.is_grad_enabled() and x.is_cuda
+                and (_ops.POINTMLP_PRECISION != "h3" or self._h3_ok())
                 and x.dtype in (torch.float32, torch.bfloat16) and self._fusable() and self.conv.out_channels % 32 == 0
                 and self.normalization in (None, 'batch') and not (self.normalization == 'batch' and self.norm.training)
                 and self.activation in (None, 'relu'))
@@ -771,6 +785,8 @@ class PointResNet(nn.Module):
         if list(self.out_channels_list) != [64, 128, 256, 384] or x.shape[1] > 16:
             return False
         ls = self.layers
+        if _ops.POINTMLP_PRECISION == "h3" and not all(l._h3_ok() for l in ls):     # weight side of the range guard: layer-wise (x3 where needed)
+            return False
         hidden_ok = all(l.normalization == 'batch' and l.activation == 'relu' for l in ls[:3])
         return hidden_ok and ls[3].normalization is None and ls[3].activation is None and x.shape[2] * 384 * 4 < 4e9
 

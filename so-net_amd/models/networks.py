@@ -42,7 +42,9 @@ def _head_inference(fn):
     def wrapper(self, *args, **kwargs):
         ts = [a for a in args if isinstance(a, torch.Tensor) and a.is_floating_point()]
         dev = ts[0].device if ts else torch.device("cpu")
-        if torch.is_grad_enabled() and not self.training:
+        # (``head.inference = False`` opts a head out: an eval-mode head with trainable weights fed with frozen encoder features
+        # then keeps its autograd graph, as in the reference)
+        if torch.is_grad_enabled() and not self.training and getattr(self, "inference", True):
             if ts and not any(t.requires_grad for t in ts) and any(getattr(t, "_sonet_inference", False) for t in ts):
                 with torch.no_grad():
                     return _ops.mark_inference(_ops.run_guarded(lambda: fn(self, *args, **kwargs), dev, True))
@@ -381,15 +383,20 @@ class Segmenter(nn.Module):
         node_in = [som_node, masked_max] + ([knn_feature_1] if self.opt.som_k >= 2 else []) + [final_pn_out]
         onehot = torch.zeros(B, 16, dtype=torch.float32, device=x.device)
         onehot.scatter_(1, label.unsqueeze(1), 1)
-        zg = torch.cat([onehot, feature], dim=1) @ w_glob.t()                       # B x Cout: per-cloud block
-        z = (_ops.pointmlp(torch.cat(node_in, dim=1).contiguous(), wp_node, ones, zeros, False, Cout) + zg.unsqueeze(2)).contiguous()
-        x2 = torch.cat(small, dim=1).contiguous()
+        zg = torch.cat([onehot, feature.float()], dim=1) @ w_glob.t()               # B x Cout: per-cloud block
+        # the pack decides the kernel and the kernel the storage type: a bf16 pack (precision "bf16") takes bfloat16 operands --
+        # the node-level maps arrive as a mix of f32 (som_node, pooled maxima) and bf16 tensors there
+        sdt = torch.bfloat16 if wp_point.dtype == torch.int16 else torch.float32
+        zn = _ops.pointmlp(torch.cat([t_.to(sdt) for t_ in node_in], dim=1).contiguous(), wp_node, ones, zeros, False, Cout)
+        z = (zn.float() + zg.unsqueeze(2)).contiguous()
+        x2 = torch.cat(small, dim=1).to(sdt).contiguous()
+        first_pn_out = first_pn_out.to(sdt)
         if wp_point.dtype == torch.int8 and _ops.POINTMLP_PRECISION == "h3":
             # the per-node block is gathered and added in the per-point launch's epilogue (one pass over B x 1024 x kN less)
             h = _ops.pointmlp_nodeadd(first_pn_out.contiguous(), wp_point, scale, shift, lyr.activation == 'relu', Cout, z, min_idx_i32, x2=x2)
         else:
             t = _ops.pointmlp(first_pn_out.contiguous(), wp_point, ones, zeros, False, Cout, x2=x2)
-            h = _ops.node_add_affine_act_(t, z, min_idx_i32, scale, shift, lyr.activation == 'relu')
+            h = _ops.node_add_affine_act_(t.float(), z, min_idx_i32, scale, shift, lyr.activation == 'relu')
         return self._tail(self.layer3(self.layer2(h)), k)
 
     def _tail(self, h, k):
@@ -408,7 +415,7 @@ class Segmenter(nn.Module):
     def _nodewise_ok(self):
         lyr = self.layer1
         return (not torch.is_grad_enabled()) and not self.training and lyr.activation in ('relu', None) \
-            and lyr.normalization in (None, 'batch') and lyr._fusable()
+            and lyr.normalization in (None, 'batch') and lyr._fusable() and (_ops.POINTMLP_PRECISION != "h3" or lyr._h3_ok())
 
 
 def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is_train=False, epoch=None):
@@ -439,9 +446,10 @@ def _segmentation_head(encoder, segmenter, pc, sn, label, feature):
         g3 = torch.gather(encoder.final_pn_out, 2, idx.expand(-1, encoder.final_pn_out.shape[1], -1))
     else:
         ids = st["a"].min_idx_i32
-        g1 = _ops.node_gather(encoder.first_pn_out_masked_max.contiguous(), ids)
-        g2 = _ops.node_gather(encoder.knn_feature_1.contiguous(), ids)
-        g3 = _ops.node_gather(encoder.final_pn_out.contiguous(), ids)
+        # (node-level maps are bf16 under precision "bf16": the gather kernel is f32, the maps are B x C x 64)
+        g1 = _ops.node_gather(encoder.first_pn_out_masked_max.float().contiguous(), ids)
+        g2 = _ops.node_gather(encoder.knn_feature_1.float().contiguous(), ids)
+        g3 = _ops.node_gather(encoder.final_pn_out.float().contiguous(), ids)
     return segmenter(encoder.x_decentered, pc, encoder.centers, sn, label, encoder.first_pn_out, g1, g2, g3, feature)
 
 

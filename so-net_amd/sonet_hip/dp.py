@@ -19,6 +19,7 @@ BatchNorm statistics stay per rank, as in the reference (no SyncBN).
 Backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` on CPU (tests).  Rendezvous via the
 MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE / LOCAL_RANK environment (torch.distributed.run).
 """
+import collections
 import os
 
 import torch
@@ -108,7 +109,7 @@ class GradientAllReducer:
         self._next_launch = 0        # buckets are launched strictly in index order (same order on every rank)
         self._dirty = False          # a second backward touched a bucket that was already on the wire
         self._sync = True            # False inside no_sync(): gradient accumulation, hooks stay quiet
-        self._exposed_events = []    # (start, end) HIP events around the waits of every reduce(): the exposed collective time
+        self._exposed_events = collections.deque(maxlen=256)   # (start, end) HIP events around the waits of the last reduce() calls
         self._live = None            # indices into self.params, flat-buffer order
         self._flat = None
         self._slices = {}            # param index -> (offset, numel)
@@ -200,7 +201,8 @@ class GradientAllReducer:
     def exposed_ms(self, last=None):
         """Mean GPU time per ``reduce()`` (over the last ``last`` calls) between "backward has queued its last kernel" and
         "every bucket has arrived": the part of the gradient exchange that was NOT hidden behind backward.  Synchronises."""
-        evs = self._exposed_events[-last:] if last else self._exposed_events
+        evs = list(self._exposed_events)
+        evs = evs[-last:] if last else evs
         if not evs:
             return 0.0
         torch.cuda.synchronize()

@@ -31,13 +31,15 @@ class GraphedForward:
         # ONE operand-range scope for the whole captured forward (sonet_hip/ops.py): its memset and the per-launch slot
         # pointers are baked into the graph, every replay refills the same log; ``range_violations()`` reads it back.
         from . import ops as _ops
-        self.range = _ops.range_scope(dev)
+        self.range = _ops.range_scope(dev, private=True)       # its own log: other graphs / eager scopes cannot clear or overwrite it
+        self._replays = 0
+        self.check_every = 0                                   # > 0: look at the range log every that many replays (synchronises) and raise
         with torch.no_grad(), torch.cuda.graph(self.graph), self.range:
             self.static_output = fn(*self.static_inputs)
 
     def range_violations(self):
         """After a replay: the h3 launches of the captured forward whose operands left the fp16-split range ([] = none;
-        synchronises).  Valid until another range scope runs on the same device."""
+        synchronises).  The log belongs to this graph alone."""
         return self.range.violations()
 
     def __call__(self, *inputs):
@@ -45,4 +47,14 @@ class GraphedForward:
             if dst is not src and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         self.graph.replay()
+        self._replays += 1
+        if self.check_every and self._replays % self.check_every == 0:
+            bad = self.range_violations()
+            if bad:
+                raise _ops_error("h3 operand range left in a graph replay: %s: %s" % bad[0])
         return self.static_output
+
+
+def _ops_error(msg):
+    from .ops import SonetHipError
+    return SonetHipError(msg)

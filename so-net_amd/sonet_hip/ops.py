@@ -381,21 +381,25 @@ def _bits_to_float(u):
 
 class range_scope:
     """``with ops.range_scope(device) as rs: <h3 launches>`` then ``rs.violations()`` (synchronises; [] = all launches in range).
-    Scopes of one device share its log: read a scope's result before opening the next one on that device."""
+    Eager scopes of one device share its log: read a scope's result before opening the next one on that device;
+    ``private=True`` gives the scope a log of its own (sonet_hip.graph.GraphedForward)."""
 
-    def __init__(self, device):
+    def __init__(self, device, private=False):
         self.device = torch.device(device)
         self.names = []
         self.enabled = RANGE_GUARD and self.device.type == "cuda"
         self.log = None
         self._prev = None
+        # private: this scope owns its 1 KiB log (a captured forward bakes the clear and the slot pointers into its HIP graph:
+        # graphs replayed concurrently, or an eager scope in between, must not clear or overwrite each other's slots)
+        self._own = torch.zeros((_RANGE_SLOTS * 8,), dtype=torch.int32, device=self.device) if (private and self.enabled) else None
 
     def __enter__(self):
         global _range_active
         self._prev = _range_active
         if self.enabled:
             idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            log = _range_logs.get(idx)
+            log = self._own if self._own is not None else _range_logs.get(idx)
             if log is None:
                 log = torch.zeros((_RANGE_SLOTS * 8,), dtype=torch.int32, device=self.device)
                 _range_logs[idx] = log
@@ -569,6 +573,36 @@ class precision:
         global POINTMLP_PRECISION
         POINTMLP_PRECISION = self.prev
         return False
+
+
+H3_COLUMN_RATIO = 128.0      # largest allowed max|w[:, c]| / min_c max|w[:, c]| of an fp16-split layer (see h3_weight_ok)
+_h3_ratio_warned = False
+
+
+def h3_weight_ok(weight2d):
+    """Per-channel side of the h3 operand-range guard, decided on the WEIGHTS (once per pack, one small reduction).
+
+    The range log checks each launch's max |x| (>= 2^-6) -- per launch, not per channel.  A channel far below the tensor maximum
+    keeps its value as fp16(x) + residual, with the scaled residual 32 (x - fp16(x)) stored in fp16: below the fp16 normal range its
+    ABSOLUTE error is up to 2^-30, whatever the channel's magnitude.  That only matters for the 1e-5 bound when the layer's weights
+    make up for the small channel: the error it feeds into an output is |w_c| 2^-30 against outputs of the order |w_typ| max|x|, i.e.
+    relative (|w_c| / |w_typ|) 2^-30 / max|x| <= ratio 2^-24 with the launch guard -- inside 2^-17 (about 1e-5) for ratio <= 2^7.
+    So: a weight whose input columns differ by more than H3_COLUMN_RATIO in magnitude is packed for the range-safe x3 arithmetic
+    (one warning); everything else cannot meet the adversarial case (tests/test_gpu_round2.py::test_h3_per_channel_range_case)."""
+    cm = weight2d.detach().abs().amax(dim=0)
+    nz = cm[cm > 0]
+    if nz.numel() < 2:
+        return True
+    return bool((nz.max() / nz.min()).item() <= H3_COLUMN_RATIO)
+
+
+def h3_ratio_warn(what):
+    global _h3_ratio_warned
+    if not _h3_ratio_warned:
+        import warnings
+        warnings.warn("sonet_hip: %s has input columns more than %gx apart in magnitude -- it runs in the range-safe x3 arithmetic "
+                      "instead of the fp16 split (sonet_hip.ops.h3_weight_ok)" % (what, H3_COLUMN_RATIO), RuntimeWarning, stacklevel=3)
+        _h3_ratio_warned = True
 
 
 def x3_supported(C1, C2, Cout):

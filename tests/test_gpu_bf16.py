@@ -427,3 +427,61 @@ def test_pointmlp_bf16_statistics_epilogue(B, C1, C2, Cout, L):
     sc = (mref.abs() + vref.sqrt()).clamp_min(1e-3)
     assert float(((m1.double() - mref).abs() / sc).max()) < 1e-6
     assert float(((v1.double() - vref).abs() / sc ** 2).max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["segmenter_b2_n256", "segmenter_b2_n1024"])
+def test_segmenter_forward_bf16(case):
+    """The part segmenter under precision('bf16') (global switch: SONET_POINTMLP_PRECISION / bench --precision): the node-wise
+    layer-1 path receives a mix of f32 (som_node, pooled maxima) and bf16 maps; both data flows run and stay within BF16_TOL of the
+    reference fixture, node ids bit-exact."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    g = golden(case)
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.6, node_num=64, k=3, som_k=9, som_k_type="center",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=50)
+    enc, seg = NW.Encoder(opt), NW.Segmenter(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(seg.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    seg.to(DEV).eval()
+    args = (cu(g["pc"]), cu(g["sn"]), cu(g["label"]), cu(g["node"]), cu(g["node_knn_I"]))
+    with ops.precision("bf16"), torch.no_grad():
+        seg.nodewise = True
+        with ops.kernel_timing() as rec:
+            score = NW.segmentation_forward(enc, seg, *args)
+        seg.nodewise = False
+        score_dense = NW.segmentation_forward(enc, seg, *args)
+    names = [n for n, _, _ in rec.records]
+    assert any(n.startswith("pointmlpbf16") for n in names), names
+    np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), g["min_idx"])
+    assert tuple(score.shape) == (B, 50, N)
+    assert_close_rms(score.float().cpu().numpy(), g["score_segmenter"], BF16_TOL, "score_segmenter (node-wise layer 1, bf16)")
+    assert_close_rms(score_dense.float().cpu().numpy(), g["score_segmenter"], BF16_TOL, "score_segmenter (dense layer 1, bf16)")
+
+
+@pytest.mark.gpu
+def test_autoencoder_forward_bf16(case="autoencoder_b2_n1024"):
+    """Encoder -> decoder -> Chamfer loss under precision('bf16'): runs, predicted clouds within BF16_TOL of the reference."""
+    from models import networks as NW, losses as LS
+    from sonet_hip import ops, synth
+    g = golden(case)
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                    activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9, som_k_type="avg",
+                    bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40,
+                    output_fc_pc_num=256, output_conv_pc_num=1024)
+    enc, dec, crit = NW.Encoder(opt), NW.Decoder(opt), LS.ChamferLoss(opt)
+    synth.fill_state_dict_(enc.state_dict(), seed)
+    synth.fill_state_dict_(dec.state_dict(), seed + 1)
+    enc.to(DEV).eval()
+    dec.to(DEV).eval()
+    with ops.precision("bf16"), torch.no_grad():
+        feature = enc(cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]), False, None)
+        pred = dec(feature)
+        loss = crit(pred.float(), cu(g["pc"])) + crit(dec.conv_pc4.float(), cu(g["pc"]))
+    assert_close_rms(feature.float().cpu().numpy(), g["feature"], BF16_TOL, "feature (bf16)")
+    assert_close_rms(pred.float().cpu().numpy(), g["predicted_pc"], BF16_TOL, "predicted_pc (bf16)")
+    assert abs(float(loss) - float(g["loss"])) <= BF16_TOL * float(g["loss"])

@@ -764,7 +764,9 @@ def test_classifier_training_step_golden(mode, fixture):
         mine = rel_rms(sub(params[k].grad), truth)
         # (floor 3e-3: at N=5000 the float32 reference happens to sit within 3e-4 .. 1.3e-3 of its float64 run; which arg-max
         #  winners flip depends on the particular rounding, and another f32-class implementation lands at 1-2e-3)
-        assert mine <= max(1.5 * float(g["ref32_dev/" + k]) + 1e-4, 3e-3), (k, mine, float(g["ref32_dev/" + k]))
+        #  (the floor applies to the N=5000 fixture only: the N=512 fixture keeps the original regression bound)
+        floor = 3e-3 if fixture == "train_step_b8_n5000" else 0.0
+        assert mine <= max(1.5 * float(g["ref32_dev/" + k]) + 1e-4, floor), (k, mine, float(g["ref32_dev/" + k]))
     assert rel_rms(sub(dict(cls.named_parameters())["fc1.linear.weight"].grad), g["grad64/cls.fc1.linear.weight"].astype(np.float64)) <= 5e-4
     assert sum(1 for p in enc.parameters() if p.grad is None) == int(g["dead_grad_count"])     # the dead Transformer
     sd = enc.state_dict()

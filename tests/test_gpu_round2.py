@@ -652,3 +652,38 @@ def test_two_graphed_forwards_in_flight_on_two_streams():
             assert all(junk)
         eager = cls(enc(inps[1]["pc"], inps[1]["sn"], inps[1]["node"], inps[1]["node_knn_I"], is_train=False))
         assert torch.equal(eager, alone[1])
+
+
+def test_h3_per_channel_range_case():
+    """The adversarial case of the per-launch range guard: ONE input channel 1e-4 x the tensor maximum, met by weights 1e4 x larger in
+    that column.  The launch's max |x| is fine, the small channel's fp16 residual is not.  The guard's weight side (ops.h3_weight_ok:
+    input columns more than 128 x apart -> x3 pack) catches it: the layer still meets 1e-5 against float64; the raw h3 kernel on the
+    same operands is printed for reference (it does not)."""
+    import warnings
+    from models import layers as Lm
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, L = 2, 64, 128, 2000
+    x = torch.randn(B, Cin, L, generator=g)
+    x[:, 5] *= 1e-4
+    lyr = Lm.EquivariantLayer(Cin, Cout, activation=None, normalization=None)
+    with torch.no_grad():
+        lyr.conv.weight.normal_(0, 0.1, generator=g)
+        lyr.conv.weight[:, 5] *= 1e4
+        lyr.conv.bias.zero_()
+    lyr.to(DEV).eval()
+    ref = torch.einsum("oc,bcl->bol", lyr.conv.weight.detach().double().cpu().reshape(Cout, Cin), x.double()).numpy()
+    assert not ops.h3_weight_ok(lyr.conv.weight.reshape(Cout, Cin))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with torch.no_grad(), ops.precision("h3"), ops.kernel_timing() as rec:
+            y = lyr(x.to(DEV))
+    names = [n for n, _, _ in rec.records]
+    assert any(n.startswith("pointmlpx3") for n in names) and not any(n.startswith("pointmlph3") for n in names), names
+    assert_close_rms(y.cpu().numpy(), ref, 1e-5, "layer with a 1e-4 channel and 1e4 weights (guarded)")
+    wp = ops.pointmlp_pack(lyr.conv.weight.detach().reshape(Cout, Cin).contiguous(), "h3")
+    raw = ops.pointmlp(x.to(DEV), wp, ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV), False, Cout).cpu().double().numpy()
+    rms = np.sqrt(np.mean(ref ** 2))
+    print("raw h3 on the adversarial operands: worst err / (1e-5 max(|ref|, rms)) = %.2f" % float((np.abs(raw - ref) / (1e-5 * np.maximum(np.abs(ref), rms))).max()))
+    # ordinary weights pass the column test (and keep the fp16 split)
+    assert ops.h3_weight_ok(torch.randn(256, 128, generator=g).to(DEV) * 0.1)
