@@ -382,6 +382,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 
     // ---- the front of a tile: x -> layer 1 (all 64 points, every wave) -> layer 2 (this wave's tile) -> LDS ----
     float xin[2][8];
+    int nid_n[2] = {-1, -1}, n0_n = 0, nlast_n = 0, pos0_n = 0;   // pool bookkeeping of the NEXT tile (read with its x: a round trip at the
+                                                                // top of the tile sat in front of barrier 1)
     u32x4_t xh[2], xm[2], xl[2];
     AF fl1;                                                     // layer 1's 4 fragments (h, l of 2 tiles)
     f16x8 fl2h, fl2l;                                           // layer 2: one tile, one chunk
@@ -403,6 +405,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e)                          // rows >= Cin0 are out of range of the descriptor: 0
                 xin[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
+            if constexpr (SEGMAX) nid_n[c] = ll0 + j < L ? ids_sorted[bb * (long long)L + ll0 + j] : -1;
+        }
+        if constexpr (SEGMAX) {
+            const int32_t *idb = ids_sorted + bb * (long long)L;
+            n0_n = idb[t0];                                      // first / last node of the tile
+            nlast_n = idb[(t0 + TPTS - 1 < L ? t0 + TPTS - 1 : L - 1)];
+            pos0_n = pos0[bb];
         }
     };
     auto front_load_w1 = [&]() __attribute__((always_inline)) {
@@ -491,14 +500,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         }
         // per-node max-pool bookkeeping of the tile's 2 x 32 (node-sorted) points (used by the epilogue, a tile later)
         int nid[2] = {-1, -1}, n0 = 0, nslots = 0, jpos0[2] = {-1, -1};
-        if constexpr (SEGMAX) {
-            const int32_t *idb = ids_sorted + b * (long long)L;
-            nid[0] = pv[0] ? idb[t0 + j] : -1;
-            nid[1] = pv[1] ? idb[t0 + 32 + j] : -1;
-            n0 = idb[t0];
-            const int nlast = idb[(t0 + TPTS - 1 < L ? t0 + TPTS - 1 : L - 1)];
+        if constexpr (SEGMAX) {                                 // (read by the front of this tile, a tile ago)
+            nid[0] = nid_n[0];
+            nid[1] = nid_n[1];
+            n0 = n0_n;
+            const int nlast = nlast_n;
             nslots = nlast - n0 + 1 < SEG_SLOTS ? nlast - n0 + 1 : SEG_SLOTS;
-            const int p0 = pos0[b];
+            const int p0 = pos0_n;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int pp = p0 - (t0 + 32 * c);
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             // only the VALUES are needed).  Layer 4 of this variant runs with the MFMA operands swapped: the accumulators
             // are TRANSPOSED, acc[mt][c][r] = Y[point 32c + prow(r)][channel 96w + 32mt + j], prow(r) = (r&3) + 8(r>>2) + 4h,
             // so the maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a cross-lane
-            // reduction of every register; the two half-waves (16 points each) meet in the LDS atomic.
+            // reduction of every register; the two half-waves (16 points each) meet in one lane exchange.
             float bias4[W4T];
 #pragma unroll
             for (int mt = 0; mt < W4T; ++mt) {
