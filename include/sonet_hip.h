@@ -326,14 +326,6 @@ int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const float *x2, int 
                                   const float *shift, int relu, float *y, int B, int Cout, int L,
                                   const float *zadd, const int32_t *zidx, int ZM, sonet_stream_t stream);
 
-/* out[b][o][m] = max over the columns l with l % M == m of act((W . cat(x1, x2)) * scale + shift)[b][o][l]: a layer followed by the
- * max over the K neighbour planes of a k-major B x Cout x (K * M) tensor -- KNNModule's last layer + torch.max(dim=3)
- * (models/layers.py:340-350) -- without materialising that tensor (ordered-integer atomic max from the layer kernel's epilogue).
- * keys_ws: B * Cout * M * 4 bytes; out [B][Cout][M] f32; L % M == 0; Cout % 128 == 0; fp16-split arithmetic (range-guarded). */
-int sonet_pointmlp_h3_kmax_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
-                               const float *shift, int relu, float *out, void *keys_ws, int B, int Cout, int L, int M,
-                               sonet_stream_t stream);
-
 /* bf16 twin: statistics of the STORED bf16 values (what the normalise pass and the backward read). */
 size_t sonet_pointmlp_bf16_stats_ws_size(int B, int Cout, int L);
 int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
@@ -419,12 +411,27 @@ int sonet_channel_affine_act_f32(float *y, const float *scale, const float *shif
  * ---------------------------------------------------------------------------------------------- */
 int sonet_chamfer_nn_f32(const float *q, const float *db, int32_t *nn, int B, int Nq, int Nd,
                          sonet_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * VARIANTS build only (make -C so-net_amd/csrc variants -> libsonet_hip_variants.so, -DSONET_VARIANTS): kernels that measured
+ * slower than what the product dispatches, kept as tested records of the experiments (tests/variants).  The product library
+ * does not export them and reads no environment variable.
+ * ---------------------------------------------------------------------------------------------- */
+#ifdef SONET_VARIANTS
+/* out[b][o][m] = max over the columns l with l % M == m of act((W . cat(x1, x2)) * scale + shift)[b][o][l]: a layer followed by the
+ * max over the K neighbour planes of a k-major B x Cout x (K * M) tensor -- KNNModule's last layer + torch.max(dim=3)
+ * (models/layers.py:340-350) -- without materialising that tensor (ordered-integer atomic max from the layer kernel's epilogue).
+ * keys_ws: B * Cout * M * 4 bytes; out [B][Cout][M] f32; L % M == 0; Cout % 128 == 0; fp16-split arithmetic (range-guarded). */
+int sonet_pointmlp_h3_kmax_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                               const float *shift, int relu, float *out, void *keys_ws, int B, int Cout, int L, int M,
+                               sonet_stream_t stream);
+
 /* Both directions of models/losses.py:255,262 from ONE sweep of the Na x Nb distance matrix: nn_ab[b][i] = nearest point of
  * cloud b for a_i, nn_ba[b][j] = nearest point of cloud a for b_j (same arithmetic, ties -> lowest index: bit-identical to two
  * sonet_chamfer_nn_f32 calls).  ws: sonet_chamfer_nn2_ws_size bytes (64-bit (distance, index) keys of the column minima). */
 size_t sonet_chamfer_nn2_ws_size(int B, int Na, int Nb);
 int sonet_chamfer_nn2_f32(const float *a, const float *b, int32_t *nn_ab, int32_t *nn_ba, void *ws, int B, int Na, int Nb,
                           sonet_stream_t stream);
+#endif /* SONET_VARIANTS */
 
 #ifdef __cplusplus
 }

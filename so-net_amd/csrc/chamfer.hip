@@ -39,6 +39,7 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_kernel(const float *__r
     }
     if (valid) nn[(size_t)b * Nq + i] = bi;
 }
+#ifdef SONET_VARIANTS   // (a measured-slower record: variants build only, tools/ + tests/variants)
 // ---- both directions in ONE sweep of the distance matrix (models/losses.py:255 and :262 together) -----------------------------
 // One thread per point of cloud A (the larger one: more workgroups); cloud B goes through LDS in tiles.  d(a_i, b_j) is
 // computed once: the row minimum (a_i's nearest b) is a register update as above; the column minimum (b_j's nearest a) is a
@@ -104,8 +105,10 @@ __global__ __launch_bounds__(256) void chamfer_nn2_finalize_kernel(const unsigne
     const unsigned long long k = colkey[t];
     nn_b[t] = k < C2_INIT ? (int32_t)(unsigned)(k & 0xFFFFFFFFull) : 0;
 }
+#endif  // SONET_VARIANTS
 }  // namespace
 
+#ifdef SONET_VARIANTS
 extern "C" size_t sonet_chamfer_nn2_ws_size(int B, int Na, int Nb)
 {
     if (B <= 0 || Na <= 0 || Nb <= 0) return 0;
@@ -132,6 +135,7 @@ extern "C" int sonet_chamfer_nn2_f32(const float *pa, const float *pb, int32_t *
     hipLaunchKernelGGL(chamfer_nn2_finalize_kernel, dim3((unsigned)sonet::ceil_div64(n, 256)), dim3(256), 0, st, colkey, nn_small, n);
     return sonet::launched(what);
 }
+#endif  // SONET_VARIANTS
 
 extern "C" int sonet_chamfer_nn_f32(const float *q, const float *db, int32_t *nn, int B, int Nq, int Nd,
                                     sonet_stream_t stream)

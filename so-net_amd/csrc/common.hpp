@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/sonet_hip.h"
 
@@ -33,6 +34,15 @@ static inline int launched(const char *what) {
 // Range log of the fp16-split ("h3") kernels: thread-local pointer to the 8-word slot the NEXT h3 launch of this thread
 // reports its operand magnitudes into (sonet_range_log_set; NULL = no report).  See include/sonet_hip.h.
 uint32_t *range_log();
+
+// Tuning / ablation knobs (SONET_* environment variables of the experiment tools): they exist only in the VARIANTS build
+// (make -C so-net_amd/csrc variants -> lib/libsonet_hip_variants.so, -DSONET_VARIANTS).  The product library reads no
+// environment variable: every knob is the constant "unset" there and the code behind it is compiled out.
+#ifdef SONET_VARIANTS
+static inline const char *knob(const char *name) { return getenv(name); }
+#else
+static inline const char *knob(const char *) { return nullptr; }
+#endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }

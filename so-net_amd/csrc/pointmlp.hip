@@ -616,7 +616,7 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
     else if (CT % 2 == 0) MT = 2;
     if (MT == 2 || (MT == 4 && CT <= 8)) S = 2;
     if (G == 1) S = 1;
-    if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
+    if (const char *e = sonet::knob("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
         const int want = atoi(e);
         if ((want == 8 || want == 6 || want == 4 || want == 2) && CT % want == 0) MT = want;
     }
@@ -628,13 +628,14 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large for one pass table", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(PM_THREADS);
-    if (const char *e = getenv("SONET_POINTMLP_S")) {       // tuning knob (bench experiments only)
+    if (const char *e = sonet::knob("SONET_POINTMLP_S")) {       // tuning knob (bench experiments only)
         const int want = atoi(e);
         if (want == 1 || want == 2 || want == 4) S = want;
     }
     int abl = 0;
-    if (const char *e = getenv("SONET_POINTMLP_ABLATE")) abl = atoi(e);   // bench-only: no stores / no X loads
+    if (const char *e = sonet::knob("SONET_POINTMLP_ABLATE")) abl = atoi(e);   // bench-only: no stores / no X loads
 #define PM_ARGS grid, block, 0, st, x1, C1, x2, C2, Wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, G, ct_per_y
+#ifdef SONET_VARIANTS
 #define PM_LAUNCH_V2(MM)                                                                              \
     do {                                                                                              \
         if (abl == 1 && S == 2)      hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 1>), PM_ARGS); \
@@ -646,8 +647,17 @@ extern "C" int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int 
         else if (S == 2)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 0>), PM_ARGS); \
         else                         hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 1, 0>), PM_ARGS); \
     } while (0)
+#else                                                          /* product: no ablation instantiations */
+#define PM_LAUNCH_V2(MM)                                                                              \
+    do {                                                                                              \
+        (void)abl;                                                                                    \
+        if (S == 4)                  hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 4, 0>), PM_ARGS); \
+        else if (S == 2)             hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 2, 0>), PM_ARGS); \
+        else                         hipLaunchKernelGGL((pointmlp_f32_wlds_kernel<MM, 1, 0>), PM_ARGS); \
+    } while (0)
+#endif
 #define PM_LAUNCH(MM, NN) hipLaunchKernelGGL((pointmlp_f32_kernel<MM, NN>), PM_ARGS)
-    const char *kenv = getenv("SONET_POINTMLP_KERNEL");      // "wlds" forces v2 (bench A/B only)
+    const char *kenv = sonet::knob("SONET_POINTMLP_KERNEL");      // "wlds" forces v2 (bench A/B only)
     const bool fits32 = (double)(C1 > C2 ? C1 : C2) * L * 4.0 < 4.0e9 && (double)Cout * L * 4.0 < 4.0e9 &&
                         (double)CT * G * 1024.0 < 4.0e9;
     const bool lean = (Cout % 32 == 0) && (ct_per_y <= 32) && fits32 && !(kenv && kenv[0] == 'w') && abl == 0;

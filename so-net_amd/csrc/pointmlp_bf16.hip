@@ -27,8 +27,10 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BF_THREADS = 256;
 constexpr int BF_WAVES = 4;
+#ifdef SONET_VARIANTS
 struct T1 { static constexpr bool value = true; };
 struct T0 { static constexpr bool value = false; };
+#endif
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // round to nearest even, NaN stays NaN
     unsigned r;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     }
 }
 
+#ifdef SONET_VARIANTS
 // ---- the big-L variant: the wave's X tile lives in REGISTERS, W goes by in groups ---------------------------------------
 // In bf16 the 320 -> 384 layer carries 175 flop per HBM byte: whatever re-reads X loses.  Here a wave loads its 64 columns x
 // all Cin channels ONCE (KC x 8 dwords per lane: 160 registers at Cin = 320) and walks the output channels in G groups of
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void pointmlp_bf16_xreg_kernel(
         if (has_next) cur = tile_of(nxt);
     }
 }
+#endif  // SONET_VARIANTS
 
 }  // namespace
 
@@ -485,11 +489,11 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     // node-level launches (a few thousand columns): with 4 tiles per group 515 -> 768 at 64 x 64 columns is 16 x 6 = 96 workgroups of
     // three groups each on 256 CUs; two tiles per group doubles the workgroups that can run side by side
     if (MT == 4 && nwg_x * (CT / 4) < 256 && CT % 2 == 0) MT = 2;
-    if (const char *e = getenv("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
+    if (const char *e = sonet::knob("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
         const int want = atoi(e);
         if ((want == 12 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
     }
-    if (const char *e = getenv("SONET_BF16_S")) {
+    if (const char *e = sonet::knob("SONET_BF16_S")) {
         const int want = atoi(e);
         if (want == 1 || want == 2) S = want;
     }
@@ -500,7 +504,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     int ysplit = CT / MT;
     for (int d = CT / MT; d >= 1; --d)
         if ((CT / MT) % d == 0 && nwg_x * d >= 512 && CT / d <= 32) ysplit = d;
-    if (const char *e = getenv("SONET_BF16_YSPLIT")) {
+    if (const char *e = sonet::knob("SONET_BF16_YSPLIT")) {
         const int want = atoi(e);
         if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;
     }
@@ -510,6 +514,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
                         ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(y)) & 3) == 0;
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp);
+#ifdef SONET_VARIANTS   // (the X-in-registers kernel: bit-identical, measured slower; variants build only)
     // big launches with dword-aligned rows: X tile in registers, W by groups (above).  (KC, MT) pairs that are instantiated:
     // K chunks 1 / 4 / 8 / 16 / 20 / 24 with the tile count that keeps two W buffers inside the LDS
     {
@@ -519,9 +524,9 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         // measured SLOWER on every first-PointNet shape (0.54 vs 0.46 ms on 320 -> 384 at B = 64): one wave per SIMD, and the
         // 160 prefetch loads of the next tile pile up behind the 6-bit vmcnt during the last group.  Kept as the record of
         // the experiment and as the skeleton of the fused bf16 kernel (pointresnet_bf16.hip), where X never comes from HBM.
-        const char *e = getenv("SONET_BF16_XREG");
+        const char *e = sonet::knob("SONET_BF16_XREG");
         const bool want = e && atoi(e) >= 1, force = e && atoi(e) == 2;
-        if (want && !stats_ws && paired && xmt > 0 && CT % xmt == 0 && Cout <= 1024 && (nwg_x >= 512 || force) && (getenv("SONET_BF16_MT") == nullptr || force)) {
+        if (want && !stats_ws && paired && xmt > 0 && CT % xmt == 0 && Cout <= 1024 && (nwg_x >= 512 || force) && (sonet::knob("SONET_BF16_MT") == nullptr || force)) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) {
                 int v = 0;
@@ -544,6 +549,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
             return sonet::launched(what);
         }
     }
+#endif  // SONET_VARIANTS
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
 #define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \

@@ -784,7 +784,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     hipStream_t st = sonet::as_stream(stream);
     const uint4 *wp = reinterpret_cast<const uint4 *>(Wp3);
     unsigned *rlog = f16 ? sonet::range_log() : nullptr;
-    const char *eg = getenv("SONET_POINTMLP_H3R");          // bench-only: 0 = the first-generation pipeline
+    const char *eg = sonet::knob("SONET_POINTMLP_H3R");          // bench-only: 0 = the first-generation pipeline
     // second-generation pipeline where it measures faster (profiles/r02y_pointmlp_h3r.log, r02zd): inputs that stay in the 256 MB
     // MALL across the CT / 4 passes over X, and point-level inputs whenever the first generation would also run 4-tile groups (CT
     // not a multiple of 6: 1024 -> 512 at 64 x 3072 columns 0.62 vs 0.78 ms).  With 6-tile groups (two passes for 384 channels
@@ -811,7 +811,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
             const long long cost = sonet::ceil_div64(nwg_x * d, slots) * (groups / d);
             if (best == 0 || cost <= best_cost) { best = d; best_cost = cost; }
         }
-        if (const char *e = getenv("SONET_POINTMLP_YSPLIT")) {
+        if (const char *e = sonet::knob("SONET_POINTMLP_YSPLIT")) {
             const int want = atoi(e);
             if (want >= 1 && groups % want == 0 && CT / want <= 32) best = want;
         }
@@ -831,11 +831,11 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     if (CT % 6 == 0) MT = 6;
     else if (CT % 4 == 0 && !(nwg_x < 64)) MT = 4;
     else if (CT % 2 == 0) MT = 2;
-    if (const char *e = getenv("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
+    if (const char *e = sonet::knob("SONET_POINTMLP_MT")) {      // tuning knob (bench experiments only)
         const int want = atoi(e);
         if ((want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
     }
-    if (const char *e = getenv("SONET_POINTMLP_S")) {
+    if (const char *e = sonet::knob("SONET_POINTMLP_S")) {
         const int want = atoi(e);
         if (want == 1 || want == 2) S = want;
     }
@@ -843,7 +843,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     int ysplit = 1;
     while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
     while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
-    if (const char *e = getenv("SONET_POINTMLP_YSPLIT")) {  // tuning knob (bench experiments only): output-channel slabs per column group.
+    if (const char *e = sonet::knob("SONET_POINTMLP_YSPLIT")) {  // tuning knob (bench experiments only): output-channel slabs per column group.
         const int want = atoi(e);                           // 1152 workgroups on 768 resident slots run 1.5 rounds; 2 slabs of half the work
         if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;   // each would run 3 rounds of half the length (X re-read twice)
     }
@@ -855,7 +855,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, false>), X3_ARGS); } } while (0)
-    if (zadd && f16 && CT % 4 == 0 && !stats_ws && nwg_x >= 512 && !getenv("SONET_POINTMLP_MT")) {      // (small launches: more slabs instead)
+    if (zadd && f16 && CT % 4 == 0 && !stats_ws && nwg_x >= 512 && !sonet::knob("SONET_POINTMLP_MT")) {      // (small launches: more slabs instead)
         // per-node addend: 4-tile groups with the gathers in flight during the K loop
         dim3 gz((unsigned)nwg_x, (unsigned)sonet::ceil_div(CT, 32));      // (slabs of <= 32 tiles: the affine table; a workgroup walks its groups)
         const int cpy = CT / (int)gz.y;
@@ -888,6 +888,7 @@ extern "C" int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const floa
                        nullptr, nullptr, nullptr, zadd, zidx, ZM);
 }
 
+#ifdef SONET_VARIANTS   // (max over the neighbour planes from the layer epilogue: measured slower than layer + planes_max; variants build only)
 namespace {
 __global__ __launch_bounds__(256) void kmax_decode_kernel(const unsigned *__restrict__ keys, float *__restrict__ out, long long n)
 {
@@ -916,6 +917,7 @@ extern "C" int sonet_pointmlp_h3_kmax_f32(const float *x1, int C1, const float *
                        reinterpret_cast<const unsigned *>(keys_ws), out, (long long)n);
     return sonet::launched(what);
 }
+#endif  // SONET_VARIANTS
 
 extern "C" size_t sonet_pointmlp_stats_ws_size(int B, int Cout, int L)
 {

@@ -866,7 +866,7 @@ extern "C" int sonet_pointresnet_bf16(const float *x, int Cin0, const void *wstr
     }
     const long long grid = ntiles < cus ? ntiles : cus;          // persistent: one workgroup per CU
     int abl = 0;
-    if (const char *e = getenv("SONET_BF16_FUSED_ABLATE")) abl = atoi(e);      // bench-only (tools/bench_bf16.py)
+    if (const char *e = sonet::knob("SONET_BF16_FUSED_ABLATE")) abl = atoi(e);      // bench-only (tools/bench_bf16.py)
     hipLaunchKernelGGL(pointresnet_bf16_kernel<false>, dim3((unsigned)grid), dim3(FB_THREADS), 0, sonet::as_stream(stream),
                        x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles, abl,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
@@ -891,7 +891,7 @@ extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, cons
     if ((double)Cin0 * L * 4.0 >= 2.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
     hipStream_t st = sonet::as_stream(stream);
     const long long npool = (long long)B * M * 384;
-    const char *e8 = getenv("SONET_BF16_POOL2");               // bench-only: 0 = the 4-wave / 64-point kernel (one workgroup per CU)
+    const char *e8 = sonet::knob("SONET_BF16_POOL2");               // bench-only: 0 = the 4-wave / 64-point kernel (one workgroup per CU)
     const bool two = !(e8 && atoi(e8) == 0);
     const int tile_pts = two ? 128 : 256, slots = two ? P2_SLOTS : FB_SLOTS;
     const int tpc = sonet::ceil_div(L, tile_pts);
@@ -908,7 +908,7 @@ extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, cons
     }
     if (two) {
         long long grid = ntiles < 2ll * cus ? ntiles : 2ll * cus;            // persistent: two workgroups per CU
-        if (const char *eg = getenv("SONET_BF16_POOL2_GRID")) { const long long v = atoll(eg); if (v > 0 && v < grid) grid = v; }   // debugging
+        if (const char *eg = sonet::knob("SONET_BF16_POOL2_GRID")) { const long long v = atoll(eg); if (v > 0 && v < grid) grid = v; }   // debugging
         hipLaunchKernelGGL(pointresnet_bf16_pool2_kernel, dim3((unsigned)grid), dim3(P2_THREADS), 0, st,
                            x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), L, tpc, ntiles,
                            ids_sorted, pos0, pooled_ws, partial_ws, v0_ws, M);
@@ -916,7 +916,7 @@ extern "C" int sonet_pointresnet_bf16_pool(const float *x_sorted, int Cin0, cons
         const long long grid = ntiles < cus ? ntiles : cus;
         hipLaunchKernelGGL(pointresnet_bf16_kernel<true>, dim3((unsigned)grid), dim3(FB_THREADS), 0, st,
                            x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (uint16_t *)nullptr,
-                           L, tpc, ntiles, getenv("SONET_BF16_FUSED_ABLATE") ? atoi(getenv("SONET_BF16_FUSED_ABLATE")) : 0,
+                           L, tpc, ntiles, sonet::knob("SONET_BF16_FUSED_ABLATE") ? atoi(sonet::knob("SONET_BF16_FUSED_ABLATE")) : 0,
                            ids_sorted, pos0, node_off, count, pooled_ws, partial_ws, v0_ws, M);
     }
     hipLaunchKernelGGL(pooled_bf16_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,

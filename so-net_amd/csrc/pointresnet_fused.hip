@@ -778,9 +778,7 @@ int cu_count() {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-#ifdef SONET_MAXCU_ENV                                          // experiment builds only (tools/build_variant.sh): cap the persistent grid
-    if (const char *e = getenv("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }
-#endif
+    if (const char *e = sonet::knob("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // (variants build only)
     return cus;
 }
 

@@ -640,7 +640,7 @@ extern "C" int sonet_som_assign_f32(const float *x, const float *node, int B, in
         return sonet::fail(SONET_ERR_LAUNCH, "%s: zero fill failed", what);
     dim3 grid(sonet::ceil_div(N, SA_THREADS), B), block(SA_THREADS);
     const size_t lds = (size_t)M * (sizeof(float4) + 3 * sizeof(double) + sizeof(unsigned));
-    const char *ek = getenv("SONET_SOM_KEYS");                  // bench / test switch: 0 = the insertion-list kernel
+    const char *ek = sonet::knob("SONET_SOM_KEYS");                  // bench / test switch: 0 = the insertion-list kernel
     const bool keys = !(ek && atoi(ek) == 0);
 #define SA_LAUNCH(KK) do { if (keys && M <= 64) hipLaunchKernelGGL((som_assign_keys_kernel<KK, 6>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws); \
                            else if (keys) hipLaunchKernelGGL((som_assign_keys_kernel<KK, 10>), grid, block, lds, st, x, node, N, M, min_idx_i32, min_idx_i64, count, sum_ws); \

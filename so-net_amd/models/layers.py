@@ -686,12 +686,9 @@ class KNNModule(nn.Module):
                                   x2=dec.to(sdt), gidx=gidx)              # B x C1 x (K*M), k-major columns
             s2, t2 = l2._eval_affine()
             wp2 = l2._packed(h.shape[1], 0)
-            if _ops.KMAX_EPILOGUE and wp2.dtype == torch.int8 and h.dtype == torch.float32 and l2.conv.out_channels % 128 == 0:
-                # the max over the K neighbour planes leaves the layer kernel's epilogue: B x C2 x K*M is never written
-                feature = _ops.pointmlp_kmax(h, wp2, s2, t2, l2.activation == 'relu', l2.conv.out_channels, coord.shape[2])
-            else:
-                h = _ops.pointmlp(h, wp2, s2, t2, l2.activation == 'relu', l2.conv.out_channels)
-                feature = _ops.planes_max(h, K)                           # B x C2 x M (storage type of h)
+            # (the max over the K planes from the layer's epilogue -- sonet_hip.variants.pointmlp_kmax -- measured slower: variants build only)
+            h = _ops.pointmlp(h, wp2, s2, t2, l2.activation == 'relu', l2.conv.out_channels)
+            feature = _ops.planes_max(h, K)                               # B x C2 x M (storage type of h)
             return center, feature
         if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
             # no-grad path: gathers, centre, de-centring and the concat in one kernel; max over K in one kernel

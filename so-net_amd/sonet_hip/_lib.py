@@ -10,6 +10,11 @@ import torch  # noqa: F401  (loads libamdhip64.so first so the library binds to 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsonet_hip.so")
+# The VARIANTS build (make -C so-net_amd/csrc variants: tuning / ablation knobs read from SONET_* environment variables, measured-slower
+# kernels kept as tested records) is never loaded unless asked for: SONET_HIP_LIB=<path> (tools/, tests/variants).
+VARIANTS_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsonet_hip_variants.so")
+if os.environ.get("SONET_HIP_LIB"):
+    LIB_PATH = os.environ["SONET_HIP_LIB"]
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -54,7 +59,6 @@ SIGNATURES = {
     "sonet_pointmlp_bf16_stats_ws_size": [_i, _i, _i],
     "sonet_pointmlp_bf16_stats": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pointmlp_h3_nodeadd_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
-    "sonet_pointmlp_h3_kmax_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_wgrad_x3_ws_size": [_i, _i, _i, _i],
     "sonet_wgrad_x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],
@@ -91,8 +95,6 @@ SIGNATURES = {
     "sonet_pointwise_bwd_apply_bf16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_channel_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_chamfer_nn_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
-    "sonet_chamfer_nn2_ws_size": [_i, _i, _i],
-    "sonet_chamfer_nn2_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
 _RESTYPES = {
     "sonet_build_arch": ctypes.c_char_p,
@@ -109,6 +111,13 @@ _RESTYPES = {
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
     "sonet_chamfer_nn2_ws_size": ctypes.c_size_t,
+}
+
+# entry points that only the variants build exports (bound when present)
+VARIANT_SIGNATURES = {
+    "sonet_chamfer_nn2_ws_size": [_i, _i, _i],
+    "sonet_chamfer_nn2_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_h3_kmax_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
 }
 
 _lib = None
@@ -135,6 +144,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    for name, args in VARIANT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
     _lib = lib
     return lib
 

@@ -69,41 +69,6 @@ def test_pointmlp_bf16_vs_same_operand_reference(B, C1, C2, Cout, L, relu):
     assert float((got != exact).double().mean()) < 0.02
 
 
-@pytest.mark.parametrize("mt", ["12", "6", "4", "2", "1"])
-def test_pointmlp_bf16_tile_variants_agree(mt, monkeypatch):
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(3)
-    x1 = torch.randn(2, 64, 700, generator=g).to(torch.bfloat16).to(DEV)
-    x2 = torch.randn(2, 256, 700, generator=g).to(torch.bfloat16).to(DEV)
-    W = (torch.randn(384, 320, generator=g) * 0.08).to(DEV)
-    wp = ops.pointmlp_pack(W, "bf16")
-    one, zero = ops.const_vec(384, 1.0, DEV), ops.const_vec(384, 0.0, DEV)
-    base = ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2).clone()
-    monkeypatch.setenv("SONET_BF16_MT", mt)
-    for s in ("1", "2"):
-        monkeypatch.setenv("SONET_BF16_S", s)
-        assert torch.equal(ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2), base), (mt, s)   # same K order: bit-identical
-
-
-@pytest.mark.parametrize("B,C1,C2,Cout,L", [(3, 6, 0, 64, 1500), (2, 64, 0, 128, 3000), (5, 128, 0, 256, 1500), (3, 64, 256, 384, 1500),
-                                            (2, 64, 256, 384, 130), (2, 256, 0, 128, 700), (2, 384, 0, 64, 900), (1, 320, 0, 384, 2), (70, 64, 256, 384, 64)])
-def test_pointmlp_bf16_xreg_equals_streaming(B, C1, C2, Cout, L, monkeypatch):
-    """The X-in-registers kernel (big launches) and the streaming kernel add the K chunks in the same order: bit-identical."""
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(L + C1)
-    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16).to(DEV)
-    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16).to(DEV) if C2 else None
-    W = (torch.randn(Cout, C1 + C2, generator=g) * 0.1).to(DEV)
-    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
-    wp = ops.pointmlp_pack(W, "bf16")
-    monkeypatch.setenv("SONET_BF16_XREG", "0")
-    base = ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2).clone()
-    monkeypatch.setenv("SONET_BF16_XREG", "2")
-    with ops.kernel_timing():
-        got = ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2)
-    assert torch.equal(got, base)
-
-
 def test_pointmlp_bf16_gather_matches_materialised():
     from sonet_hip import ops
     g = torch.Generator().manual_seed(9)

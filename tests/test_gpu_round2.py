@@ -422,59 +422,6 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "only %d GPU" % n in (r.stdout + r.stderr)
 
 
-# ------------------------------------------------------------------------------------------ Chamfer: one sweep, both directions
-@pytest.mark.parametrize("B,Na,Nb", [(8, 1280, 5000), (3, 5000, 1280), (2, 1, 1), (2, 300, 300), (1, 2049, 4100), (2, 4097, 17)])
-def test_chamfer_nn2_equals_two_one_direction_searches(B, Na, Nb):
-    """Row and column arg-min from ONE sweep of the distance matrix == two sonet_chamfer_nn_f32 launches == the oracle's exact
-    search (bit-exact indices, ties -> lowest index; duplicated points force ties)."""
-    from oracle import cpu_oracle as O
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(Na + Nb)
-    a = torch.rand(B, 3, Na, generator=g) * 2 - 1
-    b = torch.rand(B, 3, Nb, generator=g) * 2 - 1
-    if Na > 10 and Nb > 10:
-        a[:, :, 5] = a[:, :, 3]                     # exact ties in both directions
-        b[:, :, 7] = b[:, :, 2]
-    ab, ba = ops.chamfer_nn2(a.to(DEV), b.to(DEV))
-    np.testing.assert_array_equal(ab.cpu().numpy(), ops.chamfer_nn(a.to(DEV), b.to(DEV)).cpu().numpy())
-    np.testing.assert_array_equal(ba.cpu().numpy(), ops.chamfer_nn(b.to(DEV), a.to(DEV)).cpu().numpy())
-    np.testing.assert_array_equal(ab.cpu().numpy(), O.chamfer_nn(a.numpy(), b.numpy()))
-    np.testing.assert_array_equal(ba.cpu().numpy(), O.chamfer_nn(b.numpy(), a.numpy()))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,C1,C2,Cout,L,L1", [(4, 515, 0, 768, 64, 0), (3, 387, 0, 512, 576, 0), (2, 384, 3, 512, 576, 64),
-                                              (2, 256, 64, 384, 700, 0), (3, 40, 0, 128, 77, 0), (2, 17, 0, 128, 1, 0),
-                                              (1, 1347, 0, 512, 1029, 0), (5, 16, 0, 256, 33, 0)])
-def test_pointmlp_h3_second_generation_is_bit_identical(B, C1, C2, Cout, L, L1, monkeypatch):
-    """pointmlp_h3r_kernel (LDS-DMA ring, split in the MFMA shadow, XCD-aware slab order) == the first-generation fp16-split
-    kernel bit for bit -- same MFMAs in the same order per accumulator -- including K tails (Cin % 32 != 0), ragged column
-    tiles, the two-input and the gather forms; and both meet float64 within the f32-class bound."""
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(C1 + Cout + L)
-    w = (torch.randn(Cout, C1 + C2, generator=g) / (C1 + C2) ** 0.5).to(DEV)
-    x1 = torch.randn(B, C1, L1 if L1 else L, generator=g).to(DEV)
-    x2 = torch.randn(B, C2, L, generator=g).to(DEV) if C2 else None
-    gidx = torch.randint(-1, L1 + 1, (B, L), generator=g, dtype=torch.int32).to(DEV) if L1 else None
-    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
-    shift = torch.randn(Cout, generator=g).to(DEV)
-    wp = ops.pointmlp_pack(w, "h3")
-    out = {}
-    for gen in ("1", "0"):
-        monkeypatch.setenv("SONET_POINTMLP_H3R", gen)
-        with ops.kernel_timing():
-            out[gen] = ops.pointmlp(x1, wp, scale, shift, True, Cout, x2=x2, gidx=gidx)
-    assert torch.equal(out["1"], out["0"])
-    xa = x1.double()
-    if gidx is not None:
-        ok = (gidx >= 0) & (gidx < L1)
-        xa = torch.gather(xa, 2, gidx.clamp(0, L1 - 1).long().unsqueeze(1).expand(B, C1, L)) * ok.unsqueeze(1)
-    xin = torch.cat([xa, x2.double()], 1) if x2 is not None else xa
-    ref = torch.relu(torch.einsum("oc,bcl->bol", w.double(), xin) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1))
-    err = (out["1"].double() - ref).abs()
-    assert float(err.max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,C,M,L,NL", [(3, 512, 64, 576, 3), (2, 37, 10, 33, 3), (1, 8, 5, 7, 0), (2, 64, 100, 1000, 4)])
 def test_node_gather_lead_affine_act_vs_torch(B, C, M, L, NL):
@@ -591,23 +538,6 @@ def test_pointmlp_nodeadd_epilogue(B, C1, C2, Cout, L, M):
     bound = 1e-5 * max(1.0, float(ref.abs().max()))
     assert float((got.double() - ref).abs().max()) <= bound
     assert float((got - two).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,C,Cout,M,K", [(3, 512, 512, 64, 9), (2, 64, 128, 5, 3), (1, 128, 256, 100, 16)])
-def test_pointmlp_kmax_epilogue(B, C, Cout, M, K):
-    """Layer + max over the K planes of its k-major output from the epilogue == planes_max(pointmlp(...)) bit for bit (max is exact,
-    the layer kernel is the same), incl. negative outputs (no ReLU)."""
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(C + Cout + M)
-    w = cu(torch.randn(Cout, C, generator=g) / C ** 0.5)
-    x = cu(torch.randn(B, C, K * M, generator=g))
-    scale, shift = cu(torch.rand(Cout, generator=g) + 0.5), cu(torch.randn(Cout, generator=g))
-    wp = ops.pointmlp_pack(w, "h3")
-    for relu in (True, False):
-        ref = ops.planes_max(ops.pointmlp(x, wp, scale, shift, relu, Cout), K)
-        got = ops.pointmlp_kmax(x, wp, scale, shift, relu, Cout, M)
-        assert torch.equal(got, ref)
 
 
 @pytest.mark.gpu

@@ -13,9 +13,16 @@ import torch
 from conftest import GOLDEN, PKG, ROOT
 
 
-def header_functions():
+def header_functions(variants=False):
+    """Entry points the header declares: the product section, or (variants=True) the #ifdef SONET_VARIANTS section."""
     src = open(os.path.join(ROOT, "include", "sonet_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"#ifdef SONET_VARIANTS(.*?)#endif", src, flags=re.S)
+    var = m.group(1) if m else ""
+    if variants:
+        src = var
+    elif m:
+        src = src[:m.start()] + src[m.end():]
     return sorted(set(re.findall(r"\b(sonet_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -27,6 +34,21 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(raw, n), "libsonet_hip.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
+    # the variants-only entry points: declared under #ifdef SONET_VARIANTS, NOT exported by the product library, exported by the
+    # variants library when it is built; and the product library reads no environment variable (no getenv import)
+    vnames = header_functions(variants=True)
+    assert set(vnames) == set(_lib.VARIANT_SIGNATURES) and vnames
+    product = os.path.join(PKG, "lib", "libsonet_hip.so")
+    rawp = ctypes.CDLL(product)
+    for n in vnames:
+        assert not hasattr(rawp, n), "the product library exports the variants-only %s" % n
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", product], stdout=subprocess.PIPE).stdout.decode()
+    assert "getenv" not in syms, "the product library reads environment variables"
+    if os.path.exists(_lib.VARIANTS_PATH):
+        rawv = ctypes.CDLL(_lib.VARIANTS_PATH)
+        for n in names + vnames:
+            assert hasattr(rawv, n), "libsonet_hip_variants.so does not export %s" % n
     lib = _lib.load()
     assert lib.sonet_abi_version() == 1
     assert lib.sonet_build_arch() == b"gfx950"
@@ -147,7 +169,8 @@ def test_ctypes_signatures_match_the_header_prototypes():
     src = open(os.path.join(ROOT, "include", "sonet_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = re.findall(r"\b(int|size_t|const\s+char\s*\*)\s*(sonet_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src)
-    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+    allsig = dict(_lib.SIGNATURES, **_lib.VARIANT_SIGNATURES)          # (the #ifdef SONET_VARIANTS section is parsed with the rest)
+    assert len(protos) == len(allsig), (len(protos), len(allsig))
 
     def kind(param):
         p = " ".join(param.split())
@@ -161,6 +184,6 @@ def test_ctypes_signatures_match_the_header_prototypes():
 
     for ret, name, params in protos:
         want = [k for k in (kind(p) for p in params.split(",")) if k is not None]
-        assert _lib.SIGNATURES[name] == want, (name, [t.__name__ for t in want], [t.__name__ for t in _lib.SIGNATURES[name]])
+        assert allsig[name] == want, (name, [t.__name__ for t in want], [t.__name__ for t in allsig[name]])
         want_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t}.get(ret, ctypes.c_char_p)
         assert _lib._RESTYPES.get(name, ctypes.c_int) == want_ret, name

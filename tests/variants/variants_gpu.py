@@ -1,0 +1,142 @@
+"""GPU tests of the VARIANTS build (libsonet_hip_variants.so: the SONET_* tuning knobs and the measured-slower kernels kept as records).
+Not collected by the main run (the file name does not match test_*): tests/test_gpu_variants_suite.py runs it in a subprocess with
+SONET_HIP_LIB pointing at the variants library, so that the product process never loads it.
+
+    SONET_HIP_LIB=so-net_amd/lib/libsonet_hip_variants.so python -m pytest tests/variants/variants_gpu.py -q
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conftest import ROOT, assert_close_rms, golden  # noqa: E402,F401
+
+from sonet_hip import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+if os.path.abspath(_lib.LIB_PATH) != os.path.abspath(_lib.VARIANTS_PATH):
+    pytest.skip("needs SONET_HIP_LIB=%s" % _lib.VARIANTS_PATH, allow_module_level=True)
+
+from sonet_hip import variants  # noqa: E402
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("mt", ["12", "6", "4", "2", "1"])
+def test_pointmlp_bf16_tile_variants_agree(mt, monkeypatch):
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(2, 64, 700, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(2, 256, 700, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(384, 320, generator=g) * 0.08).to(DEV)
+    wp = ops.pointmlp_pack(W, "bf16")
+    one, zero = ops.const_vec(384, 1.0, DEV), ops.const_vec(384, 0.0, DEV)
+    base = ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2).clone()
+    monkeypatch.setenv("SONET_BF16_MT", mt)
+    for s in ("1", "2"):
+        monkeypatch.setenv("SONET_BF16_S", s)
+        assert torch.equal(ops.pointmlp(x1, wp, one, zero, False, 384, x2=x2), base), (mt, s)   # same K order: bit-identical
+
+
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L", [(3, 6, 0, 64, 1500), (2, 64, 0, 128, 3000), (5, 128, 0, 256, 1500), (3, 64, 256, 384, 1500),
+                                            (2, 64, 256, 384, 130), (2, 256, 0, 128, 700), (2, 384, 0, 64, 900), (1, 320, 0, 384, 2), (70, 64, 256, 384, 64)])
+def test_pointmlp_bf16_xreg_equals_streaming(B, C1, C2, Cout, L, monkeypatch):
+    """The X-in-registers kernel (big launches) and the streaming kernel add the K chunks in the same order: bit-identical."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(L + C1)
+    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16).to(DEV) if C2 else None
+    W = (torch.randn(Cout, C1 + C2, generator=g) * 0.1).to(DEV)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    wp = ops.pointmlp_pack(W, "bf16")
+    monkeypatch.setenv("SONET_BF16_XREG", "0")
+    base = ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2).clone()
+    monkeypatch.setenv("SONET_BF16_XREG", "2")
+    with ops.kernel_timing():
+        got = ops.pointmlp(x1, wp, sc, sh, True, Cout, x2=x2)
+    assert torch.equal(got, base)
+
+
+
+
+@pytest.mark.parametrize("B,Na,Nb", [(8, 1280, 5000), (3, 5000, 1280), (2, 1, 1), (2, 300, 300), (1, 2049, 4100), (2, 4097, 17)])
+def test_chamfer_nn2_equals_two_one_direction_searches(B, Na, Nb):
+    """Row and column arg-min from ONE sweep of the distance matrix == two sonet_chamfer_nn_f32 launches == the oracle's exact
+    search (bit-exact indices, ties -> lowest index; duplicated points force ties)."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(Na + Nb)
+    a = torch.rand(B, 3, Na, generator=g) * 2 - 1
+    b = torch.rand(B, 3, Nb, generator=g) * 2 - 1
+    if Na > 10 and Nb > 10:
+        a[:, :, 5] = a[:, :, 3]                     # exact ties in both directions
+        b[:, :, 7] = b[:, :, 2]
+    ab, ba = variants.chamfer_nn2(a.to(DEV), b.to(DEV))
+    np.testing.assert_array_equal(ab.cpu().numpy(), ops.chamfer_nn(a.to(DEV), b.to(DEV)).cpu().numpy())
+    np.testing.assert_array_equal(ba.cpu().numpy(), ops.chamfer_nn(b.to(DEV), a.to(DEV)).cpu().numpy())
+    np.testing.assert_array_equal(ab.cpu().numpy(), O.chamfer_nn(a.numpy(), b.numpy()))
+    np.testing.assert_array_equal(ba.cpu().numpy(), O.chamfer_nn(b.numpy(), a.numpy()))
+
+
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L,L1", [(4, 515, 0, 768, 64, 0), (3, 387, 0, 512, 576, 0), (2, 384, 3, 512, 576, 64),
+                                              (2, 256, 64, 384, 700, 0), (3, 40, 0, 128, 77, 0), (2, 17, 0, 128, 1, 0),
+                                              (1, 1347, 0, 512, 1029, 0), (5, 16, 0, 256, 33, 0)])
+def test_pointmlp_h3_second_generation_is_bit_identical(B, C1, C2, Cout, L, L1, monkeypatch):
+    """pointmlp_h3r_kernel (LDS-DMA ring, split in the MFMA shadow, XCD-aware slab order) == the first-generation fp16-split
+    kernel bit for bit -- same MFMAs in the same order per accumulator -- including K tails (Cin % 32 != 0), ragged column
+    tiles, the two-input and the gather forms; and both meet float64 within the f32-class bound."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C1 + Cout + L)
+    w = (torch.randn(Cout, C1 + C2, generator=g) / (C1 + C2) ** 0.5).to(DEV)
+    x1 = torch.randn(B, C1, L1 if L1 else L, generator=g).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(DEV) if C2 else None
+    gidx = torch.randint(-1, L1 + 1, (B, L), generator=g, dtype=torch.int32).to(DEV) if L1 else None
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    wp = ops.pointmlp_pack(w, "h3")
+    out = {}
+    for gen in ("1", "0"):
+        monkeypatch.setenv("SONET_POINTMLP_H3R", gen)
+        with ops.kernel_timing():
+            out[gen] = ops.pointmlp(x1, wp, scale, shift, True, Cout, x2=x2, gidx=gidx)
+    assert torch.equal(out["1"], out["0"])
+    xa = x1.double()
+    if gidx is not None:
+        ok = (gidx >= 0) & (gidx < L1)
+        xa = torch.gather(xa, 2, gidx.clamp(0, L1 - 1).long().unsqueeze(1).expand(B, C1, L)) * ok.unsqueeze(1)
+    xin = torch.cat([xa, x2.double()], 1) if x2 is not None else xa
+    ref = torch.relu(torch.einsum("oc,bcl->bol", w.double(), xin) * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1))
+    err = (out["1"].double() - ref).abs()
+    assert float(err.max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+
+
+@pytest.mark.parametrize("B,C,Cout,M,K", [(3, 512, 512, 64, 9), (2, 64, 128, 5, 3), (1, 128, 256, 100, 16)])
+def test_pointmlp_kmax_epilogue(B, C, Cout, M, K):
+    """Layer + max over the K planes of its k-major output from the epilogue == planes_max(pointmlp(...)) bit for bit (max is exact,
+    the layer kernel is the same), incl. negative outputs (no ReLU)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(C + Cout + M)
+    w = cu(torch.randn(Cout, C, generator=g) / C ** 0.5)
+    x = cu(torch.randn(B, C, K * M, generator=g))
+    scale, shift = cu(torch.rand(Cout, generator=g) + 0.5), cu(torch.randn(Cout, generator=g))
+    wp = ops.pointmlp_pack(w, "h3")
+    for relu in (True, False):
+        ref = ops.planes_max(ops.pointmlp(x, wp, scale, shift, relu, Cout), K)
+        got = variants.pointmlp_kmax(x, wp, scale, shift, relu, Cout, M)
+        assert torch.equal(got, ref)

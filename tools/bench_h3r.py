@@ -3,6 +3,9 @@
 import os
 import sys
 
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs / record kernels live in the variants build)
+
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "so-net_amd"))

@@ -3,6 +3,9 @@ part-segmentation (B x 50 x N scores) and autoencoder (decoder + multi-resolutio
 metric (bench.py); numbers for DESIGN.md."""
 import os
 import sys
+
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs / record kernels live in the variants build)
 import time
 from argparse import Namespace
 
@@ -121,7 +124,7 @@ def chamfer_roofline():
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / it
-        ms2 = t(lambda: ops.chamfer_nn2(pred, gt))
+        ms2 = t(lambda: __import__("sonet_hip.variants", fromlist=["x"]).chamfer_nn2(pred, gt))
         ms1 = t(lambda: (ops.chamfer_nn(pred, gt), ops.chamfer_nn(gt, pred)))
         print("chamfer B=%-3d 1280 x 5000: one sweep %.4f ms = %.2f T lane-ops/s (%.3f of the VALU roof) | two launches %.4f ms (%.3f)"
               % (B, ms2, 14 * pairs / ms2 / 1e9, 14 * pairs / (ms2 * 1e-3) / peak, ms1, 22 * pairs / (ms1 * 1e-3) / peak), flush=True)

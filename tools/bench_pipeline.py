@@ -2,6 +2,9 @@
 loop): does the node-level / SOM stage of one batch fill the CUs the other batch's kernels leave idle?"""
 import os
 import sys
+
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs / record kernels live in the variants build)
 import time
 
 import torch

@@ -2,6 +2,9 @@
 import os
 import sys
 
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs / record kernels live in the variants build)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "so-net_amd"))
 import torch  # noqa: E402

@@ -1,5 +1,10 @@
 """tools/sweep_pointmlp.py -- timings of the layer-wise split kernel on the second-stage / segmenter shapes."""
-import os, sys, torch
+import os
+import sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs live in the variants build)
+import sys
+import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "so-net_amd"))
 from sonet_hip import ops
 DEV = torch.device("cuda:0")

@@ -1,4 +1,9 @@
-import os, sys, torch
+import os
+import sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variants  # noqa: E402,F401  (knobs live in the variants build)
+import sys
+import torch
 sys.path.insert(0, "/root/repo/so-net_amd")
 from sonet_hip import ops
 DEV = torch.device("cuda:0")
