@@ -144,6 +144,8 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
         return "hbm", B * (C * kN * 4 + kN * 4 + C * M * 4)
     if name == "som_assign":
         return "hbm", B * (3 * N * 4 + 3 * M * 4 + kN * 4 + M * 4 + 3 * M * 8)
+    if name == "som_assign_sort":                              # assignment (x, nodes -> ids) + node-sorted grouping (x, sn, ids -> 6 sorted planes + ids)
+        return "hbm", B * (3 * N * 4 + 3 * M * 4 + kN * 4 + M * 4) + B * (6 * N * 4 + kN * 4 + 6 * kN * 4 + kN * 4 + 3 * M * 4 + 2 * M * 4)
     if name == "som_group":
         return "hbm", B * (6 * N * 4 + kN * 4 + M * 4 + 3 * M * 8 + 6 * kN * 4 + 3 * M * 4 + M * 4)
     if name == "knn_gather":
@@ -693,7 +695,7 @@ def main():
                 else:
                     ach = amount / (s_["mean_ms"] * 1e-3) / 1e9
                     k.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
-                    if name.startswith("som_assign"):
+                    if name.startswith("som_assign"):          # (som_assign_sort: the two launches together, distance arithmetic only)
                         # 64 nodes per 12-byte point: 13 VALU operations per node-point pair (8 for the exact, un-contracted
                         # distance, 1 to pack the key, 4 for the 4-deep min / median chain) put this kernel on the vector-issue
                         # roof long before the HBM one -- at B = 64 (320 k points, ~15 us of arithmetic) it is launch- and

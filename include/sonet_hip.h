@@ -270,6 +270,18 @@ size_t sonet_pointresnet_pool_ws_size(int B, int L, int M);
 int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
                                      const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
                                      const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream);
+/* The SOM stage of the no-grad pooled path in TWO launches: sonet_som_assign_f32 + sonet_som_sort_group_f32 in one call
+ * (util/som.py:237-269 + models/networks.py:128-172).  Same outputs -- min_idx_i32 [B][k*N] (k-major; min_idx_i64 optional),
+ * count [B][M], sum_ws [B][3][M] f64 (optional), som_node [B][3][M], row_max [B][M] (both optional), x_aug_sorted [B][6][kN],
+ * ids_sorted [B][kN], pos0 [B], node_off [B][M] -- with no clear launches, no global atomics and one LDS atomic per point copy:
+ * per-workgroup partial counts / sums and per-copy ranks in ws (sonet_som_assign_sort_ws_size bytes), sorted positions = node
+ * offset + the counts of the workgroups before + rank.  Node ids and counts are bit-identical to the two separate calls; the
+ * order of the copies inside a node differs (any order serves the per-node max-pool). */
+size_t sonet_som_assign_sort_ws_size(int B, int N, int M, int k);
+int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                              int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                              float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                              int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream);
 /* som_sort_group: som_group with the kN point copies of every cloud counting-sorted by node id.
  * x_aug_sorted [B][6][kN], ids_sorted [B][kN], pos0 [B], node_off [B][M]; cursor_ws: B*M i32 (zeroed by the callee). */
 int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,

@@ -582,7 +582,289 @@ __global__ __launch_bounds__(256) void som_sort_fill_kernel(
     for (int c = 0; c < 3; ++c) ob[(size_t)(3 + c) * kN + pos] = snb[(size_t)c * N + n];
 }
 
+
+// ---- the SOM stage of the no-grad pooled path in TWO launches (assign + rank + partial sums | totals + node-sorted fill) ----------
+// The five-launch form (clear, som_assign_keys, clear, som_sort_group, som_sort_fill) is launch- and atomics-bound at B = 64:
+// twelve LDS atomics per point (three counters and nine double-precision coordinate sums) are most of som_assign's 16 us, and the
+// sorted positions come from a global cursor that needs its own clear.  Here
+//   K1  a workgroup owns SP_T = 512 consecutive points (two per thread): node ids as above (packed keys, exact redo), ONE integer
+//       LDS atomic per point copy -- its return value is the copy's RANK among the workgroup's copies of that node --, then the
+//       copies' coordinates are staged in LDS at (node start + rank) and 3M threads add up their node's run in double precision,
+//       in slot order.  Outputs: ids, ranks, and per-workgroup partial counts / sums by PLAIN stores: nothing to clear.
+//   K2  every workgroup of a cloud adds up the (few) partials: totals, cluster means (sum / (count + 1e-5), networks.py:140-142),
+//       node offsets, and the start of ITS run inside every node = the partial counts of the workgroups before it.  The sorted
+//       position of a copy is node offset + run start + rank: no cursor, no atomics.  The six channels and the ids go to their
+//       sorted positions through an LDS transpose (workgroup-local node order), so that consecutive lanes store consecutive
+//       positions of a run (~48 copies) instead of 4-byte stores scattered over six planes.
+constexpr int SP_THREADS = 256;
+constexpr int SP_PPT = 2;                                      // points per thread
+constexpr int SP_T = SP_THREADS * SP_PPT;                      // points per workgroup
+constexpr int SP_KMAX = 4;
+
+// exclusive prefix sums over M (<= 1024) integers in LDS by the FIRST WAVE (64 per step, carry in a register): a thread-0 loop is a
+// 64-deep dependent LDS chain (~1.5 us per prefix at M = 64)
+__device__ __forceinline__ void lds_exclusive_scan(const int *in, int *out, int M, int tid)
+{
+    if (tid >= 64) return;
+    int carry = 0;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const int m = m0 + tid;
+        const int v = m < M ? in[m] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (tid >= o) incl += t; }
+        if (m < M) out[m] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+template <int KSEL, int IB>
+__device__ __forceinline__ void som_select_keys(float px, float py, float pz, const float4 *nodes, int M, int (&bi)[KSEL])
+{
+    constexpr unsigned IMASK = (1u << IB) - 1u;
+    unsigned t[KSEL + 1];
+#pragma unroll
+    for (int s = 0; s <= KSEL; ++s) t[s] = 0xFFFFFFFFu;
+    const unsigned hi_mask = ~IMASK;
+    auto visit = [&](int m) {
+        unsigned key;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(__float_as_uint(sqdist(px, py, pz, nodes[m]))), "v"(hi_mask), "s"((unsigned)m));
+#pragma unroll
+        for (int s = KSEL; s >= 1; --s) {
+            unsigned md;
+            asm("v_med3_u32 %0, %1, %2, %3" : "=v"(md) : "v"(t[s - 1]), "v"(t[s]), "v"(key));
+            t[s] = md;
+        }
+        t[0] = key < t[0] ? key : t[0];
+    };
+    int m = 0;
+    for (; m + 8 <= M; m += 8) { visit(m); visit(m + 1); visit(m + 2); visit(m + 3); visit(m + 4); visit(m + 5); visit(m + 6); visit(m + 7); }
+    for (; m < M; ++m) visit(m);
+    bool exact = t[KSEL - 1] >= 0x7F800000u;                                // the list reaches +inf / NaN: the reference keeps id 0 there
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) {
+        bi[s] = (int)(t[s] & IMASK);
+        exact = exact || ((t[s] & ~IMASK) == (t[s + 1] & ~IMASK));         // a pair the truncation may have ordered by id instead of by distance
+    }
+    if (exact) {
+        float bd[KSEL];
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) { bd[s] = __builtin_inff(); bi[s] = 0; }
+        for (int mm = 0; mm < M; ++mm) {
+            const float d = sqdist(px, py, pz, nodes[mm]);
+            bool c[KSEL];
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) c[s] = d < bd[s];
+#pragma unroll
+            for (int s = KSEL - 1; s >= 1; --s) {
+                bd[s] = c[s - 1] ? bd[s - 1] : (c[s] ? d : bd[s]);
+                bi[s] = c[s - 1] ? bi[s - 1] : (c[s] ? mm : bi[s]);
+            }
+            bd[0] = c[0] ? d : bd[0];
+            bi[0] = c[0] ? mm : bi[0];
+        }
+    }
+}
+
+// (Two points per thread with the distances in packed f32 -- v_pk_add_f32 / v_pk_mul_f32, bit-identical node sets -- measured no
+// faster: 21.1 vs 19.5 us at B = 64; the scalar form stays.)
+// LDS (dynamic): float4 nodes[M] | int cnt[M] | int lstart[M] | float stage[3][KSEL * SP_T]
+template <int KSEL, int IB>
+__global__ __launch_bounds__(SP_THREADS) void som_assign_rank_kernel(
+    const float *__restrict__ x, const float *__restrict__ node, int N, int M, int nW,
+    int32_t *__restrict__ min32, int64_t *__restrict__ min64, uint16_t *__restrict__ rank16,
+    int32_t *__restrict__ cnt_part /*[B][nW][M]*/, double *__restrict__ sum_part /*[B][nW][3][M]*/)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *nodes = reinterpret_cast<float4 *>(smem);
+    int *cnt = reinterpret_cast<int *>(smem + (size_t)M * sizeof(float4));
+    int *lstart = cnt + M;
+    float *stage = reinterpret_cast<float *>(lstart + M);
+    constexpr int CAP = KSEL * SP_T;
+    const int tid = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *nb = node + (size_t)b * 3 * M;
+    for (int m = tid; m < M; m += SP_THREADS) {
+        nodes[m] = make_float4(nb[m], nb[M + m], nb[2 * M + m], 0.f);
+        cnt[m] = 0;
+    }
+    __syncthreads();
+    const size_t kN = (size_t)KSEL * N;
+    float pc[SP_PPT][3];
+    int bi[SP_PPT][KSEL], rk[SP_PPT][KSEL];
+#pragma unroll
+    for (int p = 0; p < SP_PPT; ++p) {
+        const int n = w * SP_T + p * SP_THREADS + tid;
+        if (n < N) {
+            pc[p][0] = xb[n]; pc[p][1] = xb[N + n]; pc[p][2] = xb[2 * (size_t)N + n];
+            som_select_keys<KSEL, IB>(pc[p][0], pc[p][1], pc[p][2], nodes, M, bi[p]);
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) {
+                rk[p][s] = atomicAdd(&cnt[bi[p][s]], 1);                    // the copy's rank among this workgroup's copies of the node
+                const size_t o = (size_t)b * kN + (size_t)s * N + n;
+                min32[o] = bi[p][s];
+                if (min64 != nullptr) min64[o] = bi[p][s];
+                rank16[o] = (uint16_t)rk[p][s];
+            }
+        }
+    }
+    __syncthreads();
+    lds_exclusive_scan(cnt, lstart, M, tid);                                // node starts of the workgroup-local order
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < SP_PPT; ++p) {
+        const int n = w * SP_T + p * SP_THREADS + tid;
+        if (n < N) {
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) {
+                const int slot = lstart[bi[p][s]] + rk[p][s];
+                stage[slot] = pc[p][0]; stage[CAP + slot] = pc[p][1]; stage[2 * CAP + slot] = pc[p][2];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * M; t += SP_THREADS) {                         // one thread per (coordinate, node): its run, in slot order
+        const int c = t / M, m = t - c * M;
+        const float *sp = stage + c * CAP + lstart[m];
+        const int len = cnt[m];
+        double acc = 0.0;
+        for (int i = 0; i < len; ++i) acc += (double)sp[i];
+        sum_part[(((size_t)b * nW + w) * 3 + c) * M + m] = acc;
+        if (c == 0) cnt_part[((size_t)b * nW + w) * M + m] = len;
+    }
+}
+
+// LDS (dynamic): double tsum[3][M] | float mean[3][M] | int noff[M] | int base[M] | int lstart[M] | int tot[M] | int mine[M]
+//                | int gpos[k * SP_T] | float buf[7][k * SP_T]
+__global__ __launch_bounds__(SP_THREADS) void som_sort_fill2_kernel(
+    const float *__restrict__ x, const float *__restrict__ sn, const int32_t *__restrict__ min32, const uint16_t *__restrict__ rank16,
+    const int32_t *__restrict__ cnt_part, const double *__restrict__ sum_part, int N, int M, int k, int nW,
+    int32_t *__restrict__ count, double *__restrict__ sum_ws, float *__restrict__ som_node, int32_t *__restrict__ row_max,
+    float *__restrict__ x_aug_sorted, int32_t *__restrict__ ids_sorted, int32_t *__restrict__ pos0, int32_t *__restrict__ node_off)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    double *tsum = reinterpret_cast<double *>(smem2);
+    float *mean = reinterpret_cast<float *>(tsum + 3 * M);
+    int *noff = reinterpret_cast<int *>(mean + 3 * M);
+    int *base = noff + M, *lstart = base + M, *tot = lstart + M, *mine = tot + M;
+    const int cap = k * SP_T;
+    int *gpos = mine + M;
+    float *buf = reinterpret_cast<float *>(gpos + cap);
+    const int tid = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
+    // totals over the cloud's workgroups, one thread per (quantity, node): quantity 0 = count (+ this workgroup's run start), 1-3 = sums
+    for (int t = tid; t < 4 * M; t += SP_THREADS) {
+        const int q = t / M, m = t - q * M;
+        if (q == 0) {
+            int tt = 0, bs = 0, mi = 0;
+            for (int ww = 0; ww < nW; ++ww) {                                // fixed order: the same totals in every workgroup of the cloud
+                const int c = cnt_part[((size_t)b * nW + ww) * M + m];
+                if (ww < w) bs += c;
+                if (ww == w) mi = c;
+                tt += c;
+            }
+            tot[m] = tt; base[m] = bs; mine[m] = mi;
+        } else {
+            double acc = 0.0;
+            for (int ww = 0; ww < nW; ++ww) acc += sum_part[(((size_t)b * nW + ww) * 3 + (q - 1)) * M + m];
+            tsum[(q - 1) * M + m] = acc;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * M; t += SP_THREADS) {
+        const int c = t / M, m = t - c * M;
+        const float denom = __fadd_rn((float)tot[m], 1e-5f);                 // networks.py:142
+        const float mv = __fdiv_rn((float)tsum[t], denom);
+        mean[t] = mv;
+        if (w == 0) {
+            if (som_node != nullptr) som_node[(size_t)b * 3 * M + t] = mv;
+            if (sum_ws != nullptr) sum_ws[(size_t)b * 3 * M + t] = tsum[t];
+            if (c == 0) {
+                if (row_max != nullptr) row_max[(size_t)b * M + m] = tot[m] > 0;
+                if (count != nullptr) count[(size_t)b * M + m] = tot[m];
+            }
+        }
+    }
+    lds_exclusive_scan(tot, noff, M, tid);                                   // node offsets of the sorted cloud (first wave)
+    if (tid >= 64 && tid < 128) lds_exclusive_scan(mine, lstart, M, tid - 64);   // this workgroup's local node order (second wave)
+    __syncthreads();
+    if (w == 0) for (int m = tid; m < M; m += SP_THREADS) node_off[(size_t)b * M + m] = noff[m];
+    const size_t kN = (size_t)k * N;
+    const float *xb = x + (size_t)b * 3 * N;
+    const float *snb = sn + (size_t)b * 3 * N;
+    int nloc = N - w * SP_T;
+    nloc = (nloc > SP_T ? SP_T : nloc) * k;                                  // copies of this workgroup
+#pragma unroll
+    for (int p = 0; p < SP_PPT; ++p) {
+        const int n = w * SP_T + p * SP_THREADS + tid;
+        if (n < N) {
+            float v[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v[c] = xb[(size_t)c * N + n]; v[3 + c] = snb[(size_t)c * N + n]; }
+            for (int s_ = 0; s_ < k; ++s_) {
+                const size_t o = (size_t)b * kN + (size_t)s_ * N + n;
+                const int m = min32[o], r = (int)rank16[o];
+                const int ls = lstart[m] + r;
+                const int g = noff[m] + base[m] + r;
+                gpos[ls] = g;
+                if (n == 0 && s_ == 0) pos0[b] = g;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { buf[c * cap + ls] = __fsub_rn(v[c], mean[c * M + m]); buf[(3 + c) * cap + ls] = v[3 + c]; }
+                buf[6 * cap + ls] = __int_as_float(m);
+            }
+        }
+    }
+    __syncthreads();
+    float *ob = x_aug_sorted + (size_t)b * 6 * kN;
+    for (int i = tid; i < nloc; i += SP_THREADS) {                           // consecutive lanes: consecutive positions of a node's run
+        const int g = gpos[i];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ob[(size_t)c * kN + g] = buf[c * cap + i];
+        ids_sorted[(size_t)b * kN + g] = __float_as_int(buf[6 * cap + i]);
+    }
+}
+
 }  // namespace
+
+extern "C" size_t sonet_som_assign_sort_ws_size(int B, int N, int M, int k)
+{
+    if (B <= 0 || N <= 0 || M <= 0 || k <= 0) return 0;
+    const size_t nW = (size_t)sonet::ceil_div(N, SP_T);
+    // sum_part f64 [B][nW][3][M] | cnt_part i32 [B][nW][M] | rank16 u16 [B][kN] (8-byte aligned blocks)
+    return (size_t)B * nW * 3 * M * 8 + (((size_t)B * nW * M * 4 + 7) & ~(size_t)7) + (((size_t)B * k * N * 2 + 7) & ~(size_t)7);
+}
+
+extern "C" int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                         int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                         float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                         int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream)
+{
+    const char *what = "sonet_som_assign_sort_f32";
+    SONET_REQUIRE(x && sn && node && min_idx_i32 && count && x_aug_sorted && ids_sorted && pos0 && node_off && ws, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && N > 0 && M > 0, "%s: non-positive size B=%d N=%d M=%d", what, B, N, M);
+    SONET_REQUIRE(k >= 1 && k <= SP_KMAX && k <= M, "%s: k=%d must be in [1, min(4, M=%d)]", what, k, M);
+    if (M > 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 1024 nodes", what, M);
+    if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
+    hipStream_t st = sonet::as_stream(stream);
+    const int nW = sonet::ceil_div(N, SP_T);
+    double *sum_part = reinterpret_cast<double *>(ws);
+    int32_t *cnt_part = reinterpret_cast<int32_t *>(sum_part + (size_t)B * nW * 3 * M);
+    uint16_t *rank16 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cnt_part) + (((size_t)B * nW * M * 4 + 7) & ~(size_t)7));
+    dim3 grid((unsigned)nW, (unsigned)B), block(SP_THREADS);
+    const size_t lds1 = (size_t)M * (sizeof(float4) + 2 * sizeof(int)) + (size_t)3 * k * SP_T * sizeof(float);
+    const size_t lds2 = (size_t)M * (3 * sizeof(double) + 3 * sizeof(float) + 5 * sizeof(int)) + (size_t)8 * k * SP_T * sizeof(float);
+#define SP_LAUNCH(KK) do { \
+        if (M <= 64) { if (lds1 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_assign_rank_kernel<KK, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what); \
+                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 6>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part); } \
+        else         { if (lds1 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_assign_rank_kernel<KK, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what); \
+                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 10>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part); } } while (0)
+    switch (k) { case 1: SP_LAUNCH(1); break; case 2: SP_LAUNCH(2); break; case 3: SP_LAUNCH(3); break; default: SP_LAUNCH(4); }
+#undef SP_LAUNCH
+    if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_sort_fill2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+        return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what);
+    hipLaunchKernelGGL(som_sort_fill2_kernel, grid, block, lds2, st, x, sn, min_idx_i32, rank16, cnt_part, sum_part, N, M, k, nW,
+                       count, sum_ws, som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off);
+    return sonet::launched(what);
+}
 
 extern "C" int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,
                                         const double *sum_ws, int B, int N, int M, int k, float *som_node, int32_t *row_max,

@@ -199,16 +199,21 @@ class Encoder(nn.Module):
         xd = x.detach().float().contiguous()
         sb = self.som_builder
         sb.node = node.detach().float().contiguous()                     # networks.py:124
-        a = sb.assign(xd, opt.k)                                         # :127-128 (ids, counts, sums)
         use_sn = bool(opt.surface_normal)
         snd = sn.detach().float().contiguous() if use_sn else None
         # (a head that reads first_pn_out densely -- the segmenter -- sets want_first_pn_out: one store-variant pass then)
         fused_pool = (use_sn and _ops.FUSE_POOL and not getattr(self, 'want_first_pn_out', False)
                       and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
-                      and a.k * a.N * 384 * 4 < 4e9)
+                      and int(opt.k) * xd.shape[2] * 384 * 4 < 4e9)
+        if fused_pool and M <= 1024 and 1 <= int(opt.k) <= min(4, M):
+            # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
+            a, g = _ops.som_assign_sort(xd, snd, sb.node, opt.k)
+            sb.last_assignment = a
+        else:
+            a = sb.assign(xd, opt.k)                                     # :127-128 (ids, counts, sums)
+            g = _ops.som_sort_group(xd, snd, a) if fused_pool else None
         if fused_pool:
-            # no-grad fast path: node-sorted grouping -> first PointNet + per-node max-pool in ONE kernel (:140-185)
-            g = _ops.som_sort_group(xd, snd, a)
+            # ... -> first PointNet + per-node max-pool in ONE kernel (:175-185)
             sb.node = g["som_node"]
             self.som_node = sb.node
             self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None, centers=None, x_decentered=None)

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sonet_index_max_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_index_max_gather_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sonet_som_assign_sort_ws_size": [_i, _i, _i, _i],
+    "sonet_som_assign_sort_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_mask_i32": [_vp, _vp, _i, _i, _i, _vp],
     "sonet_node_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -110,6 +112,7 @@ _RESTYPES = {
     "sonet_pointresnet_bf16_pool_ws_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
+    "sonet_som_assign_sort_ws_size": ctypes.c_size_t,
     "sonet_chamfer_nn2_ws_size": ctypes.c_size_t,
 }
 

@@ -193,6 +193,41 @@ def som_sort_group(x, sn, a):
     return out
 
 
+def som_assign_sort(x, sn, node, k, want_i64=False):
+    """som_assign + som_sort_group of the no-grad pooled path in two launches (``sonet_som_assign_sort_f32``): -> (SomAssignment,
+    dict(som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off, count)).  Node ids / counts bit-identical to the separate calls."""
+    _chk(x, "x", torch.float32, 3)
+    _chk(sn, "sn", torch.float32, 3)
+    _chk(node, "node", torch.float32, 3)
+    B, D, N = x.shape
+    if D != 3 or node.shape[0] != B or node.shape[1] != 3 or sn.shape != x.shape:
+        raise SonetHipError("x, sn must be B x 3 x N and node B x 3 x M, got %s, %s and %s" % (tuple(x.shape), tuple(sn.shape), tuple(node.shape)))
+    M = node.shape[2]
+    dev = _same_device(x, sn, node)
+    k = int(k)
+    kN = k * N
+    lib = _lib.load()
+    r = SomAssignment()
+    r.B, r.N, r.M, r.k = B, N, M, k
+    r.min_idx_i32 = torch.empty((B, kN), dtype=torch.int32, device=dev)
+    r.min_idx_i64 = torch.empty((B, kN), dtype=torch.int64, device=dev) if want_i64 else None
+    r.sum_ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev)
+    r.count = torch.empty((B, M), dtype=torch.int32, device=dev)
+    out = dict(som_node=torch.empty((B, 3, M), dtype=torch.float32, device=dev),
+               row_max=torch.empty((B, M), dtype=torch.int32, device=dev),
+               x_aug_sorted=torch.empty((B, 6, kN), dtype=torch.float32, device=dev),
+               ids_sorted=torch.empty((B, kN), dtype=torch.int32, device=dev),
+               pos0=torch.empty((B,), dtype=torch.int32, device=dev),
+               node_off=torch.empty((B, M), dtype=torch.int32, device=dev), count=r.count)
+    ws = torch.empty((lib.sonet_som_assign_sort_ws_size(B, N, M, k),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("som_assign_sort"):
+        check(lib.sonet_som_assign_sort_f32(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
+                                            ptr(r.sum_ws), ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
+                                            ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(ws), stream_ptr()),
+              "sonet_som_assign_sort_f32")
+    return r, out
+
+
 def som_mask(min_idx_i32, M):
     _chk(min_idx_i32, "min_idx", torch.int32, 2)
     dev = _same_device(min_idx_i32)

@@ -1003,3 +1003,38 @@ def test_pooled_wgrad_matches_dense_scatter_gemm():
     G.scatter_add_(2, pos.clamp_min(0).long(), (gp.double() * ok))
     ref = torch.bmm(G, x.double().transpose(1, 2)).sum(0)
     assert_close_rms(got.cpu().numpy(), ref.cpu().numpy(), 1e-5, "pooled wgrad")
+
+
+@pytest.mark.parametrize("B,N,M,k,kind", [(64, 5000, 64, 3, "som"), (3, 1024, 64, 3, "som"), (2, 333, 64, 3, "uniform"), (2, 40, 64, 1, "uniform"),
+                                          (1, 1, 64, 3, "uniform"), (2, 2500, 100, 2, "som"), (2, 1025, 16, 4, "uniform"), (1, 3000, 9, 3, "uniform")])
+def test_som_assign_sort_equals_the_separate_launches(B, N, M, k, kind):
+    """The two-launch SOM stage (sonet_som_assign_sort_f32) against som_assign + som_sort_group: node ids, counts, node means,
+    offsets bit-identical; the sorted copies are the same MULTISET per node (order inside a node is free); and the oracle's ids."""
+    from oracle import cpu_oracle as O
+    from sonet_hip import ops, synth
+    inp = synth.make_inputs(B, N, M=M, seed=31, node_kind=kind)
+    x, sn, node = inp["pc"].to(DEV), inp["sn"].to(DEV), inp["node"].to(DEV)
+    a0 = ops.som_assign(x, node, k)
+    g0 = ops.som_sort_group(x, sn, a0)
+    a1, g1 = ops.som_assign_sort(x, sn, node, k, want_i64=True)
+    assert torch.equal(a1.min_idx_i32, a0.min_idx_i32) and torch.equal(a1.min_idx_i64, a0.min_idx_i32.long())
+    assert torch.equal(a1.count, a0.count) and torch.equal(g1["row_max"], g0["row_max"]) and torch.equal(g1["node_off"], g0["node_off"])
+    np.testing.assert_allclose(a1.sum_ws.cpu().numpy(), a0.sum_ws.cpu().numpy(), rtol=1e-12, atol=1e-12)   # double sums, other order
+    assert torch.equal(g1["som_node"], g0["som_node"])
+    if B * N <= 64 * 1024:
+        np.testing.assert_array_equal(a1.min_idx_i32.cpu().numpy(), O.som_query_topk(inp["pc"], inp["node"], k)[0])
+    ids0, ids1 = g0["ids_sorted"].cpu().numpy(), g1["ids_sorted"].cpu().numpy()
+    np.testing.assert_array_equal(ids0, ids1)                        # (sorted by node: the id sequence itself is the same)
+    assert (np.diff(ids1, axis=1) >= 0).all()
+    xa0, xa1 = g0["x_aug_sorted"].cpu().numpy(), g1["x_aug_sorted"].cpu().numpy()
+    kN = k * N
+    for b in range(min(B, 3)):                                       # same multiset of 6-vectors inside every node
+        o0 = np.lexsort(tuple(xa0[b, c] for c in range(5, -1, -1)) + (ids0[b],))
+        o1 = np.lexsort(tuple(xa1[b, c] for c in range(5, -1, -1)) + (ids1[b],))
+        np.testing.assert_array_equal(xa0[b][:, o0], xa1[b][:, o1])
+    # pos0 = the sorted position of original copy 0: its six values and its node
+    p1 = g1["pos0"].cpu().numpy()
+    for b in range(B):
+        assert ids1[b, p1[b]] == int(a1.min_idx_i32[b, 0])
+        np.testing.assert_array_equal(xa1[b, 3:, p1[b]], inp["sn"][b, :, 0].numpy())
+    assert kN == ids1.shape[1]
