@@ -350,6 +350,11 @@ int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, in
  * partial 128 x 128 blocks over column slices are summed in a fixed order (deterministic).  ws = sonet_wgrad_x3_ws_size bytes. */
 size_t sonet_wgrad_x3_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
+/* bf16 twin (BASELINE configs[1] "bf16"): g [B][Cout][L], x [B][Cin][L] as bfloat16 bit patterns (16-byte aligned), one bf16 MFMA per
+ * product, f32 accumulation, f32 partial blocks over the same column slices, the same fixed-order reduction -> dw [Cout][Cin] f32.
+ * Replaces torch.bmm(g, x^T, out_dtype=f32).sum(0) (hipBLASLt) in the bf16 training step.  ws: sonet_wgrad_bf16_ws_size bytes. */
+size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L);
+int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
 
 /* out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_{i<NL} wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]);  z [B][C][M] = the
  * layer applied to the M node features once (sonet_pointmlp_h3_f32 with unit scale), gidx [B][L] i32 (out of range: 0),

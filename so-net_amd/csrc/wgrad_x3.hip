@@ -194,6 +194,112 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
         }
 }
 
+// ---- bf16 twin (BASELINE configs[1] "bf16": activations and gradients stored in bf16) --------------------------------------------
+// g [B][Cout][L], x [B][Cin][L] as bfloat16 bit patterns: ONE v_mfma_f32_32x32x16_bf16 per product, f32 accumulation, f32 partial
+// blocks, the same column slices and the same fixed-order reduction as above (a bf16 partial would cost three of the eight
+// significand bits).  No split work and a sixth of the matrix work: the kernel is a stream of 16-byte row loads (a lane's 8 bf16 of
+// one MFMA step) -- 2 bytes per element and pass -- with the g tiles handed round through LDS as in the f32 kernel.
+// Per loop iteration a lane holds 32 consecutive columns of its g row and of its x row (four 16-byte loads each = four MFMA
+// steps); the half-waves take alternate 8-column groups, which is a permutation of the reduction axis common to both operands.
+constexpr int WB_UNIT = 64;                                     // columns per loop iteration = four MFMA steps
+__device__ __forceinline__ void wb_load32(const uint16_t *__restrict__ row, bool row_ok, int l, int L, bool vec, uint4 (&v)[4]) {
+    // this lane's four 8-column groups: columns l + 16 q + [0, 8), q = 0..3 (l already carries the half-wave's 8-column offset)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c0 = l + 16 * q;
+        if (row_ok && vec && c0 + 8 <= L) {
+            v[q] = *reinterpret_cast<const uint4 *>(row + c0);
+        } else {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned val = (row_ok && c0 + e < L) ? (unsigned)row[c0 + e] : 0u;
+                w[e >> 1] |= val << (16 * (e & 1));
+            }
+            v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16_kernel(
+    const uint16_t *__restrict__ g, const uint16_t *__restrict__ x, float *__restrict__ partial,
+    int Cout, int Cin, int L, int nL /*64-column units per cloud*/, long long units /*B * nL*/, int nsplit, int oblocks, int cblocks)
+{
+    __shared__ uint4 apieces[2][4][4][64];                      // [buffer][g tile][step][lane]: 2 x 16 KiB
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int nblk = oblocks * cblocks;
+    const int blk = blockIdx.x % nblk, sp = blockIdx.x / nblk;
+    const int ob = blk / cblocks, cb = blk - ob * cblocks;
+    const long long u0 = units * sp / nsplit, u1 = units * (sp + 1) / nsplit;
+    const int o_row = ob * WG_BLK + wave * 32 + i, c_row = cb * WG_BLK + wave * 32 + i;
+    const bool o_ok = o_row < Cout, c_ok = c_row < Cin;
+    const bool vec = (L & 7) == 0;                              // 16-byte aligned 8-column groups
+    const int n_ot = FULL ? 4 : min(4, (Cout - ob * WG_BLK + 31) >> 5);
+    const bool c_tile = FULL || cb * WG_BLK + wave * 32 < Cin;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ot][r] = 0.f;
+
+    auto load_unit = [&](long long u, uint4 (&ra)[4], uint4 (&rb)[4]) {
+        const int b = (int)(u / nL);
+        const int l = (int)(u - (long long)b * nL) * WB_UNIT + 8 * h;
+        wb_load32(g + ((size_t)b * Cout + (o_ok ? o_row : 0)) * L, o_ok, l, L, vec, ra);
+        wb_load32(x + ((size_t)b * Cin + (c_ok ? c_row : 0)) * L, c_ok, l, L, vec, rb);
+    };
+    auto step_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // (not __syncthreads: it would drain the prefetch)
+
+    uint4 ra0[4], rb0[4], ra1[4], rb1[4], ra2[4], rb2[4];
+    if (u0 < u1) {
+        load_unit(u0, ra0, rb0);
+        if (u0 + 1 < u1) load_unit(u0 + 1, ra1, rb1);
+        int buf = 0;
+        // iteration: unit u in (ra_c, rb_c), unit u + 1 on its way into (ra_n, rb_n); requests unit u + 2 into (ra_f, rb_f)
+#define WB_ITER(u, ra_c, rb_c, ra_f, rb_f)                                                \
+        {                                                                                \
+            if ((u) + 2 < u1) load_unit((u) + 2, ra_f, rb_f);                            \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) apieces[buf][wave][q][lane] = ra_c[q]; \
+            step_barrier();                                                              \
+            if (FULL || c_tile) {                                                        \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                          \
+                    const bf16x8 Bq = __builtin_bit_cast(bf16x8, rb_c[q]);               \
+                    _Pragma("unroll") for (int ot = 0; ot < 4; ++ot)                     \
+                        if (FULL || ot < n_ot)                                           \
+                            acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, apieces[buf][ot][q][lane]), Bq, acc[ot], 0, 0, 0); \
+                }                                                                        \
+            }                                                                            \
+            buf ^= 1;                                                                    \
+        }
+        long long u = u0;
+        for (; u + 3 <= u1; u += 3) {
+            WB_ITER(u, ra0, rb0, ra2, rb2)
+            WB_ITER(u + 1, ra1, rb1, ra0, rb0)
+            WB_ITER(u + 2, ra2, rb2, ra1, rb1)
+        }
+        if (u < u1) {
+            WB_ITER(u, ra0, rb0, ra2, rb2)
+            if (u + 1 < u1) WB_ITER(u + 1, ra1, rb1, ra0, rb0)
+        }
+#undef WB_ITER
+    }
+    const int Cpad = cblocks * WG_BLK;
+    const size_t Opad = (size_t)oblocks * WG_BLK;
+    float *pp = partial + ((size_t)sp * Opad + (size_t)ob * WG_BLK) * Cpad + cb * WG_BLK + wave * 32 + i;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            pp[(size_t)orow * Cpad] = acc[ot][r];
+        }
+}
+
 // dw[o][c] = sum over the column slices, in a fixed order: thread (element e, kq) adds slices kq, kq + 4, ... with four independent
 // chains, the four quarters meet in LDS -- 64 elements per workgroup (a 64 x 6 gradient summed over 1024 slices is 384 elements:
 // one thread per element walking all slices took 270 us of dependent loads).
@@ -224,12 +330,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 struct WgPlan { int oblocks, cblocks, nL, nsplit; long long units; size_t ws_bytes; };
-static WgPlan wg_plan(int B, int Cout, int Cin, int L)
+static WgPlan wg_plan(int B, int Cout, int Cin, int L, int unit = WG_UNIT)
 {
     WgPlan p;
     p.oblocks = sonet::ceil_div(Cout, WG_BLK);
     p.cblocks = sonet::ceil_div(Cin, WG_BLK);
-    p.nL = sonet::ceil_div(L, WG_UNIT);
+    p.nL = sonet::ceil_div(L, unit);
     p.units = (long long)B * p.nL;
     const int nblk = p.oblocks * p.cblocks;
     long long ns = 1024 / nblk;                                 // ~ 4 workgroups per CU in total
@@ -263,6 +369,35 @@ extern "C" int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, voi
                            Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
     else
         hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
+                           Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, reinterpret_cast<const float *>(ws), dw,
+                       Cout, Cin, p.nsplit, (size_t)p.oblocks * WG_BLK, p.cblocks * WG_BLK);
+    return sonet::launched(what);
+}
+
+extern "C" size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L)
+{
+    if (B <= 0 || Cout <= 0 || Cin <= 0 || L <= 0) return 0;
+    return wg_plan(B, Cout, Cin, L, WB_UNIT).ws_bytes;
+}
+
+extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_wgrad_bf16";
+    SONET_REQUIRE(g && x && dw && ws, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && Cout > 0 && Cin > 0 && L > 0, "%s: non-positive size", what);
+    if ((double)Cout * L * 2.0 >= 8.0e9 || (double)Cin * L * 2.0 >= 8.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
+    if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return sonet::fail(SONET_ERR_INVALID_ARG, "%s: g and x must be 16-byte aligned", what);
+    const WgPlan p = wg_plan(B, Cout, Cin, L, WB_UNIT);
+    const long long nwg = (long long)p.oblocks * p.cblocks * p.nsplit;
+    if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
+    hipStream_t st = sonet::as_stream(stream);
+    if (Cout % WG_BLK == 0 && Cin % WG_BLK == 0)
+        hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
+                           Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
                            Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, reinterpret_cast<const float *>(ws), dw,

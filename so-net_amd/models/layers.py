@@ -127,6 +127,13 @@ def _wgrad(g_raw, x):
     batched hipBLASLt GEMM (K = L is the long axis); bf16 operands accumulate and come out in f32 (a bf16 per-cloud partial
     would cost three of the eight significand bits)."""
     if g_raw.dtype == torch.bfloat16:
+        if (_ops.WGRAD_KERNEL and g_raw.is_cuda and x.dtype == torch.bfloat16 and g_raw.shape[0] * g_raw.shape[2] <= 8192
+                and g_raw.shape[1] * x.shape[1] >= 256 * 128 and g_raw.shape[2] % 8 == 0):
+            # node-level layers (64 columns per cloud, wide outputs): sonet_wgrad_bf16 -- one bf16 MFMA per product, f32 partial blocks,
+            # fixed-order reduction -- 28 / 35 us against 73 / 79 us for the batched library GEMM + sum at 768x515 / 1024x768
+            # (tools/bench_wgrad_bf16.py).  On the point-level shapes (15000 columns per cloud) its 32-byte row segments reach 2.9 TB/s
+            # against the library's 4.1: those stay on hipBLASLt.
+            return _ops.wgrad_bf16(g_raw.contiguous(), x.contiguous())
         xt = x.transpose(1, 2)
         try:
             return torch.bmm(g_raw, xt, out_dtype=torch.float32).sum(0)

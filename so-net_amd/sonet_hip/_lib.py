@@ -63,6 +63,8 @@ SIGNATURES = {
     "sonet_pointmlp_h3_nodeadd_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "sonet_wgrad_x3_ws_size": [_i, _i, _i, _i],
     "sonet_wgrad_x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_wgrad_bf16_ws_size": [_i, _i, _i, _i],
+    "sonet_wgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -105,6 +107,7 @@ _RESTYPES = {
     "sonet_pointmlp_stats_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_bf16_stats_ws_size": ctypes.c_size_t,
     "sonet_wgrad_x3_ws_size": ctypes.c_size_t,
+    "sonet_wgrad_bf16_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_bf16_pack_size": ctypes.c_size_t,
     "sonet_pointresnet_pack_size": ctypes.c_size_t,

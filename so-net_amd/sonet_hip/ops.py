@@ -286,6 +286,26 @@ def wgrad_x3(g, x):
     return dw
 
 
+def wgrad_bf16(g, x):
+    """sum_b g[b] . x[b]^T for bfloat16 operands: g B x Cout x L, x B x Cin x L -> Cout x Cin f32 (one bf16 MFMA per product, f32
+    accumulation and partials, fixed-order reduction: ``sonet_wgrad_bf16``)."""
+    _chk(g, "g", torch.bfloat16, 3)
+    _chk(x, "x", torch.bfloat16, 3)
+    dev = _same_device(g, x)
+    B, Cout, L = g.shape
+    if x.shape[0] != B or x.shape[2] != L:
+        raise SonetHipError("wgrad_bf16: g B x Cout x L and x B x Cin x L")
+    Cin = x.shape[1]
+    lib = _lib.load()
+    dw = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    if g.numel() == 0 or x.numel() == 0:
+        return dw.zero_()
+    ws = torch.empty((lib.sonet_wgrad_bf16_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("wgradbf16_%dx%d_L%d" % (Cout, Cin, L)):
+        check(lib.sonet_wgrad_bf16(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_bf16")
+    return dw
+
+
 def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
     """act((z[:, :, gidx] + wl . lead) * scale + shift): z B x C x M (the layer on the M node features), gidx B x L i32 (out of
     range -> 0), lead B x NL x L (NL <= 4 per-column channels), wl C x NL.  -> B x C x L f32."""

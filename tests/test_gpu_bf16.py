@@ -450,3 +450,20 @@ def test_autoencoder_forward_bf16(case="autoencoder_b2_n1024"):
     assert_close_rms(feature.float().cpu().numpy(), g["feature"], BF16_TOL, "feature (bf16)")
     assert_close_rms(pred.float().cpu().numpy(), g["predicted_pc"], BF16_TOL, "predicted_pc (bf16)")
     assert abs(float(loss) - float(g["loss"])) <= BF16_TOL * float(g["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cout,Cin,L", [(3, 256, 128, 1504), (2, 64, 6, 776), (4, 128, 64, 64), (1, 512, 387, 1000), (2, 1024, 768, 136),
+                                          (2, 384, 320, 3000), (3, 40, 17, 777), (1, 32, 32, 8)])
+def test_wgrad_bf16_vs_float64(B, Cout, Cin, L):
+    """sonet_wgrad_bf16 (one bf16 MFMA per product, f32 accumulation) == sum_b g[b] x[b]^T in float64 on the SAME bf16 operands, to f32
+    rounding of the partial sums; ragged shapes (partial tiles, L not a multiple of 8 -> element-wise loads, short last unit)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B * 1000 + Cout + Cin + L)
+    gg = (torch.randn(B, Cout, L, generator=g) * 1e-3).to(torch.bfloat16).to(DEV)
+    xx = torch.randn(B, Cin, L, generator=g).to(torch.bfloat16).to(DEV)
+    got = ops.wgrad_bf16(gg, xx)
+    ref = torch.bmm(gg.double(), xx.double().transpose(1, 2)).sum(0)
+    assert tuple(got.shape) == (Cout, Cin)
+    assert_close_rms(got.cpu().numpy(), ref.cpu().numpy(), 2e-5, "wgrad bf16")
+    assert torch.equal(got, ops.wgrad_bf16(gg, xx))               # deterministic (fixed-order reduction)
