@@ -1,4 +1,6 @@
-// pointresnet_fused.hip -- the whole first PointNet of the encoder as ONE kernel (eval mode), third generation.
+// pointresnet_fused.hip -- the whole first PointNet of the encoder as ONE kernel (eval mode):
+// 64 points per wave, every weight fragment read from LDS feeds TWO MFMAs, activations pre-split once, and the accumulation
+// registers owned by hand.
 //
 // Replaces the four EquivariantLayer launches of PointResNet.forward (models/layers.py:419-432, built at
 // models/networks.py:82-83 as 6 -> 64 -> 128 -> 256 -> [64 + 256] -> 384 with BN + ReLU on the first three layers)
@@ -9,33 +11,38 @@
 // accumulation ("operand split" below).  Per accumulator the MFMA sequence (K chunk order, term order l, m, h) is the
 // one of the second-generation kernel, so the results are bit-identical to it.
 //
-// Work decomposition (what changed).  The second generation gave every wave its own 32 points and ALL channels: each
-// 1-KiB weight fragment read from LDS fed one MFMA per wave, every wave re-split layer 4's input in each of its passes
-// (4.9 VALU + 0.92 LDS instructions per MFMA), and a barrier every 36 MFMAs published the shared weight ring.  Here a
-// workgroup = 4 waves owns 64 consecutive points (two 32-column MFMA tiles c = 0, 1) and the waves split the OUTPUT
-// CHANNELS of layers 2-4:
-//   layer 1 (6 -> 64):    every wave computes it for all 64 points (12 MFMAs, 2 % redundant work) and keeps the result;
-//   layer 2 (64 -> 128):  wave w computes output tile w;             its input is the wave's own layer-1 result;
-//   layer 3 (128 -> 256): wave w computes output tiles 2w, 2w+1;     its input is layer 2 of all waves, through LDS;
-//   layer 4 (320 -> 384): wave w computes output tiles 3w .. 3w+2;   input: own layer 1 + layer 3 of all waves (LDS).
-// Activations are handed over PRE-SPLIT: when a wave's accumulators are complete they are turned once (BatchNorm affine +
-// ReLU + split: a "job" of 36 VALU instructions per 8 values) into the fp16 pieces (32 xh, fp16(32 xm)) that ARE the B
-// operand of the next layer, written to LDS in fragment layout (one ds_write_b128 per piece) and read back by every
-// wave with ds_read_b128: 4 KiB of B per K chunk feed 18 MFMAs (0.22 KiB per MFMA instead of 0.67-0.92).
-// Weights never touch LDS: every wave streams ONLY its own output tiles' fragments (a quarter of the stream, packed
-// wave-major in consumption order) from L2 straight into registers, two steps ahead of their use, and every fragment
-// feeds both column tiles.  Two barriers per 64-point tile (layer-2 and layer-3 hand-over) instead of 27 per 128.
+// What limits this kernel is the traffic of the WEIGHT STREAM per point, not the matrix pipe (measured: the same MFMAs with the
+// weight requests removed run in two thirds of the time, at a higher clock).  So a workgroup = 4 waves streams the weights ONCE
+// for 256 points: every wave owns 64 points (column tiles c = 0, 1) through all four layers, the stream goes through a 3-slot
+// LDS ring by LDS-DMA (one barrier per 72 MFMAs), and each fragment read from LDS feeds both column tiles.
 //
-// Software pipeline.  The short dependent front of a tile (x -> layer 1 -> job -> layer 2 -> job -> LDS) would leave the
-// matrix pipe idle, so the front of tile i+1 is computed INSIDE layer 4 of tile i (its 36 MFMAs and 12 jobs fill VALU
-// slots behind layer 4's MFMAs); the jobs of layer 3 ride behind the first four steps of layer 4 (which read the wave's
-// own layer-1 registers, not LDS).  Per tile and wave: barrier, layer 3 (96 MFMAs), layer 4 steps 0-3 + layer-3 jobs,
-// barrier, layer 4 steps 4-19 + front of the next tile, epilogue.
+// Registers.  64 points x 256 channels of layer-3 output are 256 registers per lane on their own, and hipcc cannot place that
+// beside everything else (every attempt spilled 200+ registers: it keeps VALU-produced MFMA operands in the 256 arch VGPRs).
+// The accumulation registers a[0:255] are therefore OWNED BY HAND (inline asm with literal register numbers): the accumulators of
+// layers 1-3 live there, and when a layer-3 tile is complete it is turned IN PLACE into the fp16 pieces (32 xh, fp16(32 xm)) that
+// are the B operand of layer 4 -- the same 32 bits per value.  The compiler keeps the 256 arch VGPRs: layer 4's accumulators (96),
+// the fragments, the pieces of layers 1 / 2.  Every MFMA is an asm statement; hipcc knows nothing about a[...] and pads no hazard
+// inside or behind an asm statement, so the build is audited (tools/check_fused_asm.py, run by the CPU tests and by build()):
+// no spill, no compiler access to the accumulation file, nothing touches an MFMA's VGPR destination while it is in flight.
+//   a[  0: 63]  layer-1 accumulators (2 tiles x 2 column tiles)      dead when layer 2 is done
+//   a[128:255]  layer-2 accumulators (4 x 2)                          their jobs end during layer 3's first tile group
+//   a[  0:255]  layer-3 accumulators (8 x 2), then its pre-split output, live through layer 4
+// Activations are split ONCE ("jobs": BatchNorm affine + ReLU + split, placed 4-5 at a time behind the MFMAs of later steps).
+// A lane holds 64 + 128 + 256 activation values per tile and has 512 registers: during layer 3, half of layer 2's output waits in
+// a 64 KiB lane-private LDS park, and layer 1 (12 of 1224 MFMAs) is simply run a second time after layer 3, its output parked in
+// the same space for the four passes of layer 4.
 //
 // Register chaining.  v_mfma_f32_32x32x16_f16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r
 // of lane l and consumes B[k = 8*(l>>5) + e][col = l&31], e = 0..7.  Registers 8q .. 8q+7 of an output tile therefore
 // ARE the B operand of a 16-channel chunk of the next layer, provided the next layer's weights are packed with the
 // matching channel order     k = 8h + e   <->   channel 32*t + 16*q + (e&3) + 8*(e>>2) + 4*h     ("chained" packing).
+//
+// Weights.  All four layers are packed (pointresnet_pack_kernel) into ONE linear stream of 1-KiB slices (64 lanes x
+// 8 fp16) in exactly the order the MFMAs consume them.  A STEP = one 16-channel K chunk x NT output tiles x 2 column
+// tiles = 6 NT MFMAs fed by 2 NT slices; a stage = 24 slices.
+//   L1: 1 step (NT 2),  L2: 4 steps (NT 4),  L3: 2 tile groups x 8 steps (NT 4),  L4: 4 passes x 20 steps (NT 3).
+// Workgroups are persistent (one per CU) and walk the 256-point tiles; the weight stream simply restarts (every tile
+// is 27 whole stages), and every step -- across layers, passes and tiles -- reads the NEXT step's fragments.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -49,19 +56,25 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int PF_THREADS = 256, PF_WAVES = 4;
-constexpr int TPTS = 64;                                       // points per workgroup tile (two column tiles)
+constexpr int WPTS = 64, TPTS = PF_WAVES * WPTS;              // points per wave / per workgroup tile
 constexpr int T0 = 2, T1 = 4, T2 = 8, T3 = 12;               // output tiles (x32 channels) of the four layers
 constexpr int KC2 = 2 * T0, KC3 = 2 * T1, KC4 = 2 * T0 + 2 * T2;   // 16-channel K chunks per layer
-constexpr int W2T = T1 / PF_WAVES, W3T = T2 / PF_WAVES, W4T = T3 / PF_WAVES;   // output tiles per wave: 1, 2, 3
-static_assert(W2T == 1 && W3T == 2 && W4T == 3, "the step code below is written for this split");
+constexpr int MT4 = 3, NPASS = T3 / MT4;                      // layer-4 cout tiles per accumulator pass
+constexpr int GS = 4;                                          // cout tiles per step in layers 2 and 3
+constexpr int NSTG = 24;                                       // slices per LDS stage
 constexpr int NTERM = 2;                                       // W slices per (cout tile, K chunk): h and l
-// the weight stream: [layer 1: 4 slices, shared][wave 0: L2 8, L3 32, L4 120][wave 1 ...] ...
-constexpr int NS_L1 = T0 * NTERM, NS_L2 = KC2 * W2T * NTERM, NS_L3 = KC3 * W3T * NTERM, NS_L4 = KC4 * W4T * NTERM;
-constexpr int NS_WAVE = NS_L2 + NS_L3 + NS_L4;
-constexpr int NSLICE = NS_L1 + PF_WAVES * NS_WAVE;
+constexpr int SL1 = 8 /* 4 used + 4 pad */, SL2 = KC2 * GS * NTERM, SL3 = (T2 / GS) * KC3 * GS * NTERM;
+constexpr int OFF1 = 0, OFF2 = SL1, OFF3 = SL1 + SL2, PRE = SL1 + SL2 + SL3;
+constexpr int SL4 = KC4 * MT4 * NTERM;                         // slices per layer-4 pass
+constexpr int NSLICE = PRE + NPASS * SL4;
+constexpr int NSTAGE = NSLICE / NSTG;
+static_assert(PRE % NSTG == 0 && SL4 % NSTG == 0 && NSLICE % NSTG == 0, "layer 4 and every pass start on a stage boundary");
+static_assert(NSTG % (NTERM * GS) == 0 && NSTG % (NTERM * MT4) == 0 && OFF2 % (NTERM * GS) == 0 && OFF3 % (NTERM * GS) == 0 && T1 == GS && T2 % GS == 0,
+              "a step never straddles a stage boundary");
+constexpr int NSW = NSTG / PF_WAVES;                           // slices staged per wave
+static_assert(NSW == 6, "three DMA statements per wave and stage");
 constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
 constexpr int LB1 = 0, LB2 = 32 * T0, LB3 = 32 * (T0 + T1), LB4 = 32 * (T0 + T1 + T2);
-constexpr int C4 = 32 * T3;                                    // 384 output channels
 
 // ---- fp32 -> 3 x fp16 operand split ------------------------------------------------------------------
 // x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; 32 * (a*b) is taken as
@@ -121,31 +134,68 @@ __device__ __forceinline__ float pin_res_hi(unsigned pk, float x32) { float r; a
 // range log: max over the post-affine, pre-clamp activations (x 32) as signed-int-ordered bits (positive side: what ReLU keeps)
 __device__ __forceinline__ int pin_max3_i32(int m, float a, float b) { int r; asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
 
+// ---- the accumulation registers, by literal number --------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ float agpr_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r) : "i"(N)); return r; }
+template <int N> __device__ __forceinline__ void agpr_write(unsigned v) { asm volatile("v_accvgpr_write_b32 a[%c0], %1" :: "i"(N), "v"(v)); }
+// accumulators of layers 1-3 in a[N:N+15]: D = A . B + (ZERO ? 0 : D).  (s_nop 1: the B operand may be a VGPR a VALU instruction of
+// the compiler's has just written -- hipcc pads nothing for the inside of an asm statement.)
+template <int N, bool ZERO> __device__ __forceinline__ void mfma_agpr(f16x8 a, f16x8 b) {
+    if constexpr (ZERO) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, 0" :: "v"(a), "v"(b), "i"(N), "i"(N + 15));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(N), "i"(N + 15));
+}
+// layer 4: accumulator in VGPRs (the compiler's), the activation operand either a VGPR piece or a[N:N+3]; SWAP: the activation is
+// the A operand (the accumulator tile comes out transposed: rows = points)
+template <bool ZERO, bool SWAP> __device__ __forceinline__ void mfma_vv(f32x16 &acc, f16x8 w, f16x8 x) {
+    if constexpr (ZERO) {
+        if constexpr (SWAP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %1, 0" : "=&v"(acc) : "v"(w), "v"(x));
+        else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x));
+    } else {
+        if constexpr (SWAP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(acc) : "v"(w), "v"(x));
+        else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    }
+}
+template <int N, bool SWAP> __device__ __forceinline__ void mfma_va(f32x16 &acc, f16x8 w) {
+    if constexpr (SWAP) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%c2:%c3], %1, %0" : "+v"(acc) : "v"(w), "i"(N), "i"(N + 3));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "i"(N), "i"(N + 3));
+}
+
 struct JobSc { float2 sc[8]; };                                // (scale, 32 shift) of the job's 8 channels
 struct JobOut { u32x4_t h, m; };
-struct JobX { float x[8]; };                                   // the 8 values in flight
-constexpr int JOB_OPS = 36;
-// op I of 36 = two groups of 18 (values 4g..4g+3, neighbours independent): affine x4, range max x2, relu+clamp x4,
-// 32xh x2 (cvt), residual x4, 32xm x2 (cvt).
-template <int Q, int I> __device__ __forceinline__ void job_op(const f32x16 &a, JobX &v, const JobSc &s, JobOut &o, int &rm) {
-    static_assert(I >= 0 && I < JOB_OPS, "");
-    constexpr int g = I / 18, k = I % 18, R = 8 * Q;
-    if constexpr (k < 4) { constexpr int e = 4 * g + k; v.x[e] = pin_fma(a[R + e], s.sc[e].x, s.sc[e].y); }
-    else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); rm = pin_max3_i32(rm, v.x[e], v.x[e + 1]); }
-    else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; v.x[e] = pin_relu_clamp32(v.x[e]); }
-    else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); o.h[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
-    else if constexpr (k < 16) { constexpr int e = 4 * g + (k - 12); v.x[e] = (e & 1) ? pin_res_hi(o.h[e >> 1], v.x[e]) : pin_res_lo(o.h[e >> 1], v.x[e]); }
-    else { constexpr int P = 2 * g + (k - 16); o.m[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
+struct JobX { float x[8]; unsigned h[4], m[4]; };              // the 8 values in flight and their pieces
+// A job works on a[R .. R+7] (registers 8Q..8Q+7 of an accumulator tile).  Op list: 8 reads (all of them first: the in-place form
+// writes its pieces over the values), then two groups of 18 (values 4g..4g+3, neighbours independent): affine x4, range max x2,
+// relu+clamp x4, 32xh x2 (cvt), residual x4, 32xm x2 (cvt); the in-place form ends with 8 writes (h -> a[R..R+3], m -> a[R+4..R+7]).
+constexpr int JOB_OPS_V = 44, JOB_OPS_A = 52;
+template <int R, bool INPLACE, int I> __device__ __forceinline__ void job_op(JobX &v, const JobSc &s, int &rm) {
+    static_assert(I >= 0 && I < (INPLACE ? JOB_OPS_A : JOB_OPS_V), "");
+    if constexpr (I < 8) { v.x[I] = agpr_read<R + I>(); }
+    else if constexpr (I < 44) {
+        constexpr int g = (I - 8) / 18, k = (I - 8) % 18;
+        if constexpr (k < 4) { constexpr int e = 4 * g + k; v.x[e] = pin_fma(v.x[e], s.sc[e].x, s.sc[e].y); }
+        else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); rm = pin_max3_i32(rm, v.x[e], v.x[e + 1]); }
+        else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; v.x[e] = pin_relu_clamp32(v.x[e]); }
+        else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); v.h[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
+        else if constexpr (k < 16) { constexpr int e = 4 * g + (k - 12); v.x[e] = (e & 1) ? pin_res_hi(v.h[e >> 1], v.x[e]) : pin_res_lo(v.h[e >> 1], v.x[e]); }
+        else { constexpr int P = 2 * g + (k - 16); v.m[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
+    } else {
+        constexpr int w = I - 44;
+        if constexpr (w < 4) agpr_write<R + w>(v.h[w]); else agpr_write<R + w>(v.m[w - 4]);
+    }
 }
-template <int Q, int I0, int I1> __device__ __forceinline__ void job_ops(const f32x16 &a, JobX &v, const JobSc &s, JobOut &o, int &rm) {
-    if constexpr (I0 < I1 && I0 < JOB_OPS) { job_op<Q, I0>(a, v, s, o, rm); job_ops<Q, I0 + 1, I1>(a, v, s, o, rm); }
+template <int R, bool INPLACE, int I0, int I1> __device__ __forceinline__ void job_ops(JobX &v, const JobSc &s, int &rm) {
+    if constexpr (I0 < I1 && I0 < (INPLACE ? JOB_OPS_A : JOB_OPS_V)) { job_op<R, INPLACE, I0>(v, s, rm); job_ops<R, INPLACE, I0 + 1, I1>(v, s, rm); }
+}
+__device__ __forceinline__ JobOut job_result(const JobX &v) {
+    JobOut o;
+    o.h[0] = v.h[0]; o.h[1] = v.h[1]; o.h[2] = v.h[2]; o.h[3] = v.h[3];
+    o.m[0] = v.m[0]; o.m[1] = v.m[1]; o.m[2] = v.m[2]; o.m[3] = v.m[3];
+    return o;
 }
 
 // compile-time loop: f(integral_constant<int, i>) for i in [I0, I1)
 template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
 }
-template <int V> using IC = std::integral_constant<int, V>;
 #define SFOR(var, N) static_for<0, (N)>([&](auto var##_c_) __attribute__((always_inline)) { constexpr int var = decltype(var##_c_)::value;
 #define SEND });
 
@@ -162,42 +212,55 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
     const int i = lane & 31, h = lane >> 5;
     const float *W = nullptr;
     int Cin = 0, ct = 0, kc = 0, term = 0;
-    bool chained = true;
-    if (s < NS_L1) {                      // L1: 2 tiles x 1 chunk, standard channel order (the input comes from memory)
-        term = s % NTERM; ct = s / NTERM; kc = 0; W = W1; Cin = Cin0; chained = false;
-    } else {                              // per wave: consumption order = K chunk, then the wave's tiles, then the split term
-        const int w = (s - NS_L1) / NS_WAVE, r = (s - NS_L1) % NS_WAVE;
-        if (r < NS_L2) {
-            term = r % NTERM; kc = r / (NTERM * W2T); ct = w * W2T + (r / NTERM) % W2T; W = W2; Cin = 32 * T0;
-        } else if (r < NS_L2 + NS_L3) {
-            const int u = r - NS_L2; term = u % NTERM; kc = u / (NTERM * W3T); ct = w * W3T + (u / NTERM) % W3T; W = W3; Cin = 32 * T1;
-        } else {
-            const int u = r - NS_L2 - NS_L3; term = u % NTERM; kc = u / (NTERM * W4T); ct = w * W4T + (u / NTERM) % W4T; W = W4; Cin = 32 * (T0 + T2);
+    bool chained = true, valid = true;
+    // consumption order: per layer, tile-group major, then K chunk, then tile within the group, then split term
+    if (s < OFF2) {                       // L1: 2 tiles x 1 chunk, standard channel order (input comes from memory)
+        const int u = s - OFF1; term = u % NTERM; kc = 0; ct = u / NTERM; W = W1; Cin = Cin0; chained = false; valid = u < T0 * NTERM;
+    } else if (s < OFF3) {
+        const int u = s - OFF2; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC2;
+        ct = (u / (NTERM * GS * KC2)) * GS + mt; W = W2; Cin = 32 * T0;
+    } else if (s < PRE) {
+        const int u = s - OFF3; term = u % NTERM; const int mt = (u / NTERM) % GS; kc = (u / (NTERM * GS)) % KC3;
+        ct = (u / (NTERM * GS * KC3)) * GS + mt; W = W3; Cin = 32 * T1;
+    } else {                              // L4: pass-major, then chunk-major, MT4 tiles per chunk
+        const int u = (s - PRE) % SL4, pass = (s - PRE) / SL4;
+        term = u % NTERM; ct = pass * MT4 + (u / NTERM) % MT4; kc = u / (NTERM * MT4); W = W4; Cin = 32 * (T0 + T2);
+    }
+    unsigned w[4] = {0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float v[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const int e = 2 * p + z;
+                const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
+                v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
+            }
+            range_track(wr, v[0], v[1]);
+            // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
+            const unsigned hh = cvt_pk_f16(v[0], v[1]);
+            const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
+            w[p] = term == 0 ? hh : ll;
         }
     }
-    unsigned w4[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        float v[2];
-#pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            const int e = 2 * p + z;
-            const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
-            v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
-        }
-        range_track(wr, v[0], v[1]);
-        // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
-        const unsigned hh = cvt_pk_f16(v[0], v[1]);
-        const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
-        w4[p] = term == 0 ? hh : ll;
-    }
-    out[(long long)s * 64 + lane] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    out[(long long)s * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| over the four layers (range log, word 1)
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------
+// LDS ring of NSLOT = 3 stages of W (24 KiB each), filled by LDS-DMA.  While stage n is consumed, stage n+1 is
+// resident and published (the last step of a stage reads the A fragments of the next stage's first step from it)
+// and stage n+2 is landing in the slot stage n-1 occupied.  Boundary(n), run by every wave at the first step of
+// stage n:   s_waitcnt vmcnt(0) (this wave's pieces of stage n+1 have landed);  barrier;  issue stage n+2.
+constexpr int NSLOT = 3;
+
+
+struct AF { f16x8 h[GS], l[GS]; };                            // A fragments of one step (up to GS tiles x 2 slices)
+
 // SEGMAX = the per-node max-pool epilogue (see below) instead of the y stores; x must then be node-sorted.
-constexpr int SEG_SLOTS = 4;                                  // nodes of a 64-point tile pre-reduced in LDS (the rest: global atomics)
+constexpr int SEG_SLOTS = 16;                                 // nodes of a 256-point tile pre-reduced in LDS (the rest: global atomics)
+constexpr int PCH = 32 * MT4;                                 // channels per layer-4 pass
 constexpr unsigned SEG_INIT = 0x3B85FFFFu;                    // orderable(-1000.0f): the reference's initial running max
 
 __device__ __forceinline__ unsigned ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
@@ -211,32 +274,45 @@ constexpr int PROF_N = 32;
 __device__ long long g_prof[1024 * PROF_N];
 #define PROF_DECL long long prof_[PROF_N] = {}; const long long prof_rt0_ = (long long)__builtin_amdgcn_s_memrealtime(); long long prof_t_ = __builtin_readcyclecounter();
 #define PROF_MARK(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
+#define PROF_T0 long long pt_ = __builtin_readcyclecounter();
+#define PROF_T1(i) { const long long n_ = __builtin_readcyclecounter(); prof_[i] += n_ - pt_; pt_ = n_; }
 #define PROF_DUMP prof_[31] = (long long)__builtin_amdgcn_s_memrealtime() - prof_rt0_; /* 100 MHz constant clock */ if (lane == 0) { for (int i_ = 0; i_ < PROF_N; ++i_) g_prof[(blockIdx.x * PF_WAVES + wave) * PROF_N + i_] = prof_[i_]; }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
+#define PROF_T0
+#define PROF_T1(i)
 #define PROF_DUMP
 #endif
 
 #define PF_SB __builtin_amdgcn_sched_barrier(0);
-
-// A fragments of one step: up to 3 output tiles x (h, l)
-struct AF { f16x8 h[W4T], l[W4T]; };
+#define PF_LDA(base, slice) __builtin_bit_cast(f16x8, (base)[(slice) * 64])
+// first accumulation register of the accumulator tile (t, c) of layers 1 / 3 (a[0:...]) and of layer 2 (a[128:255])
+#define AG13(t, c) ((((t) * 2) + (c)) * 16)
+#define AG2(t, c) (128 + (((t) * 2) + (c)) * 16)
+// the whole accumulation file belongs to the asm statements of this kernel: naming it once makes the kernel descriptor allocate it
+#define PF_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define PF_CLAIM_AGPRS asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", PF_A8(1), PF_A8(2), PF_A8(3), PF_A8(4), PF_A8(5), \
+        PF_A8(6), PF_A8(7), PF_A8(8), PF_A8(9), PF_A8(10), PF_A8(11), PF_A8(12), PF_A8(13), PF_A8(14), PF_A8(15), PF_A8(16), PF_A8(17), PF_A8(18), PF_A8(19), \
+        PF_A8(20), PF_A8(21), PF_A8(22), PF_A8(23), PF_A8(24), "a250", "a251", "a252", "a253", "a254", "a255");
 
 template <bool SEGMAX>
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
-    const float *__restrict__ x, int Cin0, const u32x4_t *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
-    float *__restrict__ y, int L, int tpc /*64-point tiles per cloud*/, long long ntiles,
+    const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
+    float *__restrict__ y, int L, int tpc /*256-point tiles per cloud*/, long long ntiles,
     const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0, unsigned *__restrict__ pooled, float *__restrict__ v0, int M,
-    unsigned *__restrict__ partial /*[ntiles][SEG_SLOTS][384] keys of the tile's first SEG_SLOTS nodes*/,
+    unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][PCH] keys of the tile's first SEG_SLOTS nodes*/,
     unsigned *__restrict__ rlog /*optional range-log slot: [0] max |x in|, [1] max |w|, [2] max post-affine input of layers 2-4 (bits)*/)
 {
-    // activations in B-fragment layout: [16-channel chunk][column tile][piece h, m][lane] x 16 bytes
-    __shared__ u32x4_t act2s[KC3][2][2][64];                   // layer-2 output, 32 KiB
-    __shared__ u32x4_t act3s[2 * T2][2][2][64];                // layer-3 output, 64 KiB
+    __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 24 KiB
+    // 64 KiB lane-private parking space, [wave][chunk][column tile][piece h / m][lane]: chunks 0-3 of layer 2's output between the
+    // two tile groups of layer 3, then the four chunks of layer 1's output for the passes of layer 4
+    __shared__ u32x4_t park[PF_WAVES][KC2][2][2][64];
+    __shared__ uint4 w1s[T0 * NTERM][64];                      // layer 1's weight slices, resident (layer 1 runs twice per tile, see below)
     __shared__ __attribute__((aligned(16))) float2 aff[CH_TOTAL];
-    __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? C4 : 1];
+    __shared__ unsigned bins[SEGMAX ? SEG_SLOTS : 1][SEGMAX ? PCH : 1];
 
+    PF_CLAIM_AGPRS
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -249,488 +325,585 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         if (c >= LB4 && v.x != 1.0f) l4_unit_lane = false;
     }
     if constexpr (SEGMAX) {
-        for (int i = threadIdx.x; i < SEG_SLOTS * C4; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
+        for (int i = threadIdx.x; i < SEG_SLOTS * PCH; i += PF_THREADS) (&bins[0][0])[i] = SEG_INIT;
     }
+    static_assert(T0 * NTERM * 64 == PF_THREADS, "one 16-byte piece of layer 1's slices per thread");
+    w1s[threadIdx.x >> 6][threadIdx.x & 63] = Wst[OFF1 * 64 + threadIdx.x];
     const bool l4_unit = __syncthreads_and(l4_unit_lane) != 0;   // then max(x + b) = max(x) + b exactly: bias after the pool
     PROF_DECL
 
+    unsigned vow = (unsigned)lane * 16u;                        // (not const: a const local is not captured by a generic lambda)
     const unsigned rowB = (unsigned)L * 4u;
-    // this wave's part of the weight stream (lane-linear 16-byte fragments), read through buffer descriptors: the lane
-    // offset is ONE VGPR, every slice offset a scalar / immediate (with flat pointers hipcc hoists a 64-bit VGPR address
-    // per fragment out of the tile loop: 300+ registers)
-    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4_t *>(Wst), 0, NS_L1 * 1024, 0x00020000);
-#ifdef SONET_ABL_SAMEW                                          // experiment: every wave reads wave 0's stream (L1 hits)
-    const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4_t *>(Wst) + (size_t)NS_L1 * 64, 0, NS_WAVE * 1024, 0x00020000);
-#else
-    const __amdgpu_buffer_rsrc_t rww = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<u32x4_t *>(Wst) + (size_t)(NS_L1 + wave * NS_WAVE) * 64, 0, NS_WAVE * 1024, 0x00020000);
-#endif
-    const unsigned vow = (unsigned)lane * 16u;
-#ifndef SONET_WAUX
-#define SONET_WAUX 0
-#endif
-#define PF_WLOAD(rsrc, slice) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vow, (unsigned)(slice) * 1024u, SONET_WAUX))
-#ifdef SONET_ABL_NOW                                            // experiment: the main steps keep their first fragments (no weight traffic)
-#define PF_WLOAD_MAIN(rsrc, slice) f_keep_
-#else
-#define PF_WLOAD_MAIN(rsrc, slice) PF_WLOAD(rsrc, slice)
-#endif
-    constexpr int WO2 = 0, WO3 = NS_L2, WO4 = NS_L2 + NS_L3;     // slice offsets of layers 2-4 in the wave's stream
-    u32x4_t *const act2w = &act2s[0][0][0][lane];               // + ((chunk * 2 + c) * 2 + piece) * 64
-    u32x4_t *const act3w = &act3s[0][0][0][lane];
-#define PF_ACT(base, chunk, c, piece) (base)[(((chunk) * 2 + (c)) * 2 + (piece)) * 64]
 
-    // ---- the main steps: global step g = 0..7 layer 3 (K chunk g, tiles 2w, 2w+1), g = 8..27 layer 4 (K chunk g - 8,
-    // tiles 3w..3w+2).  A fragments live in a ring af[g % AFD]; step g starts by requesting the fragments of step g + AFD - 1
-    // into the buffer step g - 1 has just read (with 4 waves pulling 6 KiB each per step the texture path is ~2/3 busy: a
-    // request issued one step ahead arrives late).
-#ifndef SONET_AFD
-#define SONET_AFD 4
-#endif
-    constexpr int AFD = SONET_AFD;                               // fragment buffers; step g reads af[g % AFD], refilled AFD - 1 steps ahead
-    static_assert((KC3 + KC4) % AFD == 0, "the buffer of a step must not depend on the tile");
-    AF af[AFD];
-    // fragment i of global step g (wraps: next tile): i < NT the `l` slices, then the `h` slices
-    auto load_frag = [&](auto gc, auto ic, AF &f) __attribute__((always_inline)) {
-        constexpr int g = decltype(gc)::value % (KC3 + KC4), i = decltype(ic)::value;
-        const f16x8 f_keep_ = f.l[0]; (void)f_keep_;
-        if constexpr (g < KC3) {
-            if constexpr (i < W3T) f.l[i] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * i + 1);
-            else if constexpr (i < 2 * W3T) f.h[i - W3T] = PF_WLOAD_MAIN(rww, WO3 + g * NTERM * W3T + NTERM * (i - W3T));
-        } else {
-            if constexpr (i < W4T) f.l[i] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * i + 1);
-            else if constexpr (i < 2 * W4T) f.h[i - W4T] = PF_WLOAD_MAIN(rww, WO4 + (g - KC3) * NTERM * W4T + NTERM * (i - W4T));
+    // The W stream goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1 KiB slice per wave instruction,
+    // lane-linear, which is exactly the slice layout): no staging VGPRs and no ds_write pass.  hipcc does not see
+    // these loads; their completion is counted by hand (vmcnt(0) before the barrier that publishes the stage).
+    const unsigned wsm_lds = (unsigned)reinterpret_cast<size_t>(&wsm[0][0]);
+    const char *dma_g = nullptr;                                // this wave's NSW slices of the stage being streamed
+    unsigned dma_dst = 0;
+    auto dma_setup = [&](int n, int slot) __attribute__((always_inline)) {   // stream stage n (wraps: the stream restarts per tile)
+        const int sn = n % NSTAGE;
+        dma_g = reinterpret_cast<const char *>(Wst) + (size_t)(sn * NSTG + wave * NSW) * 1024u;
+        dma_dst = wsm_lds + (unsigned)(slot * NSTG + wave * NSW) * 1024u;
+    };
+    // pieces t and t+1 (t even) of the wave's NSW = 6: they share an M0 / base pair, the instruction offset moves both
+    // the global and the LDS address.  (M0 is written in the statement that uses it and not restored: nothing else
+    // in this kernel reads it.)  s_nop 4: an SGPR the compiler restored with v_readlane right in front of the statement
+    // needs 5 wait states before a VMEM instruction reads it (tools/check_dma_hazard.py).
+    auto dma_pair = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const char *g = dma_g + (t / 4) * 4096;
+        const unsigned d = dma_dst + (unsigned)(t / 4) * 4096u;
+        const unsigned vv = vow;                                   // (an asm operand alone does not make a generic lambda capture it)
+        if constexpr ((t % 4) == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(vv), "s"(g), "s"(d) : "memory");
+        else                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(vv), "s"(g), "s"(d) : "memory");
+    };
+    auto stage_dma = [&](int n, int slot) __attribute__((always_inline)) {
+        dma_setup(n, slot);
+        dma_pair(std::integral_constant<int, 0>{}); dma_pair(std::integral_constant<int, 2>{}); dma_pair(std::integral_constant<int, 4>{});
+    };
+    // ring state (wave-uniform scalars)
+    int n_cur = 0;                                              // stage being consumed
+    int slot_cur = 0, slot_nxt = 1, slot_fill = 2;
+    stage_dma(0, 0);
+    stage_dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // stages 0 and 1 are published (stage 0 is read cold)
+    const uint4 *lds_cur = &wsm[slot_cur * NSTG][lane];
+    const uint4 *lds_nxt = &wsm[slot_nxt * NSTG][lane];
+    bool first_boundary = true;
+    int pend_n = 0;
+    // SEGMAX: partial-maxima block whose LDS bins are still to be stored (at the first stage boundary AFTER the pass,
+    // between the barrier -- all lanes have published -- and the next W loads: the stores are older than those loads,
+    // so the vmcnt wait that the next boundary needs anyway covers them a whole stage later).
+    unsigned *pend = partial;
+    auto flush_bins = [&]() __attribute__((always_inline)) {
+        for (int e = threadIdx.x; e < pend_n; e += PF_THREADS) {         // only the slots the tile's nodes occupy
+            unsigned *bp = &bins[0][0] + e;
+            pend[e] = *bp;
+            *bp = SEG_INIT;
         }
     };
-#define PF_MFMA(ACCE, A_, B_, ZEROC, SWAPC)                                                              \
+    auto boundary = [&](auto flushc) __attribute__((always_inline)) {
+        constexpr bool flush = decltype(flushc)::value;
+        PROF_T0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the stage issued one boundary ago have landed
+        PROF_T1(28)
+        // a bare s_barrier, not __syncthreads(): that one waits for lgkmcnt(0) first, i.e. for the fragment reads the step before has
+        // just issued -- an LDS round trip exposed 27 times per tile.  Nothing read from LDS is shared between waves except the
+        // stage being published (written by DMA: vmcnt above) and the pool bins (the pass boundaries wait for their atomics).
+        if constexpr (SEGMAX && flush) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                          // (the intrinsic alone does not order the compiler's memory operations)
+        PROF_T1(29)
+        if (!first_boundary) {                                  // rotate: the stage just finished becomes the fill slot
+            n_cur += 1;
+            const int t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_fill; slot_fill = t;
+        }
+        first_boundary = false;
+        lds_cur = &wsm[slot_cur * NSTG][lane];
+        lds_nxt = &wsm[slot_nxt * NSTG][lane];
+        if constexpr (SEGMAX && flush) flush_bins();
+        dma_setup(n_cur + 2, slot_fill);                        // lands during this stage, published at the next boundary
+    };
+
+    // ---- one STEP: a 16-channel K chunk x NT output tiles x 2 column tiles = 6 NT MFMAs, hand-scheduled
+    // (sched_barrier after every MFMA: with one wave per SIMD nothing else hides a latency):
+    //  - on entry af.l / af.h hold this step's fragments (read by the step before) and BL0 / BL1 the derived B piece l;
+    //  - a step that opens a stage takes the boundary first and issues its NSW slices between its first MFMAs;
+    //  - term order (A.l, B.l), (A.h, B.m), (A.h, B.h) per accumulator; the freed `l` registers take the NEXT step's `l`
+    //    fragments after the second term, `h` likewise after the third (they land under the next step's first term);
+    //  - `SLOT(q)` places the VALU work of the step (jobs, next step's B piece l) behind MFMA q.
+    // PF_STEP_A: layers 1-3, accumulators a[AGB(u, c) ...], B pieces in VGPRs.  PF_STEP_V: layer 4, accumulators ACC(u, c) in VGPRs,
+    // B pieces h / m either VGPRs (FROMA false: the parked layer-1 chunk) or a[HN + 128 c', ...] (layer 3's pre-split output).
+    AF af;
+#define PF_STEP_HEAD(SIDX, SIDXN, FLUSH)                                                                 \
+        constexpr int so_ = (SIDX) % NSTG, son_ = (SIDXN) % NSTG;                                        \
+        if constexpr (so_ == 0) boundary(std::integral_constant<bool, (FLUSH)>{});                       \
+        const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;
+#define PF_STEP_A(NT, SIDX, NTN, SIDXN, AGB, BH0, BM0, BL0, BH1, BM1, BL1, ZERO, SLOT)                   \
     {                                                                                                    \
-        if constexpr (ZEROC) {                                                                           \
-            const f32x16 cz_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-            if constexpr (SWAPC) ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(B_, A_, cz_, 0, 0, 0);    \
-            else ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, cz_, 0, 0, 0);                    \
-        } else {                                                                                         \
-            if constexpr (SWAPC) ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(B_, A_, ACCE, 0, 0, 0);   \
-            else ACCE = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACCE, 0, 0, 0);                   \
-        }                                                                                                \
-    }
-    // One STEP = a 16-channel K chunk x NT output tiles x 2 column tiles = 6 NT MFMAs, hand-scheduled (sched_barrier
-    // after every MFMA: with one wave per SIMD nothing else hides a latency).  Term order (A.l, B.l), (A.h, B.m),
-    // (A.h, B.h) per accumulator; SLOT(q) places VALU / LDS work behind MFMA q; G = global step (fragment refills).
-#define PF_REQ(G, NT, qq)                                        /* 6 NT MFMAs, up to 6 fragments: one behind every NT-th */ \
-    {                                                                                                    \
-        if constexpr ((G) >= 0 && (qq) % (NT) == 0) {                                                    \
-            constexpr int gn_ = ((G) >= 0 ? (G) : 0) + AFD - 1;                                          \
-            load_frag(IC<gn_>{}, IC<(qq) / (NT)>{}, af[gn_ % AFD]);                                      \
-        }                                                                                                \
-    }
-#define PF_STEP(NT, G, FR, ACC, BH0, BM0, BL0, BH1, BM1, BL1, ZERO, SWAP, SLOT)                          \
-    {                                                                                                    \
+        PF_STEP_HEAD(SIDX, SIDXN, false)                                                                 \
         const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
-        /* ONE weight request behind every NT-th MFMA (the fragments of step G + AFD - 1, into the buffer the previous step */ \
-        /* read): a wave issues in order, and a burst of requests holds its MFMAs back while the texture unit takes them    */ \
         PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
-            PF_MFMA(ACC(u, c), FR.l[u], bl_[c], (ZERO), (SWAP))                                          \
-            PF_REQ((G), (NT), q)                                                                               \
+            mfma_agpr<AGB(u, c), (ZERO)>(af.l[u], bl_[c]);                                               \
+            if constexpr (so_ == 0 && q < 3) dma_pair(std::integral_constant<int, 2 * q>{});             \
             SLOT(q)                                                                                      \
             PF_SB                                                                                        \
         SEND                                                                                             \
-        PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
-            PF_MFMA(ACC(u, c), FR.h[u], bm_[c], false, (SWAP))                                           \
-            PF_REQ((G), (NT), 2 * (NT) + q)                                                                    \
+            mfma_agpr<AGB(u, c), false>(af.h[u], bm_[c]);                                                \
             SLOT(2 * (NT) + q)                                                                           \
             PF_SB                                                                                        \
         SEND                                                                                             \
+        SFOR(u, NTN) af.l[u] = PF_LDA(nb_, son_ + NTERM * u + 1); SEND                                   \
+        PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
-            PF_MFMA(ACC(u, c), FR.h[u], bh_[c], false, (SWAP))                                           \
-            PF_REQ((G), (NT), 4 * (NT) + q)                                                                    \
+            mfma_agpr<AGB(u, c), false>(af.h[u], bh_[c]);                                                \
             SLOT(4 * (NT) + q)                                                                           \
             PF_SB                                                                                        \
         SEND                                                                                             \
+        SFOR(u, NTN) af.h[u] = PF_LDA(nb_, son_ + NTERM * u); SEND                                       \
         PF_SB                                                                                            \
     }
-    // (scale, 32 shift) of the 8 channels of a job: channels CH + (e&3) + 8(e>>2), CH = layer base + 32 tile + 16 Q + 4 h
-#define PF_LOAD_SC(scv, CH)                                                                              \
+#define PF_STEP_V(SIDX, SIDXN, ACC, FROMA, HN0, HN1, BH0, BM0, BH1, BM1, BL0, BL1, ZERO, FLUSH, SLOT)    \
     {                                                                                                    \
-        const float4 *ap_ = reinterpret_cast<const float4 *>(&aff[(CH)]);                                \
+        PF_STEP_HEAD(SIDX, SIDXN, FLUSH)                                                                 \
+        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
+        constexpr int hn_[2] = {(HN0), (HN1)};                                                           \
+        PF_SB                                                                                            \
+        SFOR(q, 2 * MT4) constexpr int c = q / MT4, u = q % MT4;                                         \
+            mfma_vv<(ZERO), SEGMAX>(ACC(u, c), af.l[u], bl_[c]);                                         \
+            if constexpr (so_ == 0 && q < 3) dma_pair(std::integral_constant<int, 2 * q>{});             \
+            SLOT(q)                                                                                      \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        SFOR(q, 2 * MT4) constexpr int c = q / MT4, u = q % MT4;                                         \
+            if constexpr (FROMA) mfma_va<hn_[c] + 4, SEGMAX>(ACC(u, c), af.h[u]);                        \
+            else mfma_vv<false, SEGMAX>(ACC(u, c), af.h[u], bm_[c]);                                     \
+            SLOT(2 * MT4 + q)                                                                            \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        SFOR(u, MT4) af.l[u] = PF_LDA(nb_, son_ + NTERM * u + 1); SEND                                   \
+        PF_SB                                                                                            \
+        SFOR(q, 2 * MT4) constexpr int c = q / MT4, u = q % MT4;                                         \
+            if constexpr (FROMA) mfma_va<hn_[c], SEGMAX>(ACC(u, c), af.h[u]);                            \
+            else mfma_vv<false, SEGMAX>(ACC(u, c), af.h[u], bh_[c]);                                     \
+            SLOT(4 * MT4 + q)                                                                            \
+            PF_SB                                                                                        \
+        SEND                                                                                             \
+        SFOR(u, MT4) af.h[u] = PF_LDA(nb_, son_ + NTERM * u); SEND                                       \
+        PF_SB                                                                                            \
+    }
+    // (scale, 32 shift) of the 8 channels of job (tile t of the layer at LB, half Q): channel LB + 32t + 16Q + (e&3) + 8(e>>2) + 4h
+#define PF_LOAD_SC(scv, LB, t, Q)                                                                        \
+    {                                                                                                    \
+        const float4 *ap_ = reinterpret_cast<const float4 *>(&aff[(LB) + 32 * (t) + 16 * (Q) + 4 * h]);  \
         const float4 c0_ = ap_[0], c1_ = ap_[1], c2_ = ap_[4], c3_ = ap_[5];                             \
         scv.sc[0] = make_float2(c0_.x, c0_.y); scv.sc[1] = make_float2(c0_.z, c0_.w);                    \
         scv.sc[2] = make_float2(c1_.x, c1_.y); scv.sc[3] = make_float2(c1_.z, c1_.w);                    \
         scv.sc[4] = make_float2(c2_.x, c2_.y); scv.sc[5] = make_float2(c2_.z, c2_.w);                    \
         scv.sc[6] = make_float2(c3_.x, c3_.y); scv.sc[7] = make_float2(c3_.z, c3_.w);                    \
     }
-    // ops [I0, I1) of the 72 of a job PAIR (both column tiles of one (tile, half Q): same coefficients)
-#define PF_JOB2(Q, I0, I1, A0, A1, OUT0, OUT1)                                                           \
-    {                                                                                                    \
-        if constexpr ((I0) < JOB_OPS) job_ops<Q, (I0), ((I1) < JOB_OPS ? (I1) : JOB_OPS)>(A0, jx_, sc_, OUT0, rmax_); \
-        if constexpr ((I1) > JOB_OPS) job_ops<Q, ((I0) > JOB_OPS ? (I0) - JOB_OPS : 0), (I1) - JOB_OPS>(A1, jx_, sc_, OUT1, rmax_); \
-    }
-    // ... placed OPS at a time behind the MFMAs of a step, from the third on (the coefficient reads need that long)
+    // VALU slots of a step that carries TWO jobs (both column tiles of one (tile, half): same coefficients sc_): OPS of the 2 x JOPS
+    // operations behind each MFMA from the third on (the coefficient reads need that long).  R0 / R1: first register of the
+    // 8 values of each job; INPL: pieces written back in place.
 #ifdef SONET_ABL_NOJOB
 #define PF_JOBS_ON false
 #else
 #define PF_JOBS_ON true
 #endif
-#define PF_SLOT2(q, OPS, Q, A0, A1, OUT0, OUT1)                                                          \
+#define PF_SLOT2(q, OPS, JOPS, INPL, R0, R1)                                                             \
     {                                                                                                    \
-        if constexpr (PF_JOBS_ON && (q) >= 2 && (OPS) * ((q) - 2) < 2 * JOB_OPS) {                                     \
-            constexpr int i0_ = (OPS) * ((q) - 2);                                                       \
-            PF_JOB2(Q, i0_, i0_ + (OPS), A0, A1, OUT0, OUT1)                                             \
+        if constexpr (PF_JOBS_ON && (q) >= 2 && (OPS) * ((q) - 2) < 2 * (JOPS)) {                                      \
+            constexpr int i0_ = (OPS) * ((q) - 2), i1_ = i0_ + (OPS);                                    \
+            if constexpr (i0_ < (JOPS)) job_ops<(R0), (INPL), i0_, (i1_ < (JOPS) ? i1_ : (JOPS))>(jx0_, sc_, rmax_); \
+            if constexpr (i1_ > (JOPS)) job_ops<(R1), (INPL), (i0_ > (JOPS) ? i0_ - (JOPS) : 0), i1_ - (JOPS)>(jx1_, sc_, rmax_); \
         }                                                                                                \
     }
+#define PF_SLOT1(q, OPS, JOPS, INPL, R0)                                                                 \
+    {                                                                                                    \
+        if constexpr (PF_JOBS_ON && (q) >= 2 && (OPS) * ((q) - 2) < (JOPS)) {                            \
+            constexpr int i0_ = (OPS) * ((q) - 2);                                                       \
+            job_ops<(R0), (INPL), i0_, i0_ + (OPS)>(jx0_, sc_, rmax_);                                   \
+        }                                                                                                \
+    }
+    // the next step's B piece l (4 v_pk_mul_f16 per column tile), behind MFMAs QB and QB + 1 of this step; from VGPR pieces ...
+#define PF_SLOT_BL(q, QB, H0, H1, L0, L1)                                                                \
+    {                                                                                                    \
+        if constexpr ((q) == (QB)) L0 = piece_l(H0);                                                     \
+        if constexpr ((q) == (QB) + 1) L1 = piece_l(H1);                                                 \
+    }
+    // ... or from the pieces in a[HN .. HN+3]
+#define PF_SLOT_BLA(q, QB, HN0, HN1, L0, L1)                                                             \
+    {                                                                                                    \
+        if constexpr ((q) == (QB)) { u32x4_t t_; t_[0] = __float_as_uint(agpr_read<(HN0)>()); t_[1] = __float_as_uint(agpr_read<(HN0) + 1>()); t_[2] = __float_as_uint(agpr_read<(HN0) + 2>()); t_[3] = __float_as_uint(agpr_read<(HN0) + 3>()); L0 = piece_l(t_); } \
+        if constexpr ((q) == (QB) + 1) { u32x4_t t_; t_[0] = __float_as_uint(agpr_read<(HN1)>()); t_[1] = __float_as_uint(agpr_read<(HN1) + 1>()); t_[2] = __float_as_uint(agpr_read<(HN1) + 2>()); t_[3] = __float_as_uint(agpr_read<(HN1) + 3>()); L1 = piece_l(t_); } \
+    }
 
-    // ---- the front of a tile: x -> layer 1 (all 64 points, every wave) -> layer 2 (this wave's tile) -> LDS ----
-    float xin[2][8];
-    int nid_n[2] = {-1, -1}, n0_n = 0, nlast_n = 0, pos0_n = 0;   // pool bookkeeping of the NEXT tile (read with its x: a round trip at the
-                                                                // top of the tile sat in front of barrier 1)
-    u32x4_t xh[2], xm[2], xl[2];
-    AF fl1;                                                     // layer 1's 4 fragments (h, l of 2 tiles)
-    f16x8 fl2h, fl2l;                                           // layer 2: one tile, one chunk
-    f32x16 acc1[T0][2], acc2[2];
-    JobOut a1n[T0][2][2];                                       // layer-1 output of the NEXT tile [tile][half][column tile]
-    JobOut a2o[2][2];                                           // this wave's layer-2 tile [half][column tile]
-    int rmax_ = 0;                                              // range log: running max of the post-affine inputs of layers 2-4 (x 32)
-    unsigned xin_r = 0u;                                        // ... and of |network input|, as ordered bit patterns
-    auto front_load_x = [&](long long t) __attribute__((always_inline)) {
-        t = t < ntiles ? t : ntiles - 1;                        // past the end: recompute the last tile's front (never consumed)
+    PROF_MARK(0)                                                // kernel prologue
+    // inputs of a tile, read one tile ahead (in front of the previous tile's last pass): read at the top of the tile,
+    // the x / node-id loads put an HBM round trip in front of layer 1
+    float xin_n[2][8];
+    int nid_n[2] = {-1, -1}, n0_n = 0, nlast_n = 0, pos0_n = 0;
+    auto prefetch_tile = [&](long long t) __attribute__((always_inline)) {
+        t = t < ntiles ? t : ntiles - 1;                        // unconditional: the registers are dead between layer 1 and here
         const long long bb = t / tpc;
         const int t0 = (int)(t - bb * tpc) * TPTS;
         const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(x + bb * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowB), 0x00020000);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int ll0 = t0 + 32 * c;
-            const int lcc = ll0 + j < L ? ll0 + j : (ll0 < L ? ll0 : 0);
+            const int ll0 = t0 + wave * WPTS + 32 * c;
+            const bool pvv = ll0 + j < L;
+            const int lcc = pvv ? ll0 + j : (ll0 < L ? ll0 : 0);
 #pragma unroll
             for (int e = 0; e < 8; ++e)                          // rows >= Cin0 are out of range of the descriptor: 0
-                xin[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
-            if constexpr (SEGMAX) nid_n[c] = ll0 + j < L ? ids_sorted[bb * (long long)L + ll0 + j] : -1;
+                xin_n[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lcc) * 4u, (unsigned)e * rowB, 0));
+            if constexpr (SEGMAX) nid_n[c] = pvv ? ids_sorted[bb * (long long)L + ll0 + j] : -1;
         }
         if constexpr (SEGMAX) {
             const int32_t *idb = ids_sorted + bb * (long long)L;
-            n0_n = idb[t0];                                      // first / last node of the tile
+            n0_n = idb[t0];                                                        // first / last node of the workgroup's tile
             nlast_n = idb[(t0 + TPTS - 1 < L ? t0 + TPTS - 1 : L - 1)];
             pos0_n = pos0[bb];
         }
     };
-    auto front_load_w1 = [&]() __attribute__((always_inline)) {
-        SFOR(u, T0) fl1.h[u] = PF_WLOAD(rw1, NTERM * u); fl1.l[u] = PF_WLOAD(rw1, NTERM * u + 1); SEND
-    };
-    auto front_split_x = [&]() __attribute__((always_inline)) {
+    prefetch_tile(blockIdx.x);
+    // range log: running max of the post-affine inputs of layers 2-4 (x 32) and of |network input|, as ordered bit patterns
+    int rmax_ = 0;
+    unsigned xin_r = 0u;
+    u32x4_t *const park_w = &park[wave][0][0][0][lane];           // this lane's 16 bytes of [chunk][column tile][piece]
+#define PF_PARK(kc, c, piece) park_w[(((kc) * 2 + (c)) * 2 + (piece)) * 64]
+
+    // cold start: fragments of the very first step (layer 1 of this workgroup's first tile) from stage 0
+    SFOR(u, T0) af.l[u] = PF_LDA(lds_cur, NTERM * u + 1); af.h[u] = PF_LDA(lds_cur, NTERM * u); SEND
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long b = tile / tpc;
+        const int t0w = (int)(tile - b * tpc) * TPTS + wave * WPTS;      // first point of this wave
+        bool pv[2]; int lc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int l0 = t0w + 32 * c;
+            pv[c] = l0 + j < L;
+            lc[c] = pv[c] ? l0 + j : (l0 < L ? l0 : 0);
+        }
+        // per-node max-pool bookkeeping of this wave's 2 x 32 (node-sorted) points
+        int nid[2] = {-1, -1}, n0 = 0, nslots = 0, jpos0[2] = {-1, -1};
+        if constexpr (SEGMAX) {
+            nid[0] = nid_n[0]; nid[1] = nid_n[1];
+            n0 = n0_n;
+            nslots = nlast_n - n0_n + 1 < SEG_SLOTS ? nlast_n - n0_n + 1 : SEG_SLOTS;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int p0 = pos0_n - (t0w + 32 * c);
+                jpos0[c] = (p0 >= 0 && p0 < 32) ? p0 : -1;
+            }
+        }
+        // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
+        u32x4_t xh[2], xm[2], xl[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const unsigned a0 = __float_as_uint(xin[c][2 * p]) & 0x7FFFFFFFu, a1 = __float_as_uint(xin[c][2 * p + 1]) & 0x7FFFFFFFu;
-                xin_r = max(max(xin_r, a0), a1);
+                // (pinned: left to itself hipcc sinks this to the end of the tile and keeps the 16 inputs alive until there)
+                unsigned a0, a1;
+                asm volatile("v_and_b32 %0, 0x7fffffff, %1" : "=v"(a0) : "v"(xin_n[c][2 * p]));
+                asm volatile("v_and_b32 %0, 0x7fffffff, %1" : "=v"(a1) : "v"(xin_n[c][2 * p + 1]));
+                asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(xin_r) : "v"(a0), "v"(a1));
             }
-            split_input(xin[c], xh[c], xm[c]);
+            split_input(xin_n[c], xh[c], xm[c]);
             xl[c] = piece_l(xh[c]);
         }
-    };
-#define ACC1(u, c) acc1[u][c]
+        PROF_MARK(1)                                            // tile prologue
 #define NOSLOT(q)
-    auto front_l1 = [&]() __attribute__((always_inline)) {      // 12 MFMAs
-        PF_STEP(T0, -1, fl1, ACC1, xh[0], xm[0], xl[0], xh[1], xm[1], xl[1], true, false, NOSLOT)
-    };
-    auto front_load_w2 = [&](auto kcc) __attribute__((always_inline)) {
-        constexpr int kc = decltype(kcc)::value;
-        fl2h = PF_WLOAD(rww, WO2 + kc * NTERM); fl2l = PF_WLOAD(rww, WO2 + kc * NTERM + 1);
-    };
-    auto front_l2 = [&](auto kcc) __attribute__((always_inline)) {    // 6 MFMAs: chunk kc of layer 2, this wave's tile
-        constexpr int kc = decltype(kcc)::value, t = kc >> 1, q = kc & 1;
-        const f16x8 b0l = as_f16x8(piece_l(a1n[t][q][0].h)), b1l = as_f16x8(piece_l(a1n[t][q][1].h));
-        PF_SB
-        PF_MFMA(acc2[0], fl2l, b0l, (kc == 0), false) PF_SB
-        PF_MFMA(acc2[1], fl2l, b1l, (kc == 0), false) PF_SB
-        PF_MFMA(acc2[0], fl2h, as_f16x8(a1n[t][q][0].m), false, false) PF_SB
-        PF_MFMA(acc2[1], fl2h, as_f16x8(a1n[t][q][1].m), false, false) PF_SB
-        PF_MFMA(acc2[0], fl2h, as_f16x8(a1n[t][q][0].h), false, false) PF_SB
-        PF_MFMA(acc2[1], fl2h, as_f16x8(a1n[t][q][1].h), false, false) PF_SB
-    };
-    auto front_store_a2 = [&]() __attribute__((always_inline)) {  // this wave's layer-2 tile = chunks 2w, 2w+1 of layer 3's input
-        SFOR(q, 2) SFOR(c, 2)
-            PF_ACT(act2w, 2 * wave + q, c, 0) = a2o[q][c].h; PF_ACT(act2w, 2 * wave + q, c, 1) = a2o[q][c].m;
-        SEND SEND
-    };
-    auto front_exposed = [&](long long t) __attribute__((always_inline)) {   // the whole front back to back (first tile of a workgroup)
-        front_load_x(t);
-        front_load_w1();
-        front_split_x();
-        front_l1();
-        SFOR(ck, KC2)
-            JobSc sc_; JobX jx_;
-            PF_LOAD_SC(sc_, LB1 + 32 * (ck >> 1) + 16 * (ck & 1) + 4 * h)
-            PF_JOB2((ck & 1), 0, 2 * JOB_OPS, acc1[ck >> 1][0], acc1[ck >> 1][1], a1n[ck >> 1][ck & 1][0], a1n[ck >> 1][ck & 1][1])
-        SEND
-        SFOR(kc, KC2)
-            front_load_w2(IC<kc>{});
-            front_l2(IC<kc>{});
-        SEND
-        SFOR(q, 2)
-            JobSc sc_; JobX jx_;
-            PF_LOAD_SC(sc_, LB2 + 32 * wave + 16 * q + 4 * h)
-            PF_JOB2(q, 0, 2 * JOB_OPS, acc2[0], acc2[1], a2o[q][0], a2o[q][1])
-        SEND
-        front_store_a2();
-    };
-
-    PROF_MARK(0)                                                // kernel prologue
-    front_exposed(blockIdx.x);
-    // fragments of the first two main steps
-#ifdef SONET_ABL_NOW
-    SFOR(u, W4T) af[0].l[u] = PF_WLOAD(rww, WO4 + 2 * u + 1); af[0].h[u] = PF_WLOAD(rww, WO4 + 2 * u); af[1].l[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u + 1); af[1].h[u] = PF_WLOAD(rww, WO4 + 6 + 2 * u); SEND
-#else
-    SFOR(g, AFD - 1) SFOR(i, 2 * W4T) load_frag(IC<g>{}, IC<i>{}, af[g]); SEND SEND
-#endif
-    PROF_MARK(1)                                                // first front
-
-    int pend_n = 0;
-    unsigned *pend = partial;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long b = tile / tpc;
-        const int t0 = (int)(tile - b * tpc) * TPTS;             // first point of the tile (same 64 points for all four waves)
-        bool pv[2]; int lc[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int l0 = t0 + 32 * c;
-            pv[c] = l0 + j < L;
-            lc[c] = pv[c] ? l0 + j : (l0 < L ? l0 : 0);
-        }
-        // per-node max-pool bookkeeping of the tile's 2 x 32 (node-sorted) points (used by the epilogue, a tile later)
-        int nid[2] = {-1, -1}, n0 = 0, nslots = 0, jpos0[2] = {-1, -1};
-        if constexpr (SEGMAX) {                                 // (read by the front of this tile, a tile ago)
-            nid[0] = nid_n[0];
-            nid[1] = nid_n[1];
-            n0 = n0_n;
-            const int nlast = nlast_n;
-            nslots = nlast - n0 + 1 < SEG_SLOTS ? nlast - n0 + 1 : SEG_SLOTS;
-            const int p0 = pos0_n;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int pp = p0 - (t0 + 32 * c);
-                jpos0[c] = (pp >= 0 && pp < 32) ? pp : -1;
-            }
-        }
-        // the layer-1 output of THIS tile (made by the front a tile ago) moves out of the front's registers
+        PF_STEP_A(T0, OFF1, GS, OFF2, AG13, xh[0], xm[0], xl[0], xh[1], xm[1], xl[1], true, NOSLOT)
+        // layer-1 output, pre-split: a1[tile][half][column tile]
         JobOut a1[T0][2][2];
-        SFOR(t, T0) SFOR(q, 2) SFOR(c, 2) a1[t][q][c] = a1n[t][q][c]; SEND SEND SEND
-
-        __syncthreads();                                        // #1: layer 2 of this tile is in LDS; everyone is done with the previous tile
-        if constexpr (SEGMAX) {                                 // the previous tile's maxima: LDS bins -> its partial block
-            for (int e = threadIdx.x; e < pend_n; e += PF_THREADS) {
-                unsigned *bp = &bins[0][0] + e;
-                pend[e] = *bp;
-                *bp = SEG_INIT;
-            }
+        u32x4_t bl0, bl1;                                       // piece l of the NEXT step's B chunk
+        {                                                       // layer transition: chunk 0 of layer 2's input, nothing to overlap with
+            asm volatile("s_nop 15" ::: );                      // (the last MFMAs' results: 12 wait states before anything reads them)
+            JobSc sc_; JobX jx0_, jx1_;
+            PF_LOAD_SC(sc_, LB1, 0, 0)
+            job_ops<AG13(0, 0), false, 0, JOB_OPS_V>(jx0_, sc_, rmax_);
+            job_ops<AG13(0, 1), false, 0, JOB_OPS_V>(jx1_, sc_, rmax_);
+            a1[0][0][0] = job_result(jx0_); a1[0][0][1] = job_result(jx1_);
+            bl0 = piece_l(a1[0][0][0].h); bl1 = piece_l(a1[0][0][1].h);
         }
-        PROF_MARK(2)                                            // tile prologue + barrier 1
-        // ---- layer 3: 8 steps, tiles 2w, 2w+1, B = layer 2 from LDS ----
-        f32x16 acc3[W3T][2];
-#define ACC3(u, c) acc3[u][c]
-        u32x4_t bh[2], bm[2], bl[2];                            // B pieces of the current step
-        bh[0] = PF_ACT(act2w, 0, 0, 0); bm[0] = PF_ACT(act2w, 0, 0, 1); bh[1] = PF_ACT(act2w, 0, 1, 0); bm[1] = PF_ACT(act2w, 0, 1, 1);
-        bl[0] = piece_l(bh[0]); bl[1] = piece_l(bh[1]);
-        SFOR(kc, KC3)
-            u32x4_t nh[2], nm[2], nl[2];                        // next step's B chunk, read now
-            if constexpr (kc + 1 < KC3) {
-#ifdef SONET_ABL_NOB
-                nh[0] = bh[0]; nm[0] = bm[0]; nh[1] = bh[1]; nm[1] = bm[1];
-#else
-                nh[0] = PF_ACT(act2w, kc + 1, 0, 0); nm[0] = PF_ACT(act2w, kc + 1, 0, 1); nh[1] = PF_ACT(act2w, kc + 1, 1, 0); nm[1] = PF_ACT(act2w, kc + 1, 1, 1);
-#endif
-            } else {                                            // layer 4 starts with the wave's own layer-1 chunk 0
-                nh[0] = a1[0][0][0].h; nm[0] = a1[0][0][0].m; nh[1] = a1[0][0][1].h; nm[1] = a1[0][0][1].m;
-            }
-#define SLOT_L3(q) { if constexpr ((q) == 8) nl[0] = piece_l(nh[0]); if constexpr ((q) == 9) nl[1] = piece_l(nh[1]); }
-            PF_STEP(W3T, kc, af[kc % AFD], ACC3, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), false, SLOT_L3)
-#undef SLOT_L3
-            bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1];
+        PROF_MARK(6)                                            // layer 1
+        // ---- layer 2: 4 steps over the K chunks of the layer-1 output, all 4 output tiles (accumulators a[128:255]) ----
+        SFOR(k, KC2)
+            constexpr int tk = k >> 1, qk = k & 1;              // this step's chunk = a1[tk][qk]
+            constexpr int kn = k + 1, tn = (kn >> 1) & 1, qn = kn & 1;   // jobs of this step: chunk k + 1 (k < 3)
+            constexpr int sidx = OFF2 + k * NTERM * GS;
+            JobSc sc_; JobX jx0_, jx1_;
+            if constexpr (k + 1 < KC2) PF_LOAD_SC(sc_, LB1, tn, qn)
+            u32x4_t nl0 = bl0, nl1 = bl1;
+#define SLOT_L2(q) { if constexpr (k + 1 < KC2) { PF_SLOT2(q, 5, JOB_OPS_V, false, AG13(tn, 0) + 8 * qn, AG13(tn, 1) + 8 * qn) \
+                       if constexpr ((q) == 20) { a1[tn][qn][0] = job_result(jx0_); a1[tn][qn][1] = job_result(jx1_); } \
+                       PF_SLOT_BL(q, 21, a1[tn][qn][0].h, a1[tn][qn][1].h, nl0, nl1) } }
+            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG2, a1[tk][qk][0].h, a1[tk][qk][0].m, bl0, a1[tk][qk][1].h, a1[tk][qk][1].m, bl1, (k == 0), SLOT_L2)
+#undef SLOT_L2
+            bl0 = nl0; bl1 = nl1;
         SEND
-        PROF_MARK(3)                                            // layer 3
-        // ---- layer 4: 20 steps, tiles 3w..3w+2; chunks 0-3 = own layer-1 output, 4-19 = layer 3 from LDS ----
-        f32x16 acc[W4T][2];
-#define ACC4(u, c) acc[u][c]
-        // steps 0-3: the 8 jobs of layer 3 (step s: tile s>>1, half s&1, both column tiles), stored when complete
-        SFOR(kc, KC2)
-            constexpr int ju = kc >> 1, jq = kc & 1;
-            JobSc sc_; JobX jx_;
-            JobOut a3o[2];                                      // the job pair's outputs on their way to LDS
-            PF_LOAD_SC(sc_, LB3 + 32 * (W3T * wave + ju) + 16 * jq + 4 * h)
-            u32x4_t nh[2], nm[2], nl[2];
-            if constexpr (kc + 1 < KC2) {
-                constexpr int tn = (kc + 1) >> 1, qn = (kc + 1) & 1;
-                nh[0] = a1[tn][qn][0].h; nm[0] = a1[tn][qn][0].m; nh[1] = a1[tn][qn][1].h; nm[1] = a1[tn][qn][1].m;
+        // layer-2 output, pre-split
+        JobOut a2[T1][2][2];
+        {                                                       // layer transition: chunk 0 of layer 3's input
+            asm volatile("s_nop 15" ::: );
+            JobSc sc_; JobX jx0_, jx1_;
+            PF_LOAD_SC(sc_, LB2, 0, 0)
+            job_ops<AG2(0, 0), false, 0, JOB_OPS_V>(jx0_, sc_, rmax_);
+            job_ops<AG2(0, 1), false, 0, JOB_OPS_V>(jx1_, sc_, rmax_);
+            a2[0][0][0] = job_result(jx0_); a2[0][0][1] = job_result(jx1_);
+            bl0 = piece_l(a2[0][0][0].h); bl1 = piece_l(a2[0][0][1].h);
+        }
+        PROF_MARK(7)                                            // layer 2
+        // ---- layer 3: two groups of 4 output tiles x 8 K chunks (accumulators a[0:127], then a[128:255]) ----
+#define AG3A(u, c) AG13(u, c)
+#define AG3B(u, c) AG13(GS + (u), c)
+        u32x4_t pbh[2], pbm[2];                                 // a chunk read back from the park
+        SFOR(k, KC3)                                            // group 0; jobs: the layer-2 chunk of the next step
+            constexpr int tk = k >> 1, qk = k & 1;
+            if constexpr (k + 1 == KC3) {                       // the second group starts with chunk 0 again (parked at step 0)
+                pbh[0] = PF_PARK(0, 0, 0); pbm[0] = PF_PARK(0, 0, 1);
+                pbh[1] = PF_PARK(0, 1, 0); pbm[1] = PF_PARK(0, 1, 1);
             }
-#define SLOT_L4A(q) { PF_SLOT2(q, 6, jq, acc3[ju][0], acc3[ju][1], a3o[0], a3o[1]) \
-                      if constexpr (kc + 1 < KC2) { if constexpr ((q) == 14) nl[0] = piece_l(nh[0]); if constexpr ((q) == 15) nl[1] = piece_l(nh[1]); } }
-            PF_STEP(W4T, KC3 + kc, af[kc % AFD], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], (kc == 0), SEGMAX, SLOT_L4A)
-#undef SLOT_L4A
-            SFOR(c, 2)
-                PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 0) = a3o[c].h; PF_ACT(act3w, 2 * (W3T * wave + ju) + jq, c, 1) = a3o[c].m;
+            constexpr int kn = k + 1, tn = (kn >> 1) & 3, qn = kn & 1;
+            constexpr int sidx = OFF3 + k * NTERM * GS;
+            JobSc sc_; JobX jx0_, jx1_;
+            if constexpr (k + 1 < KC3) PF_LOAD_SC(sc_, LB2, tn, qn)
+            u32x4_t nl0 = bl0, nl1 = bl1;
+#define SLOT_L3A(q) { if constexpr (k + 1 < KC3) { PF_SLOT2(q, 5, JOB_OPS_V, false, AG2(tn, 0) + 8 * qn, AG2(tn, 1) + 8 * qn) \
+                        if constexpr ((q) == 20) { a2[tn][qn][0] = job_result(jx0_); a2[tn][qn][1] = job_result(jx1_); } \
+                        PF_SLOT_BL(q, 21, a2[tn][qn][0].h, a2[tn][qn][1].h, nl0, nl1) } \
+                      else { PF_SLOT_BL(q, 4, pbh[0], pbh[1], nl0, nl1) } }
+            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG3A, a2[tk][qk][0].h, a2[tk][qk][0].m, bl0, a2[tk][qk][1].h, a2[tk][qk][1].m, bl1, (k == 0), SLOT_L3A)
+#undef SLOT_L3A
+            bl0 = nl0; bl1 = nl1;
+            if constexpr (k < KC2) {                            // chunks 0-3 wait in LDS for the second tile group, 4-7 in registers
+                PF_PARK(k, 0, 0) = a2[tk][qk][0].h; PF_PARK(k, 0, 1) = a2[tk][qk][0].m;
+                PF_PARK(k, 1, 0) = a2[tk][qk][1].h; PF_PARK(k, 1, 1) = a2[tk][qk][1].m;
+            }
+        SEND
+        PROF_MARK(8)                                            // layer 3, tiles 0-3
+        float xagain[2][8];
+        SFOR(k, KC3)                                            // group 1; jobs: the layer-3 outputs of group 0 (tile k>>1, half k&1), in place
+            constexpr int tk = k >> 1, qk = k & 1;
+            constexpr int kn = (k + 1) % KC3, tn = kn >> 1, qn = kn & 1;
+            constexpr int sidx = OFF3 + (KC3 + k) * NTERM * GS;
+            constexpr int ntn = k + 1 < KC3 ? GS : MT4;         // the last step reads the fragments of layer 4's first step
+            constexpr bool cur_park = k < KC2, nxt_park = k + 1 < KC2;
+            JobSc sc_; JobX jx0_, jx1_;
+            PF_LOAD_SC(sc_, LB3, tk, qk)
+            u32x4_t nl0 = bl0, nl1 = bl1;
+            const u32x4_t ch0 = cur_park ? pbh[0] : a2[tk][qk][0].h, cm0 = cur_park ? pbm[0] : a2[tk][qk][0].m;
+            const u32x4_t ch1 = cur_park ? pbh[1] : a2[tk][qk][1].h, cm1 = cur_park ? pbm[1] : a2[tk][qk][1].m;
+            if constexpr (nxt_park) {
+                pbh[0] = PF_PARK(k + 1, 0, 0); pbm[0] = PF_PARK(k + 1, 0, 1);
+                pbh[1] = PF_PARK(k + 1, 1, 0); pbm[1] = PF_PARK(k + 1, 1, 1);
+            }
+            if constexpr (k + 1 == KC3) {                       // the tile's input again (from L2), for the second run of layer 1
+                const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(x + b * (long long)Cin0 * L), 0, (int)((unsigned)Cin0 * rowB), 0x00020000);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        xagain[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lc[c]) * 4u, (unsigned)e * rowB, 0));
+            }
+#define SLOT_L3B(q) { PF_SLOT2(q, 5, JOB_OPS_A, true, AG13(tk, 0) + 8 * qk, AG13(tk, 1) + 8 * qk) \
+                      if constexpr (nxt_park) { PF_SLOT_BL(q, 22, pbh[0], pbh[1], nl0, nl1) } \
+                      else if constexpr (k + 1 < KC3) { PF_SLOT_BL(q, 22, a2[tn][qn][0].h, a2[tn][qn][1].h, nl0, nl1) } }
+            PF_STEP_A(GS, sidx, ntn, sidx + NTERM * GS, AG3B, ch0, cm0, bl0, ch1, cm1, bl1, (k == 0), SLOT_L3B)
+#undef SLOT_L3B
+            bl0 = nl0; bl1 = nl1;
+        SEND
+        PROF_MARK(9)                                            // layer 3, tiles 4-7
+        // ---- layer 1 once more, for layer 4's first four K chunks (its output could not stay anywhere during layer 3: 64 points x
+        // (64 + 128 + 256) channels are more registers than a lane has): same MFMAs, same order, accumulators in VGPRs this time ----
+        {
+            f32x16 r1[T0][2];
+            f16x8 wh[T0], wl[T0];
+            SFOR(u, T0) wl[u] = __builtin_bit_cast(f16x8, w1s[NTERM * u + 1][lane]); wh[u] = __builtin_bit_cast(f16x8, w1s[NTERM * u][lane]); SEND
+            u32x4_t xh0, xm0, xh1, xm1;
+            split_input(xagain[0], xh0, xm0);
+            split_input(xagain[1], xh1, xm1);
+            const u32x4_t xl0 = piece_l(xh0), xl1 = piece_l(xh1);
+            const f16x8 bh_[2] = {as_f16x8(xh0), as_f16x8(xh1)}, bm_[2] = {as_f16x8(xm0), as_f16x8(xm1)}, bl_[2] = {as_f16x8(xl0), as_f16x8(xl1)};
+            PF_SB
+            SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<true, false>(r1[u][c], wl[u], bl_[c]); PF_SB SEND
+            SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<false, false>(r1[u][c], wh[u], bm_[c]); PF_SB SEND
+            SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<false, false>(r1[u][c], wh[u], bh_[c]); PF_SB SEND
+            asm volatile("s_nop 15" ::: );                      // (MFMA results: 12 wait states before a VALU instruction reads them)
+            int rdummy = 0;                                     // (these values went through the range log the first time)
+            SFOR(kk, KC2)
+                constexpr int tk = kk >> 1, qk = kk & 1;
+                JobSc sc_;
+                PF_LOAD_SC(sc_, LB1, tk, qk)
+                SFOR(c, 2)
+                    JobX jx_;
+                    SFOR(i, 8) jx_.x[i] = r1[tk][c][8 * qk + i]; SEND
+                    job_ops<0, false, 8, JOB_OPS_V>(jx_, sc_, rdummy);
+                    const JobOut o = job_result(jx_);
+                    PF_PARK(kk, c, 0) = o.h; PF_PARK(kk, c, 1) = o.m;
+                    if constexpr (kk == 0) { pbh[c] = o.h; pbm[c] = o.m; }
+                SEND
             SEND
-            if constexpr (kc + 1 < KC2) { bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1]; }
-        SEND
-        PROF_MARK(4)                                            // layer 4, steps 0-3 (+ layer-3 jobs)
-        __syncthreads();                                        // #2: layer 3 of this tile is in LDS
-        PROF_MARK(5)
-        bh[0] = PF_ACT(act3w, 0, 0, 0); bm[0] = PF_ACT(act3w, 0, 0, 1); bh[1] = PF_ACT(act3w, 0, 1, 0); bm[1] = PF_ACT(act3w, 0, 1, 1);
-        bl[0] = piece_l(bh[0]); bl[1] = piece_l(bh[1]);
-        // steps 4-19 carry the front of the NEXT tile of this workgroup:
-        //   step 4: x loads + layer-1 fragments;  6: split x;  7: layer 1 (12 MFMAs);  8-11: its 8 jobs (a pair per step);
-        //   12-15: layer 2, one chunk per step (6 MFMAs, fragments read a step ahead);  16-17: its 4 jobs;  18: stores to LDS.
-        SFOR(s, KC4 - KC2)
-            constexpr int kc = KC2 + s;
-            u32x4_t nh[2], nm[2], nl[2];
-            if constexpr (kc + 1 < KC4) {
-#ifdef SONET_ABL_NOB
-                nh[0] = bh[0]; nm[0] = bm[0]; nh[1] = bh[1]; nm[1] = bm[1];
-#else
-                nh[0] = PF_ACT(act3w, kc + 1 - KC2, 0, 0); nm[0] = PF_ACT(act3w, kc + 1 - KC2, 0, 1);
-                nh[1] = PF_ACT(act3w, kc + 1 - KC2, 1, 0); nm[1] = PF_ACT(act3w, kc + 1 - KC2, 1, 1);
+            bl0 = piece_l(pbh[0]); bl1 = piece_l(pbh[1]);
+        }
+        PROF_MARK(2)                                            // layer 1 again
+        // ---- layer 4: NPASS passes x KC4 steps of MT4 output tiles; chunks 0-3 = layer-1 output (park), 4-19 = layer 3 (a[...]) ----
+        // Pass 0 carries the in-place jobs of layer 3's second tile group (one per step, steps 0-15: tile 4 + s/4, half (s/2)&1,
+        // column tile s&1 -- tile 4 is complete when step 12 needs it); passes 1-3 run the same steps without jobs.
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
+#define ACC4(u, c) acc[u][c]
+#define PF_L4_BODY(JOBS)                                                                                 \
+            SFOR(kc, KC4)                                                                                \
+                constexpr int sidx = PRE + kc * NTERM * MT4;                                             \
+                constexpr int kn = (kc + 1) % KC4;                                                       \
+                constexpr bool cur_park = kc < KC2, nxt_park = kn < KC2;                                 \
+                constexpr int t3 = cur_park ? 0 : (kc - KC2) >> 1, q3 = cur_park ? 0 : (kc - KC2) & 1;   \
+                constexpr int t3n = nxt_park ? 0 : (kn - KC2) >> 1, q3n = nxt_park ? 0 : (kn - KC2) & 1; \
+                constexpr int jt = T2 / 2 + kc / 4, jq = (kc >> 1) & 1, jc = kc & 1;                     \
+                constexpr bool job = (JOBS) && kc < 16;                                                  \
+                JobSc sc_; JobX jx0_;                                                                    \
+                if constexpr (job) PF_LOAD_SC(sc_, LB3, (job ? jt : 0), jq)                              \
+                const u32x4_t ch0 = pbh[0], cm0 = pbm[0], ch1 = pbh[1], cm1 = pbm[1];                    \
+                if constexpr (nxt_park) {                        /* the step reads this chunk's registers first (copies above) */ \
+                    pbh[0] = PF_PARK(kn, 0, 0); pbm[0] = PF_PARK(kn, 0, 1);                              \
+                    pbh[1] = PF_PARK(kn, 1, 0); pbm[1] = PF_PARK(kn, 1, 1);                              \
+                }                                                                                        \
+                u32x4_t nl0 = bl0, nl1 = bl1;                                                            \
+                PF_STEP_V(sidx, sidx + NTERM * MT4, ACC4, !cur_park, AG13(t3, 0) + 8 * q3, AG13(t3, 1) + 8 * q3, ch0, cm0, ch1, cm1, bl0, bl1, (kc == 0), (kc == 0), SLOT_L4) \
+                bl0 = nl0; bl1 = nl1;                                                                    \
+            SEND
+#define SLOT_L4(q) { if constexpr (job) { PF_SLOT1(q, 4, JOB_OPS_A, true, AG13((job ? jt : 0), jc) + 8 * jq) } \
+                     if constexpr (nxt_park) { PF_SLOT_BL(q, 15, pbh[0], pbh[1], nl0, nl1) } else { PF_SLOT_BLA(q, 15, AG13(t3n, 0) + 8 * q3n, AG13(t3n, 1) + 8 * q3n, nl0, nl1) } }
+        // the epilogue of a layer-4 pass
+        auto epilogue = [&](f32x16 (&acc)[MT4][2], const int pass) __attribute__((always_inline)) {
+#ifdef SONET_ABL_NOEPI
+            if (M != 12345) return;
 #endif
-            }
-            constexpr bool j1 = kc >= 8 && kc < 12, j2 = kc >= 16 && kc < 18;      // a layer-1 / layer-2 job pair rides on this step
-            constexpr int ck1 = j1 ? kc - 8 : 0, q2 = j2 ? kc - 16 : 0;
-            JobSc sc_; JobX jx_;
-            if constexpr (kc == 4) { front_load_x(tile + gridDim.x); front_load_w1(); }
-            if constexpr (kc == 6) front_split_x();
-            if constexpr (j1) PF_LOAD_SC(sc_, LB1 + 32 * (ck1 >> 1) + 16 * (ck1 & 1) + 4 * h)
-            if constexpr (j2) PF_LOAD_SC(sc_, LB2 + 32 * wave + 16 * q2 + 4 * h)
-#define SLOT_L4B(q) { \
-                if constexpr (kc + 1 < KC4) { if constexpr ((q) == 0) nl[0] = piece_l(nh[0]); if constexpr ((q) == 1) nl[1] = piece_l(nh[1]); } \
-                if constexpr (j1) PF_SLOT2(q, 6, (ck1 & 1), acc1[ck1 >> 1][0], acc1[ck1 >> 1][1], a1n[ck1 >> 1][ck1 & 1][0], a1n[ck1 >> 1][ck1 & 1][1]) \
-                if constexpr (j2) PF_SLOT2(q, 6, q2, acc2[0], acc2[1], a2o[q2][0], a2o[q2][1]) \
-            }
-            PF_STEP(W4T, KC3 + kc, af[kc % AFD], ACC4, bh[0], bm[0], bl[0], bh[1], bm[1], bl[1], false, SEGMAX, SLOT_L4B)
-#undef SLOT_L4B
-            if constexpr (kc == 7) front_l1();
-            if constexpr (kc >= 12 && kc < 16) front_l2(IC<(kc >= 12 && kc < 16 ? kc - 12 : 0)>{});
-            if constexpr (kc >= 11 && kc < 15) front_load_w2(IC<(kc >= 11 && kc < 15 ? kc - 11 : 0)>{});   // (after the chunk before it has been consumed)
-            if constexpr (kc == 18) front_store_a2();
-            if constexpr (kc + 1 < KC4) { bh[0] = nh[0]; bm[0] = nm[0]; bl[0] = nl[0]; bh[1] = nh[1]; bm[1] = nm[1]; bl[1] = nl[1]; }
-        SEND
-        PROF_MARK(6)                                            // layer 4, steps 4-19 (+ front of the next tile)
-        // ---- epilogue: this wave's 96 channels x 64 points ----
-        if constexpr (SEGMAX) {
-            // per-node max-pool (replaces index_max + masked gather, models/networks.py:180-185, for the no-grad path:
-            // only the VALUES are needed).  Layer 4 of this variant runs with the MFMA operands swapped: the accumulators
-            // are TRANSPOSED, acc[mt][c][r] = Y[point 32c + prow(r)][channel 96w + 32mt + j], prow(r) = (r&3) + 8(r>>2) + 4h,
-            // so the maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a cross-lane
-            // reduction of every register; the two half-waves (16 points each) meet in one lane exchange.
-            float bias4[W4T];
+            asm volatile("s_nop 15" ::: );                      // the last MFMAs' results: 12 wait states before the compiler's code reads them
+            if constexpr (SEGMAX) {
+                // ---- per-node max-pool of this pass's 96 channels (replaces index_max + masked gather,
+                //      models/networks.py:180-185, for the no-grad path: only the VALUES are needed) ----
+                // Layer 4 of this variant runs with the MFMA operands swapped: the accumulators are TRANSPOSED,
+                // acc[mt][c][r] = Y[point 32c + prow(r)][channel 32 mt + j] with prow(r) = (r&3) + 8 (r>>2) + 4 h, so the
+                // maximum over a node's points is a maximum over REGISTERS (15 v_max per tile) instead of a cross-lane
+                // reduction of every register; the two half-waves (16 points each) meet in the LDS atomic.
+                float bias4[MT4];
 #pragma unroll
-            for (int mt = 0; mt < W4T; ++mt) {
-                const float2 ss = aff[LB4 + (W4T * wave + mt) * 32 + j];
-                bias4[mt] = ss.y;
-                if (!l4_unit) {
+                for (int mt = 0; mt < MT4; ++mt) {
+                    const float2 ss = aff[LB4 + (pass * MT4 + mt) * 32 + j];
+                    bias4[mt] = ss.y;
+                    if (!l4_unit) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                        for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mt][c][r] = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                            for (int r = 0; r < 16; ++r) acc[mt][c][r] = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                    }
                 }
-            }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (jpos0[c] >= 0) {                                              // wave-uniform: features of original copy 0
+                for (int c = 0; c < 2; ++c) {
+                    if (jpos0[c] >= 0) {                                          // wave-uniform: one wave per cloud; features of original copy 0
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0[c]) {
+                        for (int r = 0; r < 16; ++r)
+                            if ((r & 3) + 8 * (r >> 2) + 4 * h == jpos0[c]) {
 #pragma unroll
-                            for (int mt = 0; mt < W4T; ++mt) v0[b * C4 + (W4T * wave + mt) * 32 + j] = l4_unit ? __fmaf_rn(acc[mt][c][r], ACC_UNSCALE, bias4[mt]) : acc[mt][c][r];
-                        }
-                }
-                // per node present in this column tile (usually 1, 2 at a node boundary; ids are sorted, so a node's
-                // points are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's
-                // '>' does), published by integer atomicMax on orderable keys -- to the LDS bins of the tile's
-                // first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
-                unsigned remaining = (unsigned)__ballot(pv[c]);                   // lanes 0..31 <-> the column tile's 32 points
-                while (remaining != 0u) {
-                    const int s0 = __builtin_ctz(remaining);
-                    const int node = __builtin_amdgcn_readlane(nid[c], s0);
-                    const unsigned segmask = (unsigned)__ballot(pv[c] && nid[c] == node);
-                    remaining &= ~segmask;
-                    const int e0 = s0 + __builtin_popcount(segmask);
-                    const bool whole = (s0 == 0 && e0 == 32);
-                    const int slot = node - n0;
-                    float mx[W4T];
-                    if (whole) {
+                                for (int mt = 0; mt < MT4; ++mt) v0[b * (32 * T3) + (pass * MT4 + mt) * 32 + j] = l4_unit ? __fmaf_rn(acc[mt][c][r], ACC_UNSCALE, bias4[mt]) : acc[mt][c][r];
+                            }
+                    }
+                    // per node present in this column tile (usually 1, 2 at a node boundary; ids are sorted, so a node's
+                    // points are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's
+                    // '>' does), published by integer atomicMax on orderable keys -- to the LDS bins of the workgroup's
+                    // first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
+                    unsigned remaining = (unsigned)__ballot(pv[c]);               // lanes 0..31 <-> the column tile's 32 points
+                    while (remaining != 0u) {
+                        const int s0 = __builtin_ctz(remaining);
+                        const int node = __builtin_amdgcn_readlane(nid[c], s0);
+                        const unsigned segmask = (unsigned)__ballot(pv[c] && nid[c] == node);
+                        remaining &= ~segmask;
+                        const int e0 = s0 + __builtin_popcount(segmask);
+                        const bool whole = (s0 == 0 && e0 == 32);
+                        const int slot = node - n0;
+                        float mx[MT4];
+                        if (whole) {
 #pragma unroll
-                        for (int mt = 0; mt < W4T; ++mt) {
-                            float m = acc[mt][c][0];
+                            for (int mt = 0; mt < MT4; ++mt) {
+                                float m = acc[mt][c][0];
 #pragma unroll
-                            for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][c][r]));
-                            mx[mt] = m;
-                        }
-                    } else {
+                                for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][c][r]));
+                                mx[mt] = m;
+                            }
+                        } else {
 #pragma unroll
-                        for (int mt = 0; mt < W4T; ++mt) mx[mt] = -__builtin_inff();
+                            for (int mt = 0; mt < MT4; ++mt) mx[mt] = -__builtin_inff();
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const bool in = prow >= s0 && prow < e0;
+                            for (int r = 0; r < 16; ++r) {
+                                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const bool in = prow >= s0 && prow < e0;
 #pragma unroll
-                            for (int mt = 0; mt < W4T; ++mt) {
-                                const float v = in ? acc[mt][c][r] : -__builtin_inff();
-                                asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));
+                                for (int mt = 0; mt < MT4; ++mt) {
+                                    const float v = in ? acc[mt][c][r] : -__builtin_inff();
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));
+                                }
                             }
                         }
+                        if (l4_unit) {                                            // fl(x / 32 + b) is monotone in x: after the max
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
+                        }
+                        // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
+                        // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
+                        if (slot < SEG_SLOTS) {
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(&bins[slot][32 * mt + j], ord_f32(__float_as_uint(mx[mt])));
+                        } else {
+                            unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * PCH;
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
+                        }
                     }
-                    if (l4_unit) {                                                // fl(x / 32 + b) is monotone in x: after the max
+                }
+                pend_n = nslots * PCH;
+                pend = partial + ((tile * NPASS + pass) * SEG_SLOTS) * (long long)PCH;   // stored at the next flush boundary
+            } else {
 #pragma unroll
-                        for (int mt = 0; mt < W4T; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
-                    }
-                    // two explicit paths: a generic pointer here would make FLAT atomics (and FLAT operations count on
-                    // both vmcnt and lgkmcnt)
-                    if (slot < SEG_SLOTS) {
+                for (int c = 0; c < 2; ++c) {
+                    if (!pv[c]) continue;
 #pragma unroll
-                        for (int mt = 0; mt < W4T; ++mt) atomicMax(&bins[slot][(W4T * wave + mt) * 32 + j], ord_f32(__float_as_uint(mx[mt])));
-                    } else {
-                        unsigned *gdst = pooled + ((long long)b * M + node) * C4 + (W4T * wave) * 32;
+                    for (int mt = 0; mt < MT4; ++mt) {
+                        const int ct = pass * MT4 + mt;
+                        const unsigned so_tile = (unsigned)(ct * 32) * rowB;
 #pragma unroll
-                        for (int mt = 0; mt < W4T; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
+                        for (int r = 0; r < 16; ++r) {
+                            const int orow = (r & 3) + 8 * (r >> 2);
+                            const float2 ss = aff[LB4 + ct * 32 + orow + 4 * h];
+                            const float v = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (unsigned)(4 * h * L + lc[c]) * 4u,
+                                                                  so_tile + (unsigned)orow * rowB, 0);
+                        }
                     }
                 }
             }
-            pend_n = nslots * C4;
-            pend = partial + (tile * SEG_SLOTS) * (long long)C4;                   // stored after the next barrier 1
-        } else {
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-                y + b * (long long)C4 * L, 0, (int)((unsigned)C4 * rowB), 0x00020000);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (!pv[c]) continue;
-#pragma unroll
-                for (int mt = 0; mt < W4T; ++mt) {
-                    const int ct = W4T * wave + mt;
-                    const unsigned so_tile = (unsigned)(ct * 32) * rowB;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int orow = (r & 3) + 8 * (r >> 2);
-                        const float2 ss = aff[LB4 + ct * 32 + orow + 4 * h];
-                        const float v = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (unsigned)(4 * h * L + lc[c]) * 4u,
-                                                              so_tile + (unsigned)orow * rowB, 0);
-                    }
-                }
-            }
+        };
+        {                                                       // pass 0 (peeled: it carries the jobs of layer 3's second tile group)
+            f32x16 acc[MT4][2];
+            PF_L4_BODY(true)
+            // the next tile's inputs (here and not in the pass loop: a conditional load in the loop would keep the registers occupied
+            // from the top of the tile on)
+            prefetch_tile(tile + gridDim.x);
+            PROF_MARK(10)                                       // layer-4 pass 0 (carries jobs)
+            epilogue(acc, 0);
+            PROF_MARK(4)                                        // epilogue (pool or stores)
         }
-        PROF_MARK(7)                                            // epilogue (pool or stores)
+        for (int pass = 1; pass < NPASS; ++pass) {
+            f32x16 acc[MT4][2];
+            PF_L4_BODY(false)
+            PROF_MARK(3)
+            epilogue(acc, pass);
+            PROF_MARK(4)
+        }
+#undef SLOT_L4
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the stages streamed ahead of the last tile
     if constexpr (SEGMAX) {
         __syncthreads();
-        for (int e = threadIdx.x; e < pend_n; e += PF_THREADS) pend[e] = (&bins[0][0])[e];
+        flush_bins();
     }
     if (rlog != nullptr) {
         range_publish(rlog, wave_umax(xin_r), lane);
-        // the jobs logged 32 x: take the factor out of the exponent (a NaN / inf stays far above the fp16 range)
+        // the job logged 32 x: take the factor out of the exponent (a NaN / inf stays far above the fp16 range)
         unsigned rb = wave_umax((unsigned)(rmax_ > 0 ? rmax_ : 0));
         rb = rb > (5u << 23) ? rb - (5u << 23) : 0u;
         range_publish(rlog + 2, rb, lane);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wst + (long long)NSLICE * 64)[0]);
     }
-    PROF_MARK(8)
+    PROF_MARK(5)
     PROF_DUMP
 }
 
@@ -750,26 +923,28 @@ __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__re
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // over [B][M][384], c fastest (coalesced partial reads)
     if (t >= total) return;
-    const int c = (int)(t % C4);
-    const long long bm = t / C4;
+    const int C = 32 * T3;
+    const int c = (int)(t % C);
+    const long long bm = t / C;
     const int m = (int)(bm % M);
     const long long b = bm / M;
     unsigned key = pooled[t];
     const int cnt = count[b * M + m];
     if (cnt > 0) {
         const int off = node_off[b * M + m];
+        const int pass = c / PCH, cl = c - pass * PCH;
         for (int tl = off / TPTS; tl <= (off + cnt - 1) / TPTS; ++tl) {
             const int slot = m - ids_sorted[b * L + tl * TPTS];
             if (slot < SEG_SLOTS) {
-                const unsigned k2 = partial[((b * tpc + tl) * SEG_SLOTS + slot) * (long long)C4 + c];
+                const unsigned k2 = partial[((((b * tpc + tl) * NPASS + pass) * SEG_SLOTS) + slot) * (long long)PCH + cl];
                 key = k2 > key ? k2 : key;
             }
         }
     }
     float v;
     if (key > SEG_INIT) v = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
-    else v = v0[b * C4 + c];
-    out[(b * C4 + c) * M + m] = v;
+    else v = v0[b * C + c];
+    out[(b * C + c) * M + m] = v;
 }
 
 int cu_count() {
@@ -778,7 +953,6 @@ int cu_count() {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    if (const char *e = sonet::knob("SONET_FUSED_MAXCU")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }   // (variants build only)
     return cus;
 }
 
@@ -805,13 +979,13 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     const char *what = "sonet_pointresnet_fused_f32";
     SONET_REQUIRE(x && wstream && affine && y, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d Cin0=%d", what, B, L, Cin0);
-    if ((double)C4 * L * 4.0 >= 4.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
+    if ((double)(32 * T3) * L * 4.0 >= 4.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 4 GiB", what);
     const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
     const int cus = cu_count();
     const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
     hipLaunchKernelGGL((pointresnet_fused_kernel<false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
-                       x, Cin0, reinterpret_cast<const u32x4_t *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
+                       x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log());
     return sonet::launched(what);
 }
@@ -820,7 +994,7 @@ extern "C" size_t sonet_pointresnet_pool_ws_size(int B, int L, int M)
 {
     if (B <= 0 || L <= 0 || M <= 0) return 0;
     const long long ntiles = (long long)B * sonet::ceil_div(L, TPTS);
-    return (size_t)((long long)B * M * C4 + ntiles * SEG_SLOTS * C4) * 4 + (size_t)B * C4 * 4;
+    return (size_t)((long long)B * M * (32 * T3) + ntiles * NPASS * SEG_SLOTS * PCH) * 4 + (size_t)B * (32 * T3) * 4;
 }
 
 extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
@@ -831,17 +1005,17 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
     SONET_REQUIRE(x_sorted && wstream && affine && ids_sorted && pos0 && node_off && count && ws && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && M > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d M=%d Cin0=%d", what, B, L, M, Cin0);
     hipStream_t st = sonet::as_stream(stream);
-    const long long npool = (long long)B * M * C4;
+    const long long npool = (long long)B * M * (32 * T3);
     const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
     unsigned *pooled_ws = reinterpret_cast<unsigned *>(ws);
     unsigned *partial_ws = pooled_ws + npool;
-    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * SEG_SLOTS * C4);
+    float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * NPASS * SEG_SLOTS * PCH);
     hipLaunchKernelGGL(pooled_init_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, npool);
     const int cus = cu_count();
     const long long grid = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL((pointresnet_fused_kernel<true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st,
-                       x_sorted, Cin0, reinterpret_cast<const u32x4_t *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
+                       x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log());
     hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
                        ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);

@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 from argparse import Namespace
 
 import pytest
@@ -187,3 +188,17 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert allsig[name] == want, (name, [t.__name__ for t in want], [t.__name__ for t in allsig[name]])
         want_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t}.get(ret, ctypes.c_char_p)
         assert _lib._RESTYPES.get(name, ctypes.c_int) == want_ret, name
+
+
+def test_fused_kernel_build_leaves_the_accumulation_registers_alone():
+    """The fused first-PointNet kernel owns a[0:255] through inline asm; hipcc must never use them itself (a VGPR spilled into
+    an 'unused' AGPR would be overwritten by the kernel's MFMAs), must not spill to scratch, and must not touch the VGPR
+    destination of an asm MFMA while it is in flight.  tools/check_fused_asm.py compiles the source to ISA and checks."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_fused_asm
+    kernels = check_fused_asm.audit(os.path.join(ROOT, "so-net_amd", "csrc", "pointresnet_fused.hip"), [])
+    fused = {k: v for k, v in kernels.items() if "fused_kernel" in k}
+    assert len(fused) == 2, list(kernels)
+    for name, k in fused.items():
+        assert k["mfma"] == 1224, (name, k)
+        assert k["accvgpr_by_compiler"] == 0 and k["scratch"] == 0 and k["early_reads"] == 0, (name, k)

@@ -39,22 +39,31 @@ NP = 32
 buf = np.zeros(1024 * NP, dtype=np.int64)
 assert lib.sonet_prof_read(buf.ctypes.data, buf.size) == 0
 p = buf.reshape(1024, NP).astype(np.float64)
-tiles = B * ((15000 + 63) // 64) / float(min(256, int(os.environ.get("SONET_FUSED_MAXCU", "256"))))
-# phase slots of the third-generation kernel (PROF_MARK in pointresnet_fused.hip); MFMA-only ideal = 32 cycles per MFMA
-names = ["kernel prologue", "first front (exposed)", "tile prologue + barrier 1", "layer 3 (96 MFMAs)", "layer 4 steps 0-3 + layer-3 jobs (72)",
-         "barrier 2", "layer 4 steps 4-19 + next front (324)", "epilogue", "tail"]
-ideal = [0, 0, 0, 96 * 32, 72 * 32, 0, 324 * 32, 0, 0]
-tot = p[:, :9].sum(1).mean()
-print("mode %s: %.0f cycles per wave, %.2f tiles per workgroup, MFMA-only ideal per tile %d" % (mode, tot, tiles, sum(ideal)))
-for i, n in enumerate(names):
+GEN4 = os.environ.get("GEN", "4") == "4"
+TP = 256 if GEN4 else 64
+tiles = B * ((15000 + TP - 1) // TP) / float(min(256, int(os.environ.get("SONET_FUSED_MAXCU", "256"))))
+if GEN4:
+    # phase slots of the fourth-generation kernel (PROF_MARK in pointresnet_fused.hip); MFMA-only ideal = 32 cycles per MFMA
+    slots = [(0, "kernel prologue", 0), (1, "tile prologue (split x)", 0), (6, "layer 1 + first jobs", 12), (7, "layer 2 + transition jobs", 96),
+             (8, "layer 3, tiles 0-3", 192), (9, "layer 3, tiles 4-7", 192), (2, "layer 1 again (exposed)", 12), (10, "layer 4, pass 0 (+ jobs)", 360), (3, "layer 4, passes 1-3", 1080),
+             (4, "epilogues (4)", 0), (5, "tail", 0)]
+    waits = [(28, "  of which: wait for own W pieces (vmcnt)"), (29, "  of which: stage barriers")]
+else:
+    slots = [(0, "kernel prologue", 0), (1, "first front (exposed)", 0), (2, "tile prologue + barrier 1", 0), (3, "layer 3", 96),
+             (4, "layer 4 steps 0-3 + layer-3 jobs", 72), (5, "barrier 2", 0), (6, "layer 4 steps 4-19 + next front", 324), (7, "epilogue", 0), (8, "tail", 0)]
+    waits = []
+idx = [i for i, _, _ in slots]
+tot = p[:, idx].sum(1).mean()
+print("mode %s: %.0f cycles per wave, %.2f tiles per workgroup, MFMA-only ideal per tile %d" % (mode, tot, tiles, 32 * sum(m for _, _, m in slots)))
+for i, n, m in slots + [(i, n, 0) for i, n in waits]:
     per_tile = p[:, i].mean() / tiles
-    print("  %-42s %9.0f cycles/tile  (%4.1f%%)%s" % (n, per_tile, 100 * p[:, i].mean() / tot,
-          "   MFMA-only ideal %d -> %.0f%%" % (ideal[i], 100 * ideal[i] / per_tile) if ideal[i] else ""))
+    print("  %-44s %9.0f cycles/tile  (%4.1f%%)%s" % (n, per_tile, 100 * p[:, i].mean() / tot,
+          "   MFMA-only ideal %d -> %.0f%%" % (32 * m, 100 * 32 * m / per_tile) if m else ""))
 pw = p.reshape(-1, 4, NP)
-print("  per wave (cycles/tile):   total  barrier1    layer3   l4a   barrier2    l4b  epilogue")
+print("  per wave (cycles/tile): total " + " ".join("%8s" % ("slot%d" % i) for i in idx))
 for w in range(4):
     m = pw[:, w, :].mean(0) / tiles
-    print("    wave %d               %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f" % (w, pw[:, w, :9].sum(1).mean() / tiles, m[2], m[3], m[4], m[5], m[6], m[7]))
+    print("    wave %d           %8.0f " % (w, pw[:, w, idx].sum(1).mean() / tiles) + " ".join("%8.0f" % m[i] for i in idx))
 rt = p[:, 31].mean()                                            # s_memrealtime ticks (100 MHz) per wave
-cyc = p[:, :9].sum(1).mean()
+cyc = tot
 print("  shader clock while the kernel runs: %.0f cycles in %.1f us = %.3f GHz" % (cyc, rt / 100.0, cyc / (rt * 10.0) if rt else 0.0))
