@@ -621,9 +621,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             JobSc sc_; JobX jx0_, jx1_;
             if constexpr (k + 1 < KC2) PF_LOAD_SC(sc_, LB1, tn, qn)
             u32x4_t nl0 = bl0, nl1 = bl1;
-#define SLOT_L2(q) { if constexpr (k + 1 < KC2) { PF_SLOT2(q, 5, JOB_OPS_V, false, AG13(tn, 0) + 8 * qn, AG13(tn, 1) + 8 * qn) \
-                       if constexpr ((q) == 20) { a1[tn][qn][0] = job_result(jx0_); a1[tn][qn][1] = job_result(jx1_); } \
-                       PF_SLOT_BL(q, 21, a1[tn][qn][0].h, a1[tn][qn][1].h, nl0, nl1) } }
+#define SLOT_L2(q) { if constexpr (k + 1 < KC2) { PF_SLOT2(q, 4, JOB_OPS_V, false, AG13(tn, 0) + 8 * qn, AG13(tn, 1) + 8 * qn) \
+                       if constexpr ((q) == 23) { a1[tn][qn][0] = job_result(jx0_); a1[tn][qn][1] = job_result(jx1_); nl0 = piece_l(a1[tn][qn][0].h); nl1 = piece_l(a1[tn][qn][1].h); } } }
             PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG2, a1[tk][qk][0].h, a1[tk][qk][0].m, bl0, a1[tk][qk][1].h, a1[tk][qk][1].m, bl1, (k == 0), SLOT_L2)
 #undef SLOT_L2
             bl0 = nl0; bl1 = nl1;
@@ -655,9 +654,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             JobSc sc_; JobX jx0_, jx1_;
             if constexpr (k + 1 < KC3) PF_LOAD_SC(sc_, LB2, tn, qn)
             u32x4_t nl0 = bl0, nl1 = bl1;
-#define SLOT_L3A(q) { if constexpr (k + 1 < KC3) { PF_SLOT2(q, 5, JOB_OPS_V, false, AG2(tn, 0) + 8 * qn, AG2(tn, 1) + 8 * qn) \
-                        if constexpr ((q) == 20) { a2[tn][qn][0] = job_result(jx0_); a2[tn][qn][1] = job_result(jx1_); } \
-                        PF_SLOT_BL(q, 21, a2[tn][qn][0].h, a2[tn][qn][1].h, nl0, nl1) } \
+#define SLOT_L3A(q) { if constexpr (k + 1 < KC3) { PF_SLOT2(q, 4, JOB_OPS_V, false, AG2(tn, 0) + 8 * qn, AG2(tn, 1) + 8 * qn) \
+                        if constexpr ((q) == 23) { a2[tn][qn][0] = job_result(jx0_); a2[tn][qn][1] = job_result(jx1_); nl0 = piece_l(a2[tn][qn][0].h); nl1 = piece_l(a2[tn][qn][1].h); } } \
                       else { PF_SLOT_BL(q, 4, pbh[0], pbh[1], nl0, nl1) } }
             PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG3A, a2[tk][qk][0].h, a2[tk][qk][0].m, bl0, a2[tk][qk][1].h, a2[tk][qk][1].m, bl1, (k == 0), SLOT_L3A)
 #undef SLOT_L3A
@@ -811,25 +809,28 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                         const bool whole = (s0 == 0 && e0 == 32);
                         const int slot = node - n0;
                         float mx[MT4];
+                        // (v_max3_f32: two rows per instruction, same NaN rule as v_max_f32)
                         if (whole) {
 #pragma unroll
                             for (int mt = 0; mt < MT4; ++mt) {
-                                float m = acc[mt][c][0];
+                                float m;
+                                asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(acc[mt][c][0]), "v"(acc[mt][c][1]));
 #pragma unroll
-                                for (int r = 1; r < 16; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[mt][c][r]));
+                                for (int r = 2; r < 16; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[mt][c][r]), "v"(acc[mt][c][r + 1]));
                                 mx[mt] = m;
                             }
                         } else {
 #pragma unroll
                             for (int mt = 0; mt < MT4; ++mt) mx[mt] = -__builtin_inff();
+                            const unsigned nrows = (unsigned)(e0 - s0);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                                const bool in = prow >= s0 && prow < e0;
+                            for (int r = 0; r < 16; r += 2) {
+                                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;          // rows prow, prow + 1 (r even: same group of four)
+                                const bool in0 = (unsigned)(prow - s0) < nrows, in1 = (unsigned)(prow + 1 - s0) < nrows;
 #pragma unroll
                                 for (int mt = 0; mt < MT4; ++mt) {
-                                    const float v = in ? acc[mt][c][r] : -__builtin_inff();
-                                    asm("v_max_f32 %0, %1, %2" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v));
+                                    const float v0_ = in0 ? acc[mt][c][r] : -__builtin_inff(), v1_ = in1 ? acc[mt][c][r + 1] : -__builtin_inff();
+                                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx[mt]) : "v"(mx[mt]), "v"(v0_), "v"(v1_));
                                 }
                             }
                         }

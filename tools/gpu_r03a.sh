@@ -1,5 +1,13 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03p; mkdir -p $O; cd $R
-export TMPDIR=/tmp
-echo "== pytest"; timeout 1700 python -m pytest tests/test_gpu_variants_suite.py tests/test_gpu_bf16.py -m gpu -x -q 2>&1 | tail -6
-for prec in bf16; do timeout 600 python bench.py --mode train --precision $prec --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; l=json.loads(sys.stdin.read()); print('$prec', l['ms_per_step'], l['value'])"; done
+# scratch: per-kernel times of variants of the fused kernel
+cd /tmp && export TMPDIR=/tmp
+for v in "$@"; do
+  rm -rf /tmp/rp_$v
+  ITERS=31 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$v -o r -- python $GRAFT_REPO_ROOT/tools/fused_variants.py --child $v /tmp/$v.npz > /dev/null 2>&1 < /dev/null
+  f=$(find /tmp/rp_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; if [ -n "$f" ]; then python3 -c "
+import csv,sys
+for i,r in enumerate(csv.DictReader(open('$f'))):
+    if i<5: print('%-60s calls %4s avg %10.1f us' % (r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3))
+"; fi
+done
