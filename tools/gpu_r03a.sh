@@ -1,13 +1,12 @@
 #!/bin/bash
-# scratch: per-kernel times of variants of the fused kernel
-cd /tmp && export TMPDIR=/tmp
-for v in "$@"; do
-  rm -rf /tmp/rp_$v
-  ITERS=31 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$v -o r -- python $GRAFT_REPO_ROOT/tools/fused_variants.py --child $v /tmp/$v.npz > /dev/null 2>&1 < /dev/null
-  f=$(find /tmp/rp_$v -name "*kernel_stats.csv" | head -1)
-  echo "== $v"; if [ -n "$f" ]; then python3 -c "
-import csv,sys
-for i,r in enumerate(csv.DictReader(open('$f'))):
-    if i<5: print('%-60s calls %4s avg %10.1f us' % (r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3))
-"; fi
-done
+# scratch wrapper: the round's measurement set + SQ counters of the fused kernel + training kernel stats
+TAG=${1:-r03a}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+SKIP="7" bash tools/gpu_round.sh $TAG
+P=$R/gpurun_out/$TAG/profiles
+timeout 400 bash tools/pmc_sq.sh fused_pool > $R/gpurun_out/$TAG/pmc_sq.log 2>&1
+for p in a b c; do f=$R/gpurun_out/pmc_sq_fused_pool_$p/pmc_counter_collection.csv; [ -f $f ] && cp $f $P/${TAG}_pmc_sq_fused_pool_$p.csv; done
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/rocprof_train -o tr -- python $R/bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/$TAG/rocprof_train.err < /dev/null)
+f=$(find $R/gpurun_out/$TAG/rocprof_train -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $P/${TAG}_kernel_stats_train.csv
+ls $P

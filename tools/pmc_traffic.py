@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WIDE_READERS = ("index_max",)
 NAMES = [("pointresnet_bf16_pool2_kernel", "pointresnet_bf16_pool_L15000"), ("pointresnet_fused_kernel", "pointresnet_fused_pool_L15000"), ("index_max_kernel", "index_max_gather"),
-         ("som_assign_keys_kernel", "som_assign"), ("som_assign_kernel", "som_assign"), ("som_sort_group_kernel", "som_sort_group"), ("som_group_kernel", "som_group")]
+         ("som_assign_rank_kernel", "som_assign_sort"), ("som_sort_fill2_kernel", "som_assign_sort"), ("som_assign_keys_kernel", "som_assign"), ("som_assign_kernel", "som_assign"), ("som_sort_group_kernel", "som_sort_group"), ("som_group_kernel", "som_group")]
 
 
 def load(counter):
@@ -36,8 +36,8 @@ def main():
         if f is None or w is None:
             continue
         fbytes = f * 1024 * (2 if name.startswith(WIDE_READERS) else 1)
-        out[name] = int(fbytes + w * 1024)
-        print("%-28s FETCH_SIZE %.4g  WRITE_SIZE %.4g  -> %.1f MB per launch" % (name, f, w, out[name] / 1e6))
+        out[name] = out.get(name, 0) + int(fbytes + w * 1024)     # (several kernels of one entry point add up)
+        print("%-28s %-28s FETCH_SIZE %.4g  WRITE_SIZE %.4g  -> %.1f MB per launch" % (name, needle, f, w, (fbytes + w * 1024) / 1e6))
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     allv = json.load(open(path)) if os.path.exists(path) else {}
     allv[tag] = out
