@@ -447,7 +447,13 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 constexpr int H3R_MT = 4, H3R_S = 2, H3R_SLOTS = 4, H3R_SLOT_SL = H3R_S * H3R_MT * 2;
 constexpr int H3R_WAIT = 2 * 4 + 2 * H3R_S * 8;               // the DMAs of two later stages + the X loads of two stages
 
-__global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
+// NC = 32-column tiles per wave; the product instantiates NC = 1.  NC = 2 (variants build, a measured record): every A fragment read
+// from LDS feeds two MFMAs, the weight stream is fetched once per 256 columns instead of 128, one workgroup per CU with 128
+// accumulator registers per lane.  A lane then owns the ADJACENT columns 2j, 2j+1 (tile c = column parity), so X loads and Y stores
+// are 8 bytes wide and their count per stage -- which the hand-counted vmcnt relies on -- is the same as for NC = 1.  Needs an even
+// L and no gather index.
+template <int NC>
+__global__ __launch_bounds__(X3_THREADS, NC == 1 ? 2 : 1) void pointmlp_h3r_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp2,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
     int Cout, int L, int gpc, long long ngroups, int CT, int KC, int ct_per_y,
@@ -476,9 +482,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const bool wave_valid = q < ngroups;
     q = wave_valid ? q : 0;
     const long long b = q / gpc;
-    const int l0 = (int)(q - b * gpc) * 32;
-    const bool pv = wave_valid && (l0 + j < L);
-    const int lc = (l0 + j < L) ? l0 + j : l0;
+    const int l0 = (int)(q - b * gpc) * (32 * NC);              // gpc = groups of 32 NC columns per cloud
+    const bool pv = wave_valid && (l0 + NC * j < L);            // (NC = 2: L is even, so column 2j + 1 is valid with 2j)
+    const int lc = (l0 + NC * j < L) ? l0 + NC * j : l0;        // the lane's first column
 
     const unsigned rowB = (unsigned)L * 4u, rowB1 = (unsigned)L1 * 4u;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -489,9 +495,11 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
         y + b * (long long)Cout * L, 0, (int)((unsigned)Cout * rowB), 0x00020000);
     const unsigned vox = (unsigned)(8 * h * L + lc) * 4u;
     unsigned vox1 = vox;
-    if (gidx) {
-        const int src = gidx[b * L + lc];
-        vox1 = (unsigned)src < (unsigned)L1 ? (unsigned)(8 * h * L1 + src) * 4u : 0x7FFFFF00u;
+    if constexpr (NC == 1) {
+        if (gidx) {
+            const int src = gidx[b * L + lc];
+            vox1 = (unsigned)src < (unsigned)L1 ? (unsigned)(8 * h * L1 + src) * 4u : 0x7FFFFF00u;
+        }
     }
     const unsigned voy = (unsigned)(4 * h * L + lc) * 4u;
     const unsigned vow = (unsigned)lane * 16u;
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
     const int KC1 = C2 > 0 ? (C1 >> 4) : KC;
     const int nstage = (KC + S - 1) / S;
 
-    auto load_b = [&](float (&raw)[S][8], int st) {
+    auto load_b = [&](float (&raw)[S][8][NC], int st) {
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int kc = st * S + i;                          // (a chunk past KC reads past both panels: zeros)
@@ -509,8 +517,14 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const unsigned so = row0 + (unsigned)t * rb;
-                raw[i][t] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
-                                                              : __builtin_amdgcn_raw_buffer_load_b32(r1, vox1, so, 0));
+                if constexpr (NC == 1) {
+                    raw[i][t][0] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
+                                                                     : __builtin_amdgcn_raw_buffer_load_b32(r1, vox1, so, 0));
+                } else {
+                    const f32x2_t v2 = __builtin_bit_cast(f32x2_t, second ? __builtin_amdgcn_raw_buffer_load_b64(r2, vox, so, 0)
+                                                                           : __builtin_amdgcn_raw_buffer_load_b64(r1, vox1, so, 0));
+                    raw[i][t][0] = v2[0]; raw[i][t][1] = v2[1];
+                }
             }
         }
     };
@@ -527,11 +541,13 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 
     RangeAcc xr = {0, 0u};
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
-        f32x16 acc[MT];
+        f32x16 acc[MT][NC];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
 
         const char *gw = reinterpret_cast<const char *>(Wp2) + ((size_t)(ct0 + wave) * KCP) * 2048u;
         auto dma = [&](int st) {                               // stage st (clamped) -> slot st % H3R_SLOTS
@@ -550,17 +566,20 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
         // slot layout = pack layout of the four tiles side by side: [mt][i][term] -> slice (mt * S + i) * 2 + term
         // (the range maxima are tracked unconditionally -- two v_max3 per value pair in the MFMA shadow; a branch here would cut
         // the scheduling region that interleaves the split with the MFMAs -- and published by slab 0 only)
-        auto split = [&](const float (&raw)[8], unsigned (&bh)[4], unsigned (&bm)[4], unsigned (&bl)[4]) {
+        auto split = [&](const float (&raw)[8][NC], unsigned (&bh)[NC][4], unsigned (&bm)[NC][4], unsigned (&bl)[NC][4]) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) range_track(xr, raw[2 * p], raw[2 * p + 1]);
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) split16_pair_med3(raw[2 * p], raw[2 * p + 1], bh[p], bm[p], bl[p]);
+                for (int p = 0; p < 4; ++p) range_track(xr, raw[2 * p][c], raw[2 * p + 1][c]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) split16_pair_med3(raw[2 * p][c], raw[2 * p + 1][c], bh[c][p], bm[c][p], bl[c][p]);
+            }
         };
         // one MFMA, then VALU_PER of the split's vector instructions in its shadow (a wave issues in order: twelve MFMAs in a row
         // followed by the split leave the matrix pipe idle for the ~200 cycles of the split; hipcc emits exactly that by itself)
         auto interleave = [&]() {
 #pragma unroll
-            for (int k = 0; k < 3 * MT; ++k) {
+            for (int k = 0; k < 3 * MT * NC; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
@@ -573,20 +592,30 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 Ah[mt] = base[((mt * S + i) * 2 + 0) * 64];
             }
         };
-        auto mfmas = [&](const uint4 (&Ar)[MT], const uint4 (&Ah)[MT], const unsigned (&bh)[4], const unsigned (&bm)[4], const unsigned (&bl)[4]) {
-            const f16x8 Bh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));     // 32 xh
-            const f16x8 Bm = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));     // 32 * residual
-            const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh
+        auto mfmas = [&](const uint4 (&Ar)[MT], const uint4 (&Ah)[MT], const unsigned (&bh)[NC][4], const unsigned (&bm)[NC][4], const unsigned (&bl)[NC][4]) {
+            f16x8 Bh[NC], Bm[NC], Bl[NC];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[mt]), Bl, acc[mt], 0, 0, 0);
+            for (int c = 0; c < NC; ++c) {
+                Bh[c] = __builtin_bit_cast(f16x8, make_uint4(bh[c][0], bh[c][1], bh[c][2], bh[c][3]));     // 32 xh
+                Bm[c] = __builtin_bit_cast(f16x8, make_uint4(bm[c][0], bm[c][1], bm[c][2], bm[c][3]));     // 32 * residual
+                Bl[c] = __builtin_bit_cast(f16x8, make_uint4(bl[c][0], bl[c][1], bl[c][2], bl[c][3]));     // xh
+            }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bm, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bh, acc[mt], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) acc[mt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[mt]), Bl[c], acc[mt][c], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[mt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bm[c], acc[mt][c], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[mt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[mt]), Bh[c], acc[mt][c], 0, 0, 0);
         };
 
-        float xa[S][8], xb[S][8], xc[S][8];
-        unsigned bh[2][4], bm[2][4], bl[2][4];
+        float xa[S][8][NC], xb[S][8][NC], xc[S][8][NC];
+        unsigned bh[2][NC][4], bm[2][NC][4], bl[2][NC][4];
         __syncthreads();                                        // every wave is done with the previous tile group's slots (and the affine table is written)
         dma(0); dma(1); dma(2);
         load_b(xa, 0);
@@ -624,6 +653,11 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
 #undef H3R_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped re-loads of the tail: nothing may land after the next group starts
 
+        // y (c = 0 .. NC-1: the lane's adjacent columns) leaves as one 4 NC-byte store per (row, lane)
+        auto store_row = [&](const float (&v)[NC], unsigned vo, unsigned so) {
+            if constexpr (NC == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[0]), ry, vo, so, 0);
+            else { const f32x2_t v2 = {v[0], v[1]}; __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(ry, 0u, 0u, 0)), v2), ry, vo, so, 0); }
+        };
         if (stats_partial != nullptr) {                        // BatchNorm batch statistics from the epilogue (see pointmlp_x3_kernel)
             const unsigned voy_s = pv ? voy : 0x7FFFFF00u;
 #pragma unroll
@@ -634,11 +668,17 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int orow = (r & 3) + 8 * (r >> 2);
                     const float2 ss = aff[orow];
-                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                    if (relu) v = (v < 0.f) ? 0.f : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy_s, so_tile + (unsigned)orow * rowB, 0);
-                    const float sv = pv ? v : 0.f;
-                    const float s1 = row32_sum(sv), s2 = row32_sum(sv * sv);
+                    float v[NC], sv = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        v[c] = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                        if (relu) v[c] = (v[c] < 0.f) ? 0.f : v[c];
+                        const float vv = pv ? v[c] : 0.f;
+                        sv = c == 0 ? vv : sv + vv;
+                        sq = c == 0 ? vv * vv : sq + vv * vv;
+                    }
+                    store_row(v, voy_s, so_tile + (unsigned)orow * rowB);
+                    const float s1 = row32_sum(sv), s2 = row32_sum(sq);
                     if (j == 0) lds.red[wave][mt * 32 + orow + 4 * h] = make_float2(s1, s2);
                 }
             }
@@ -651,7 +691,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 dst[1] = qq;
             }
             __syncthreads();
-        } else if (kmax != nullptr) {
+        } else if (NC == 1 && kmax != nullptr) {
             // max over the neighbour planes in the epilogue: column l of a k-major tensor belongs to node l % KM; a 32-column tile of
             // one plane is 32 consecutive nodes, so a store instruction's 32 lanes hit 32 consecutive keys of one channel row -- an
             // atomic per element costs what the store would, and B x C x K*M never exists (torch.max(dim=3) of models/layers.py:350).
@@ -665,7 +705,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                     for (int r = 0; r < 16; ++r) {
                         const int orow = (r & 3) + 8 * (r >> 2);
                         const float2 ss = aff[orow];
-                        float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                        float v = __fmaf_rn(acc[mt][0][r], ss.x, ss.y);
                         if (relu) v = (v < 0.f) ? 0.f : v;
                         const unsigned u = __float_as_uint(v);
                         atomicMax(kb + (size_t)((ct0 + mt) * 32 + orow + 4 * h) * KM, (u & 0x80000000u) ? ~u : (u | 0x80000000u));
@@ -673,9 +713,14 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 }
             }
         } else if (pv && zadd != nullptr) {                    // per-node addend gathered here (see pointmlp_x3_kernel)
-            const int zm = zidx[b * L + lc];
-            const bool zok = (unsigned)zm < (unsigned)ZM;
-            const float *zb = zadd + ((size_t)b * Cout) * ZM + (zok ? zm : 0);
+            const float *zb[NC];
+            bool zok[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int zm = zidx[b * L + lc + c];
+                zok[c] = (unsigned)zm < (unsigned)ZM;
+                zb[c] = zadd + ((size_t)b * Cout) * ZM + (zok[c] ? zm : 0);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
@@ -684,10 +729,14 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int orow = (r & 3) + 8 * (r >> 2);
                     const float2 ss = aff[orow];
-                    const float zv = zok ? zb[(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
-                    float v = __fmaf_rn(acc[mt][r], ss.x, __fmaf_rn(zv, ss.x * 32.f, ss.y));
-                    if (relu) v = (v < 0.f) ? 0.f : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                    float v[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const float zv = zok[c] ? zb[c][(size_t)((ct0 + mt) * 32 + orow + 4 * h) * ZM] : 0.f;
+                        v[c] = __fmaf_rn(acc[mt][c][r], ss.x, __fmaf_rn(zv, ss.x * 32.f, ss.y));
+                        if (relu) v[c] = (v[c] < 0.f) ? 0.f : v[c];
+                    }
+                    store_row(v, voy, so_tile + (unsigned)orow * rowB);
                 }
             }
         } else if (pv) {
@@ -699,9 +748,13 @@ __global__ __launch_bounds__(X3_THREADS, 2) void pointmlp_h3r_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int orow = (r & 3) + 8 * (r >> 2);
                     const float2 ss = aff[orow];
-                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                    if (relu) v = (v < 0.f) ? 0.f : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                    float v[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        v[c] = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                        if (relu) v[c] = (v[c] < 0.f) ? 0.f : v[c];
+                    }
+                    store_row(v, voy, so_tile + (unsigned)orow * rowB);
                 }
             }
         }
@@ -794,6 +847,43 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const bool h3r_pick = h3r_fits || (CT % 6 != 0 && Cin >= 512 && (long long)B * L >= 256);
     // (the per-node addend form measured better on the first generation: 0.86 vs 0.98 ms for 393 -> 1024 at 64 x 3072 columns)
     if (kmax && !(f16 && CT % H3R_MT == 0)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the max-reduced form needs Cout %% 128 == 0", what);
+#ifdef SONET_VARIANTS
+    // Two column tiles per wave (NC = 2), variants build only (SONET_POINTMLP_NC=2; tools/bench_h3w.py): bit-identical, and measured
+    // 2 % faster on the two K >= 512 segmenter layers but 3-18 % SLOWER everywhere else (profiles/r03b_pointmlp_two_tiles.log) -- the
+    // per-layer kernel is bound by its X stream, where two waves per SIMD hide more than the halved weight stream saves.
+    const char *enc = sonet::knob("SONET_POINTMLP_NC");
+    const bool wide = enc && atoi(enc) == 2 && f16 && CT % H3R_MT == 0 && !gidx && !kmax && (L % 2 == 0);
+    if (wide) {
+        const int gpc2 = sonet::ceil_div(L, 64);
+        const long long ngroups2 = (long long)B * gpc2, nwg_x2 = sonet::ceil_div64(ngroups2, (long long)X3_WAVES);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        // output-channel slabs: as below, with one workgroup per CU
+        const int groups = CT / H3R_MT;
+        int best = 0;
+        long long best_cost = 0;
+        for (int d = 1; d <= groups; ++d) {
+            if (groups % d != 0 || CT / d > 32) continue;
+            const long long cost = sonet::ceil_div64(nwg_x2 * d, (long long)cus) * (groups / d);
+            if (best == 0 || cost <= best_cost) { best = d; best_cost = cost; }
+        }
+        if (const char *e = sonet::knob("SONET_POINTMLP_YSPLIT")) {
+            const int want = atoi(e);
+            if (want >= 1 && groups % want == 0 && CT / want <= 32) best = want;
+        }
+        if (best == 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
+        const long long nwg = sonet::ceil_div64(nwg_x2, 8) * 8 * best;
+        if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
+        hipLaunchKernelGGL(pointmlp_h3r_kernel<2>, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
+                           x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc2, ngroups2, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x2,
+                           zadd, zidx, ZM, kmax, KM, stats_ws);
+        if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x2, Cout, 1.0 / ((double)B * L), mean, var, st);
+        return sonet::launched(what);
+    }
+#endif
     if (f16 && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
@@ -818,7 +908,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         if (best == 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
         const long long nwg = sonet::ceil_div64(nwg_x, 8) * 8 * best;
         if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many points", what);
-        hipLaunchKernelGGL(pointmlp_h3r_kernel, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
+        hipLaunchKernelGGL(pointmlp_h3r_kernel<1>, dim3((unsigned)nwg), dim3(X3_THREADS), 0, st,
                            x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, CT / best, gidx, L1, rlog, KCP, best, (int)nwg_x,
                            zadd, zidx, ZM, kmax, KM, stats_ws);
         if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);

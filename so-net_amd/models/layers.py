@@ -27,6 +27,8 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from sonet_hip import ops as _ops
 from . import operations
 
+H3_CHECK_EVERY = 16                                              # training: weight-side range test every so many weight versions
+
 
 class Swish(nn.Module):
     def forward(self, x):
@@ -341,11 +343,33 @@ class _FusedPointwise(nn.Module):
         """Weight side of the h3 range guard (sonet_hip.ops.h3_weight_ok), cached per weight version."""
         w = self.conv.weight
         key = (w._version, w.data_ptr(), w.device)
-        if getattr(self, '_h3ok_key', None) != key:
-            self._h3ok = _ops.h3_weight_ok(self._weight2d()) if w.is_cuda else True
-            self._h3ok_key = key
-            if not self._h3ok:
-                _ops.h3_ratio_warn("a point-wise layer's weight (%d x %d)" % (w.shape[0], w.shape[1]))
+        if getattr(self, '_h3ok_key', None) == key:
+            return self._h3ok
+        if not w.is_cuda:
+            self._h3ok, self._h3ok_key = True, key
+            return True
+        if torch.is_grad_enabled() and w.requires_grad and hasattr(self, '_h3ok'):
+            # training: the weight changes every step and a host read would drain the stream once per layer and step.  The test runs
+            # on the device every H3_CHECK_EVERY versions and its verdict is read when it has arrived (pinned memory + event) --
+            # like the activation side of the guard, a violation takes effect one check late.
+            pend = getattr(self, '_h3ok_pending', None)
+            if pend is not None and pend[1].query():
+                self._h3ok = bool(int(pend[0][0]))
+                self._h3ok_pending = pend = None
+                if not self._h3ok:
+                    _ops.h3_ratio_warn("a point-wise layer's weight (%d x %d)" % (w.shape[0], w.shape[1]))
+            if pend is None and w._version % H3_CHECK_EVERY == 0 and getattr(self, '_h3ok_checked', None) != w._version:
+                self._h3ok_checked = w._version
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(_ops.h3_weight_ratio_flag(self._weight2d()), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._h3ok_pending = (host, ev)
+            return self._h3ok
+        self._h3ok = _ops.h3_weight_ok(self._weight2d())
+        self._h3ok_key = key
+        if not self._h3ok:
+            _ops.h3_ratio_warn("a point-wise layer's weight (%d x %d)" % (w.shape[0], w.shape[1]))
         return self._h3ok
 
     def _packed(self, C1=None, C2=0):

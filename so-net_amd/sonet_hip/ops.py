@@ -644,11 +644,16 @@ def h3_weight_ok(weight2d):
     relative (|w_c| / |w_typ|) 2^-30 / max|x| <= ratio 2^-24 with the launch guard -- inside 2^-17 (about 1e-5) for ratio <= 2^7.
     So: a weight whose input columns differ by more than H3_COLUMN_RATIO in magnitude is packed for the range-safe x3 arithmetic
     (one warning); everything else cannot meet the adversarial case (tests/test_gpu_round2.py::test_h3_per_channel_range_case)."""
+    return bool(h3_weight_ratio_flag(weight2d).item())
+
+
+def h3_weight_ratio_flag(weight2d):
+    """The test of h3_weight_ok as a one-element device tensor (1 = fine), without a host synchronisation: the training path
+    (weights change every step) reads it one check late through pinned memory (models/layers.py::_h3_ok)."""
     cm = weight2d.detach().abs().amax(dim=0)
-    nz = cm[cm > 0]
-    if nz.numel() < 2:
-        return True
-    return bool((nz.max() / nz.min()).item() <= H3_COLUMN_RATIO)
+    big = cm.max()
+    small = torch.where(cm > 0, cm, big).min()                 # smallest non-zero column (all-zero weight: big == small == 0)
+    return (big <= small * H3_COLUMN_RATIO).to(torch.int32).reshape(1)
 
 
 def h3_ratio_warn(what):

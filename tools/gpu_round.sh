@@ -23,9 +23,9 @@ export TMPDIR=/tmp
 skip 1 || { run 1 "pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -x -q > $P/${TAG}_pytest_gpu.log 2>&1; tail -3 $P/${TAG}_pytest_gpu.log; }
 skip 2 || { run 2 smoke; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $P/${TAG}_smoke.log 2>&1; tail -1 $P/${TAG}_smoke.log; }
 skip 3 || { run 3 "bench forward"; timeout 600 python bench.py --steps 50 --warmup 10 2> $O/bench_forward.err | tail -1 > $P/${TAG}_bench_forward.json; head -c 400 $P/${TAG}_bench_forward.json; echo; }
-skip 4 || { run 4 "rocprofv3 kernel stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_fwd -o fwd -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > /dev/null 2> $O/rocprof_fwd.err);
-            f=$(find $O/rocprof_fwd -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $P/${TAG}_kernel_stats_forward.csv && head -8 $f; }
-skip 5 || { run 5 "PMC traffic"; timeout 900 bash tools/pmc_traffic.sh; python tools/pmc_traffic.py B64_N5000 && cp profiles/pmc_traffic.json $P/pmc_traffic.json; }
+skip 4 || { run 4 "rocprofv3 kernel stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_${TAG}_fwd -o fwd -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-other-configs > /dev/null 2> $O/rocprof_fwd.err);
+            f=$(find /tmp/rp_${TAG}_fwd -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $P/${TAG}_kernel_stats_forward.csv && head -8 $f; }
+skip 5 || { run 5 "PMC traffic"; timeout 900 bash tools/pmc_traffic.sh; python tools/pmc_traffic.py B64_N5000 && cp profiles/pmc_traffic.json $P/pmc_traffic.json; rm -rf $R/gpurun_out/pmc_traffic_FETCH_SIZE $R/gpurun_out/pmc_traffic_WRITE_SIZE; }   # (raw traces stay off the 64 MiB return path)
 skip 6 || { run 6 "bench train"; timeout 600 python bench.py --mode train --steps 20 --warmup 5 2> $O/bench_train.err | tail -1 > $P/${TAG}_bench_train.json; head -c 300 $P/${TAG}_bench_train.json; echo; }
 skip 7 || { run 7 microbench; timeout 600 python tools/microbench.py > $P/${TAG}_microbench.log 2>&1; grep -i "index_max\|som " $P/${TAG}_microbench.log | head; }
 echo "== done: $(ls $P | wc -l) files under gpurun_out/$TAG/profiles"

@@ -5,5 +5,5 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_traffic_$c -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-other-precisions --no-parity-check $EXTRA > /dev/null 2> $R/gpurun_out/pmc_traffic_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_traffic_$c -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-other-precisions --no-parity-check --no-other-configs $EXTRA > /dev/null 2> $R/gpurun_out/pmc_traffic_$c.err
 done
