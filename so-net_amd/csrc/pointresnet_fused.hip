@@ -29,7 +29,7 @@
 //   a[  0:255]  layer-3 accumulators (8 x 2), then its pre-split output, live through layer 4
 // Activations are split ONCE ("jobs": BatchNorm affine + ReLU + split, placed 4-5 at a time behind the MFMAs of later steps).
 // A lane holds 64 + 128 + 256 activation values per tile and has 512 registers: during layer 3, half of layer 2's output waits in
-// a 64 KiB lane-private LDS park, and layer 1 (12 of 1224 MFMAs) is simply run a second time after layer 3, its output parked in
+// a 64 KiB lane-private LDS park, and layer 1 (12 of 1944 MFMAs per tile and wave) is simply run a second time after layer 3, its output parked in
 // the same space for the four passes of layer 4.
 //
 // Register chaining.  v_mfma_f32_32x32x16_f16 produces D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r

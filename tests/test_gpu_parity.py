@@ -860,8 +860,12 @@ def test_sort_group_and_fused_pool():
     old = (ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET)
     ops.POINTMLP_PRECISION, ops.FUSE_POINTRESNET = "h3", True
     try:
-        for B, N, M, k, kind in [(3, 5000, 64, 3, "som"), (2, 333, 64, 3, "uniform"), (2, 40, 64, 1, "uniform"), (1, 1, 64, 3, "uniform")]:
-            inp = synth.make_inputs(B, N, M=M, som_k=9, seed=N + k, node_kind=kind)
+        # (sizes around the kernel's tiling: 256 points per workgroup tile, 64 per wave, 32 per column tile; more than 16 nodes in one
+        # tile -- the straight-to-memory atomics --, nodes spanning many tiles, a single point)
+        for B, N, M, k, kind in [(3, 5000, 64, 3, "som"), (2, 333, 64, 3, "uniform"), (2, 40, 64, 1, "uniform"), (1, 1, 64, 3, "uniform"),
+                                 (2, 86, 9, 3, "uniform"), (1, 64, 4, 1, "uniform"), (2, 171, 64, 3, "uniform"), (1, 2000, 4, 3, "uniform"),
+                                 (3, 97, 64, 2, "uniform")]:
+            inp = synth.make_inputs(B, N, M=M, som_k=min(9, M), seed=N + k, node_kind=kind)
             x, sn = inp["pc"].to(DEV), inp["sn"].to(DEV)
             a = ops.som_assign(x, inp["node"].to(DEV), k)
             g = ops.som_group(x, sn, a, want_augmented=True)
