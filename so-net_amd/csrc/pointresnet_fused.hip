@@ -9,7 +9,8 @@
 //
 // Arithmetic: fp32 operands split into fp16 pieces, three v_mfma_f32_32x32x16_f16 per product set with fp32
 // accumulation ("operand split" below).  Per accumulator the MFMA sequence (K chunk order, term order l, m, h) is the
-// one of the second-generation kernel, so the results are bit-identical to it.
+// one of the second-generation kernel and every product differs from that kernel's by an exact factor 32, so the results are
+// bit-identical to it.
 //
 // What limits this kernel is the traffic of the WEIGHT STREAM per point, not the matrix pipe (measured: the same MFMAs with the
 // weight requests removed run in two thirds of the time, at a higher clock).  So a workgroup = 4 waves streams the weights ONCE
@@ -77,37 +78,29 @@ constexpr int CH_TOTAL = 32 * (T0 + T1 + T2 + T3);
 constexpr int LB1 = 0, LB2 = 32 * T0, LB3 = 32 * (T0 + T1), LB4 = 32 * (T0 + T1 + T2);
 
 // ---- fp32 -> 3 x fp16 operand split ------------------------------------------------------------------
-// x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; 32 * (a*b) is taken as
-//     ah * (32 bh)  +  ah * fp16(32 bm)  +  fp16(32 am) * bh
+// x = xh + xm exactly, xh = fp16(x) (11 significand bits), xm the residual; a product is taken as
+//     1024 a*b  =  (32 ah) * (32 bh)  +  (32 ah) * fp16(32 bm)  +  fp16(32 am) * (32 bh)
 // i.e. THREE fp16 MFMAs with fp32 accumulation (the dropped am*bm and the rounding of the scaled residuals are
-// <= 2^-22 relative).  The factor 32 keeps the residuals out of the fp16 subnormals; it is carried by the ACCUMULATOR
-// (every power-of-two scaling is exact) and taken out again by the layer's affine, so the first two terms share ONE
-// weight operand: the stream holds two slices per (cout tile, K chunk), ah and fp16(32 am), for three MFMAs.
-// Operand range: |x| <= 2047 (32 x must fit fp16); the split clamps and the range log reports it.
-// Naming: B side pieces h = 32 bh, m = fp16(32 bm), l = bh = h * 2^-5 (derived when used, never stored);
-// terms in accumulation order: (A.l, B.l), (A.h, B.m), (A.h, B.h).
+// <= 2^-22 relative).  The factors 32 keep the residuals out of the fp16 subnormals; they ride in the ACCUMULATOR (1024 = 2^10;
+// every power-of-two scaling is exact, so the bits are those of the unscaled sum) and leave through the layer's affine.  With
+// both main pieces carrying their 32 there are only TWO forms of each operand: the stream holds two slices per (cout tile, K
+// chunk), 32 ah and fp16(32 am), an activation is two pieces, 32 bh and fp16(32 bm) -- nothing is derived at the point of use
+// (a third piece bh = (32 bh) * 2^-5 computed per step cost 2.4 % of the kernel).
+// Operand range: |x| <= 2047 and |w| <= 2047 (32 x and 32 w must fit fp16); the split clamps and the range log reports both.
+// Naming: B side pieces h = 32 bh, m = fp16(32 bm); A side slices h = 32 ah, l = fp16(32 am);
+// terms in accumulation order: (A.l, B.h), (A.h, B.m), (A.h, B.h).
 constexpr float F16_MAX = 2047.0f;                             // 32 * 2047 = 65504, the largest fp16
 constexpr float F16_MAX32 = 65504.0f;
-constexpr float ACC_UNSCALE = 0.03125f;                        // accumulators hold 32 * (W . x)
-constexpr unsigned F16_2_M5_PK = 0x28002800u;                  // packed fp16 (2^-5, 2^-5)
+constexpr float ACC_UNSCALE = 0.0009765625f;                   // accumulators hold 1024 * (W . x)
+constexpr float ACC_TO_X32 = 0.03125f;                         // ... and 32 x = acc * (scale / 32) + 32 shift
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {        // one v_cvt_pk_f16_f32 (round to nearest even)
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
 __device__ __forceinline__ float f16_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
 __device__ __forceinline__ float f16_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
-__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b) {
-    const f16x2_t r = __builtin_bit_cast(f16x2_t, a) * __builtin_bit_cast(f16x2_t, b);
-    return __builtin_bit_cast(unsigned, r);
-}
 __device__ __forceinline__ float clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -F16_MAX), F16_MAX); }
 __device__ __forceinline__ f16x8 as_f16x8(u32x4_t v) { return __builtin_bit_cast(f16x8, v); }
-__device__ __forceinline__ u32x4_t piece_l(u32x4_t h) {        // xh = (32 xh) * 2^-5 (exact)
-    u32x4_t r;
-    r[0] = pk_mul_f16(h[0], F16_2_M5_PK); r[1] = pk_mul_f16(h[1], F16_2_M5_PK);
-    r[2] = pk_mul_f16(h[2], F16_2_M5_PK); r[3] = pk_mul_f16(h[3], F16_2_M5_PK);
-    return r;
-}
 // the network input (clamped, no affine): 8 channel values of one point -> (h, m)
 __device__ __forceinline__ void split_input(const float (&v)[8], u32x4_t &h, u32x4_t &m) {
 #pragma unroll
@@ -122,8 +115,8 @@ __device__ __forceinline__ void split_input(const float (&v)[8], u32x4_t &h, u32
 // ---- a "job": BatchNorm affine + ReLU + split of 8 accumulator values (registers 8Q..8Q+7 of an output tile) ----
 // One VALU instruction at a time (volatile asm: instruction selection floats pure VALU ops across sched_barrier and
 // clumps them; a clump of dependent VALU between two MFMAs stalls the matrix pipe), so that the steps can place a few
-// of them behind each MFMA.  The accumulators hold 32 W.x and the coefficients are (scale, 32 shift): the affine
-// delivers 32 x directly (bit-identical to 32 * fl(acc * scale/32 + shift): power-of-two scalings commute with the
+// of them behind each MFMA.  The accumulators hold 1024 W.x and the coefficients are (scale / 32, 32 shift): the affine
+// delivers 32 x directly (bit-identical to 32 * fl(acc * scale/1024 + shift): power-of-two scalings commute with the
 // rounding), ReLU and the fp16 range clamp are one v_med3 against 32 * 2047.
 __device__ __forceinline__ float pin_fma(float a, float s, float b) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
 __device__ __forceinline__ float pin_relu_clamp32(float a) { float r; asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(F16_MAX32)); return r; }
@@ -237,10 +230,10 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
                 const int c = chained ? kc * 16 + (e & 3) + 8 * (e >> 2) + 4 * h : kc * 16 + 8 * h + e;
                 v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
             }
-            range_track(wr, v[0], v[1]);
-            // A-side slices: 0 = fp16(w) (terms h and m), 1 = fp16(32 * (w - h)) (term l)
-            const unsigned hh = cvt_pk_f16(v[0], v[1]);
-            const unsigned ll = cvt_pk_f16(32.f * (v[0] - f16_lo(hh)), 32.f * (v[1] - f16_hi(hh)));
+            range_track(wr, 32.f * v[0], 32.f * v[1]);              // (logged as 32 |w|: the fp16 range applies to that)
+            // A-side slices: 0 = fp16(32 w) = 32 wh (terms h and m), 1 = fp16(32 (w - wh)) = fp16(32 w - 32 wh) (term l)
+            const unsigned hh = cvt_pk_f16(32.f * v[0], 32.f * v[1]);
+            const unsigned ll = cvt_pk_f16(32.f * v[0] - f16_lo(hh), 32.f * v[1] - f16_hi(hh));
             w[p] = term == 0 ? hh : ll;
         }
     }
@@ -319,9 +312,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     bool l4_unit_lane = true;                                   // layer 4 has no BatchNorm in the reference: scale == 1
     for (int c = threadIdx.x; c < CH_TOTAL; c += PF_THREADS) {
         const float2 v = affine_g[c];
-        // layers 1-3: the split wants 32 x = acc * scale + 32 shift (the accumulators carry a factor 32);
-        // layer 4: y = acc * scale / 32 + shift
-        aff[c] = c < LB4 ? make_float2(v.x, 32.f * v.y) : make_float2(v.x * ACC_UNSCALE, v.y);
+        // layers 1-3: the split wants 32 x = acc * scale / 32 + 32 shift (the accumulators carry a factor 1024);
+        // layer 4: y = acc * scale / 1024 + shift
+        aff[c] = c < LB4 ? make_float2(v.x * ACC_TO_X32, 32.f * v.y) : make_float2(v.x * ACC_UNSCALE, v.y);
         if (c >= LB4 && v.x != 1.0f) l4_unit_lane = false;
     }
     if constexpr (SEGMAX) {
@@ -421,13 +414,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         constexpr int so_ = (SIDX) % NSTG, son_ = (SIDXN) % NSTG;                                        \
         if constexpr (so_ == 0) boundary(std::integral_constant<bool, (FLUSH)>{});                       \
         const uint4 *nb_ = son_ == 0 ? lds_nxt : lds_cur;
-#define PF_STEP_A(NT, SIDX, NTN, SIDXN, AGB, BH0, BM0, BL0, BH1, BM1, BL1, ZERO, SLOT)                   \
+#define PF_STEP_A(NT, SIDX, NTN, SIDXN, AGB, BH0, BM0, BH1, BM1, ZERO, SLOT)                             \
     {                                                                                                    \
         PF_STEP_HEAD(SIDX, SIDXN, false)                                                                 \
-        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
+        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)};    \
         PF_SB                                                                                            \
         SFOR(q, 2 * (NT)) constexpr int c = q / (NT), u = q % (NT);                                      \
-            mfma_agpr<AGB(u, c), (ZERO)>(af.l[u], bl_[c]);                                               \
+            mfma_agpr<AGB(u, c), (ZERO)>(af.l[u], bh_[c]);                                               \
             if constexpr (so_ == 0 && q < 3) dma_pair(std::integral_constant<int, 2 * q>{});             \
             SLOT(q)                                                                                      \
             PF_SB                                                                                        \
@@ -447,14 +440,15 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         SFOR(u, NTN) af.h[u] = PF_LDA(nb_, son_ + NTERM * u); SEND                                       \
         PF_SB                                                                                            \
     }
-#define PF_STEP_V(SIDX, SIDXN, ACC, FROMA, HN0, HN1, BH0, BM0, BH1, BM1, BL0, BL1, ZERO, FLUSH, SLOT)    \
+#define PF_STEP_V(SIDX, SIDXN, ACC, FROMA, HN0, HN1, BH0, BM0, BH1, BM1, ZERO, FLUSH, SLOT)              \
     {                                                                                                    \
         PF_STEP_HEAD(SIDX, SIDXN, FLUSH)                                                                 \
-        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)}, bl_[2] = {as_f16x8(BL0), as_f16x8(BL1)}; \
+        const f16x8 bh_[2] = {as_f16x8(BH0), as_f16x8(BH1)}, bm_[2] = {as_f16x8(BM0), as_f16x8(BM1)};    \
         constexpr int hn_[2] = {(HN0), (HN1)};                                                           \
         PF_SB                                                                                            \
         SFOR(q, 2 * MT4) constexpr int c = q / MT4, u = q % MT4;                                         \
-            mfma_vv<(ZERO), SEGMAX>(ACC(u, c), af.l[u], bl_[c]);                                         \
+            if constexpr (FROMA) mfma_va<hn_[c], SEGMAX>(ACC(u, c), af.l[u]);                            \
+            else mfma_vv<(ZERO), SEGMAX>(ACC(u, c), af.l[u], bh_[c]);                                    \
             if constexpr (so_ == 0 && q < 3) dma_pair(std::integral_constant<int, 2 * q>{});             \
             SLOT(q)                                                                                      \
             PF_SB                                                                                        \
@@ -509,19 +503,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             job_ops<(R0), (INPL), i0_, i0_ + (OPS)>(jx0_, sc_, rmax_);                                   \
         }                                                                                                \
     }
-    // the next step's B piece l (4 v_pk_mul_f16 per column tile), behind MFMAs QB and QB + 1 of this step; from VGPR pieces ...
-#define PF_SLOT_BL(q, QB, H0, H1, L0, L1)                                                                \
-    {                                                                                                    \
-        if constexpr ((q) == (QB)) L0 = piece_l(H0);                                                     \
-        if constexpr ((q) == (QB) + 1) L1 = piece_l(H1);                                                 \
-    }
-    // ... or from the pieces in a[HN .. HN+3]
-#define PF_SLOT_BLA(q, QB, HN0, HN1, L0, L1)                                                             \
-    {                                                                                                    \
-        if constexpr ((q) == (QB)) { u32x4_t t_; t_[0] = __float_as_uint(agpr_read<(HN0)>()); t_[1] = __float_as_uint(agpr_read<(HN0) + 1>()); t_[2] = __float_as_uint(agpr_read<(HN0) + 2>()); t_[3] = __float_as_uint(agpr_read<(HN0) + 3>()); L0 = piece_l(t_); } \
-        if constexpr ((q) == (QB) + 1) { u32x4_t t_; t_[0] = __float_as_uint(agpr_read<(HN1)>()); t_[1] = __float_as_uint(agpr_read<(HN1) + 1>()); t_[2] = __float_as_uint(agpr_read<(HN1) + 2>()); t_[3] = __float_as_uint(agpr_read<(HN1) + 3>()); L1 = piece_l(t_); } \
-    }
-
     PROF_MARK(0)                                                // kernel prologue
     // inputs of a tile, read one tile ahead (in front of the previous tile's last pass): read at the top of the tile,
     // the x / node-id loads put an HBM round trip in front of layer 1
@@ -583,7 +564,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             }
         }
         // ---- layer 1 (slice 0 opens stage 0 of this tile) ----
-        u32x4_t xh[2], xm[2], xl[2];
+        u32x4_t xh[2], xm[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -595,14 +576,12 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(xin_r) : "v"(a0), "v"(a1));
             }
             split_input(xin_n[c], xh[c], xm[c]);
-            xl[c] = piece_l(xh[c]);
         }
         PROF_MARK(1)                                            // tile prologue
 #define NOSLOT(q)
-        PF_STEP_A(T0, OFF1, GS, OFF2, AG13, xh[0], xm[0], xl[0], xh[1], xm[1], xl[1], true, NOSLOT)
+        PF_STEP_A(T0, OFF1, GS, OFF2, AG13, xh[0], xm[0], xh[1], xm[1], true, NOSLOT)
         // layer-1 output, pre-split: a1[tile][half][column tile]
         JobOut a1[T0][2][2];
-        u32x4_t bl0, bl1;                                       // piece l of the NEXT step's B chunk
         {                                                       // layer transition: chunk 0 of layer 2's input, nothing to overlap with
             asm volatile("s_nop 15" ::: );                      // (the last MFMAs' results: 12 wait states before anything reads them)
             JobSc sc_; JobX jx0_, jx1_;
@@ -610,7 +589,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             job_ops<AG13(0, 0), false, 0, JOB_OPS_V>(jx0_, sc_, rmax_);
             job_ops<AG13(0, 1), false, 0, JOB_OPS_V>(jx1_, sc_, rmax_);
             a1[0][0][0] = job_result(jx0_); a1[0][0][1] = job_result(jx1_);
-            bl0 = piece_l(a1[0][0][0].h); bl1 = piece_l(a1[0][0][1].h);
         }
         PROF_MARK(6)                                            // layer 1
         // ---- layer 2: 4 steps over the K chunks of the layer-1 output, all 4 output tiles (accumulators a[128:255]) ----
@@ -620,12 +598,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr int sidx = OFF2 + k * NTERM * GS;
             JobSc sc_; JobX jx0_, jx1_;
             if constexpr (k + 1 < KC2) PF_LOAD_SC(sc_, LB1, tn, qn)
-            u32x4_t nl0 = bl0, nl1 = bl1;
 #define SLOT_L2(q) { if constexpr (k + 1 < KC2) { PF_SLOT2(q, 4, JOB_OPS_V, false, AG13(tn, 0) + 8 * qn, AG13(tn, 1) + 8 * qn) \
-                       if constexpr ((q) == 23) { a1[tn][qn][0] = job_result(jx0_); a1[tn][qn][1] = job_result(jx1_); nl0 = piece_l(a1[tn][qn][0].h); nl1 = piece_l(a1[tn][qn][1].h); } } }
-            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG2, a1[tk][qk][0].h, a1[tk][qk][0].m, bl0, a1[tk][qk][1].h, a1[tk][qk][1].m, bl1, (k == 0), SLOT_L2)
+                       if constexpr ((q) == 23) { a1[tn][qn][0] = job_result(jx0_); a1[tn][qn][1] = job_result(jx1_); } } }
+            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG2, a1[tk][qk][0].h, a1[tk][qk][0].m, a1[tk][qk][1].h, a1[tk][qk][1].m, (k == 0), SLOT_L2)
 #undef SLOT_L2
-            bl0 = nl0; bl1 = nl1;
         SEND
         // layer-2 output, pre-split
         JobOut a2[T1][2][2];
@@ -636,7 +612,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             job_ops<AG2(0, 0), false, 0, JOB_OPS_V>(jx0_, sc_, rmax_);
             job_ops<AG2(0, 1), false, 0, JOB_OPS_V>(jx1_, sc_, rmax_);
             a2[0][0][0] = job_result(jx0_); a2[0][0][1] = job_result(jx1_);
-            bl0 = piece_l(a2[0][0][0].h); bl1 = piece_l(a2[0][0][1].h);
         }
         PROF_MARK(7)                                            // layer 2
         // ---- layer 3: two groups of 4 output tiles x 8 K chunks (accumulators a[0:127], then a[128:255]) ----
@@ -653,13 +628,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             constexpr int sidx = OFF3 + k * NTERM * GS;
             JobSc sc_; JobX jx0_, jx1_;
             if constexpr (k + 1 < KC3) PF_LOAD_SC(sc_, LB2, tn, qn)
-            u32x4_t nl0 = bl0, nl1 = bl1;
 #define SLOT_L3A(q) { if constexpr (k + 1 < KC3) { PF_SLOT2(q, 4, JOB_OPS_V, false, AG2(tn, 0) + 8 * qn, AG2(tn, 1) + 8 * qn) \
-                        if constexpr ((q) == 23) { a2[tn][qn][0] = job_result(jx0_); a2[tn][qn][1] = job_result(jx1_); nl0 = piece_l(a2[tn][qn][0].h); nl1 = piece_l(a2[tn][qn][1].h); } } \
-                      else { PF_SLOT_BL(q, 4, pbh[0], pbh[1], nl0, nl1) } }
-            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG3A, a2[tk][qk][0].h, a2[tk][qk][0].m, bl0, a2[tk][qk][1].h, a2[tk][qk][1].m, bl1, (k == 0), SLOT_L3A)
+                        if constexpr ((q) == 23) { a2[tn][qn][0] = job_result(jx0_); a2[tn][qn][1] = job_result(jx1_); } } }
+            PF_STEP_A(GS, sidx, GS, sidx + NTERM * GS, AG3A, a2[tk][qk][0].h, a2[tk][qk][0].m, a2[tk][qk][1].h, a2[tk][qk][1].m, (k == 0), SLOT_L3A)
 #undef SLOT_L3A
-            bl0 = nl0; bl1 = nl1;
             if constexpr (k < KC2) {                            // chunks 0-3 wait in LDS for the second tile group, 4-7 in registers
                 PF_PARK(k, 0, 0) = a2[tk][qk][0].h; PF_PARK(k, 0, 1) = a2[tk][qk][0].m;
                 PF_PARK(k, 1, 0) = a2[tk][qk][1].h; PF_PARK(k, 1, 1) = a2[tk][qk][1].m;
@@ -669,13 +641,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         float xagain[2][8];
         SFOR(k, KC3)                                            // group 1; jobs: the layer-3 outputs of group 0 (tile k>>1, half k&1), in place
             constexpr int tk = k >> 1, qk = k & 1;
-            constexpr int kn = (k + 1) % KC3, tn = kn >> 1, qn = kn & 1;
             constexpr int sidx = OFF3 + (KC3 + k) * NTERM * GS;
             constexpr int ntn = k + 1 < KC3 ? GS : MT4;         // the last step reads the fragments of layer 4's first step
             constexpr bool cur_park = k < KC2, nxt_park = k + 1 < KC2;
             JobSc sc_; JobX jx0_, jx1_;
             PF_LOAD_SC(sc_, LB3, tk, qk)
-            u32x4_t nl0 = bl0, nl1 = bl1;
             const u32x4_t ch0 = cur_park ? pbh[0] : a2[tk][qk][0].h, cm0 = cur_park ? pbm[0] : a2[tk][qk][0].m;
             const u32x4_t ch1 = cur_park ? pbh[1] : a2[tk][qk][1].h, cm1 = cur_park ? pbm[1] : a2[tk][qk][1].m;
             if constexpr (nxt_park) {
@@ -691,12 +661,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     for (int e = 0; e < 8; ++e)
                         xagain[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (unsigned)(8 * h * L + lc[c]) * 4u, (unsigned)e * rowB, 0));
             }
-#define SLOT_L3B(q) { PF_SLOT2(q, 5, JOB_OPS_A, true, AG13(tk, 0) + 8 * qk, AG13(tk, 1) + 8 * qk) \
-                      if constexpr (nxt_park) { PF_SLOT_BL(q, 22, pbh[0], pbh[1], nl0, nl1) } \
-                      else if constexpr (k + 1 < KC3) { PF_SLOT_BL(q, 22, a2[tn][qn][0].h, a2[tn][qn][1].h, nl0, nl1) } }
-            PF_STEP_A(GS, sidx, ntn, sidx + NTERM * GS, AG3B, ch0, cm0, bl0, ch1, cm1, bl1, (k == 0), SLOT_L3B)
+#define SLOT_L3B(q) { PF_SLOT2(q, 5, JOB_OPS_A, true, AG13(tk, 0) + 8 * qk, AG13(tk, 1) + 8 * qk) }
+            PF_STEP_A(GS, sidx, ntn, sidx + NTERM * GS, AG3B, ch0, cm0, ch1, cm1, (k == 0), SLOT_L3B)
 #undef SLOT_L3B
-            bl0 = nl0; bl1 = nl1;
         SEND
         PROF_MARK(9)                                            // layer 3, tiles 4-7
         // ---- layer 1 once more, for layer 4's first four K chunks (its output could not stay anywhere during layer 3: 64 points x
@@ -708,10 +675,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
             u32x4_t xh0, xm0, xh1, xm1;
             split_input(xagain[0], xh0, xm0);
             split_input(xagain[1], xh1, xm1);
-            const u32x4_t xl0 = piece_l(xh0), xl1 = piece_l(xh1);
-            const f16x8 bh_[2] = {as_f16x8(xh0), as_f16x8(xh1)}, bm_[2] = {as_f16x8(xm0), as_f16x8(xm1)}, bl_[2] = {as_f16x8(xl0), as_f16x8(xl1)};
+            const f16x8 bh_[2] = {as_f16x8(xh0), as_f16x8(xh1)}, bm_[2] = {as_f16x8(xm0), as_f16x8(xm1)};
             PF_SB
-            SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<true, false>(r1[u][c], wl[u], bl_[c]); PF_SB SEND
+            SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<true, false>(r1[u][c], wl[u], bh_[c]); PF_SB SEND
             SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<false, false>(r1[u][c], wh[u], bm_[c]); PF_SB SEND
             SFOR(q, 2 * T0) constexpr int c = q / T0, u = q % T0; mfma_vv<false, false>(r1[u][c], wh[u], bh_[c]); PF_SB SEND
             asm volatile("s_nop 15" ::: );                      // (MFMA results: 12 wait states before a VALU instruction reads them)
@@ -729,7 +695,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     if constexpr (kk == 0) { pbh[c] = o.h; pbm[c] = o.m; }
                 SEND
             SEND
-            bl0 = piece_l(pbh[0]); bl1 = piece_l(pbh[1]);
         }
         PROF_MARK(2)                                            // layer 1 again
         // ---- layer 4: NPASS passes x KC4 steps of MT4 output tiles; chunks 0-3 = layer-1 output (park), 4-19 = layer 3 (a[...]) ----
@@ -744,7 +709,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 constexpr int kn = (kc + 1) % KC4;                                                       \
                 constexpr bool cur_park = kc < KC2, nxt_park = kn < KC2;                                 \
                 constexpr int t3 = cur_park ? 0 : (kc - KC2) >> 1, q3 = cur_park ? 0 : (kc - KC2) & 1;   \
-                constexpr int t3n = nxt_park ? 0 : (kn - KC2) >> 1, q3n = nxt_park ? 0 : (kn - KC2) & 1; \
                 constexpr int jt = T2 / 2 + kc / 4, jq = (kc >> 1) & 1, jc = kc & 1;                     \
                 constexpr bool job = (JOBS) && kc < 16;                                                  \
                 JobSc sc_; JobX jx0_;                                                                    \
@@ -754,12 +718,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     pbh[0] = PF_PARK(kn, 0, 0); pbm[0] = PF_PARK(kn, 0, 1);                              \
                     pbh[1] = PF_PARK(kn, 1, 0); pbm[1] = PF_PARK(kn, 1, 1);                              \
                 }                                                                                        \
-                u32x4_t nl0 = bl0, nl1 = bl1;                                                            \
-                PF_STEP_V(sidx, sidx + NTERM * MT4, ACC4, !cur_park, AG13(t3, 0) + 8 * q3, AG13(t3, 1) + 8 * q3, ch0, cm0, ch1, cm1, bl0, bl1, (kc == 0), (kc == 0), SLOT_L4) \
-                bl0 = nl0; bl1 = nl1;                                                                    \
+                PF_STEP_V(sidx, sidx + NTERM * MT4, ACC4, !cur_park, AG13(t3, 0) + 8 * q3, AG13(t3, 1) + 8 * q3, ch0, cm0, ch1, cm1, (kc == 0), (kc == 0), SLOT_L4) \
             SEND
-#define SLOT_L4(q) { if constexpr (job) { PF_SLOT1(q, 4, JOB_OPS_A, true, AG13((job ? jt : 0), jc) + 8 * jq) } \
-                     if constexpr (nxt_park) { PF_SLOT_BL(q, 15, pbh[0], pbh[1], nl0, nl1) } else { PF_SLOT_BLA(q, 15, AG13(t3n, 0) + 8 * q3n, AG13(t3n, 1) + 8 * q3n, nl0, nl1) } }
+#define SLOT_L4(q) { if constexpr (job) { PF_SLOT1(q, 4, JOB_OPS_A, true, AG13((job ? jt : 0), jc) + 8 * jq) } }
         // the epilogue of a layer-4 pass
         auto epilogue = [&](f32x16 (&acc)[MT4][2], const int pass) __attribute__((always_inline)) {
 #ifdef SONET_ABL_NOEPI

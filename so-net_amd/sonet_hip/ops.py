@@ -493,10 +493,12 @@ class range_scope:
                 out.append((name, "max |x| = %g exceeds 2047" % _bits_to_float(x)))
             elif low_ok and 0 < x < _B_XLOW:
                 out.append((name, "max |x| = %g is below 2^-6 (fp16 residuals go subnormal)" % _bits_to_float(x)))
+            # (the fused first-PointNet kernel keeps its weights as fp16(32 w) and logs 32 |w|: its limits are 2047 and 2^-13)
+            wdiv = 32.0 if name.startswith("pointresnet_fused") else 1.0
             if wt > _B_65504:
-                out.append((name, "max |w| = %g exceeds 65504" % _bits_to_float(wt)))
+                out.append((name, "max |w| = %g exceeds %g" % (_bits_to_float(wt) / wdiv, 65504.0 / wdiv)))
             elif low_ok and 0 < wt < _B_WLOW:
-                out.append((name, "max |w| = %g is below 2^-8" % _bits_to_float(wt)))
+                out.append((name, "max |w| = %g is below 2^%d" % (_bits_to_float(wt) / wdiv, -8 if wdiv == 1.0 else -13)))
             if hid > _B_2047:
                 out.append((name, "a hidden activation reaches %g > 2047" % _bits_to_float(hid)))
         return out

@@ -74,3 +74,8 @@ if __name__ == "__main__":
             for k in first.files:
                 same = np.array_equal(first[k].view(np.uint32), cur[k].view(np.uint32))
                 print("%-14s %-5s output %s the first variant's" % (name, k, "bit-identical to" if same else "DIFFERS from"), flush=True)
+                if not same:
+                    a64, b64 = first[k].astype(np.float64), cur[k].astype(np.float64)
+                    print("%-14s %-5s   max |diff| %.3g, rms diff / rms value %.3g, %d of %d elements differ" % (
+                        name, k, np.abs(a64 - b64).max(), np.sqrt(np.mean((a64 - b64) ** 2)) / np.sqrt(np.mean(a64 ** 2)),
+                        int((first[k].view(np.uint32) != cur[k].view(np.uint32)).sum()), a64.size), flush=True)
