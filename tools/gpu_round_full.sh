@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch wrapper: the round's measurement set + SQ counters of the fused kernel + training kernel stats
+# tools/gpu_round_full.sh TAG -- tools/gpu_round.sh plus the SQ counters of the fused kernel (tools/pmc_sq.sh) and the training-step kernel stats;
+# raw traces stay under /tmp on the GPU box, the summaries land in gpurun_out/TAG/profiles (copy them into profiles/).
 TAG=${1:-r03a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
