@@ -1,5 +1,5 @@
-"""tools/check_fused_asm.py [SOURCE] [-D...] -- audit of a build of the fused first-PointNet kernel whose accumulation registers are
-owned by inline asm (literal a[N:M] operands the compiler does not know about).
+"""tools/check_fused_asm.py [SOURCE ...] [-D...] -- audit of the builds of the kernels whose accumulation registers are owned by
+inline asm (literal a[N:M] operands the compiler does not know about): the fused first PointNet (pointresnet_fused.hip).
 
 The build is valid only if hipcc itself never touches the accumulation file: a compiler-generated v_accvgpr_* (a VGPR spilled into
 what it believes is a free AGPR) would be overwritten by the kernel's MFMAs, silently.  Checks, per kernel of the source:
@@ -16,6 +16,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASM_OWNED = ["pointresnet_fused.hip"]                          # sources with kernels that own a[...] through inline asm
+ASM_OWNED_KERNELS = ["pointresnet_fused_kernel"]
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wno-unused-function".split()
 
 
@@ -70,11 +72,11 @@ def audit(src, extra):
 if __name__ == "__main__":
     args = sys.argv[1:]
     extra = [a for a in args if a.startswith("-")]
-    srcs = [a for a in args if not a.startswith("-")] or [os.path.join(ROOT, "so-net_amd", "csrc", "pointresnet_fused.hip")]
+    srcs = [a for a in args if not a.startswith("-")] or [os.path.join(ROOT, "so-net_amd", "csrc", f) for f in ASM_OWNED]
     bad = False
     for src in srcs:
         for name, k in audit(src, extra).items():
-            if "fused_kernel" not in name:
+            if not any(k_ in name for k_ in ASM_OWNED_KERNELS):
                 continue
             ok = k["accvgpr_by_compiler"] == 0 and k["scratch"] == 0 and k["early_reads"] == 0
             bad |= not ok
