@@ -878,35 +878,48 @@ __global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__
 // partial (slot = m - first node of the tile), combined with the rare straight-to-memory fallback in `pooled`
 // (tiles spanning more than SEG_SLOTS nodes).  Nodes that never beat -1000 (empty, or all values <= -1000) take the
 // features of original point copy 0, as gather index 0 does in the reference (models/networks.py:185).
+// One workgroup = 32 nodes x 32 channels of one cloud: the keys are read with the channel fastest (as the fused kernel wrote them),
+// the output [B][384][M] is written with the node fastest, through a 32 x 33 LDS tile.
 __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
                                                              const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
                                                              const int32_t *__restrict__ count, const float *__restrict__ v0,
-                                                             float *__restrict__ out, int M, int L, int tpc, long long total)
+                                                             float *__restrict__ out, int M, int L, int tpc)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // over [B][M][384], c fastest (coalesced partial reads)
-    if (t >= total) return;
-    const int C = 32 * T3;
-    const int c = (int)(t % C);
-    const long long bm = t / C;
-    const int m = (int)(bm % M);
-    const long long b = bm / M;
-    unsigned key = pooled[t];
-    const int cnt = count[b * M + m];
-    if (cnt > 0) {
-        const int off = node_off[b * M + m];
-        const int pass = c / PCH, cl = c - pass * PCH;
-        for (int tl = off / TPTS; tl <= (off + cnt - 1) / TPTS; ++tl) {
-            const int slot = m - ids_sorted[b * L + tl * TPTS];
-            if (slot < SEG_SLOTS) {
-                const unsigned k2 = partial[((((b * tpc + tl) * NPASS + pass) * SEG_SLOTS) + slot) * (long long)PCH + cl];
-                key = k2 > key ? k2 : key;
+    constexpr int C = 32 * T3;
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.z;
+    const int m0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int c = c0 + lx;                                      // (C is a multiple of 32)
+    const int pass = c / PCH, cl = c - pass * PCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ly + 8 * i;
+        if (m < M) {
+            unsigned key = pooled[(b * M + m) * C + c];
+            const int cnt = count[b * M + m];
+            if (cnt > 0) {
+                const int off = node_off[b * M + m];
+                for (int tl = off / TPTS; tl <= (off + cnt - 1) / TPTS; ++tl) {
+                    const int slot = m - ids_sorted[b * L + tl * TPTS];
+                    if (slot < SEG_SLOTS) {
+                        const unsigned k2 = partial[((((b * tpc + tl) * NPASS + pass) * SEG_SLOTS) + slot) * (long long)PCH + cl];
+                        key = k2 > key ? k2 : key;
+                    }
+                }
             }
+            float v;
+            if (key > SEG_INIT) v = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+            else v = v0[b * C + c];
+            tile[ly + 8 * i][lx] = v;
         }
     }
-    float v;
-    if (key > SEG_INIT) v = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
-    else v = v0[b * C + c];
-    out[(b * C + c) * M + m] = v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ly + 8 * i, m = m0 + lx;
+        if (m < M) out[(b * C + cc) * M + m] = tile[lx][ly + 8 * i];
+    }
 }
 
 int cu_count() {
@@ -966,6 +979,7 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
     const char *what = "sonet_pointresnet_fused_pool_f32";
     SONET_REQUIRE(x_sorted && wstream && affine && ids_sorted && pos0 && node_off && count && ws && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && M > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d M=%d Cin0=%d", what, B, L, M, Cin0);
+    if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
     hipStream_t st = sonet::as_stream(stream);
     const long long npool = (long long)B * M * (32 * T3);
     const int tpc = sonet::ceil_div(L, TPTS);
@@ -979,8 +993,8 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
     hipLaunchKernelGGL((pointresnet_fused_kernel<true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st,
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log());
-    hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, partial_ws,
-                       ids_sorted, node_off, count, v0_ws, out, M, L, tpc, npool);
+    hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)(32 * T3 / 32), (unsigned)sonet::ceil_div(M, 32), (unsigned)B), dim3(256), 0, st,
+                       pooled_ws, partial_ws, ids_sorted, node_off, count, v0_ws, out, M, L, tpc);
     return sonet::launched(what);
 }
 
