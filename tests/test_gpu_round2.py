@@ -122,7 +122,7 @@ def test_fused_kernel_reports_hidden_activation_range():
 
 
 # ------------------------------------------------------------------------------------------ range guard: model level
-@pytest.mark.parametrize("case", ["act_1e4", "act_1e5_bn", "input_3e4", "nan_input"])
+@pytest.mark.parametrize("case", ["act_1e4", "act_1e5_bn", "input_3e4", "nan_input", "weight_5e3"])
 def test_encoder_out_of_range_activations_fall_back_to_x3(case):
     """Weights / inputs scaled so that activations leave the fp16-split range: the default (h3) forward must still match
     the oracle at 1e-5 -- through the guard's x3 recomputation -- and say so once."""
@@ -139,6 +139,10 @@ def test_encoder_out_of_range_activations_fall_back_to_x3(case):
         for sd in (enc.state_dict(), enc_sd):
             sd["first_pointnet.layers.3.conv.weight"].mul_(2.0e4)
             sd["knnlayer.layers.0.conv.weight"][:, 3:].mul_(1.0 / 2.0e4)
+    elif case == "weight_5e3":                               # weights of the fused kernel's last layer ~5e3: 32 w leaves fp16 (its limit is 2047)
+        for sd in (enc.state_dict(), enc_sd):
+            sd["first_pointnet.layers.3.conv.weight"].mul_(1.0e5)
+            sd["knnlayer.layers.0.conv.weight"][:, 3:].mul_(1.0e-5)
     elif case == "input_3e4":                                # de-centred coordinates ~1e4
         for key in ("pc", "node"):
             inp[key] = inp[key] * 3.0e4
