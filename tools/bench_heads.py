@@ -42,7 +42,7 @@ def timeit(fn, steps=10, warmup=3):
     with ops.kernel_timing() as rec:
         fn()
     torch.cuda.synchronize()
-    top = sorted(rec.summary().items(), key=lambda kv: -kv[1]["total_ms"])[:6]
+    top = sorted(rec.summary().items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("TOP", "6"))]
     return dt * 1e3, top
 
 
