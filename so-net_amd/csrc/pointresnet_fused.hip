@@ -159,13 +159,13 @@ struct JobX { float x[8]; unsigned h[4], m[4]; };              // the 8 values i
 // writes its pieces over the values), then two groups of 18 (values 4g..4g+3, neighbours independent): affine x4, range max x2,
 // relu+clamp x4, 32xh x2 (cvt), residual x4, 32xm x2 (cvt); the in-place form ends with 8 writes (h -> a[R..R+3], m -> a[R+4..R+7]).
 constexpr int JOB_OPS_V = 44, JOB_OPS_A = 52;
-template <int R, bool INPLACE, int I> __device__ __forceinline__ void job_op(JobX &v, const JobSc &s, int &rm) {
+template <int R, bool INPLACE, int I, bool RANGE = true> __device__ __forceinline__ void job_op(JobX &v, const JobSc &s, int &rm) {
     static_assert(I >= 0 && I < (INPLACE ? JOB_OPS_A : JOB_OPS_V), "");
     if constexpr (I < 8) { v.x[I] = agpr_read<R + I>(); }
     else if constexpr (I < 44) {
         constexpr int g = (I - 8) / 18, k = (I - 8) % 18;
         if constexpr (k < 4) { constexpr int e = 4 * g + k; v.x[e] = pin_fma(v.x[e], s.sc[e].x, s.sc[e].y); }
-        else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); rm = pin_max3_i32(rm, v.x[e], v.x[e + 1]); }
+        else if constexpr (k < 6) { constexpr int e = 4 * g + 2 * (k - 4); if constexpr (RANGE) rm = pin_max3_i32(rm, v.x[e], v.x[e + 1]); }
         else if constexpr (k < 10) { constexpr int e = 4 * g + k - 6; v.x[e] = pin_relu_clamp32(v.x[e]); }
         else if constexpr (k < 12) { constexpr int P = 2 * g + (k - 10); v.h[P] = pin_cvt(v.x[2 * P], v.x[2 * P + 1]); }
         else if constexpr (k < 16) { constexpr int e = 4 * g + (k - 12); v.x[e] = (e & 1) ? pin_res_hi(v.h[e >> 1], v.x[e]) : pin_res_lo(v.h[e >> 1], v.x[e]); }
@@ -175,8 +175,8 @@ template <int R, bool INPLACE, int I> __device__ __forceinline__ void job_op(Job
         if constexpr (w < 4) agpr_write<R + w>(v.h[w]); else agpr_write<R + w>(v.m[w - 4]);
     }
 }
-template <int R, bool INPLACE, int I0, int I1> __device__ __forceinline__ void job_ops(JobX &v, const JobSc &s, int &rm) {
-    if constexpr (I0 < I1 && I0 < (INPLACE ? JOB_OPS_A : JOB_OPS_V)) { job_op<R, INPLACE, I0>(v, s, rm); job_ops<R, INPLACE, I0 + 1, I1>(v, s, rm); }
+template <int R, bool INPLACE, int I0, int I1, bool RANGE = true> __device__ __forceinline__ void job_ops(JobX &v, const JobSc &s, int &rm) {
+    if constexpr (I0 < I1 && I0 < (INPLACE ? JOB_OPS_A : JOB_OPS_V)) { job_op<R, INPLACE, I0, RANGE>(v, s, rm); job_ops<R, INPLACE, I0 + 1, I1, RANGE>(v, s, rm); }
 }
 __device__ __forceinline__ JobOut job_result(const JobX &v) {
     JobOut o;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                 SFOR(c, 2)
                     JobX jx_;
                     SFOR(i, 8) jx_.x[i] = r1[tk][c][8 * qk + i]; SEND
-                    job_ops<0, false, 8, JOB_OPS_V>(jx_, sc_, rdummy);
+                    job_ops<0, false, 8, JOB_OPS_V, false>(jx_, sc_, rdummy);
                     const JobOut o = job_result(jx_);
                     PF_PARK(kk, c, 0) = o.h; PF_PARK(kk, c, 1) = o.m;
                     if constexpr (kk == 0) { pbh[c] = o.h; pbm[c] = o.m; }
@@ -760,7 +760,50 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     // points are the rows [s, e)): max over its rows (v_max_f32 ignores a NaN operand, as the reference's
                     // '>' does), published by integer atomicMax on orderable keys -- to the LDS bins of the workgroup's
                     // first SEG_SLOTS nodes, else straight to memory.  All branches are wave-uniform.
+                    auto publish = [&](int node, float (&mx)[MT4]) __attribute__((always_inline)) {
+                        if (l4_unit) {                                            // fl(x / 1024 + b) is monotone in x: after the max
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
+                        }
+                        // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
+                        // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
+                        const int slot = node - n0;
+                        if (slot < SEG_SLOTS) {
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(&bins[slot][32 * mt + j], ord_f32(__float_as_uint(mx[mt])));
+                        } else {
+                            unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * PCH;
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
+                        }
+                    };
                     unsigned remaining = (unsigned)__ballot(pv[c]);               // lanes 0..31 <-> the column tile's 32 points
+                    if (remaining == 0xFFFFFFFFu) {
+                        // the common boundary case -- exactly two nodes in 32 valid points, rows [0, e) and [e, 32) -- in one sweep:
+                        // one comparison per row serves both maxima
+                        const int node_a = __builtin_amdgcn_readlane(nid[c], 0), node_b = __builtin_amdgcn_readlane(nid[c], 31);
+                        const int e = __builtin_popcount((unsigned)__ballot(nid[c] == node_a));
+                        if (node_a != node_b && __builtin_amdgcn_readlane(nid[c], e & 31) == node_b) {
+                            float ma[MT4], mb[MT4];
+#pragma unroll
+                            for (int mt = 0; mt < MT4; ++mt) ma[mt] = mb[mt] = -__builtin_inff();
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) {
+                                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const bool in0 = prow < e, in1 = prow + 1 < e;
+#pragma unroll
+                                for (int mt = 0; mt < MT4; ++mt) {
+                                    const float a0 = in0 ? acc[mt][c][r] : -__builtin_inff(), a1 = in1 ? acc[mt][c][r + 1] : -__builtin_inff();
+                                    const float b0 = in0 ? -__builtin_inff() : acc[mt][c][r], b1 = in1 ? -__builtin_inff() : acc[mt][c][r + 1];
+                                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ma[mt]) : "v"(ma[mt]), "v"(a0), "v"(a1));
+                                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mb[mt]) : "v"(mb[mt]), "v"(b0), "v"(b1));
+                                }
+                            }
+                            publish(node_a, ma);
+                            publish(node_b, mb);
+                            remaining = 0u;
+                        }
+                    }
                     while (remaining != 0u) {
                         const int s0 = __builtin_ctz(remaining);
                         const int node = __builtin_amdgcn_readlane(nid[c], s0);
@@ -768,7 +811,6 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                         remaining &= ~segmask;
                         const int e0 = s0 + __builtin_popcount(segmask);
                         const bool whole = (s0 == 0 && e0 == 32);
-                        const int slot = node - n0;
                         float mx[MT4];
                         // (v_max3_f32: two rows per instruction, same NaN rule as v_max_f32)
                         if (whole) {
@@ -795,20 +837,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                                 }
                             }
                         }
-                        if (l4_unit) {                                            // fl(x / 32 + b) is monotone in x: after the max
-#pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) mx[mt] = __fmaf_rn(mx[mt], ACC_UNSCALE, bias4[mt]);
-                        }
-                        // two explicit paths: a generic pointer here makes FLAT atomics, and with a FLAT operation anywhere in
-                        // the loop hipcc replaces every counted lgkmcnt wait of the MFMA steps by lgkmcnt(0)
-                        if (slot < SEG_SLOTS) {
-#pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) atomicMax(&bins[slot][32 * mt + j], ord_f32(__float_as_uint(mx[mt])));
-                        } else {
-                            unsigned *gdst = pooled + ((long long)b * M + node) * (32 * T3) + pass * PCH;
-#pragma unroll
-                            for (int mt = 0; mt < MT4; ++mt) atomicMax(gdst + 32 * mt + j, ord_f32(__float_as_uint(mx[mt])));
-                        }
+                        publish(node, mx);
                     }
                 }
                 pend_n = nslots * PCH;
