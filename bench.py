@@ -263,20 +263,35 @@ def _encoder_parity(enc, inp, P=2, tol=1e-5, **kw):
     return res
 
 
-def _windows(fn, steps, n=3):
-    ts = []
+def _windows(fn, steps, n=3, dev=None, collective=False):
+    """n timed windows of `steps` calls.  collective (a job of several ranks): a barrier on both sides of every window and the MAX over
+    ranks, as for the headline; returns (seconds per step of the job, seconds per step of this rank)."""
+    from sonet_hip import dp
+    ts, mine = [], []
     for _ in range(n):
+        if collective:
+            dp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) / steps)
-    return ts
+        me = (time.perf_counter() - t0) / steps
+        if collective:
+            dp.barrier()
+            torch.cuda.synchronize()
+            ts.append(dp.all_reduce_max((time.perf_counter() - t0) / steps, dev))
+        else:
+            ts.append(me)
+        mine.append(me)
+    return ts, mine
 
 
-def other_configs(args, dev):
-    """The other BASELINE.json configs on one GPU, after the headline (same process, inputs resident, >= 30 timed steps per
+def other_configs(args, dev, world=1, rank=0):
+    """world > 1 (the driver's --gpus N command, EVERY rank calls this): BASELINE configs[4] -- the data-parallel training step, global
+    batch 64 x N, bucketed RCCL gradient all-reduce -- in bf16 and in the f32-class arithmetic, timed like the headline (barrier on both
+    sides, max over ranks); returns the entries on rank 0, None elsewhere.  world == 1:
+    the other BASELINE.json configs on one GPU, after the headline (same process, inputs resident, >= 30 timed steps per
     window, three windows, the median reported): configs[1] the 5000-point classifier TRAINING step in bf16 and in the f32-class
     arithmetic (models/classifier.py:78-99), configs[2] the part segmenter at 1024 points (models/segmenter.py:79-109),
     configs[3] the autoencoder forward with the Chamfer loss (models/autoencoder.py:66-103).  Each entry carries the roofline of
@@ -305,8 +320,8 @@ def other_configs(args, dev):
             synth.fill_state_dict_(cls.state_dict(), 1)
             enc.to(dev).train()
             cls.to(dev).train()
-            inp = synth.make_inputs(B, N, seed=100, device=dev)
-            dp.init_distributed(force=True)                       # a one-rank RCCL group: the same bucketed exchange as the 8-GPU job
+            inp = synth.make_inputs(B, N, seed=100 + rank, device=dev)     # this rank's shard of the global batch
+            dp.init_distributed(force=True)                       # (world 1: a one-rank RCCL group, the same bucketed exchange as the 8-GPU job)
             dp.broadcast_parameters([enc, cls])
             opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
             opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
@@ -324,15 +339,17 @@ def other_configs(args, dev):
                 opt_e.step()
                 opt_c.step()
                 state["loss"] = loss
-            # the batch that is about to be timed, eval forward with the initial weights, against the oracle (gates `ok`)
-            enc.eval()
-            with torch.no_grad():
-                enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
-            par = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
-            enc.train()
+            # the batch that is about to be timed, eval forward with the initial weights, against the oracle (gates `ok`; rank 0's shard)
+            par = None
+            if rank == 0:
+                enc.eval()
+                with torch.no_grad():
+                    enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+                par = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
+                enc.train()
             for _ in range(5):
                 step()
-            ts = _windows(step, K)
+            ts, mine = _windows(step, K, dev=dev, collective=world > 1)
             exposed_us = reducer.exposed_ms(last=K) * 1e3
             assert torch.isfinite(state["loss"])
             with ops.kernel_timing() as rec:
@@ -341,6 +358,13 @@ def other_configs(args, dev):
                 torch.cuda.synchronize()
             top, roof = _kernel_top(rec, 3, B, N)
             reducer.remove_hooks()
+            my_med = sorted(mine)[len(mine) // 2]
+            per_rank = [my_med]
+            if world > 1:
+                per_rank = [None] * world
+                torch.distributed.all_gather_object(per_rank, my_med)
+            if rank != 0:
+                return None
             # the model that was just trained, in eval mode, against the oracle with the SAME (updated) weights
             enc.eval()
             with torch.no_grad():
@@ -350,9 +374,12 @@ def other_configs(args, dev):
                                             "what": "the same check with the weights and BatchNorm running statistics the timed Adam steps left behind "
                                                     "(random labels, %d steps): reported, not gated -- the bound is the reference fixtures' bound" % (5 + 3 * K + 3)}
             med = sorted(ts)[len(ts) // 2]
-            return {"workload": "ModelNet40 classifier TRAINING step (forward + backward + gradient all-reduce + Adam), %d x %d pts" % (B, N),
-                    "arithmetic": precision, "clouds_per_s": round(B / med, 1), "ms_per_step": round(med * 1e3, 4),
+            return {"workload": "ModelNet40 classifier TRAINING step (forward + backward + gradient all-reduce + Adam), %d rank(s) x %d x %d pts" % (world, B, N),
+                    "arithmetic": precision, "n_gpus": world, "batch_per_gpu": B, "global_batch": B * world,
+                    "clouds_per_s": round(world * B / med, 1), "ms_per_step": round(med * 1e3, 4),
                     "ms_per_step_windows": [round(t * 1e3, 4) for t in ts], "steps_per_window": K,
+                    "per_rank_ms_per_step": {"min": round(min(per_rank) * 1e3, 4), "max": round(max(per_rank) * 1e3, 4),
+                                             "what": "each rank's own median window, without the closing barrier"},
                     "allreduce": {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
                                   "bytes_per_step": state["nbytes"], "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1)},
                     "top_kernels": top, "roofline": roof,
@@ -373,7 +400,7 @@ def other_configs(args, dev):
             call = lambda: g(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])     # noqa: E731
             for _ in range(3):
                 call()
-            ts = _windows(call, K)
+            ts, _ = _windows(call, K)
             bad = g.range_violations()
             for _ in range(2):
                 fwd(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
@@ -440,6 +467,14 @@ def other_configs(args, dev):
         return graphed(fwd, inp, B, N, "autoencoder forward (encoder + decoder + two-resolution Chamfer loss, eval), %d x %d pts vs %d + %d predicted"
                        % (B, N, 256 + 1024, 1024), parity)
 
+    if world > 1:
+        # (no exception guard: a rank that failed alone would leave the others waiting in the next collective)
+        for precision in ("bf16", "h3"):
+            t0 = time.perf_counter()
+            e = train(precision)
+            if e is not None:
+                out["configs[4] train %s" % precision] = dict(e, wall_s=round(time.perf_counter() - t0, 1))
+        return out if rank == 0 else None
     guarded("configs[1] train bf16", lambda: train("bf16"))
     guarded("configs[1] train h3", lambda: train("h3"))
     guarded("configs[2] segmenter", segmenter)
@@ -674,6 +709,13 @@ def main():
     value = world * B * args.steps / elapsed
     ranks = rank_evidence(world, rank, dev, B * args.steps / my_elapsed)
 
+    train_entries = None
+    if world > 1 and not args.no_other_configs:
+        # BASELINE configs[4] on the driver's multi-GPU command: every rank takes part (gradient all-reduce), rank 0 keeps the entries
+        if use_graph:
+            del graphs, graphed
+        torch.cuda.empty_cache()
+        train_entries = other_configs(args, dev, world, rank)
     if rank != 0:
         return
     dtype = ("bf16 (bf16 storage, one bf16 MFMA per product, f32 accumulate; features within 5e-2 of the f32 oracle, indices exact)" if ops.POINTMLP_PRECISION == "bf16"
@@ -775,7 +817,9 @@ def main():
         if use_graph:
             del graphs, graphed
         torch.cuda.empty_cache()
-        line["other_configs"] = other_configs(args, dev)
+        line["other_configs"] = other_configs(args, dev, 1, 0)
+    elif train_entries:
+        line["other_configs"] = train_entries
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
     return line

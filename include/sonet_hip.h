@@ -209,6 +209,32 @@ int sonet_pointmlp_h3_f32(const float *x1, int C1, const float *x2, int C2, cons
                           const float *scale, const float *shift, int relu, float *y,
                           int B, int Cout, int L, sonet_stream_t stream);
 
+/* Third generation of the fp16-split layer: PRE-SPLIT activations ("P16" planes; so-net_amd/csrc/pointmlp_h3p.hip).
+ *   reference: models/layers.py:282-296 (EquivariantLayer.forward) / :313-367 (the 1x1 Conv2d layers of KNNModule).
+ * P16 layout of a B x C x L activation: P[b][kc][form][h][l][8] fp16, kc < ceil(C/16); form 0 = fp16(32 x), form 1 = fp16(32 x - form 0);
+ * element e of half h is channel 16 kc + 4 h + (e & 3) + 8 (e >> 2), zeros past C: sonet_p16_size(B, C, L) = 64 B ceil(C/16) L bytes (the
+ * bytes of the f32 tensor).  The split (clamp to +-2047, scale, two roundings) runs once where the activation is PRODUCED -- in the
+ * epilogue of sonet_pointmlp_h3p (output yp) or in sonet_p16_from_f32 (optionally through a per-channel affine + ReLU: the training
+ * forward's normalise pass) -- and the consuming layer's operand loads are finished MFMA B fragments.  The producer reports its largest
+ * post-activation magnitude in word 2 of the range log.  sonet_p16_to_f32 returns (form 0 + form 1) / 32.
+ * sonet_pointmlp_h3p: y = act((W . cat(x1, x2) [+ zadd[b][o][zidx[b][l]]]) * scale + shift); x1p / x2p P16 (x1: C1 channels x L1 columns,
+ * read through gidx [B][L] i32 when given -- out of range: zeros --, L1 = L otherwise; C1 % 16 == 0 when x2 is given), Wp from
+ * sonet_pointmlp_h3p_pack (sonet_pointmlp_h3p_pack_size bytes; K slots in P16 channel order, weights as fp16(32 w) + fp16 residual,
+ * |w| <= 2047 logged in word 1 of the range log), outputs y (f32 [B][Cout][L]) and / or yp (P16); Cout % 32 == 0.
+ * stats_ws / mean / var (all or none; y only): BatchNorm batch statistics of y from the epilogue, as sonet_pointmlp_h3_stats_f32
+ * (stats_ws: sonet_pointmlp_h3p_stats_ws_size bytes).  zadd [B][Cout][ZM] f32 / zidx [B][L] i32: as sonet_pointmlp_h3_nodeadd_f32. */
+size_t sonet_p16_size(int B, int C, int L);
+int sonet_p16_from_f32(const float *x, void *p16, int B, int C, int L, const float *scale, const float *shift, int relu,
+                       sonet_stream_t stream);
+int sonet_p16_to_f32(const void *p16, float *x, int B, int C, int L, sonet_stream_t stream);
+size_t sonet_pointmlp_h3p_pack_size(int Cin, int Cout);
+int sonet_pointmlp_h3p_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream);
+size_t sonet_pointmlp_h3p_stats_ws_size(int B, int Cout, int L);
+int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t *gidx, const void *x2p, int C2, const void *Wp,
+                       const float *scale, const float *shift, int relu, float *y, void *yp, int B, int Cout, int L,
+                       const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
+                       sonet_stream_t stream);
+
 /* The same layer with bf16 STORAGE and bf16 MFMA (BASELINE configs[1] "bf16"; the reference is f32-only, so this is the
  * reduced-precision twin of models/layers.py:282-296, not a bit-compatible replacement): x1, x2, y are bfloat16 bit
  * patterns [B][C][L], one v_mfma_f32_32x32x16_bf16 per product with f32 accumulation, the epilogue

@@ -423,7 +423,7 @@ WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torc
 # whole mechanism off (no log, no read-back).
 RANGE_GUARD = _os.environ.get("SONET_RANGE_GUARD", "1") != "0"
 _RANGE_SLOTS = 32
-_B_2047, _B_65504, _B_XLOW, _B_WLOW = 0x44FFE000, 0x477FE000, 0x3C800000, 0x3B800000     # bits of 2047, 65504, 2^-6, 2^-8
+_B_2047, _B_65504, _B_XLOW, _B_WLOW, _B_WLOW32 = 0x44FFE000, 0x477FE000, 0x3C800000, 0x3B800000, 0x3E000000   # bits of 2047, 65504, 2^-6, 2^-8, 2^-3
 _range_logs = {}            # device index -> int32[_RANGE_SLOTS * 8]
 _range_active = None        # the innermost open scope
 _range_ptr_set = False      # whether the library currently holds a non-NULL slot pointer for this thread
@@ -493,12 +493,23 @@ class range_scope:
                 out.append((name, "max |x| = %g exceeds 2047" % _bits_to_float(x)))
             elif low_ok and 0 < x < _B_XLOW:
                 out.append((name, "max |x| = %g is below 2^-6 (fp16 residuals go subnormal)" % _bits_to_float(x)))
-            # (the fused first-PointNet kernel keeps its weights as fp16(32 w) and logs 32 |w|: its limits are 2047 and 2^-13)
-            wdiv = 32.0 if name.startswith("pointresnet_fused") else 1.0
-            if wt > _B_65504:
-                out.append((name, "max |w| = %g exceeds %g" % (_bits_to_float(wt) / wdiv, 65504.0 / wdiv)))
+            # Weight side.  The second-generation layer keeps fp16(w) (limits 65504 and 2^-8).  The fused first PointNet and the third
+            # generation (pointmlph3p*) keep fp16(32 w) + fp16(32 w - hi): |w| <= 2047, and max |w| >= 2^-8 -- below that the residual
+            # piece is an fp16 subnormal with absolute error 2^-30 on w, i.e. up to 2^-22 relative (the fused kernel logs 32 |w|).
+            if name.startswith("pointresnet_fused"):
+                if wt > _B_65504:
+                    out.append((name, "max |w| = %g exceeds %g" % (_bits_to_float(wt) / 32.0, 65504.0 / 32.0)))
+                elif low_ok and 0 < wt < _B_WLOW32:
+                    out.append((name, "max |w| = %g is below 2^-8" % (_bits_to_float(wt) / 32.0)))
+            elif name.startswith("pointmlph3p"):
+                if wt > _B_2047:
+                    out.append((name, "max |w| = %g exceeds 2047" % _bits_to_float(wt)))
+                elif low_ok and 0 < wt < _B_WLOW:
+                    out.append((name, "max |w| = %g is below 2^-8" % _bits_to_float(wt)))
+            elif wt > _B_65504:
+                out.append((name, "max |w| = %g exceeds 65504" % _bits_to_float(wt)))
             elif low_ok and 0 < wt < _B_WLOW:
-                out.append((name, "max |w| = %g is below 2^%d" % (_bits_to_float(wt) / wdiv, -8 if wdiv == 1.0 else -13)))
+                out.append((name, "max |w| = %g is below 2^-8" % _bits_to_float(wt)))
             if hid > _B_2047:
                 out.append((name, "a hidden activation reaches %g > 2047" % _bits_to_float(hid)))
         return out
@@ -864,6 +875,135 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
         check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
                  stream_ptr()), "sonet_pointmlp_stats")
     return y, mean, var
+
+
+# ---- third generation of the fp16-split layer: pre-split activations ("P16" planes, csrc/pointmlp_h3p.hip) -------------------------
+class P16:
+    """A B x C x L activation in the P16 layout (include/sonet_hip.h): two fp16 planes per value, in MFMA B-fragment order.
+    ``data`` is the raw byte tensor (64 * ceil(C / 16) * L bytes per cloud).  Produced by ``p16_from_f32`` or by ``pointmlp_h3p(...,
+    out="p16")``, consumed by ``pointmlp_h3p``; ``float()`` decodes it."""
+
+    __slots__ = ("data", "B", "C", "L")
+
+    def __init__(self, data, B, C, L):
+        self.data, self.B, self.C, self.L = data, B, C, L
+
+    @property
+    def shape(self):
+        return (self.B, self.C, self.L)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def float(self):
+        return p16_to_f32(self)
+
+
+def p16_empty(B, C, L, device):
+    n = _lib.load().sonet_p16_size(B, C, L)
+    return P16(torch.empty((n,), dtype=torch.uint8, device=device), B, C, L)
+
+
+def p16_from_f32(x, scale=None, shift=None, relu=False):
+    """f32 B x C x L -> P16 planes of act(x * scale + shift) (scale / shift per channel, both or none).  Inside a range scope the
+    launch logs the largest magnitude it split (word 2 of its slot: the consumers of the planes cannot check it any more)."""
+    _chk(x, "x", torch.float32, 3)
+    B, C, L = x.shape
+    dev = _same_device(x, scale, shift)
+    out = p16_empty(B, C, L, dev)
+    if x.numel() == 0:
+        return out
+    if scale is not None:
+        _chk(scale, "scale", torch.float32, 1)
+        _chk(shift, "shift", torch.float32, 1)
+    name = "p16_from_f32_%d_L%d" % (C, L)
+    _range_arm(name)
+    with torch.cuda.device(dev), _timed(name):
+        check(_lib.load().sonet_p16_from_f32(ptr(x), ptr(out.data), B, C, L, ptr(scale), ptr(shift), int(bool(relu)), stream_ptr()),
+              "sonet_p16_from_f32")
+    return out
+
+
+def p16_to_f32(p):
+    x = torch.empty((p.B, p.C, p.L), dtype=torch.float32, device=p.device)
+    if x.numel():
+        with torch.cuda.device(p.device), _timed("p16_to_f32"):
+            check(_lib.load().sonet_p16_to_f32(ptr(p.data), ptr(x), p.B, p.C, p.L, stream_ptr()), "sonet_p16_to_f32")
+    return x
+
+
+def pointmlp_h3p_pack(weight2d):
+    """[Cout][Cin] f32 -> the h3p pack (int32 tensor marks the flavour): K slots in P16 channel order, fp16(32 w) + residual."""
+    _chk(weight2d, "weight", torch.float32, 2)
+    dev = _same_device(weight2d)
+    Cout, Cin = weight2d.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        wp = torch.empty((lib.sonet_pointmlp_h3p_pack_size(Cin, Cout) // 4,), dtype=torch.int32, device=dev)
+        check(lib.sonet_pointmlp_h3p_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_h3p_pack")
+    return wp
+
+
+def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None, z=None, zidx=None, stats=False):
+    """y = act((W . cat(x1, x2) [+ z[:, :, zidx]]) * scale + shift) on P16 inputs (x1, x2: ``P16``).
+    out: "f32" -> B x Cout x L f32 tensor, "p16" -> ``P16``, "both" -> (f32, P16).  gidx (B x L i32): column l of x1 is x1[:, :, gidx[b, l]].
+    stats=True (out "f32" only): also the per-channel (mean, biased var) of y over (B, L) -> (y, mean, var)."""
+    if not isinstance(x1, P16) or (x2 is not None and not isinstance(x2, P16)):
+        raise SonetHipError("pointmlp_h3p: P16 inputs (ops.p16_from_f32)")
+    if wp.dtype != torch.int32:
+        raise SonetHipError("pointmlp_h3p: an h3p pack (ops.pointmlp_h3p_pack)")
+    B, C1, L1 = x1.shape
+    L = L1
+    if gidx is not None:
+        _chk(gidx, "gidx", torch.int32, 2)
+        if gidx.shape[0] != B:
+            raise SonetHipError("pointmlp_h3p: gidx must have B rows")
+        L = gidx.shape[1]
+    C2 = 0
+    if x2 is not None:
+        if x2.B != B or x2.L != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.C
+        if C1 % 16 != 0:
+            raise SonetHipError("pointmlp_h3p: with a second input C1 must be a multiple of 16")
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    if (z is None) != (zidx is None):
+        raise SonetHipError("pointmlp_h3p: z and zidx come together")
+    ZM = 0
+    if z is not None:
+        _chk(z, "z", torch.float32, 3)
+        _chk(zidx, "zidx", torch.int32, 2)
+        if tuple(z.shape[:2]) != (B, Cout) or tuple(zidx.shape) != (B, L):
+            raise SonetHipError("pointmlp_h3p: z must be B x Cout x M and zidx B x L")
+        ZM = z.shape[2]
+    if out not in ("f32", "p16", "both") or (stats and out != "f32"):
+        raise SonetHipError("pointmlp_h3p: out is 'f32', 'p16' or 'both' (statistics: 'f32')")
+    dev = _same_device(x1.data, x2.data if x2 is not None else None, wp, scale, shift, gidx, z, zidx)
+    lib = _lib.load()
+    # the pack's K range is the concatenation of the inputs' 16-channel chunks
+    cin_pack = (C1 + C2) if C2 else C1
+    if wp.numel() * 4 != lib.sonet_pointmlp_h3p_pack_size(cin_pack, Cout):
+        raise SonetHipError("packed weight has %d bytes, expected %d for Cin=%d Cout=%d"
+                            % (wp.numel() * 4, lib.sonet_pointmlp_h3p_pack_size(cin_pack, Cout), cin_pack, Cout))
+    y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev) if out in ("f32", "both") else None
+    yp = p16_empty(B, Cout, L, dev) if out in ("p16", "both") else None
+    mean = var = ws = None
+    if stats:
+        mean = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        var = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.sonet_pointmlp_h3p_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
+    if B * L * Cout != 0:
+        name = "pointmlph3p%s_%dx%d_L%d" % ("_nodeadd" if z is not None else "_stats" if stats else "", C1 + C2, Cout, L)
+        _range_arm(name)
+        with torch.cuda.device(dev), _timed(name):
+            check(lib.sonet_pointmlp_h3p(ptr(x1.data), C1, L1, ptr(gidx), ptr(x2.data) if x2 is not None else None, C2, ptr(wp), ptr(scale), ptr(shift),
+                                         int(bool(relu)), ptr(y), ptr(yp.data) if yp is not None else None, B, Cout, L, ptr(z), ptr(zidx), ZM,
+                                         ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_h3p")
+    if stats:
+        return y, mean, var
+    return y if out == "f32" else yp if out == "p16" else (y, yp)
 
 
 def pointresnet_pack(w1, w2, w3, w4):

@@ -36,3 +36,14 @@ def test_bench_line_end_to_end_on_the_visible_gpus():
             assert key in oc and "error" not in oc[key], (key, oc.get(key))
             assert oc[key]["clouds_per_s"] > 0 and oc[key]["parity_checked"]["ok"], (key, oc[key]["parity_checked"])
         assert oc["configs[1] train bf16"]["allreduce"]["backend"] == "nccl"
+        train_keys = ["configs[1] train bf16", "configs[1] train h3"]
+    else:
+        # the driver's multi-GPU command: the forward line above AND BASELINE configs[4] (data-parallel training, RCCL all-reduce)
+        oc = line["other_configs"]
+        train_keys = ["configs[4] train bf16", "configs[4] train h3"]
+    for key in train_keys:
+        e = oc[key]
+        assert e["n_gpus"] == n and e["global_batch"] == n * e["batch_per_gpu"] and e["clouds_per_s"] > 0
+        assert e["allreduce"]["rccl_world_size"] == n and e["allreduce"]["bytes_per_step"] > 0 and e["allreduce"]["exposed_us_per_step"] >= 0
+        assert 0 < e["per_rank_ms_per_step"]["min"] <= e["per_rank_ms_per_step"]["max"] <= e["ms_per_step"] * 1.5
+        assert e["parity_checked"]["ok"]
