@@ -113,7 +113,7 @@ def parity_check(args, enc, cls, inp, out, enc_sd, cls_sd, n_clouds=4):
 
     # node ids of EVERY cloud of the timed batch against the C restatement of BatchSOM.query_topk (util/som.py:237-269)
     all_idx = enc.min_idx.cpu().numpy()
-    ids_ok = bool(np.array_equal(all_idx, O.som_query_topk(inp["pc"].cpu(), inp["node"].cpu(), 3)[0]))
+    ids_ok = bool(np.array_equal(all_idx, O.som_query_topk(inp["pc"].cpu(), inp["node"].cpu(), int(enc.opt.k))[0]))
     res = {"clouds": P, "of_the_timed_batch": True, "min_idx_bit_exact": bool(np.array_equal(got_idx, ref["min_idx"])),
            "node_ids_bit_exact_all_clouds": {"clouds": args.batch, "ok": bool(ids_ok)},
            "feature_err_over_bound": round(worst(feat[:P], ref["feature"]), 4),

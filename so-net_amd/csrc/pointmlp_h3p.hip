@@ -170,6 +170,8 @@ struct H3pArgs {
     const int32_t *zidx;
     unsigned *rlog;                       // range-log slot (word 1: max |w| bits, word 2: max of the P16 output)
     double *stats_partial;                // optional [ncol][Cout][2] (sum, sum of squares of the f32 output over the workgroup's columns)
+    int abl;                              // (variants build) ablations: 1 = outputs dropped (stores issued, out of range), 2 = every X load reads chunk 0, 4 = every W request reads chunk 0
+    unsigned long long *prof;             // (variants build) phase cycle counters: [0] workgroups, [1] prologue, [2] chunk loops, [3] epilogues, [4] whole
     long long ngroups;                    // B * gpc
     int KC1, KC2, L1, L, Cout, CT, KC, KCr, KCP, ct_per_y, nslab, ncol, gpc, relu, ZM;
 };
@@ -188,11 +190,14 @@ __device__ __forceinline__ u32x4 bload16(i32x4_t rsrc, unsigned voff, unsigned s
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     return r;
 }
-__device__ __forceinline__ void bstore16(i32x4_t rsrc, unsigned voff, unsigned soff, u32x4 v) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+// Stores go through the compiler's builtins: nothing about a store needs hiding from hipcc (it never waits for one), and an inline-asm
+// buffer_store_dwordx4 needs wait states before its data registers may be rewritten that hipcc does not add behind an asm statement
+// (the first version of the transposed epilogue lost the last two values of a quad that way).
+__device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 0);
 }
-__device__ __forceinline__ void bstore4(i32x4_t rsrc, unsigned voff, unsigned soff, float v) {
-    asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, soff, 0);
 }
 // "at most N vector-memory operations of this wave are outstanding", then the workgroup barrier; the registers the wait is FOR are
 // in/out operands, so that every later use depends on this statement
@@ -221,19 +226,17 @@ __device__ __forceinline__ void sched_pair() {
 // MT output tiles per pass (even), NC 32-column tiles per wave, OCC workgroups per CU the register budget is cut for.
 // EPI: 0 = plain, 1 = per-node addend (zadd) staged through LDS, 3 = per-node addend gathered from global memory (any ZM, any column
 // grouping: the fallback), 2 = statistics (training forward).  OUT: bit 0 = f32 output y, bit 1 = P16 output yp.
-// SWP (f32 output only, L % 4 == 0): the MFMA operands change places (X as A, W as B -- the per-lane register contents of a fragment are
-// the same in either role), which transposes the accumulator tile: a lane then holds 16 POINTS of ONE output channel, four consecutive
-// points per register quad.  The f32 rows leave as 16-byte stores (a quarter of the store instructions of the row-per-register
-// orientation), scale / shift are two values per lane and tile, and the batch statistics are sums over a lane's own registers.
-template <int MT, int NC, int OCC, int EPI, int OUT, int SWP>
+// (A transposed orientation -- X as the MFMA's A operand, so that a lane holds 16 points of one channel and the f32 rows leave as 16-byte
+// stores -- was built and dropped: its stores write 32-byte pieces of 32 rows per instruction and measured 12 % slower than two full
+// 128-byte lines per dword store, docs/findings.md R4.2.)
+template <int MT, int NC, int OCC, int EPI, int OUT>
 __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pArgs a)
 {
     static_assert(OUT >= 1 && OUT <= 3 && (EPI != 2 || (OUT & 1)), "output mode");
-    static_assert(SWP == 0 || (OUT == 1 && (EPI == 0 || EPI == 2)), "the transposed orientation serves the f32-only outputs");
     static_assert(MT % 2 == 0 && (NC == 1 || NC == 2), "tile shape");
-    // X look-ahead: 3 chunks; 2 for the 64-column tiles at two workgroups per CU (16 registers less: that shape sits at the 256-register limit,
-    // and the second workgroup of the CU covers the shorter look-ahead)
-    constexpr int PB = (OCC >= 2 && NC == 2) ? 2 : 3, NB = 4, D = 3, NSLOT = D + 2;
+    // X look-ahead: 3 chunks (2 measured 3-5 % slower on the 64-column tiles); 2 for the 64-column tiles with the addend rows in LDS at two
+    // workgroups per CU: 16 registers less, that instantiation sits at the 256-register limit
+    constexpr int PB = (OCC >= 2 && NC == 2 && (EPI == 1 || EPI == 3)) ? 2 : 3, NB = 4, D = 3, NSLOT = D + 2;
     static_assert(D >= PB && PB >= 2, "the wait count below assumes the W request of a chunk is older than its X request");
     constexpr int NSL = MT * 2;                                // 1 KiB slices per chunk: [tile][form]
     constexpr int ND = NSL / 4;                                // LDS-DMA instructions per wave and chunk
@@ -243,7 +246,10 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     static_assert(KWAIT < 64, "vmcnt is a 6-bit counter");
     struct Lds {
         u32x4 wsm[NSLOT][NSL][64];                            // W ring first: LDS-DMA addresses below 64 KiB
-        float aff_scale[EPI == 1 ? 512 : 1024], aff_shift[EPI == 1 ? 512 : 1024];   // (EPI 1: slabs of <= 16 tiles, the addend rows need the space)
+        // scale / 1024 and shift of the slab's rows (EPI 1: slabs of <= 16 tiles, the addend rows need the space) as [tile][h][scale, shift][16]:
+        // the 16 rows of a tile a lane's registers hold (row (r & 3) + 8 (r >> 2) + 4 h in register r), contiguous, so that a tile's 32 values
+        // are eight 16-byte reads at the top of the tile instead of 32 reads inside it
+        float aff[EPI == 1 ? 1024 : 2048];
         float2 red[EPI == 2 ? 4 : 1][EPI == 2 ? MT * 32 : 1];
         float zl[EPI == 1 ? MT * 32 : 1][EPI == 1 ? 64 : 1];      // (EPI 1) the pass's rows of the per-node addend, when the workgroup sits in one cloud
     };
@@ -280,31 +286,44 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
         }
         voy[c] = pv[c] ? (unsigned)(4 * h * L + l) * 4u : OOB;
         voyp[c] = pv[c] ? (unsigned)(h * L + l) * 16u : OOB;
+#ifdef SONET_VARIANTS
+        if (a.abl & 1) { voy[c] = OOB; voyp[c] = OOB; pv[c] = false; }
+#endif
     }
     const i32x4_t r1 = make_rsrc(static_cast<const char *>(a.x1) + (size_t)b * a.KC1 * 64 * L1, (unsigned)a.KC1 * 64u * (unsigned)L1);
     const i32x4_t r2 = make_rsrc(a.x2 ? static_cast<const char *>(a.x2) + (size_t)b * a.KC2 * 64 * L : static_cast<const char *>(a.x1),
                                  a.x2 ? (unsigned)a.KC2 * 64u * (unsigned)L : 0u);
-    const i32x4_t ry = make_rsrc(a.y ? reinterpret_cast<char *>(a.y) + (size_t)b * a.Cout * L * 4 : nullptr, a.y ? (unsigned)a.Cout * (unsigned)L * 4u : 0u);
-    const i32x4_t ryp = make_rsrc(a.yp ? static_cast<char *>(a.yp) + (size_t)b * (a.Cout / 16) * 64 * L : nullptr,
-                                  a.yp ? (unsigned)(a.Cout / 16) * 64u * (unsigned)L : 0u);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y ? reinterpret_cast<char *>(a.y) + (size_t)b * a.Cout * L * 4 : nullptr, 0, a.y ? (int)((unsigned)a.Cout * (unsigned)L * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(
+        a.yp ? static_cast<char *>(a.yp) + (size_t)b * (a.Cout / 16) * 64 * L : nullptr, 0, a.yp ? (int)((unsigned)(a.Cout / 16) * 64u * (unsigned)L) : 0, 0x00020000);
 
     const int ct_begin = wg_slab * a.ct_per_y;
     const int ct_end = min(a.CT, ct_begin + a.ct_per_y);
     const int npass = (ct_end - ct_begin) / MT;                // (the host makes ct_per_y a multiple of MT)
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += P_THREADS)
     {
-        lds.aff_scale[o - ct_begin * 32] = a.scale[o] * (1.f / 1024.f);                              // accumulators hold 1024 W.x
-        lds.aff_shift[o - ct_begin * 32] = a.shift[o];
+        const int rel = o - ct_begin * 32, rr = rel & 31;
+        const float scv = o < a.Cout ? a.scale[o] * (1.f / 1024.f) : 0.f, shv = o < a.Cout ? a.shift[o] : 0.f;      // accumulators hold 1024 W.x
+        float *t = lds.aff + (rel >> 5) * 64 + ((rr >> 2) & 1) * 32 + ((rr & 3) | ((rr >> 3) << 2));
+        t[0] = scv;
+        t[16] = shv;
     }
     __syncthreads();
 
     const int KCr = a.KCr, KC1 = a.KC1;
+#ifdef SONET_VARIANTS
+    unsigned long long pt0 = __builtin_readcyclecounter(), pt_loop = 0, pt_epi = 0, pt_pro = 0;
+#endif
     const unsigned wsm_lds = (unsigned)reinterpret_cast<size_t>(&lds.wsm[0][0][0]);
     const unsigned vow = (unsigned)lane * 16u;
     const char *wp = static_cast<const char *>(a.Wp);
 
     // X chunk kc (of this wave's columns) -> registers: [c][form]
     auto load_b = [&](u32x4 (&bb)[NBL], int kc) {
+#ifdef SONET_VARIANTS
+        if (a.abl & 2) kc = 0;
+#endif
         const bool second = kc >= KC1;
         const int kk = second ? kc - KC1 : kc;
         const unsigned rowb = (unsigned)(second ? L : L1) * 32u;             // bytes of one (chunk, form) plane pair
@@ -318,6 +337,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     };
     // W chunk (pass, kc) -> ring slot: this wave moves slices wave, wave + 4, ...; slice sl = tile sl / 2, form sl % 2
     auto dma = [&](int pass, int kc, int slot) {
+#ifdef SONET_VARIANTS
+        if (a.abl & 4) { kc = 0; pass = 0; }
+#endif
         const int ps = pass < npass ? pass : npass - 1;
         const char *g0 = wp + ((size_t)(ct_begin + ps * MT) * a.KCP + kc) * 2048u;
         const unsigned d0 = wsm_lds + (unsigned)slot * (unsigned)(NSL * 1024);
@@ -355,95 +377,50 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                 for (int c = 0; c < NC; ++c)
                 {
                     const f16x8 wf = __builtin_bit_cast(f16x8, A[2 * tt + (term == 0 ? 1 : 0)]), xf = term == 1 ? Bm[c] : Bh[c];
-                    acc[2 * p + tt][c] = SWP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, wf, acc[2 * p + tt][c], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[2 * p + tt][c], 0, 0, 0);
+                    acc[2 * p + tt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[2 * p + tt][c], 0, 0, 0);
                 }
     };
 
     RangeAcc yr = {0, 0u};
     const float relu_thr = a.relu ? 0.f : -__builtin_inff();   // v < thr ? 0 : v  (a NaN stays a NaN, as torch's ReLU leaves it)
     const float split_lo = a.relu ? 0.f : -2047.f;             // lower clamp of the split: ReLU and clamp are one v_med3_f32
+    // (EPI 1 / 3) the node of each of this lane's columns: loaded once per workgroup (a compiler-visible load inside the pass loop would make
+    // hipcc wait for vmcnt(0) there: the look-ahead requests included)
+    int zm[NC];
+    bool zok[NC];
+    unsigned zvo[NC], zla[NC];
+    const i32x4_t rz = make_rsrc(a.zadd ? a.zadd + (size_t)b * a.Cout * a.ZM : nullptr, a.zadd ? (unsigned)a.Cout * (unsigned)a.ZM * 4u : 0u);
+    if constexpr (EPI == 1 || EPI == 3) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            zm[c] = a.zidx[(size_t)b * L + lcl[c]];
+            zok[c] = (unsigned)zm[c] < (unsigned)a.ZM;
+            zm[c] = zok[c] ? zm[c] : 0;
+            zvo[c] = zok[c] ? (unsigned)(zm[c] + 4 * h * a.ZM) * 4u : OOB;      // (the gather path: row 4 h, node zm; out of range: 0 through the descriptor)
+            // (the LDS path: ONE opaque address register per column tile and row offsets in the instruction -- the rows sit beyond the
+            // 64 KiB an LDS instruction's offset field reaches from 0, and hipcc otherwise keeps a hoisted address register per row)
+            zla[c] = (unsigned)reinterpret_cast<size_t>(&lds.zl[4 * h][zm[c]]);
+            asm volatile("" : "+v"(zla[c]));
+        }
+    }
     // epilogue of one pass: tiles ct0 .. ct0 + MT - 1, one (tile, column tile) at a time (a scheduling barrier in between: left alone,
     // hipcc lifts all 16 MT NC accumulator registers out of the accumulation file at once and spills)
     auto epilogue = [&](int ct0) {
-        if constexpr (SWP != 0) {
-            // lane (c = lane & 31, h): channel (ct0 + mt) 32 + c, points l0 + 32 cc + 8 g + 4 h + (0..3) in registers 4 g .. 4 g + 3
-            const int cch = lane & 31;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float sc = lds.aff_scale[(ct0 - ct_begin + mt) * 32 + cch], sf = lds.aff_shift[(ct0 - ct_begin + mt) * 32 + cch];
-                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * (unsigned)L * 4u;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int p0 = l0 + 32 * c + 4 * h;
-                    const unsigned vbase = ((unsigned)cch * (unsigned)L + (unsigned)p0) * 4u;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float av[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if constexpr (OCC == 1) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av[e]) : "a"(acc[mt][c][4 * gq + e]));
-                            else av[e] = acc[mt][c][4 * gq + e];
-                        }
-                        const bool ok = wave_valid && (p0 + 8 * gq < L);          // (L % 4 == 0: four points are valid together)
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = __fmaf_rn(av[e], sc, sf);
-                            o[e] = v < relu_thr ? 0.f : v;
-                        }
-                        const u32x4 pk = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
-                        bstore16(ry, ok ? vbase : OOB, so_tile + (unsigned)(32 * gq), pk);
-                        if constexpr (EPI == 2) {
-                            // Training forward: BatchNorm's batch statistics of the output (models/layers.py:60-70): a lane sums its own points
-                            if (ok) {
-                                s1 += (o[0] + o[1]) + (o[2] + o[3]);
-                                s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if constexpr (EPI == 2) {
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (h == 0) lds.red[wave][mt * 32 + cch] = make_float2(s1, s2);
-                }
-            }
-            if constexpr (EPI == 2) {
-                __syncthreads();
-                for (int t = threadIdx.x; t < MT * 32; t += P_THREADS) {
-                    const double s = ((double)lds.red[0][t].x + (double)lds.red[1][t].x) + ((double)lds.red[2][t].x + (double)lds.red[3][t].x);
-                    const double qq = ((double)lds.red[0][t].y + (double)lds.red[1][t].y) + ((double)lds.red[2][t].y + (double)lds.red[3][t].y);
-                    double *dst = a.stats_partial + ((size_t)wg_col * a.Cout + (size_t)ct0 * 32 + t) * 2;
-                    dst[0] = s;
-                    dst[1] = qq;
-                }
-                __syncthreads();
-            }
-            return;
-        }
-        const float *asc = lds.aff_scale + (ct0 - ct_begin) * 32 + 4 * h, *ash = lds.aff_shift + (ct0 - ct_begin) * 32 + 4 * h;
-        int zm[NC];
-        bool zok[NC];
-        unsigned zvo[NC], zla[NC];
-        const i32x4_t rz = make_rsrc(a.zadd ? a.zadd + (size_t)b * a.Cout * a.ZM : nullptr, a.zadd ? (unsigned)a.Cout * (unsigned)a.ZM * 4u : 0u);
-        if constexpr (EPI == 1 || EPI == 3) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                zm[c] = a.zidx[(size_t)b * L + lcl[c]];
-                zok[c] = (unsigned)zm[c] < (unsigned)a.ZM;
-                zm[c] = zok[c] ? zm[c] : 0;
-                zvo[c] = zok[c] ? (unsigned)(zm[c] + 4 * h * a.ZM) * 4u : OOB;      // (the gather path: row 4 h, node zm; out of range: 0 through the descriptor)
-                // (the LDS path: ONE opaque address register per column tile and row offsets in the instruction -- the rows sit beyond the
-                // 64 KiB an LDS instruction's offset field reaches from 0, and hipcc otherwise keeps a hoisted address register per row)
-                zla[c] = (unsigned)reinterpret_cast<size_t>(&lds.zl[4 * h][zm[c]]);
-                asm volatile("" : "+v"(zla[c]));
-            }
-        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if ((ct0 + mt) * 32 >= a.Cout) continue;              // (the zero tile behind an odd tile count)
+            float asc16[16], ash16[16];
+            {
+                const float4 *t4 = reinterpret_cast<const float4 *>(lds.aff + (ct0 - ct_begin + mt) * 64 + h * 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 s4 = t4[u], h4 = t4[4 + u];
+                    asc16[4 * u] = s4.x; asc16[4 * u + 1] = s4.y; asc16[4 * u + 2] = s4.z; asc16[4 * u + 3] = s4.w;
+                    ash16[4 * u] = h4.x; ash16[4 * u + 1] = h4.y; ash16[4 * u + 2] = h4.z; ash16[4 * u + 3] = h4.w;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float st1[EPI == 2 ? 16 : 1], st2[EPI == 2 ? 16 : 1];          // (EPI 2) per register: this lane's sum / sum of squares over its column tiles
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -479,7 +456,7 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float sc = asc[row0 + e], sf = ash[row0 + e];
+                            const float sc = asc16[r0 + e], sf = ash16[r0 + e];
                             if constexpr (EPI == 1 || EPI == 3) {
                                 // per-node addend: the layer's input concatenates per-column channels (the GEMM above) with channels that are
                                 // constant per node -- their block of W . x is computed once per node by another launch and added here
@@ -497,14 +474,11 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                                 const float o = v[e] < relu_thr ? 0.f : v[e];
                                 bstore4(ry, voy[c], (unsigned)((ct0 + mt) * 32 + orow) * (unsigned)L * 4u, o);
                                 if constexpr (EPI == 2) {
-                                    // Training forward: BatchNorm's batch statistics of the output (models/layers.py:60-70) from this epilogue.  A
-                                    // row's 32 columns sit in the 32 lanes of a half wave; all lanes take part (a padded column adds 0).
+                                    // Training forward: BatchNorm's batch statistics of the output (models/layers.py:60-70) from this epilogue: a lane
+                                    // first sums its column tiles (a padded column adds 0), the 32 lanes of a row meet once per row below
                                     const float vv = pv[c] ? o : 0.f;
-                                    const float s1 = row32_sum(vv), s2 = row32_sum(vv * vv);
-                                    if (j == 0) {
-                                        float2 *rd = &lds.red[wave][mt * 32 + orow + 4 * h];
-                                        *rd = c == 0 ? make_float2(s1, s2) : make_float2(rd->x + s1, rd->y + s2);
-                                    }
+                                    st1[r0 + e] = c == 0 ? vv : st1[r0 + e] + vv;
+                                    st2[r0 + e] = c == 0 ? vv * vv : st2[r0 + e] + vv * vv;
                                 }
                             }
                         }
@@ -517,8 +491,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                                        hh[2 * hf + p], mm[2 * hf + p]);
                             }
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (EPI == 1 || EPI == 3 || OUT == 3) __builtin_amdgcn_sched_barrier(0);      // (register pressure; the plain epilogues run 8 values per fence)
                     }
+                    if constexpr ((OUT & 2) == 0) __builtin_amdgcn_sched_barrier(0);
                     if constexpr ((OUT & 2) != 0) {
                         const unsigned so = (unsigned)(((ct0 + mt) * 2 + qq) * 2) * (unsigned)L * 32u;
                         const u32x4 hv = {hh[0], hh[1], hh[2], hh[3]}, mv = {mm[0], mm[1], mm[2], mm[3]};
@@ -528,10 +503,19 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                     }
                 }
             }
+            if constexpr (EPI == 2) {
+                // a row's 32 columns sit in the 32 lanes of a half wave: four DPP adds + one swizzle per quantity, all lanes active
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s1 = row32_sum(st1[r]), s2 = row32_sum(st2[r]);
+                    if (j == 0) lds.red[wave][mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = make_float2(s1, s2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if constexpr (EPI == 2) {
             __syncthreads();
-            for (int t = threadIdx.x; t < MT * 32; t += P_THREADS) {
+            for (int t = threadIdx.x; t < MT * 32 && ct0 * 32 + t < a.Cout; t += P_THREADS) {
                 const double s = ((double)lds.red[0][t].x + (double)lds.red[1][t].x) + ((double)lds.red[2][t].x + (double)lds.red[3][t].x);
                 const double qq = ((double)lds.red[0][t].y + (double)lds.red[1][t].y) + ((double)lds.red[2][t].y + (double)lds.red[3][t].y);
                 double *dst = a.stats_partial + ((size_t)wg_col * a.Cout + (size_t)ct0 * 32 + t) * 2;
@@ -581,6 +565,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     else wait_barrier<KWAIT>(bq[0][0], bq[0][1], bq[0][2], bq[0][3]);
     dma(0, D, D);
     read_a(Aq[0], 0, 0);
+#ifdef SONET_VARIANTS
+    pt_pro = __builtin_readcyclecounter() - pt0;
+#endif
 
     int kcb = PB;                                              // chunk of the X prefetch of body t (t + PB, wrapped)
     int kcd = (1 + D) % KCr, passd = (1 + D) / KCr;            // (pass, chunk) of the DMA of body t (t + 1 + D)
@@ -624,16 +611,35 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
         z_dma(ct_begin + pass * MT);
+#ifdef SONET_VARIANTS
+        const unsigned long long pl0 = __builtin_readcyclecounter();
+#endif
         for (int k4 = 0; k4 < KCr; k4 += 4) {
             H3P_BODY(0)
             H3P_BODY(1)
             H3P_BODY(2)
             H3P_BODY(3)
         }
+#ifdef SONET_VARIANTS
+        const unsigned long long pl1 = __builtin_readcyclecounter();
+        pt_loop += pl1 - pl0;
+#endif
         epilogue(ct_begin + pass * MT);
+#ifdef SONET_VARIANTS
+        pt_epi += __builtin_readcyclecounter() - pl1;
+#endif
     }
 #undef H3P_BODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead requests of the tail: nothing may land after the workgroup has left
+#ifdef SONET_VARIANTS
+    if (a.prof != nullptr && threadIdx.x == 0) {
+        atomicAdd(a.prof + 0, 1ull);
+        atomicAdd(a.prof + 1, pt_pro);
+        atomicAdd(a.prof + 2, pt_loop);
+        atomicAdd(a.prof + 3, pt_epi);
+        atomicAdd(a.prof + 4, (unsigned long long)__builtin_readcyclecounter() - pt0);
+    }
+#endif
 
     if (a.rlog != nullptr && ct_begin == 0) {
         if (a.yp) {
@@ -688,7 +694,8 @@ extern "C" size_t sonet_pointmlp_h3p_pack_size(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0) return 0;
     const size_t kcp = (size_t)sonet::ceil_div(Cin, 16 * P_KPAD) * P_KPAD;
-    return (size_t)sonet::ceil_div(Cout, 32) * kcp * 2048 + 64;
+    // (an even number of 32-row tiles -- the kernels take tiles in pairs; the rows past Cout are zeros)
+    return (size_t)(sonet::ceil_div(Cout, 64) * 2) * kcp * 2048 + 64;
 }
 
 extern "C" int sonet_pointmlp_h3p_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream)
@@ -697,7 +704,7 @@ extern "C" int sonet_pointmlp_h3p_pack(const float *W, void *Wp, int Cin, int Co
     SONET_REQUIRE(W && Wp, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
     const int KCP = sonet::ceil_div(Cin, 16 * P_KPAD) * P_KPAD;
-    const long long total = (long long)sonet::ceil_div(Cout, 32) * KCP * 64;
+    const long long total = (long long)(sonet::ceil_div(Cout, 64) * 2) * KCP * 64;
     unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(Wp) + total * 2);
     if (sonet::zero_words(trailer, 64, sonet::as_stream(stream)) != 0) return sonet::fail(SONET_ERR_LAUNCH, "%s: clearing the trailer failed", what);
     hipLaunchKernelGGL(h3p_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
@@ -716,17 +723,17 @@ namespace {
 struct Shape { int MT, NC, OCC; };
 
 template <int MT, int NC, int OCC>
-int launch_shape(int epi, int out, int swp, unsigned nwg, hipStream_t st, const H3pArgs &a)
+int launch_shape(int epi, int out, unsigned nwg, hipStream_t st, const H3pArgs &a)
 {
-#define H3P_GO(E, O, S) hipLaunchKernelGGL((pointmlp_h3p_kernel<MT, NC, OCC, E, O, S>), dim3(nwg), dim3(P_THREADS), 0, st, a)
-    if (epi == 2 && out == 1) { if (swp) H3P_GO(2, 1, 1); else H3P_GO(2, 1, 0); }
-    else if (epi == 1 && out == 1) { if constexpr (MT <= 8) H3P_GO(1, 1, 0); else return 1; }     // (ring + addend rows must fit the LDS)
-    else if (epi == 1 && out == 2) { if constexpr (MT <= 8) H3P_GO(1, 2, 0); else return 1; }
-    else if (epi == 3 && out == 1) H3P_GO(3, 1, 0);
-    else if (epi == 3 && out == 2) H3P_GO(3, 2, 0);
-    else if (epi == 0 && out == 1) { if (swp) H3P_GO(0, 1, 1); else H3P_GO(0, 1, 0); }
-    else if (epi == 0 && out == 2) H3P_GO(0, 2, 0);
-    else if (epi == 0 && out == 3) H3P_GO(0, 3, 0);
+#define H3P_GO(E, O) hipLaunchKernelGGL((pointmlp_h3p_kernel<MT, NC, OCC, E, O>), dim3(nwg), dim3(P_THREADS), 0, st, a)
+    if (epi == 2 && out == 1) H3P_GO(2, 1);
+    else if (epi == 1 && out == 1) { if constexpr (MT <= 8) H3P_GO(1, 1); else return 1; }     // (ring + addend rows must fit the LDS)
+    else if (epi == 1 && out == 2) { if constexpr (MT <= 8) H3P_GO(1, 2); else return 1; }
+    else if (epi == 3 && out == 1) H3P_GO(3, 1);
+    else if (epi == 3 && out == 2) H3P_GO(3, 2);
+    else if (epi == 0 && out == 1) H3P_GO(0, 1);
+    else if (epi == 0 && out == 2) H3P_GO(0, 2);
+    else if (epi == 0 && out == 3) H3P_GO(0, 3);
     else return 1;
 #undef H3P_GO
     return 0;
@@ -753,7 +760,7 @@ extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t
     const int KC1 = sonet::ceil_div(C1, 16), KC2 = sonet::ceil_div(C2, 16), KC = KC1 + KC2;
     const int KCP = sonet::ceil_div(C1 + C2, 16 * P_KPAD) * P_KPAD;
     const int KCr = sonet::ceil_div(KC, 4) * 4;
-    const int CT = Cout / 32;
+    const int CT = sonet::ceil_div(Cout, 64) * 2;              // tiles incl. the pack's zero tile behind an odd count: nothing of it is stored
     if ((double)KC1 * 64.0 * L1 >= 2.0e9 || (double)KC2 * 64.0 * L >= 2.0e9 || (double)Cout * L * 4.0 >= 2.0e9 || (double)CT * KCP * 2048.0 >= 2.0e9)
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 2 GiB", what);
     const long long cols = (long long)B * L;
@@ -790,25 +797,26 @@ extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t
     H3pArgs a;
     a.x1 = x1p; a.x2 = x2p; a.Wp = Wp; a.scale = scale; a.shift = shift; a.y = y; a.yp = yp; a.gidx = gidx; a.zadd = zadd; a.zidx = zidx;
     a.rlog = sonet::range_log(); a.stats_partial = reinterpret_cast<double *>(stats_ws); a.ngroups = ngroups;
+    a.prof = nullptr; a.abl = 0;
+#ifdef SONET_VARIANTS
+    if (const char *e = sonet::knob("SONET_H3P_ABL")) a.abl = atoi(e);
+    if (const char *e = sonet::knob("SONET_H3P_PROF")) a.prof = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));   // device address of 5 u64 counters
+#endif
     a.KC1 = KC1; a.KC2 = KC2; a.L1 = L1; a.L = L; a.Cout = Cout; a.CT = CT; a.KC = KC; a.KCr = KCr; a.KCP = KCP; a.ct_per_y = CT / nslab;
     a.nslab = nslab; a.ncol = (int)ncol; a.gpc = gpc; a.relu = relu; a.ZM = ZM;
     hipStream_t st = sonet::as_stream(stream);
     // (addend rows through LDS: the four waves of a workgroup in one cloud, 256-byte rows, slabs of <= 16 tiles)
-    const int epi = stats_ws ? 2 : zadd ? ((ZM == 64 && gpc % 4 == 0 && CT / nslab <= 16) ? 1 : 3) : 0;
+    const int epi = stats_ws ? 2 : zadd ? ((ZM == 64 && gpc % 4 == 0 && CT / nslab <= 16 && Cout % 64 == 0) ? 1 : 3) : 0;
     const unsigned g = (unsigned)nwg;
     const int out = (y ? 1 : 0) | (yp ? 2 : 0);
-    int swp = (out == 1 && epi != 1 && L % 4 == 0) ? 1 : 0;
-#ifdef SONET_VARIANTS
-    if (const char *e = sonet::knob("SONET_H3P_SWAP")) swp = swp && atoi(e) != 0;
-#endif
     int miss = 1;
-    if (sh.MT == 4 && sh.NC == 2) miss = launch_shape<4, 2, 2>(epi, out, swp, g, st, a);
-    else if (sh.MT == 4 && sh.NC == 1) miss = launch_shape<4, 1, 2>(epi, out, swp, g, st, a);
-    else if (sh.MT == 2 && sh.NC == 1) miss = launch_shape<2, 1, 2>(epi, out, swp, g, st, a);
+    if (sh.MT == 4 && sh.NC == 2) miss = launch_shape<4, 2, 2>(epi, out, g, st, a);
+    else if (sh.MT == 4 && sh.NC == 1) miss = launch_shape<4, 1, 2>(epi, out, g, st, a);
+    else if (sh.MT == 2 && sh.NC == 1) miss = launch_shape<2, 1, 2>(epi, out, g, st, a);
 #ifdef SONET_VARIANTS
-    else if (sh.MT == 8 && sh.NC == 2) miss = launch_shape<8, 2, 1>(epi, out, swp, g, st, a);
-    else if (sh.MT == 6 && sh.NC == 2) miss = launch_shape<6, 2, 1>(epi, out, swp, g, st, a);
-    else if (sh.MT == 12 && sh.NC == 1) miss = launch_shape<12, 1, 1>(epi, out, swp, g, st, a);
+    else if (sh.MT == 8 && sh.NC == 2) miss = launch_shape<8, 2, 1>(epi, out, g, st, a);
+    else if (sh.MT == 6 && sh.NC == 2) miss = launch_shape<6, 2, 1>(epi, out, g, st, a);
+    else if (sh.MT == 12 && sh.NC == 1) miss = launch_shape<12, 1, 1>(epi, out, g, st, a);
 #endif
     if (miss) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: no kernel for tile shape %d x %d with epilogue %d and outputs %d", what, sh.MT, sh.NC, epi, out);
     if (stats_ws) sonet::launch_stats_finalize(reinterpret_cast<const double *>(stats_ws), (int)ncol, Cout, 1.0 / ((double)B * L), mean, var, st);

@@ -345,6 +345,9 @@ class _FusedPointwise(nn.Module):
         key = (w._version, w.data_ptr(), w.device)
         if getattr(self, '_h3ok_key', None) == key:
             return self._h3ok
+        if getattr(self, '_h3ok_dev', None) != w.device:            # moved to another device: a pending verdict belongs to the old copy
+            self._h3ok_pending, self._h3ok_dev = None, w.device
+            self.__dict__.pop('_h3ok_checked', None)
         if not w.is_cuda:
             self._h3ok, self._h3ok_key = True, key
             return True
@@ -358,7 +361,8 @@ class _FusedPointwise(nn.Module):
                 self._h3ok_pending = pend = None
                 if not self._h3ok:
                     _ops.h3_ratio_warn("a point-wise layer's weight (%d x %d)" % (w.shape[0], w.shape[1]))
-            if pend is None and w._version % H3_CHECK_EVERY == 0 and getattr(self, '_h3ok_checked', None) != w._version:
+            # (elapsed versions, not a modulo: an optimizer that bumps the version twice per step would never hit an even multiple)
+            if pend is None and w._version - getattr(self, '_h3ok_checked', -H3_CHECK_EVERY) >= H3_CHECK_EVERY:
                 self._h3ok_checked = w._version
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(_ops.h3_weight_ratio_flag(self._weight2d()), non_blocking=True)

@@ -205,10 +205,9 @@ class Encoder(nn.Module):
         fused_pool = (use_sn and _ops.FUSE_POOL and not getattr(self, 'want_first_pn_out', False)
                       and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
                       and int(opt.k) * xd.shape[2] * 384 * 4 < 4e9)
-        if fused_pool and M <= 1024 and 1 <= int(opt.k) <= min(4, M):
-            # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
-            a, g = _ops.som_assign_sort(xd, snd, sb.node, opt.k)
-            sb.last_assignment = a
+        fast = sb.assign_sort(xd, snd, opt.k) if fused_pool else None   # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
+        if fast is not None:
+            a, g = fast
         else:
             a = sb.assign(xd, opt.k)                                     # :127-128 (ids, counts, sums)
             g = _ops.som_sort_group(xd, snd, a) if fused_pool else None

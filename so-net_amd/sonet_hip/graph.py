@@ -14,6 +14,8 @@ synchronise or allocate outside the caching allocator.
 """
 import torch
 
+CHECK_EVERY = 16        # default period (replays) of the non-blocking operand-range check of a GraphedForward
+
 
 class GraphedForward:
     def __init__(self, fn, example_inputs, warmup=3):
@@ -33,7 +35,12 @@ class GraphedForward:
         from . import ops as _ops
         self.range = _ops.range_scope(dev, private=True)       # its own log: other graphs / eager scopes cannot clear or overwrite it
         self._replays = 0
-        self.check_every = 0                                   # > 0: look at the range log every that many replays (synchronises) and raise
+        # Every ``check_every`` replays the graph's 1 KiB range log is copied to pinned host memory behind the replay (async, on the
+        # replaying stream) with an event; later calls POLL the event (no host wait) and raise when a delivered log shows a launch
+        # outside the fp16-split range -- a serving loop cannot get clamped features for more than check_every + the copy's latency
+        # replays without an error.  0 disables; ``range_violations()`` is the synchronous form.
+        self.check_every = CHECK_EVERY
+        self._pending = []                                     # [(event, pinned copy, replay number)]
         with torch.no_grad(), torch.cuda.graph(self.graph), self.range:
             self.static_output = fn(*self.static_inputs)
 
@@ -48,11 +55,28 @@ class GraphedForward:
                 dst.copy_(src)
         self.graph.replay()
         self._replays += 1
-        if self.check_every and self._replays % self.check_every == 0:
-            bad = self.range_violations()
-            if bad:
-                raise _ops_error("h3 operand range left in a graph replay: %s: %s" % bad[0])
+        if self.range.enabled and self.range.names:
+            if self.check_every and self._replays % self.check_every == 0 and len(self._pending) < 4:
+                host = torch.empty_like(self.range.log, device="cpu", pin_memory=True)
+                host.copy_(self.range.log, non_blocking=True)          # ordered behind the replay on the current stream
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending.append((ev, host, self._replays))
+            self.poll_range()
         return self.static_output
+
+    def poll_range(self):
+        """Look at every delivered copy of the range log (no waiting); raises SonetHipError on a violation."""
+        from . import ops as _ops
+        while self._pending and self._pending[0][0].query():
+            _, host, n = self._pending.pop(0)
+            probe = _ops.range_scope.__new__(_ops.range_scope)
+            probe.enabled, probe.names, probe.log = True, self.range.names, host
+            bad = probe.violations()
+            if bad:
+                self._pending.clear()
+                raise _ops_error("h3 operand range left in graph replay %d: %s: %s (re-run the batch eagerly: Encoder.forward falls back "
+                                 "to the range-safe x3 arithmetic)" % (n, bad[0][0], bad[0][1]))
 
 
 def _ops_error(msg):

@@ -97,6 +97,20 @@ class BatchSOM():
         self.last_assignment = a
         return a
 
+    def assign_sort(self, x, sn, k):
+        """Assignment + node-sorted grouping in two launches (the no-grad pooled path of the level-2 Encoder): -> (assignment,
+        grouping dict), or None when the batch is outside what the fused launches take (B > 65535, M > 1024, k > 4) -- the caller
+        then uses assign() + som_sort_group."""
+        node = self.node
+        if node.dtype != torch.float32 or not node.is_contiguous():
+            node = node.float().contiguous()
+        M = node.shape[2]
+        if x.shape[0] > 65535 or M > 1024 or not (1 <= int(k) <= min(4, M)):
+            return None
+        a, g = _ops.som_assign_sort(x.contiguous(), sn, node, int(k))
+        self.last_assignment = a
+        return a, g
+
     def query_topk(self, x, k):
         """-> mask B x kN x M int32, mask_row_max B x M int32, min_idx B x kN int64 (k-major)."""
         a = self.assign(x, k, want_i64=True)

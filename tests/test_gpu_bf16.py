@@ -352,7 +352,7 @@ def test_classifier_training_step_bf16(fixture):
     # gradient to another column -- so the end-to-end gradient of EVERY layer (also the ones right behind the loss: measured
     # cosine 0.83-0.88 on all of them, against 1e-3 rel-rms for the f32-class arithmetics) is a different, equally valid
     # sub-gradient, not a noisy copy of the float64 one (0.73-0.81 at N=5000, where a node's pool has ~700 candidates).  Bar here:
-    # same direction (cosine > 0.6).  What pins the bf16 backward arithmetic itself are test_bf16_layer_backward_vs_float64 (1-2e-2
+    # same direction (cosine above the fixture's measured floor, below).  What pins the bf16 backward arithmetic itself are test_bf16_layer_backward_vs_float64 (1-2e-2
     # per layer) and test_bf16_first_pointnet_backward_with_fixed_routing_vs_float64 (the whole first PointNet incl. the sparse
     # pooled dgrad / wgrad, gathered at the same winners) above.
     cosines = {}
@@ -364,7 +364,8 @@ def test_classifier_training_step_bf16(fixture):
         mine = f[::max(1, f.numel() // 16384)].cpu().numpy().astype(np.float64)
         cosines[k] = float(np.dot(mine, truth) / (np.linalg.norm(mine) * np.linalg.norm(truth)))
     print("bf16 training step: gradient cosine vs the float64 reference:", {k: "%.3f" % v for k, v in cosines.items()})
-    assert min(cosines.values()) > 0.6, cosines
+    # gate at what this fixture measures (0.83-0.88 at N = 512, 0.73-0.81 at N = 5000), not at a generic 0.6
+    assert min(cosines.values()) > {"train_step_b16_n512": 0.80, "train_step_b8_n5000": 0.70}[fixture], cosines
     assert sum(1 for p in enc.parameters() if p.grad is None) == int(g["dead_grad_count"])
     sd = enc.state_dict()
     for k in [k[3:] for k in g.files if k.startswith("bn/")]:

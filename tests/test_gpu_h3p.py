@@ -120,7 +120,7 @@ def test_pointmlp_h3p_vs_oracle(B, C1, C2, Cout, L, relu):
     if Cout % 32 == 0 and (C2 == 0 or C1 % 16 == 0):
         wp2 = ops.pointmlp_pack(cu(W), "h3")
         y2 = ops.pointmlp(cu(x[:, :C1]), wp2, cu(scale), cu(shift), relu, Cout, x2=cu(x[:, C1:]) if C2 else None)
-        assert_close_rms(y.cpu().numpy(), y2.cpu().numpy(), 5e-6, "third vs second generation")
+        assert_close_rms(y.cpu().numpy(), y2.cpu().numpy(), 1e-5, "third vs second generation")
 
 
 def test_pointmlp_h3p_chain_stays_f32_class():

@@ -45,6 +45,34 @@ def test_autoencoder_forward_and_chamfer_golden_at_the_configs3_size(mode):
     T.test_autoencoder_forward_and_chamfer_golden(mode, "autoencoder_b2_n5000")
 
 
+def test_every_cloud_of_the_bench_batch_matches_the_oracle():
+    """The headline workload of bench.py (64 clouds x 5000 points, its seeds, its weights): node ids of ALL 64 clouds bit-exact and the
+    features / scores of ALL 64 clouds within 1e-5 of the oracle (bench.py itself checks four clouds per run; the pooled kernel is
+    otherwise compared with the store kernel + index_max)."""
+    import bench
+    from models import networks as NW
+    from oracle import cpu_oracle as O
+    from sonet_hip import synth
+    B, N = 64, 5000
+    dev = torch.device(DEV)
+    opt = bench.make_opt(dev, B, N)
+    enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    enc_sd = {k: v.clone() for k, v in synth.fill_state_dict_(enc.state_dict(), 0).items()}
+    cls_sd = {k: v.clone() for k, v in synth.fill_state_dict_(cls.state_dict(), 1).items()}
+    enc.to(dev).eval()
+    cls.to(dev).eval()
+    inp = synth.make_inputs(B, N, seed=100, device=dev)
+    with torch.no_grad():
+        feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+        score = cls(feat)
+    ref = O.encoder_forward(enc_sd, inp["pc"].cpu(), inp["sn"].cpu(), inp["node"].cpu(), inp["node_knn_I"].cpu(),
+                            use_ref_index_max=O.ref_module() is not None)
+    np.testing.assert_array_equal(enc.min_idx.cpu().numpy(), ref["min_idx"])
+    assert_close_rms(enc.first_pn_out_masked_max.cpu().numpy(), ref["first_pn_out_masked_max"].numpy(), 1e-5, "pooled first PointNet, 64 clouds")
+    assert_close_rms(feat.cpu().numpy(), ref["feature"].numpy(), 1e-5, "feature, 64 clouds")
+    assert_close_rms(score.cpu().numpy(), O.classifier_forward(cls_sd, ref["feature"]).numpy(), 1e-5, "score, 64 clouds")
+
+
 def test_forward_properties_at_the_benchmark_shape():
     """Size-independent properties of the classifier forward at the bench.py workload shape (5000 points, 8x8 SOM, k=3),
     no oracle needed: (1) a batch shard computed alone equals the same clouds inside the full batch -- the property that

@@ -199,6 +199,31 @@ def test_graphed_forward_exposes_the_range_log():
     assert fwd.range_violations() == []
 
 
+def test_graphed_forward_polls_the_range_log_without_being_asked():
+    """A serving loop that only replays: the default periodic, non-blocking check raises within check_every (+ the copy's latency)
+    replays of out-of-range data; in-range replays never raise."""
+    from sonet_hip import synth
+    from sonet_hip.graph import GraphedForward, CHECK_EVERY
+    from sonet_hip.ops import SonetHipError
+    enc, cls, _, _ = build(2, 400)
+    enc.to(DEV).eval()
+    cls.to(DEV).eval()
+    inp = synth.make_inputs(2, 400, seed=2, device=DEV)
+    args = (inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])
+    fwd = GraphedForward(lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn)), tuple(t.clone() for t in args))
+    assert fwd.check_every == CHECK_EVERY and CHECK_EVERY > 0
+    for _ in range(3 * CHECK_EVERY):
+        fwd(*args)
+    torch.cuda.synchronize()
+    fwd.poll_range()
+    big = (args[0] * 1.0e5, args[1], args[2] * 1.0e5, args[3])
+    with pytest.raises(SonetHipError, match="operand range"):
+        for _ in range(4 * CHECK_EVERY):
+            fwd(*big)
+        torch.cuda.synchronize()
+        fwd.poll_range()
+
+
 def test_training_forward_range_violation_switches_to_x3_one_step_late():
     from sonet_hip import ops, synth
     enc, cls, _, _ = build(4, 300, seed=5)

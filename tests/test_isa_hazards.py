@@ -29,9 +29,18 @@ def test_built_kernels_have_no_lds_dma_hazard():
         pytest.skip("object files of the in-tree build (so-net_amd/build) or llvm-objdump not present")
     total_dma = 0
     for o in objs:
-        if os.path.basename(o) not in ("pointmlp_x3.o", "pointresnet_bf16.o", "pointresnet_fused.o"):
+        if os.path.basename(o) not in ("pointmlp_x3.o", "pointmlp_h3p.o", "pointresnet_bf16.o", "pointresnet_fused.o"):
             continue
         ins = H.disassemble(o)
         total_dma += sum(1 for mn, _ in ins if mn.startswith("global_load_lds"))
         assert H.scan(ins) == [], os.path.basename(o)
     assert total_dma > 0, "the kernels that stream weights by LDS-DMA were not found in the build"
+
+
+def test_third_generation_layer_has_no_compiler_waits_or_spills_in_its_pass_loop():
+    """pointmlp_h3p.hip counts its vector-memory requests by hand: hipcc must not have added a vmcnt wait of its own (a spill reload or a
+    compiler-visible load inside the loop drains the look-ahead every iteration) -- tools/check_h3p_asm.py compiles the source and checks."""
+    import check_h3p_asm
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not present")
+    assert check_h3p_asm.main([]) == 0
