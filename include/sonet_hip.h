@@ -265,6 +265,11 @@ int sonet_pointresnet_pack(const float *W1, const float *W2, const float *W3, co
                            void *wstream, sonet_stream_t stream);
 int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void *wstream, const float *affine,
                                 float *y, int B, int L, sonet_stream_t stream);
+/* The same launch also writes y pre-split: yp = the P16 planes of y (sonet_p16_size(B, 384, L) bytes; layout under sonet_pointmlp_h3p
+ * above), the operand format of sonet_pointmlp_h3p -- the part segmenter's first layer reads first_pn_out per point copy
+ * (models/networks.py:296-326, models/segmenter.py:90-109).  The largest split magnitude joins word 2 of the range log. */
+int sonet_pointresnet_fused_p16_f32(const float *x, int Cin0, const void *wstream, const float *affine,
+                                    float *y, void *yp, int B, int L, sonet_stream_t stream);
 
 /* bf16 twin of sonet_pointresnet_fused_f32 (BASELINE configs[1] "bf16"): one bf16 MFMA per product, activations rounded to
  * bf16 between the layers (what the layer-wise sonet_pointmlp_bf16 launches would store), f32 accumulation; x [B][Cin0][L] f32

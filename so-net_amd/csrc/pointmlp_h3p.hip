@@ -110,21 +110,34 @@ __global__ __launch_bounds__(256) void p16_from_f32_kernel(const float *__restri
                                                             const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                                                             unsigned *__restrict__ rlog)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned wmax[4];
     const int kc = blockIdx.y >> 1, hh = blockIdx.y & 1, b = blockIdx.z;
     RangeAcc xr = {0, 0u};
-    if (l < L) {
-        const float *xb = x + (size_t)b * C * L + l;
+    const float *xb0 = x + (size_t)b * C * L;
+    uint4 *pb = p + (size_t)b * KC * 4 * L;
+    float sc[8], sf[8];
+    if constexpr (AFFINE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = kc * 16 + p16_channel(hh, e);
+            sc[e] = c < C ? scale[c] : 0.f;
+            sf[e] = c < C ? shift[c] : 0.f;
+        }
+    }
+    // 1024 columns per workgroup (four per thread, each step coalesced over the workgroup's 256 consecutive columns)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int l = blockIdx.x * 1024 + it * 256 + threadIdx.x;
+        if (l >= L) break;
+        const float *xb = xb0 + l;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = kc * 16 + p16_channel(hh, e);
             float t = c < C ? xb[(size_t)c * L] : 0.f;
             if constexpr (AFFINE) {
-                if (c < C) {
-                    t = __fmaf_rn(t, scale[c], shift[c]);
-                    if (relu) t = t < 0.f ? 0.f : t;
-                }
+                t = __fmaf_rn(t, sc[e], sf[e]);
+                if (relu) t = t < 0.f ? 0.f : t;
             }
             v[e] = t;
         }
@@ -134,11 +147,19 @@ __global__ __launch_bounds__(256) void p16_from_f32_kernel(const float *__restri
             range_track(xr, v[2 * q], v[2 * q + 1]);
             split_act<false>(v[2 * q], v[2 * q + 1], h[q], m[q]);
         }
-        uint4 *pb = p + (size_t)b * KC * 4 * L;
         pb[((size_t)(kc * 2 + 0) * 2 + hh) * L + l] = make_uint4(h[0], h[1], h[2], h[3]);
         pb[((size_t)(kc * 2 + 1) * 2 + hh) * L + l] = make_uint4(m[0], m[1], m[2], m[3]);
     }
-    if (rlog != nullptr) range_publish(rlog + 2, wave_umax(range_amax_bits(xr)), threadIdx.x & 63);
+    if (rlog != nullptr) {                                     // one atomic per workgroup at most (every wave publishing: ~60 us of contention on a 7 MB tensor)
+        const unsigned wm = wave_umax(range_amax_bits(xr));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = wm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], c2 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+            const unsigned mx = a > c2 ? a : c2;
+            if (mx > __atomic_load_n(rlog + 2, __ATOMIC_RELAXED)) atomicMax(rlog + 2, mx);
+        }
+    }
 }
 
 // P16 planes -> f32 [B][C][L]: (hi + mid) / 32 (exact sum: both are fp16 values whose exponents are at most 11 apart)
@@ -671,7 +692,7 @@ extern "C" int sonet_p16_from_f32(const float *x, void *p16, int B, int C, int L
     SONET_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", what);
     const int KC = sonet::ceil_div(C, 16);
     if (B > 65535 || KC * 2 > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B or C too large for one launch", what);
-    dim3 grid((unsigned)sonet::ceil_div(L, 256), (unsigned)(KC * 2), (unsigned)B);
+    dim3 grid((unsigned)sonet::ceil_div(L, 1024), (unsigned)(KC * 2), (unsigned)B);
     unsigned *rlog = sonet::range_log();
     if (scale) hipLaunchKernelGGL(p16_from_f32_kernel<true>, grid, dim3(256), 0, sonet::as_stream(stream), x, reinterpret_cast<uint4 *>(p16), C, L, KC, scale, shift, relu, rlog);
     else       hipLaunchKernelGGL(p16_from_f32_kernel<false>, grid, dim3(256), 0, sonet::as_stream(stream), x, reinterpret_cast<uint4 *>(p16), C, L, KC, scale, shift, relu, rlog);

@@ -289,14 +289,19 @@ __device__ long long g_prof[1024 * PROF_N];
         PF_A8(6), PF_A8(7), PF_A8(8), PF_A8(9), PF_A8(10), PF_A8(11), PF_A8(12), PF_A8(13), PF_A8(14), PF_A8(15), PF_A8(16), PF_A8(17), PF_A8(18), PF_A8(19), \
         PF_A8(20), PF_A8(21), PF_A8(22), PF_A8(23), PF_A8(24), "a250", "a251", "a252", "a253", "a254", "a255");
 
-template <bool SEGMAX>
+// P16OUT (store variant only): y ALSO leaves pre-split, in the P16 planes of csrc/pointmlp_h3p.hip (the segmenter's first layer consumes
+// first_pn_out per point copy: its operand loads are then finished MFMA fragments and the separate conversion pass is gone).
+template <bool SEGMAX, bool P16OUT = false>
 __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
     const float *__restrict__ x, int Cin0, const uint4 *__restrict__ Wst, const float2 *__restrict__ affine_g /*[CH_TOTAL] (scale, shift); last layer (1, bias)*/,
     float *__restrict__ y, int L, int tpc /*256-point tiles per cloud*/, long long ntiles,
     const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ pos0, unsigned *__restrict__ pooled, float *__restrict__ v0, int M,
     unsigned *__restrict__ partial /*[ntiles][NPASS][SEG_SLOTS][PCH] keys of the tile's first SEG_SLOTS nodes*/,
-    unsigned *__restrict__ rlog /*optional range-log slot: [0] max |x in|, [1] max |w|, [2] max post-affine input of layers 2-4 (bits)*/)
+    unsigned *__restrict__ rlog /*optional range-log slot: [0] max |x in|, [1] max |w|, [2] max post-affine input of layers 2-4 (bits)*/,
+    void *__restrict__ yp = nullptr /*P16OUT: [B][24][2][2][L][16 B]*/)
 {
+    static_assert(!(SEGMAX && P16OUT), "the pooled variant has no per-point output");
+    RangeAcc yr4 = {0, 0u};                                    // (P16OUT) magnitudes of the layer-4 output that was split
     __shared__ uint4 wsm[NSLOT * NSTG][64];                    // 3 x 24 KiB
     // 64 KiB lane-private parking space, [wave][chunk][column tile][piece h / m][lane]: chunks 0-3 of layer 2's output between the
     // two tile groups of layer 3, then the four chunks of layer 1's output for the passes of layer 4
@@ -702,6 +707,8 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         // column tile s&1 -- tile 4 is complete when step 12 needs it); passes 1-3 run the same steps without jobs.
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(
+            P16OUT ? static_cast<char *>(yp) + b * (long long)(2 * T3) * 64 * L : nullptr, 0, P16OUT ? (int)((unsigned)(2 * T3) * 64u * (unsigned)L) : 0, 0x00020000);
 #define ACC4(u, c) acc[u][c]
 #define PF_L4_BODY(JOBS)                                                                                 \
             SFOR(kc, KC4)                                                                                \
@@ -850,13 +857,35 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
                     for (int mt = 0; mt < MT4; ++mt) {
                         const int ct = pass * MT4 + mt;
                         const unsigned so_tile = (unsigned)(ct * 32) * rowB;
+                        float vv[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int orow = (r & 3) + 8 * (r >> 2);
                             const float2 ss = aff[LB4 + ct * 32 + orow + 4 * h];
                             const float v = __fmaf_rn(acc[mt][c][r], ss.x, ss.y);
+                            vv[r] = v;
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (unsigned)(4 * h * L + lc[c]) * 4u,
                                                                   so_tile + (unsigned)orow * rowB, 0);
+                        }
+                        if constexpr (P16OUT) {
+                            // registers 8 q .. 8 q + 7 of tile ct ARE chunk 2 ct + q, half h, elements 0..7 of the P16 planes (pointmlp_h3p.hip):
+                            // clamp to the fp16-split range, scale by 32, two roundings, two 16-byte stores per q
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                unsigned hh[4], mm[4];
+#pragma unroll
+                                for (int p = 0; p < 4; ++p) {
+                                    const float x0 = vv[8 * q + 2 * p], x1 = vv[8 * q + 2 * p + 1];
+                                    range_track(yr4, x0, x1);
+                                    const float X0 = 32.f * __builtin_amdgcn_fmed3f(x0, -2047.f, 2047.f), X1 = 32.f * __builtin_amdgcn_fmed3f(x1, -2047.f, 2047.f);
+                                    hh[p] = cvt_pk_f16(X0, X1);
+                                    mm[p] = cvt_pk_f16(X0 - f16_lo(hh[p]), X1 - f16_hi(hh[p]));
+                                }
+                                const unsigned so = (unsigned)((ct * 2 + q) * 2) * (unsigned)L * 32u;
+                                const u32x4_t hv = {hh[0], hh[1], hh[2], hh[3]}, mv = {mm[0], mm[1], mm[2], mm[3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(hv, ryp, (unsigned)(h * L + lc[c]) * 16u, so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(mv, ryp, (unsigned)(h * L + lc[c]) * 16u, so + (unsigned)L * 32u, 0);
+                            }
                         }
                     }
                 }
@@ -891,6 +920,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         // the job logged 32 x: take the factor out of the exponent (a NaN / inf stays far above the fp16 range)
         unsigned rb = wave_umax((unsigned)(rmax_ > 0 ? rmax_ : 0));
         rb = rb > (5u << 23) ? rb - (5u << 23) : 0u;
+        if constexpr (P16OUT) {                                // (the split output is an operand of the next layer: its range counts too)
+            const unsigned ob = wave_umax(range_amax_bits(yr4));
+            rb = rb > ob ? rb : ob;
+        }
         range_publish(rlog + 2, rb, lane);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(rlog + 1, reinterpret_cast<const unsigned *>(Wst + (long long)NSLICE * 64)[0]);
     }
@@ -991,6 +1024,25 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     hipLaunchKernelGGL((pointresnet_fused_kernel<false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
                        x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log());
+    return sonet::launched(what);
+}
+
+/* sonet_pointresnet_fused_f32 that also writes y pre-split: yp = the P16 planes of y (sonet_p16_size(B, 384, L) bytes, include/sonet_hip.h),
+ * the operand format of sonet_pointmlp_h3p -- the segmenter's first layer reads first_pn_out per point copy (models/networks.py:296-326). */
+extern "C" int sonet_pointresnet_fused_p16_f32(const float *x, int Cin0, const void *wstream, const float *affine,
+                                               float *y, void *yp, int B, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointresnet_fused_p16_f32";
+    SONET_REQUIRE(x && wstream && affine && y && yp, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && L > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d Cin0=%d", what, B, L, Cin0);
+    if ((double)(32 * T3) * L * 4.0 >= 2.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 2 GiB", what);
+    const int tpc = sonet::ceil_div(L, TPTS);
+    const long long ntiles = (long long)B * tpc;
+    const int cus = cu_count();
+    const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
+    hipLaunchKernelGGL((pointresnet_fused_kernel<false, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
+                       x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log(), yp);
     return sonet::launched(what);
 }
 

@@ -425,6 +425,35 @@ class _FusedPointwise(nn.Module):
                 and self.normalization in (None, 'batch') and not (self.normalization == 'batch' and self.norm.training)
                 and self.activation in (None, 'relu'))
 
+    def _packed_p16(self, make=None, tag=None):
+        """h3p pack (third-generation layer, P16 operands) of this layer's weight -- or of ``make()``, a column selection of it the
+        caller keeps apart under ``tag`` (the segmenter's per-point block of layer 1; built only when the weight has changed)."""
+        w = self.conv.weight
+        key = (w._version, w.data_ptr(), w.device, tag)
+        cache = self.__dict__.setdefault('_wp16', {})
+        if cache.get(tag, (None, None))[0] != key:
+            with torch.no_grad():
+                src = self._weight2d().detach() if make is None else make()
+                cache[tag] = (key, _ops.pointmlp_h3p_pack(src.contiguous().float()))
+        return cache[tag][1]
+
+    def _p16_ok(self):
+        """Eval-mode, no-grad, h3: this layer can run on pre-split (P16) operands and hand its output on in that form."""
+        return (_ops.POINTMLP_PRECISION == "h3" and _ops.P16_CHAINS and not torch.is_grad_enabled() and self.conv.weight.is_cuda
+                and self._h3_ok() and self._fusable() and self.conv.out_channels % 32 == 0
+                and self.normalization in (None, 'batch') and not (self.normalization == 'batch' and self.norm.training)
+                and self.activation in (None, 'relu'))
+
+    def run_p16(self, x, x2=None, out="p16", **kw):
+        """The layer on P16 operands (``sonet_hip.ops.P16``; f32 tensors are converted first): out "p16" | "f32" | "both".
+        Only when ``_p16_ok()``."""
+        if not isinstance(x, _ops.P16):
+            x = _ops.p16_from_f32(self._prep(x).float())
+        if x2 is not None and not isinstance(x2, _ops.P16):
+            x2 = _ops.p16_from_f32(self._prep(x2).float())
+        scale, shift = self._eval_affine()
+        return _ops.pointmlp_h3p(x, self._packed_p16(), scale, shift, self.activation == 'relu', self.conv.out_channels, x2=x2, out=out, **kw)
+
     def _bias(self):
         if self.conv.bias is not None:
             return self.conv.bias
@@ -855,10 +884,15 @@ class PointResNet(nn.Module):
         return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M)
 
     def forward(self, x, epoch=None):
+        self.last_p16 = None
         if self._fusable_eval(x):
             wstream, affine = self._fused_state()
             if _ops.POINTMLP_PRECISION == "bf16":
                 return _ops.pointresnet_bf16(x.float().contiguous(), wstream, affine)
+            if getattr(self, "emit_p16", False) and _ops.P16_CHAINS:
+                # a caller that feeds the output to a third-generation layer (the segmenter) takes it pre-split from the same launch
+                y, self.last_p16 = _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine, want_p16=True)
+                return y
             return _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine)
         n = len(self.out_channels_list)
         skip = self.layers[0](x, epoch)

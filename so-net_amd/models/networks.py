@@ -375,7 +375,7 @@ class Segmenter(nn.Module):
         return self._l1_wp_point, self._l1_wp_node, self._l1_w_glob
 
     def forward_nodewise(self, x_decentered, x, sn, label, first_pn_out, som_node, masked_max, knn_feature_1, final_pn_out, feature,
-                         min_idx_i32):
+                         min_idx_i32, first_pn_out_p16=None):
         """Same result as forward() on the gathered tensors, for eval / no-grad: node-level inputs B x C x M + node ids."""
         B, N, k = x.size()[0], x.size()[2], self.opt.k
         lyr = self.layer1
@@ -395,6 +395,20 @@ class Segmenter(nn.Module):
         z = (zn.float() + zg.unsqueeze(2)).contiguous()
         x2 = torch.cat(small, dim=1).to(sdt).contiguous()
         first_pn_out = first_pn_out.to(sdt)
+        if (wp_point.dtype == torch.int8 and lyr._p16_ok() and self.layer2._p16_ok() and self.layer3._p16_ok()
+                and first_pn_out.shape[1] % 16 == 0):
+            # third-generation layers: the three kN-column layers hand their activations on pre-split (P16), the split of layer 1's
+            # input is one pass over first_pn_out; the per-node block is added in layer 1's epilogue from LDS
+            def wsel():
+                blk = self._layer1_blocks()
+                w = lyr.conv.weight
+                W = w.detach().reshape(w.shape[0], w.shape[1]).float()
+                return torch.cat([W[:, blk[n][0]:blk[n][1]] for n in ("first", "x_dec", "x", "sn")], dim=1)
+            fp16 = first_pn_out_p16 if first_pn_out_p16 is not None else _ops.p16_from_f32(first_pn_out.contiguous())
+            h = _ops.pointmlp_h3p(fp16, lyr._packed_p16(wsel, "seg_point"), scale, shift,
+                                  lyr.activation == 'relu', Cout, x2=_ops.p16_from_f32(x2), z=z, zidx=min_idx_i32, out="p16")
+            h = self.layer2.run_p16(h, out="p16")
+            return self._tail(self.layer3.run_p16(h, out="f32"), k)
         if wp_point.dtype == torch.int8 and _ops.POINTMLP_PRECISION == "h3":
             # the per-node block is gathered and added in the per-point launch's epilogue (one pass over B x 1024 x kN less)
             h = _ops.pointmlp_nodeadd(first_pn_out.contiguous(), wp_point, scale, shift, lyr.activation == 'relu', Cout, z, min_idx_i32, x2=x2)
@@ -428,6 +442,9 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
     node-level feature maps back to the kN copies; here the int32 ids are already there and one kernel does
     each gather (autograd falls back to torch.gather when gradients are needed)."""
     encoder.want_first_pn_out = True                  # layer 1 consumes first_pn_out per point copy
+    # ... pre-split when the head runs its third-generation chain (the fused first PointNet then writes the P16 planes itself)
+    encoder.first_pointnet.emit_p16 = bool(segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True) and segmenter.layer1._p16_ok()
+                                           and segmenter.layer2._p16_ok() and segmenter.layer3._p16_ok())
     feature = encoder(pc, sn, node, node_knn_I, is_train, epoch)
     head = lambda: _segmentation_head(encoder, segmenter, pc, sn, label, feature)      # noqa: E731
     if torch.is_grad_enabled() and not segmenter.training and getattr(encoder, "_infer_tag", False):
@@ -441,7 +458,8 @@ def _segmentation_head(encoder, segmenter, pc, sn, label, feature):
     if segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True):
         return segmenter.forward_nodewise(encoder.x_decentered, pc, sn, label, encoder.first_pn_out, encoder.som_node,
                                           encoder.first_pn_out_masked_max.contiguous(), encoder.knn_feature_1.contiguous(),
-                                          encoder.final_pn_out.contiguous(), feature, st["a"].min_idx_i32)
+                                          encoder.final_pn_out.contiguous(), feature, st["a"].min_idx_i32,
+                                          first_pn_out_p16=getattr(encoder.first_pointnet, "last_p16", None))
     need_grad = torch.is_grad_enabled() and encoder.first_pn_out_masked_max.requires_grad
     if need_grad:
         idx = encoder.min_idx.unsqueeze(1)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sonet_pointresnet_pack_size": [],
     "sonet_pointresnet_pack": [_vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sonet_pointresnet_fused_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "sonet_pointresnet_fused_p16_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "sonet_pointresnet_pool_ws_size": [_i, _i, _i],
     "sonet_pointresnet_fused_pool_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_som_sort_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -411,6 +411,8 @@ FUSE_POOL = _os.environ.get("SONET_FUSE_POOL", "1") != "0"
 GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
 # KNNModule layer 1 as (layer on the M node features) + gather + coordinate channels instead of a layer over K * M gathered columns
 NODE_LINEAR_SPLIT = _os.environ.get("SONET_NODE_LINEAR_SPLIT", "1") != "0"
+# no-grad h3 chains of point-wise layers hand their activations on pre-split (P16 planes, csrc/pointmlp_h3p.hip) instead of as f32
+P16_CHAINS = _os.environ.get("SONET_P16_CHAINS", "1") != "0"
 WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 
@@ -1021,8 +1023,9 @@ def pointresnet_pack(w1, w2, w3, w4):
     return ws
 
 
-def pointresnet_fused(x, wstream, affine):
-    """x B x Cin0 x L f32 -> B x 384 x L f32 (whole first PointNet, eval BN folded into ``affine`` 832 x 2)."""
+def pointresnet_fused(x, wstream, affine, want_p16=False):
+    """x B x Cin0 x L f32 -> B x 384 x L f32 (whole first PointNet, eval BN folded into ``affine`` 832 x 2).
+    want_p16: -> (y, P16 planes of y), written by the same launch (the operand format of ``pointmlp_h3p``)."""
     _chk(x, "x", torch.float32, 3)
     _chk(affine, "affine", torch.float32, 2)
     if tuple(affine.shape) != (832, 2):
@@ -1030,13 +1033,18 @@ def pointresnet_fused(x, wstream, affine):
     dev = _same_device(x, wstream, affine)
     B, Cin0, L = x.shape
     y = torch.empty((B, 384, L), dtype=torch.float32, device=dev)
+    yp = p16_empty(B, 384, L, dev) if want_p16 else None
     if y.numel() == 0:
-        return y
+        return (y, yp) if want_p16 else y
     _range_arm("pointresnet_fused_L%d" % L)
-    with torch.cuda.device(dev), _timed("pointresnet_fused_L%d" % L):
-        check(_lib.load().sonet_pointresnet_fused_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
-              "sonet_pointresnet_fused_f32")
-    return y
+    with torch.cuda.device(dev), _timed("pointresnet_fused%s_L%d" % ("_p16" if want_p16 else "", L)):
+        if want_p16:
+            check(_lib.load().sonet_pointresnet_fused_p16_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), ptr(yp.data), B, L, stream_ptr()),
+                  "sonet_pointresnet_fused_p16_f32")
+        else:
+            check(_lib.load().sonet_pointresnet_fused_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
+                  "sonet_pointresnet_fused_f32")
+    return (y, yp) if want_p16 else y
 
 
 def pointresnet_fused_pool(sg, wstream, affine, M):

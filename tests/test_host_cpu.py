@@ -198,7 +198,7 @@ def test_fused_kernel_build_leaves_the_accumulation_registers_alone():
     import check_fused_asm
     kernels = check_fused_asm.audit(os.path.join(ROOT, "so-net_amd", "csrc", "pointresnet_fused.hip"), [])
     fused = {k: v for k, v in kernels.items() if "fused_kernel" in k}
-    assert len(fused) == 2, list(kernels)
+    assert len(fused) == 3, list(kernels)          # store, store + P16 planes, pooled
     for name, k in fused.items():
         assert k["mfma"] == 1224, (name, k)
         assert k["accvgpr_by_compiler"] == 0 and k["scratch"] == 0 and k["early_reads"] == 0, (name, k)
