@@ -369,10 +369,29 @@ def other_configs(args, dev, world=1, rank=0):
             enc.eval()
             with torch.no_grad():
                 enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
-            after = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
-            par["after_the_timed_steps"] = {"min_idx_bit_exact": after["min_idx_bit_exact"], "feature_err_over_bound": after["feature_err_over_bound"],
-                                            "what": "the same check with the weights and BatchNorm running statistics the timed Adam steps left behind "
-                                                    "(random labels, %d steps): reported, not gated -- the bound is the reference fixtures' bound" % (5 + 3 * K + 3)}
+            tol = BF16_TOL if precision == "bf16" else 1e-5
+            after = _encoder_parity(enc, inp, 2, tol=tol)
+            # ~100 Adam steps on random labels overfit the 64 clouds and leave a WORSE-CONDITIONED network behind (the folded BatchNorm scale
+            # of the first layer grows 2 -> 5.7, running variances fall 0.5 -> 0.06: tools/bf16_drift.py, profiles/r04i_bf16_drift.log), so every
+            # arithmetic is further from the oracle than on the fixtures' weights -- the f32-class forward too (3.6e-6 -> 1.0e-5).  What the
+            # step must preserve is the ARITHMETIC: the same weights in the f32-class arithmetic give the conditioning, and the bf16 error
+            # must stay within the ratio of the unit roundoffs of that (2^-9 / 2^-22 = 2^13, gated at 2^14); node ids stay bit-exact.
+            gate = {"min_idx_bit_exact": after["min_idx_bit_exact"], "feature_err_over_bound": after["feature_err_over_bound"]}
+            if precision == "bf16":
+                with torch.no_grad(), ops.precision("h3"):
+                    enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
+                ref32 = _encoder_parity(enc, inp, 2, tol=1e-5)
+                ratio = (after["feature_err_over_bound"] * tol) / max(ref32["feature_err_over_bound"] * 1e-5, 1e-12)
+                gate.update(f32_class_same_weights_err_over_1e5_bound=ref32["feature_err_over_bound"], bf16_over_f32_class_error=round(ratio, 1),
+                            ok=bool(after["min_idx_bit_exact"] and ratio <= 16384.0))
+            else:
+                gate.update(ok=bool(after["min_idx_bit_exact"] and after["feature_err_over_bound"] <= 4.0))
+            gate["what"] = ("the same check with the weights and BatchNorm running statistics the timed Adam steps left behind (random labels, %d steps: "
+                            "a worse-conditioned network, see tools/bf16_drift.py).  Gate: node ids bit-exact and -- bf16 -- an error within 2^14 x the "
+                            "f32-class arithmetic's on the same weights (unit roundoffs 2^-9 vs 2^-22); f32-class: within 4 x the fixtures' bound"
+                            % (5 + 3 * K + 3))
+            par["after_the_timed_steps"] = gate
+            par["ok"] = bool(par["ok"] and gate["ok"])
             med = sorted(ts)[len(ts) // 2]
             return {"workload": "ModelNet40 classifier TRAINING step (forward + backward + gradient all-reduce + Adam), %d rank(s) x %d x %d pts" % (world, B, N),
                     "arithmetic": precision, "n_gpus": world, "batch_per_gpu": B, "global_batch": B * world,
