@@ -235,6 +235,21 @@ int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t *gidx, con
                        const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
                        sonet_stream_t stream);
 
+/* Node-level pieces of the training step (so-net_amd/csrc/node_train.hip).
+ * sonet_lastdim_argmax_*: out[r] = max over the K contiguous values of row r, idx[r] = index of the FIRST maximum (a NaN wins) -- torch.max
+ *   over the K' neighbours of KNNModule (models/layers.py:350-365) and over the M nodes (models/networks.py:197) with the routing its
+ *   backward needs; sonet_lastdim_max_bwd_*: gx[r][k] = (k == idx[r]) ? g[r] : 0 (the whole row is written).
+ * sonet_knn_gather_bwd_*: backward of knn_gather_by_indexing (models/operations.py:38-54): gx[b][c][m] = sum of g[b][c][m'][k] over the
+ *   (m', k) with knn_I[b][m'][k] == m, gathered over per-cloud inverse lists in a fixed order (f32 accumulation, bitwise reproducible);
+ *   ws: sonet_knn_gather_bwd_ws_size(B, M, K) bytes; M <= 1024; indices outside [0, M) contribute nowhere. */
+int sonet_lastdim_argmax_f32(const float *x, float *out, int32_t *idx, long long rows, int K, sonet_stream_t stream);
+int sonet_lastdim_argmax_bf16(const uint16_t *x, uint16_t *out, int32_t *idx, long long rows, int K, sonet_stream_t stream);
+int sonet_lastdim_max_bwd_f32(const float *g, const int32_t *idx, float *gx, long long rows, int K, sonet_stream_t stream);
+int sonet_lastdim_max_bwd_bf16(const uint16_t *g, const int32_t *idx, uint16_t *gx, long long rows, int K, sonet_stream_t stream);
+size_t sonet_knn_gather_bwd_ws_size(int B, int M, int K);
+int sonet_knn_gather_bwd_f32(const float *g, const int64_t *knn_I, float *gx, void *ws, int B, int C, int M, int K, sonet_stream_t stream);
+int sonet_knn_gather_bwd_bf16(const uint16_t *g, const int64_t *knn_I, float *gx, void *ws, int B, int C, int M, int K, sonet_stream_t stream);
+
 /* The same layer with bf16 STORAGE and bf16 MFMA (BASELINE configs[1] "bf16"; the reference is f32-only, so this is the
  * reduced-precision twin of models/layers.py:282-296, not a bit-compatible replacement): x1, x2, y are bfloat16 bit
  * patterns [B][C][L], one v_mfma_f32_32x32x16_bf16 per product with f32 accumulation, the epilogue

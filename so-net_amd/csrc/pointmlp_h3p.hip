@@ -322,16 +322,6 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     const int ct_begin = wg_slab * a.ct_per_y;
     const int ct_end = min(a.CT, ct_begin + a.ct_per_y);
     const int npass = (ct_end - ct_begin) / MT;                // (the host makes ct_per_y a multiple of MT)
-    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += P_THREADS)
-    {
-        const int rel = o - ct_begin * 32, rr = rel & 31;
-        const float scv = o < a.Cout ? a.scale[o] * (1.f / 1024.f) : 0.f, shv = o < a.Cout ? a.shift[o] : 0.f;      // accumulators hold 1024 W.x
-        float *t = lds.aff + (rel >> 5) * 64 + ((rr >> 2) & 1) * 32 + ((rr & 3) | ((rr >> 3) << 2));
-        t[0] = scv;
-        t[16] = shv;
-    }
-    __syncthreads();
-
     const int KCr = a.KCr, KC1 = a.KC1;
 #ifdef SONET_VARIANTS
     unsigned long long pt0 = __builtin_readcyclecounter(), pt_loop = 0, pt_epi = 0, pt_pro = 0;
@@ -508,8 +498,12 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
                             for (int p = 0; p < 2; ++p) {
                                 const float x0 = v[2 * p], x1 = v[2 * p + 1];
                                 range_track(yr, x0, x1);
-                                split2(32.f * __builtin_amdgcn_fmed3f(x0, split_lo, 2047.f), 32.f * __builtin_amdgcn_fmed3f(x1, split_lo, 2047.f),
-                                       hh[2 * hf + p], mm[2 * hf + p]);
+                                if constexpr (OUT == 2)             // (the values are 32 x already: see the affine table)
+                                    split2(__builtin_amdgcn_fmed3f(x0, split_lo * 32.f, 65504.f), __builtin_amdgcn_fmed3f(x1, split_lo * 32.f, 65504.f),
+                                           hh[2 * hf + p], mm[2 * hf + p]);
+                                else
+                                    split2(32.f * __builtin_amdgcn_fmed3f(x0, split_lo, 2047.f), 32.f * __builtin_amdgcn_fmed3f(x1, split_lo, 2047.f),
+                                           hh[2 * hf + p], mm[2 * hf + p]);
                             }
                         }
                         if constexpr (EPI == 1 || EPI == 3 || OUT == 3) __builtin_amdgcn_sched_barrier(0);      // (register pressure; the plain epilogues run 8 values per fence)
@@ -586,6 +580,19 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     else wait_barrier<KWAIT>(bq[0][0], bq[0][1], bq[0][2], bq[0][3]);
     dma(0, D, D);
     read_a(Aq[0], 0, 0);
+    // scale / shift of the slab into LDS -- AFTER the prologue's requests have been issued: the two loads per row fly under them.
+    // OUT == 2 (P16 planes only): the table holds scale / 32 and 32 shift, so that the epilogue's value already is 32 x (the split's
+    // scaling; powers of two commute with the rounding of the fma, the planes are bit-identical to scaling afterwards).
+    for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += P_THREADS)
+    {
+        const int rel = o - ct_begin * 32, rr = rel & 31;
+        constexpr float pre = OUT == 2 ? 32.f : 1.f;
+        const float scv = o < a.Cout ? a.scale[o] * (pre / 1024.f) : 0.f, shv = o < a.Cout ? a.shift[o] * pre : 0.f;   // accumulators hold 1024 W.x
+        float *t = lds.aff + (rel >> 5) * 64 + ((rr >> 2) & 1) * 32 + ((rr & 3) | ((rr >> 3) << 2));
+        t[0] = scv;
+        t[16] = shv;
+    }
+    __syncthreads();
 #ifdef SONET_VARIANTS
     pt_pro = __builtin_readcyclecounter() - pt0;
 #endif
@@ -666,7 +673,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
         if (a.yp) {
             // (after a ReLU only the positive side -- and a NaN of either sign -- can leave the range)
             const unsigned pos = yr.mp > 0 ? (unsigned)yr.mp : 0u, nan_neg = yr.mn > 0xFF800000u ? (yr.mn & 0x7FFFFFFFu) : 0u;
-            range_publish(a.rlog + 2, wave_umax(a.relu ? (pos > nan_neg ? pos : nan_neg) : range_amax_bits(yr)), lane);
+            unsigned bits = wave_umax(a.relu ? (pos > nan_neg ? pos : nan_neg) : range_amax_bits(yr));
+            if constexpr (OUT == 2) bits = bits > (5u << 23) ? bits - (5u << 23) : 0u;       // (32 x was tracked: take the factor out of the exponent)
+            range_publish(a.rlog + 2, bits, lane);
         }
         if (wg_col == 0 && threadIdx.x == 0)
             atomicMax(a.rlog + 1, reinterpret_cast<const unsigned *>(wp + (size_t)a.CT * a.KCP * 2048u)[0]);

@@ -454,18 +454,27 @@ __global__ __launch_bounds__(256) void stats_vec_kernel(const uint4 *__restrict_
         float gv[N], rv[N];
         VecIO<BF>::unpack(nt_load16(g + t), gv);
         if (raw) VecIO<BF>::unpack(nt_load16(r + t), rv);
+        // the N values of one access are summed in f32 (pairwise), then carried in f64: N x fewer f64 operations (they run at half the
+        // f32 rate and were what bounded the bf16 pass: 3.0 TB/s), error <= N 2^-24 of one access's partial
+        float p1[N], p2[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             if (raw) {
                 float gg = gv[e];
                 if (relu && !(__fmaf_rn(rv[e], sc, sh) > 0.f)) gg = 0.f;
-                s1 += (double)gg;
-                s2 += (double)gg * (double)rv[e];
+                p1[e] = gg;
+                p2[e] = gg * rv[e];
             } else {
-                s1 += (double)gv[e];
-                s2 += (double)gv[e] * (double)gv[e];
+                p1[e] = gv[e];
+                p2[e] = gv[e] * gv[e];
             }
         }
+#pragma unroll
+        for (int w = N / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int e = 0; e < w; ++e) { p1[e] += p1[e + w]; p2[e] += p2[e + w]; }
+        s1 += (double)p1[0];
+        s2 += (double)p2[0];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -773,7 +773,7 @@ class KNNModule(nn.Module):
         for layer in self.layers:
             h = layer(h, epoch)
         if torch.is_grad_enabled() and h.requires_grad:
-            feature, _ = torch.max(h, dim=3, keepdim=False)            # autograd must route to ONE arg-max like the reference
+            feature = _ops.lastdim_max_autograd(h)                     # autograd routes to ONE arg-max (the first), like the reference's torch.max
         else:
             feature = torch.amax(h, dim=3)                             # values only (torch.max also builds indices)
         return center.squeeze(3).detach(), feature

@@ -254,7 +254,7 @@ class Encoder(nn.Module):
         self.final_pn_out = (forward_cat(lead, feat, epoch) if forward_cat is not None
                              else self.final_pointnet(torch.cat((lead, feat), dim=1), epoch))
         if torch.is_grad_enabled() and self.final_pn_out.requires_grad:
-            self.feature, _ = torch.max(self.final_pn_out, dim=2, keepdim=False)     # :197; amax would split the gradient over ties
+            self.feature = _ops.lastdim_max_autograd(self.final_pn_out)              # :197 torch.max: the gradient goes to ONE arg-max (amax would split it over ties)
         else:
             self.feature = _ops.lastdim_max(self.final_pn_out.contiguous())
         if self.feature.dtype != torch.float32:

@@ -2,7 +2,7 @@
 
 Same two functions and argument meaning; the gather itself is the gfx950 kernel behind
 ``sonet_knn_gather_f32`` (one thread per output element, no B x C x M*K int64 index expansion).
-Differentiable w.r.t. the feature tensor (backward = scatter-add, only used in training).
+Differentiable w.r.t. the feature tensor (backward = a gather over inverse neighbour lists, ``sonet_knn_gather_bwd_*``; training only).
 """
 import torch
 
@@ -20,6 +20,9 @@ class _KnnGather(torch.autograd.Function):
     def backward(ctx, g):
         (knn_I,) = ctx.saved_tensors
         B, C, M, K = g.shape
+        if g.is_cuda and g.dtype in (torch.float32, torch.bfloat16) and M == ctx.M and M <= 1024:
+            # gather over per-cloud inverse neighbour lists: fixed summation order, no index expansion, no fill
+            return _ops.knn_gather_bwd(g.contiguous(), knn_I.contiguous(), ctx.M).to(g.dtype), None
         idx = knn_I.reshape(B, 1, M * K).expand(B, C, M * K)
         gx = torch.zeros((B, C, ctx.M), dtype=g.dtype, device=g.device)
         gx.scatter_add_(2, idx, g.reshape(B, C, M * K))

@@ -70,6 +70,13 @@ SIGNATURES = {
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_h3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_h3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_lastdim_argmax_f32": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "sonet_lastdim_argmax_bf16": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "sonet_lastdim_max_bwd_f32": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "sonet_lastdim_max_bwd_bf16": [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "sonet_knn_gather_bwd_ws_size": [_i, _i, _i],
+    "sonet_knn_gather_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_knn_gather_bwd_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_p16_size": [_i, _i, _i],
     "sonet_p16_from_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "sonet_p16_to_f32": [_vp, _vp, _i, _i, _i, _vp],
@@ -118,6 +125,7 @@ _RESTYPES = {
     "sonet_wgrad_bf16_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_p16_size": ctypes.c_size_t,
+    "sonet_knn_gather_bwd_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_h3p_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_h3p_stats_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_bf16_pack_size": ctypes.c_size_t,

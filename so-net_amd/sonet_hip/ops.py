@@ -387,6 +387,63 @@ def knn_gather(x, knn_I):
     return out
 
 
+def knn_gather_bwd(g, knn_I, M):
+    """Backward of knn_gather: g B x C x M' x K (f32 / bf16), knn_I B x M' x K i64 -> B x C x M f32 (fixed summation order)."""
+    if g.dtype not in (torch.float32, torch.bfloat16):
+        raise SonetHipError("knn_gather_bwd: f32 or bf16 gradient")
+    _chk(g, "g", g.dtype, 4)
+    _chk(knn_I, "som_node_knn_I", torch.int64, 3)
+    B, C, Mq, K = g.shape
+    if tuple(knn_I.shape) != (B, Mq, K) or Mq != M:
+        raise SonetHipError("knn_gather_bwd: knn_I must be B x M x K with the M of the gathered tensor")
+    dev = _same_device(g, knn_I)
+    lib = _lib.load()
+    gx = torch.empty((B, C, M), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.sonet_knn_gather_bwd_ws_size(B, M, K),), dtype=torch.uint8, device=dev)
+    fn = lib.sonet_knn_gather_bwd_bf16 if g.dtype == torch.bfloat16 else lib.sonet_knn_gather_bwd_f32
+    with torch.cuda.device(dev), _timed("knn_gather_bwd"):
+        check(fn(ptr(g), ptr(knn_I), ptr(gx), ptr(ws), B, C, M, K, stream_ptr()), "sonet_knn_gather_bwd")
+    return gx
+
+
+class _LastDimMax(torch.autograd.Function):
+    """torch.max(x, dim=-1).values with its single-arg-max routing: forward = one kernel (value + index of the first maximum),
+    backward = one kernel that writes the whole gradient (no fill + scatter)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        K = xc.shape[-1]
+        rows = xc.numel() // K
+        out = torch.empty(xc.shape[:-1], dtype=xc.dtype, device=xc.device)
+        idx = torch.empty(xc.shape[:-1], dtype=torch.int32, device=xc.device)
+        lib = _lib.load()
+        fn = lib.sonet_lastdim_argmax_bf16 if xc.dtype == torch.bfloat16 else lib.sonet_lastdim_argmax_f32
+        with torch.cuda.device(xc.device), _timed("lastdim_argmax"):
+            check(fn(ptr(xc), ptr(out), ptr(idx), rows, K, stream_ptr()), "sonet_lastdim_argmax")
+        ctx.save_for_backward(idx)
+        ctx.K = K
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gc = g.contiguous()
+        gx = torch.empty(tuple(gc.shape) + (ctx.K,), dtype=gc.dtype, device=gc.device)
+        lib = _lib.load()
+        fn = lib.sonet_lastdim_max_bwd_bf16 if gc.dtype == torch.bfloat16 else lib.sonet_lastdim_max_bwd_f32
+        with torch.cuda.device(gc.device), _timed("lastdim_max_bwd"):
+            check(fn(ptr(gc), ptr(idx), ptr(gx), gc.numel(), ctx.K, stream_ptr()), "sonet_lastdim_max_bwd")
+        return gx
+
+
+def lastdim_max_autograd(x):
+    """max over the last dimension of a CUDA f32 / bf16 tensor, differentiable (gradient to the FIRST maximum, as torch.max)."""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or x.numel() == 0:
+        return torch.max(x, dim=-1)[0]
+    return _LastDimMax.apply(x)
+
+
 # ------------------------------------------------------------------------------------------ pointmlp
 import os as _os
 

@@ -70,10 +70,10 @@ def main():
         byt = 4.0 * (Cin + Cout) * B * L
         print("%s  (B=%d, L=%d): %.1f GFLOP, %.2f GB in+out" % (name, B, L, flop / 1e9, byt / 1e9), flush=True)
         wp2 = ops.pointmlp_pack(W, "h3")
-        if nodeadd:
-            line("2nd gen (f32 in, f32 out)", timeit(lambda: ops.pointmlp_nodeadd(x1, wp2, sc, sh, True, Cout, z, zi, x2=x2)), flop, byt)
-        else:
-            line("2nd gen (f32 in, f32 out)", timeit(lambda: ops.pointmlp(x1, wp2, sc, sh, True, Cout, x2=x2)), flop, byt)
+        gen2 = ((lambda: ops.pointmlp_nodeadd(x1, wp2, sc, sh, True, Cout, z, zi, x2=x2)) if nodeadd
+                else (lambda: ops.pointmlp(x1, wp2, sc, sh, True, Cout, x2=x2)))
+        timeit(gen2, iters=40)                                 # (the first launches behind the host-side set-up run ~15 % slow: clocks)
+        line("2nd gen (f32 in, f32 out)", timeit(gen2), flop, byt)
         line("p16_from_f32 (both inputs)", timeit(lambda: (ops.p16_from_f32(x1), ops.p16_from_f32(x2) if C2 else None)), 0.0, 8.0 * Cin * B * L)
         p1, p2 = ops.p16_from_f32(x1), (ops.p16_from_f32(x2) if C2 else None)
         wp = ops.pointmlp_h3p_pack(W)
@@ -103,6 +103,7 @@ def main():
                 line("3rd gen %s -> p16" % tag, timeit(lambda: ops.pointmlp_h3p(p1, wp, sc, sh, True, Cout, out="p16", **kw)), flop, byt)
             except Exception as e:                            # a shape the launcher refuses
                 print("    %-34s %s" % (tag, str(e)[:90]))
+        line("2nd gen again (after the others)", timeit(gen2), flop, byt)
         del x1, x2, p1, p2
         torch.cuda.empty_cache()
 
