@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict_
 
 // PAIRED: L even -> one dword per (lane, channel row) covers the lane's two points.  Otherwise 2-byte accesses with two
 // independent column offsets per lane (odd L; the gather variant).
-template <int MT, int S, bool PAIRED>
+template <int MT, int S, bool PAIRED, int NXB = 2>
 __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_kernel(      // <= 4 tiles: two workgroups per CU (<= 256 VGPRs)
     const uint16_t *__restrict__ x1, int C1, const uint16_t *__restrict__ x2, int C2, const uint4 *__restrict__ Wp,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
@@ -109,7 +109,13 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     const unsigned vow = (unsigned)lane * 16u;
 
     const int KC1 = C2 > 0 ? (C1 >> 4) : KC;                  // chunks fed by x1 (C1 % 16 == 0 when x2 exists)
+#ifdef SONET_VARIANTS   // ablation bits ride in the upper bits of ``relu`` (tools only): 1 no stores, 2 no K loop, 4 stores into four rows
+    const int abl = relu >> 1;
+    relu &= 1;
+    const int nstage = (abl & 2) ? 0 : (KC + S - 1) / S;
+#else
     const int nstage = (KC + S - 1) / S;
+#endif
     constexpr int NR = PAIRED ? 8 : 16;                       // raw registers per chunk
 
     auto load_b = [&](unsigned (&raw)[S][NR], int st) {
@@ -193,10 +199,11 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
         i32x4_t wreg[NS];
         unsigned b0[S][NR], b1[S][NR];
         __syncthreads();
-        stage_load(wreg, 0);
-        load_b(b0, 0);
-        stage_write(wreg, 0);
-        stage_load(wreg, nstage > 1 ? 1 : 0);
+        if constexpr (NXB == 2) {
+            stage_load(wreg, 0);
+            load_b(b0, 0);
+            stage_write(wreg, 0);
+            stage_load(wreg, nstage > 1 ? 1 : 0);
 #define BF_STAGE(st, bcur, bnxt, slot)                                        \
         {                                                                    \
             __syncthreads();                                                 \
@@ -205,13 +212,54 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
             load_b(bnxt, (st) + 1);                                          \
             compute(bcur, slot, st);                                         \
         }
-        int st = 0;
-        for (; st + 2 <= nstage; st += 2) {
-            BF_STAGE(st, b0, b1, 0)
-            BF_STAGE(st + 1, b1, b0, 1)
-        }
-        if (st < nstage) BF_STAGE(st, b0, b1, 0)
+            int st = 0;
+            for (; st + 2 <= nstage; st += 2) {
+                BF_STAGE(st, b0, b1, 0)
+                BF_STAGE(st + 1, b1, b0, 1)
+            }
+            if (st < nstage) BF_STAGE(st, b0, b1, 0)
 #undef BF_STAGE
+        } else {
+            // X AND W two stages ahead (three X register sets, two W sets).  One stage ahead, every stage top waited for the W slices
+            // requested a stage (~0.25 us of MFMA issue) earlier: an L2 round trip per stage.  Issue order per stage: W(st + 3),
+            // X(st + 2); the prologue leaves the same queue behind (hipcc merges the wait-counter states of loop entry and back edge)
+            unsigned b2[S][NR];
+            i32x4_t wreg1[NS];
+            auto clampst = [&](int t) { return t < nstage ? t : nstage - 1; };
+            stage_load(wreg1, 0);
+            stage_load(wreg, clampst(1));
+            load_b(b0, 0);
+            stage_write(wreg1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_load(wreg1, clampst(2));
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(b1, clampst(1));
+            __builtin_amdgcn_sched_barrier(0);
+#define BF_STAGE3(st, bcur, bfar, wset)                                       \
+        {                                                                    \
+            const int slot_ = (st) & 1;                                      \
+            __syncthreads();                                                 \
+            stage_write(wset, slot_ ^ 1);                                    \
+            stage_load(wset, clampst((st) + 3));                             \
+            load_b(bfar, clampst((st) + 2));     /* (unconditional: a branch here makes hipcc wait for vmcnt(0)) */ \
+            compute(bcur, slot_, st);                                        \
+        }
+            int st = 0;
+            for (; st + 6 <= nstage; st += 6) {
+                BF_STAGE3(st, b0, b2, wreg)
+                BF_STAGE3(st + 1, b1, b0, wreg1)
+                BF_STAGE3(st + 2, b2, b1, wreg)
+                BF_STAGE3(st + 3, b0, b2, wreg1)
+                BF_STAGE3(st + 4, b1, b0, wreg)
+                BF_STAGE3(st + 5, b2, b1, wreg1)
+            }
+            if (st < nstage) BF_STAGE3(st, b0, b2, wreg)
+            if (st + 1 < nstage) BF_STAGE3(st + 1, b1, b0, wreg1)
+            if (st + 2 < nstage) BF_STAGE3(st + 2, b2, b1, wreg)
+            if (st + 3 < nstage) BF_STAGE3(st + 3, b0, b2, wreg1)
+            if (st + 4 < nstage) BF_STAGE3(st + 4, b1, b0, wreg)
+#undef BF_STAGE3
+        }
 
         if (stats_partial != nullptr) {
             // training forward: batch statistics of the STORED values (what the normalise pass and the backward read) from this
@@ -261,7 +309,12 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
                     float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
                     if (relu) { va = (va < 0.f) ? 0.f : va; vb = (vb < 0.f) ? 0.f : vb; }     // NaN propagates
                     const unsigned pk = cvt_pk_bf16(va, vb);
+#ifdef SONET_VARIANTS
+                    const unsigned so = (abl & 4) ? (unsigned)(orow & 3) * rowB : so_tile + (unsigned)orow * rowB;
+                    if (abl & 1) { asm volatile("" :: "v"(pk)); continue; }
+#else
                     const unsigned so = so_tile + (unsigned)orow * rowB;
+#endif
                     if constexpr (PAIRED) {
                         __builtin_amdgcn_raw_buffer_store_b32((int)pk, ry, voya, so, 0);
                     } else {
@@ -270,6 +323,230 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
                     }
                 }
             }
+        }
+    }
+}
+
+// ---- the streaming generation: W resident in LDS, persistent waves, X requests that never go cold -----------------------------
+// Why: on the first PointNet's layers (64 x 15000 columns) the kernel above spends a constant ~10 us per (workgroup, pass) whatever
+// the K extent -- a cold X request at the head of every pass, the drain of its 64 dword stores at the end, two workgroups per CU to
+// hide both (profiles/r04s_bf16_layers.log: 1.6 TB/s of writes in every shape; without stores AND without the K loop the launch
+// still takes 0.15 ms).  Here a workgroup of 8 waves (2 per SIMD, one workgroup per CU) copies its slab of W -- tps cout tiles x all
+// K chunks, <= 144 KiB -- into the LDS ONCE and never meets a barrier again; every wave walks its own sequence of (64-column group,
+// pass of MT tiles) units, and its X requests run a fixed 4 chunks (32 dword loads, 8 KiB) ahead of the MFMAs ACROSS unit and group
+// boundaries, so the stores of a unit's epilogue are in flight next to the next unit's loads.  All X loads are inline asm with
+// hand-counted s_waitcnt vmcnt (the counter is in order and counts stores: 24 = three chunks behind the one consumed; + the 16 MT
+// stores of an epilogue for the first four chunks after one, capped at 63).
+typedef int i32x4_t_ __attribute__((ext_vector_type(4)));
+
+struct BfrArgs {
+    const uint16_t *x1, *x2;
+    const uint4 *Wp;
+    const float *scale, *shift;
+    uint16_t *y;
+    double *stats_partial;                // [nstream][Cout][2] (STATS)
+    int C1, C2, Cout, L, gpc, relu, KC, KC1, tps /*cout tiles per slab*/, nslab, nstream /*column streams = workgroups per slab*/;
+    int ngroups;                          // B * gpc
+    int sync;                             // workgroup barriers (rows that are not cache-line aligned): 1 per column group, 2 + per four chunks
+};
+
+__device__ __forceinline__ i32x4_t_ bfr_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i32x4_t_ r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xFFFFu));      // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+// "at most N vector-memory operations of this wave outstanding", then the chunk's eight dwords (channel rows 2p, 2p + 1: even | odd
+// point) sorted into the two B fragments -- ONE statement, the ring registers plain inputs: a wait with the registers as in/out
+// operands made hipcc hand it COPIES, taken before the wait (tools/check_bf16r_asm.py looks for any move out of a ring register).
+template <int N>
+__device__ __forceinline__ void bfr_wait_perm(const unsigned (&x)[8], unsigned (&ba)[4], unsigned (&bb)[4]) {
+    asm volatile("s_waitcnt vmcnt(%16)\n\t"
+                 "v_perm_b32 %0, %9, %8, %17\n\tv_perm_b32 %4, %9, %8, %18\n\t"
+                 "v_perm_b32 %1, %11, %10, %17\n\tv_perm_b32 %5, %11, %10, %18\n\t"
+                 "v_perm_b32 %2, %13, %12, %17\n\tv_perm_b32 %6, %13, %12, %18\n\t"
+                 "v_perm_b32 %3, %15, %14, %17\n\tv_perm_b32 %7, %15, %14, %18"
+                 : "=&v"(ba[0]), "=&v"(ba[1]), "=&v"(ba[2]), "=&v"(ba[3]), "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3])
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                   "n"(N), "s"(0x05040100u), "s"(0x07060302u)
+                 : "memory");
+}
+
+template <int MT, bool STATS>
+__global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
+{
+    extern __shared__ uint4 bfr_lds[];
+    uint4 *wl = bfr_lds;                                                       // [tps][KC][64]
+    float2 *aff = reinterpret_cast<float2 *>(wl + (size_t)a.tps * a.KC * 64);  // [tps * 32]
+    float2 *stl = aff + a.tps * 32;                                            // STATS: [8 waves][tps * 32] (sum, sum of squares)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // workgroup -> (slab, column stream): the nslab workgroups of one stream read the same X, they sit on the same XCD (ids 8 apart)
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int slab = kq % a.nslab, stream = xcd + 8 * (kq / a.nslab);
+    const int ct_begin = slab * a.tps;
+    const int KC = a.KC, L = a.L;
+    const unsigned rowB = (unsigned)L * 2u;
+
+    {
+        const uint4 *src = a.Wp + (size_t)ct_begin * KC * 64;
+        const int n = a.tps * KC * 64;                          // a multiple of 512 (tps even, KC a multiple of 4)
+        int i0 = 0;
+        for (; i0 + 512 * 8 <= n; i0 += 512 * 8) {              // eight requests per thread in flight, then the eight LDS writes
+            const uint4 *sp = src + i0 + (int)threadIdx.x;
+            uint4 *dp = wl + i0 + (int)threadIdx.x;
+            const uint4 t0 = sp[0], t1 = sp[512], t2 = sp[1024], t3 = sp[1536], t4 = sp[2048], t5 = sp[2560], t6 = sp[3072], t7 = sp[3584];
+            dp[0] = t0; dp[512] = t1; dp[1024] = t2; dp[1536] = t3; dp[2048] = t4; dp[2560] = t5; dp[3072] = t6; dp[3584] = t7;
+        }
+        for (; i0 < n; i0 += 512) wl[i0 + (int)threadIdx.x] = src[i0 + (int)threadIdx.x];
+        for (int o = threadIdx.x; o < a.tps * 32; o += 512) aff[o] = make_float2(a.scale[ct_begin * 32 + o], a.shift[ct_begin * 32 + o]);
+        if constexpr (STATS)
+            for (int o = threadIdx.x; o < 8 * a.tps * 32; o += 512) stl[o] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+
+    const int npass = a.tps / MT;
+    const int wv = stream * 8 + wave, stride = a.nstream * 8;
+    const int ngw = wv < a.ngroups ? (a.ngroups - wv + stride - 1) / stride : 0;     // this wave's column groups: wv, wv + stride, ...
+    const int ngw_wg = stream * 8 < a.ngroups ? (a.ngroups - stream * 8 + stride - 1) / stride : 0;   // ... and those of the workgroup's wave 0 (the most)
+
+    // ---- load side: a cursor (group, chunk) that runs 4 chunks ahead of the multiplications
+    int lg = 0, lkc = 0, lrep = 0;                  // index into this wave's groups / chunk / pass counter (X is re-read per pass)
+    i32x4_t_ r1, r2;
+    unsigned voa = 0;
+    auto set_load_group = [&](int gi) {
+        const int g = wv + (gi < ngw ? gi : ngw - 1) * stride;       // (past the end: the last group again -- harmless re-reads)
+        const int b = g / a.gpc;
+        const int ca = (g - b * a.gpc) * 64 + 2 * j;
+        const int cca = ca < L ? ca : (g - b * a.gpc) * 64;
+        r1 = bfr_rsrc(a.x1 + (size_t)b * a.C1 * L, (unsigned)a.C1 * rowB);
+        r2 = bfr_rsrc(a.x2 ? a.x2 + (size_t)b * a.C2 * L : a.x1, (unsigned)(a.x2 ? a.C2 : 0) * rowB);
+        voa = (unsigned)(8 * h * L + cca) * 2u;
+    };
+    auto issue = [&](unsigned (&x)[8]) {             // the cursor's chunk -> x, cursor + 1
+        const bool second = lkc >= a.KC1;
+        const i32x4_t_ rs = second ? r2 : r1;
+        const unsigned row0 = (unsigned)(16 * (second ? lkc - a.KC1 : lkc)) * rowB;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(x[t]) : "v"(voa), "s"(rs), "s"(row0 + (unsigned)t * rowB) : "memory");
+        if (++lkc == KC) {
+            lkc = 0;
+            if (++lrep == npass) { lrep = 0; set_load_group(++lg); }
+        }
+    };
+
+    if (ngw > 0) {
+        unsigned X[4][8];
+        set_load_group(0);
+        issue(X[0]); issue(X[1]); issue(X[2]); issue(X[3]);
+        // 16 MT stores that land nowhere (offset outside the buffer): the first unit then starts behind the same queue as every other
+        // one -- four chunks of loads, then an epilogue's stores -- and ONE wait count serves the first four chunks of every unit.  (Two
+        // counts selected by a branch made hipcc hand the wait statements COPIES of the ring registers, taken before the wait.)
+        {
+            const i32x4_t_ r0 = bfr_rsrc(a.y, 4);              // (asm: as builtins hipcc folds the identical stores into one)
+            const unsigned oob = 0x7FFFFF00u, zero = 0u;
+#pragma unroll
+            for (int t = 0; t < 16 * MT; ++t)
+                asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(zero), "v"(oob), "s"(r0) : "memory");
+        }
+
+        for (int gi = 0; gi < ngw_wg; ++gi) {
+            // Rows that do not start on a cache line (15000 columns: 30000 bytes): the 128-byte windows of neighbouring groups
+            // (= neighbouring waves) share lines, and waves that drift microseconds apart each fetch the shared line from memory
+            // (PMC: 1.8 x the bytes of the aligned case, profiles/r04u_bf16r_alignment.md).  Barriers keep the eight waves within
+            // four chunks of each other: 0.54 -> 0.40 ms on 320 -> 384 (rows of 15040 columns, no barrier: 0.35).
+            if (a.sync) __builtin_amdgcn_s_barrier();
+            if (gi >= ngw) {
+                if (a.sync == 2) for (int t = 0; t < npass * (KC / 4); ++t) __builtin_amdgcn_s_barrier();
+                continue;
+            }
+            const int g = wv + gi * stride;
+            const int b = g / a.gpc;
+            const int ca = (g - b * a.gpc) * 64 + 2 * j;
+            const bool pva = ca < L;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * L, 0, (int)((unsigned)a.Cout * rowB), 0x00020000);
+            const unsigned voya = pva ? (unsigned)(4 * h * L + ca) * 2u : 0x7FFFFF00u;       // padded columns: the store falls outside the buffer
+
+            for (int pass = 0; pass < npass; ++pass) {
+                f32x16 acc[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
+                const uint4 *wpass = wl + (size_t)pass * MT * KC * 64 + lane;
+
+#define BFR_BODY(q, kc, FIRST4)                                                                         \
+                {                                                                                       \
+                    unsigned ba[4], bb[4];                                                              \
+                    bfr_wait_perm<(FIRST4 ? (24 + 16 * MT > 63 ? 63 : 24 + 16 * MT) : 24)>(X[q], ba, bb); \
+                    issue(X[q]);                                                                        \
+                    const bf16x8 Ba = __builtin_bit_cast(bf16x8, make_uint4(ba[0], ba[1], ba[2], ba[3])); \
+                    const bf16x8 Bb = __builtin_bit_cast(bf16x8, make_uint4(bb[0], bb[1], bb[2], bb[3])); \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                 \
+                        const bf16x8 A = __builtin_bit_cast(bf16x8, wpass[(size_t)(mt * KC + (kc)) * 64]); \
+                        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Ba, acc[mt][0], 0, 0, 0); \
+                        acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bb, acc[mt][1], 0, 0, 0); \
+                    }                                                                                   \
+                }
+                if (a.sync == 2) __builtin_amdgcn_s_barrier();
+                BFR_BODY(0, 0, true) BFR_BODY(1, 1, true) BFR_BODY(2, 2, true) BFR_BODY(3, 3, true)
+                for (int kc = 4; kc < KC; kc += 4) {
+                    if (a.sync == 2) __builtin_amdgcn_s_barrier();
+                    BFR_BODY(0, kc, false) BFR_BODY(1, kc + 1, false) BFR_BODY(2, kc + 2, false) BFR_BODY(3, kc + 3, false)
+                }
+#undef BFR_BODY
+
+                // epilogue: affine + ReLU, two points per dword; statistics of the STORED values (what the normalise pass and the
+                // backward read) into this wave's own LDS rows
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int tl = pass * MT + mt;                           // tile inside the slab
+                    const unsigned so_tile = (unsigned)((ct_begin + tl) * 32) * rowB;
+                    const float2 *af = aff + tl * 32 + 4 * h;
+                    float mine = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int orow = (r & 3) + 8 * (r >> 2);
+                        const float2 ss = af[orow];
+                        float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
+                        if (a.relu & 1) { va = (va < 0.f) ? 0.f : va; vb = (vb < 0.f) ? 0.f : vb; }     // NaN propagates
+                        const unsigned pk = cvt_pk_bf16(va, vb);
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pk, ry, voya, so_tile + (unsigned)orow * rowB, 0);
+                        if constexpr (STATS) {
+                            const float ra = pva ? __uint_as_float(pk << 16) : 0.f, rb = pva ? __uint_as_float(pk & 0xFFFF0000u) : 0.f;
+                            const float s1 = row32_sum(ra + rb), s2 = row32_sum(__fmaf_rn(ra, ra, rb * rb));
+                            // every lane of the half holds both sums: lane j keeps the one of register r = j & 15 (sum for j < 16, sum of
+                            // squares for j >= 16) -- ONE LDS update per tile instead of a read-add-write chain per row
+                            mine = ((j & 15) == r) ? (j < 16 ? s1 : s2) : mine;
+                        }
+                    }
+                    if constexpr (STATS) {
+                        const int rr = j & 15;
+                        float *d = reinterpret_cast<float *>(stl + (size_t)wave * a.tps * 32 + tl * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h) + (j >> 4);
+                        *d += mine;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead requests of the tail: nothing may land after the wave has left
+    } else if (a.sync) {
+        const int nb = a.sync == 2 ? 1 + npass * (KC / 4) : 1;
+        for (int gi = 0; gi < ngw_wg * nb; ++gi) __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < a.tps * 32; t += 512) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < 8; ++w) { const float2 v = stl[(size_t)w * a.tps * 32 + t]; s1 += (double)v.x; s2 += (double)v.y; }
+            double *dst = a.stats_partial + ((size_t)stream * a.Cout + (size_t)ct_begin * 32 + t) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
         }
     }
 }
@@ -493,6 +770,9 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         const int want = atoi(e);
         if ((want == 12 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
     }
+#ifdef SONET_VARIANTS
+    if (const char *e = sonet::knob("SONET_BF16_ABL")) relu = (relu & 1) | (atoi(e) << 1);
+#endif
     if (const char *e = sonet::knob("SONET_BF16_S")) {
         const int want = atoi(e);
         if (want == 1 || want == 2) S = want;
@@ -550,6 +830,46 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         }
     }
 #endif  // SONET_VARIANTS
+    // big launches with dword-aligned rows: the streaming generation (W slab resident in LDS, persistent waves)
+    {
+        bool want = paired && KC % 4 == 0 && CT % 2 == 0 && ngroups >= 8192 && ngroups < 0x7FFFFFFFll;
+        if (const char *e = sonet::knob("SONET_BF16_STREAM")) want = want && atoi(e) != 0;
+        int best_ns = 0, best_cost = 1 << 30;
+        for (int ns = 1; want && ns <= CT / 2; ++ns) {
+            if (CT % ns) continue;
+            const int tps = CT / ns;
+            if (tps % 2 || tps * KC > 144) continue;
+            const int cost = ns * (tps / (tps % 4 == 0 ? 4 : 2));            // times X goes through the vector memory path
+            if (cost < best_cost) { best_cost = cost; best_ns = ns; }
+        }
+        int cus = 256;
+        {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) cus = v;
+        }
+        const int spx = best_ns > 0 ? (cus / 8) / best_ns : 0;            // column streams per XCD
+        if (want && best_ns > 0 && spx > 0) {
+            BfrArgs a;
+            a.x1 = x1; a.x2 = x2; a.Wp = wp; a.scale = scale; a.shift = shift; a.y = y; a.stats_partial = stats_ws;
+            a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.L = L; a.gpc = gpc; a.relu = relu & 1; a.KC = KC; a.KC1 = C2 > 0 ? (C1 >> 4) : KC;
+            a.tps = CT / best_ns; a.nslab = best_ns; a.nstream = 8 * spx; a.ngroups = (int)ngroups;
+            a.sync = ((unsigned)L * 2u) % 128u != 0 ? 2 : 0;
+            if (const char *e = sonet::knob("SONET_BF16_SYNC")) a.sync = atoi(e);
+            const size_t lds = (size_t)a.tps * KC * 1024 + (size_t)a.tps * 32 * 8 + (stats_ws ? (size_t)8 * a.tps * 32 * 8 : 0);
+            const dim3 gridr((unsigned)(8 * spx * best_ns)), blockr(512);
+#define BFR_LAUNCH(MM, SS) do { static bool attr_set = false;                                                                         \
+                if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pointmlp_bf16r_kernel<MM, SS>),             \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)       \
+                                     return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
+                                 attr_set = true; }                                                                                   \
+                hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, SS>), gridr, blockr, lds, st, a); } while (0)
+            if (a.tps % 4 == 0) { if (stats_ws) BFR_LAUNCH(4, true); else BFR_LAUNCH(4, false); }
+            else                { if (stats_ws) BFR_LAUNCH(2, true); else BFR_LAUNCH(2, false); }
+#undef BFR_LAUNCH
+            if (stats_ws) sonet::launch_stats_finalize(stats_ws, a.nstream, Cout, 1.0 / ((double)B * L), mean, var, st);
+            return sonet::launched(what);
+        }
+    }
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
 #define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
@@ -557,6 +877,16 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
                            else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, false>), BF_ARGS); } } while (0)
     if (MT == 12) S = 1;                                      // (12 slices per chunk already: one chunk per stage)
+    // big launches (HBM-bound: the wave needs ~8 KiB of X in flight to cover the memory latency): X two stages ahead
+    int nxb = (paired && S == 2 && (MT == 4 || MT == 2) && KC >= 6 && nwg_x >= 1024) ? 3 : 2;
+    if (const char *e = sonet::knob("SONET_BF16_NXB")) {
+        const int want = atoi(e);
+        if (want == 2 || (want == 3 && paired && S == 2 && (MT == 4 || MT == 2))) nxb = want;
+    }
+    if (nxb == 3) {
+        if (MT == 4) hipLaunchKernelGGL((pointmlp_bf16_kernel<4, 2, true, 3>), BF_ARGS);
+        else         hipLaunchKernelGGL((pointmlp_bf16_kernel<2, 2, true, 3>), BF_ARGS);
+    } else
     switch (MT) {
         case 12: BF_LAUNCH(12); break;
         case 6: BF_LAUNCH(6); break;

@@ -191,7 +191,7 @@ struct H3pArgs {
     const int32_t *zidx;
     unsigned *rlog;                       // range-log slot (word 1: max |w| bits, word 2: max of the P16 output)
     double *stats_partial;                // optional [ncol][Cout][2] (sum, sum of squares of the f32 output over the workgroup's columns)
-    int abl;                              // (variants build) ablations: 1 = outputs dropped (stores issued, out of range), 2 = every X load reads chunk 0, 4 = every W request reads chunk 0
+    int abl;                              // (variants build) ablations: 1 = outputs dropped (stores issued, out of range), 2 = every X load reads chunk 0, 4 = every W request reads chunk 0, 8 = no epilogue at all
     unsigned long long *prof;             // (variants build) phase cycle counters: [0] workgroups, [1] prologue, [2] chunk loops, [3] epilogues, [4] whole
     long long ngroups;                    // B * gpc
     int KC1, KC2, L1, L, Cout, CT, KC, KCr, KCP, ct_per_y, nslab, ncol, gpc, relu, ZM;
@@ -651,6 +651,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
 #ifdef SONET_VARIANTS
         const unsigned long long pl1 = __builtin_readcyclecounter();
         pt_loop += pl1 - pl0;
+#endif
+#ifdef SONET_VARIANTS
+        if (!(a.abl & 8))
 #endif
         epilogue(ct_begin + pass * MT);
 #ifdef SONET_VARIANTS

@@ -396,6 +396,38 @@ def test_pointmlp_bf16_statistics_epilogue(B, C1, C2, Cout, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,C1,C2,Cout,L,relu", [
+    (36, 64, 0, 128, 15000, True), (36, 64, 256, 384, 15000, False), (64, 128, 0, 256, 8192, True), (41, 256, 0, 128, 13002, True),
+    (36, 128, 0, 64, 15000, False), (33, 64, 0, 192, 16000, True)])
+def test_pointmlp_bf16_streaming_generation(B, C1, C2, Cout, L, relu):
+    """Launches of >= 8192 column groups with K a multiple of 64 take the streaming kernel (W slab resident in LDS, persistent waves,
+    hand-counted X look-ahead across units): bit-identical to the staged kernel, which the same layer takes on batches of <= 16
+    clouds (same K order, same f32 MFMA chain), with and without the statistics epilogue; statistics against f64 sums."""
+    from sonet_hip import ops
+    assert B * ((L + 63) // 64) >= 8192 and 16 * ((L + 63) // 64) < 8192
+    g = torch.Generator().manual_seed(C1 + 3 * Cout + L)
+    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16).to(DEV) if C2 else None
+    W = (torch.randn(Cout, C1 + C2, generator=g) * (2.0 / (C1 + C2)) ** 0.5).to(DEV)
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    wp = ops.pointmlp_pack(W, "bf16")
+    y = ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
+    parts = [ops.pointmlp(x1[b0:b0 + 16].contiguous(), wp, scale, shift, relu, Cout, x2=x2[b0:b0 + 16].contiguous() if C2 else None)
+             for b0 in range(0, B, 16)]
+    ref = torch.cat(parts, dim=0)
+    assert torch.equal(y, ref), "streaming and staged kernels differ in %d values" % int((y != ref).sum())
+    y2 = ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)                       # (and run to run)
+    assert torch.equal(y, y2)
+    ys, m1, v1 = ops.pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=x2)
+    assert torch.equal(ys, y)
+    yd = y.double()
+    mref, vref = yd.mean(dim=(0, 2)), yd.var(dim=(0, 2), unbiased=False)
+    sc = (mref.abs() + vref.sqrt()).clamp_min(1e-3)
+    assert float(((m1.double() - mref).abs() / sc).max()) < 1e-6
+    assert float(((v1.double() - vref).abs() / sc ** 2).max()) < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["segmenter_b2_n256", "segmenter_b2_n1024"])
 def test_segmenter_forward_bf16(case):
     """The part segmenter under precision('bf16') (global switch: SONET_POINTMLP_PRECISION / bench --precision): the node-wise

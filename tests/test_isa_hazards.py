@@ -44,3 +44,19 @@ def test_third_generation_layer_has_no_compiler_waits_or_spills_in_its_pass_loop
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not present")
     assert check_h3p_asm.main([]) == 0
+
+
+def test_streaming_bf16_layer_never_touches_an_x_register_in_flight():
+    """pointmlp_bf16r_kernel (pointmlp_bf16.hip) issues its X loads as inline asm: hipcc believes the destination registers are valid at
+    once, and a move out of one (a copy for a tied asm operand, a phi copy) before the hand-counted wait reads a stale value -- which is
+    how the first version of the kernel returned wrong columns.  tools/check_bf16r_asm.py compiles the source and follows every ring
+    register from its load to the wait + perm statement; it also counts the stores the wait counts are built on."""
+    import check_bf16r_asm
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not present")
+    sys_argv = sys.argv
+    sys.argv = ["check_bf16r_asm.py"]
+    try:
+        assert check_bf16r_asm.main() == 0
+    finally:
+        sys.argv = sys_argv

@@ -1,0 +1,11 @@
+#!/bin/bash
+# bf16 streaming layer kernel after the statistics-epilogue change; tests; the bf16 training step
+python tools/bench_bf16_layers.py 2>&1 | grep -v amdgpu | head -9
+timeout 900 python -m pytest tests/test_gpu_bf16.py -x -q 2>&1 | tail -3
+python bench.py --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1])
+print('value', d['value'], 'ms', d['ms_per_step'])
+for k,v in d.get('other_configs',{}).items():
+    print(k, {kk: v[kk] for kk in v if kk in ('ms_per_step','clouds_per_s','parity')} if isinstance(v,dict) else v)
+"
