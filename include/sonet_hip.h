@@ -441,6 +441,12 @@ int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const ui
                              float *gw_partial, sonet_stream_t stream);
 int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                              int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream);
+/* ... the same gradient as a dense product on the matrix cores: the 64-column tile of the (never built) gradient of first_pn_out is
+ * assembled in LDS from the entries and multiplied by W^T.  wt_pack = sonet_pointmlp_bf16_pack of W^T ([C1 + C2] x C); g and W rounded
+ * to bfloat16, f32 accumulate (the dense bf16 dgrad of the other layers does the same).  L even, C a multiple of 16 and <= 384, an even
+ * number (<= 12) of 32-row tiles in C1 + C2; same workspace as above.  SONET_ERR_UNSUPPORTED otherwise (the caller takes _obf16). */
+int sonet_pooled_dgrad_mfma_bf16(const float *g_pooled, const int32_t *pos, const void *wt_pack, int B, int C, int M, int C1, int C2,
+                                 int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream);
 
 /* Per-channel coefficients of training BatchNorm, forward (invstd = 1/sqrt(var+eps), scale = gamma*invstd,
  * shift = beta - mean*scale) and backward (from the two sums of sonet_pointwise_bwd_stats_f32, n = B*L:

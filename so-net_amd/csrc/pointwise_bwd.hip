@@ -724,8 +724,13 @@ extern "C" int sonet_node_gather_lead_affine_act_bf16(const uint16_t *z, const i
 // result does not depend on the order the bucket atomics happened to take.
 namespace {
 
-constexpr int PD_TL = 32;                      // columns per tile (41 KB of LDS at 320 channels: 3 workgroups per CU)
-constexpr int PD_SORT = 1024;                  // entries per tile sorted in LDS (more: chunks in arrival order)
+constexpr int PD_TL = 128;                     // columns per tile: 256-byte (bf16) / 512-byte (f32) row segments on the way out.  (Round 3: 32
+                                               // columns x all 320 channels -- 64-byte bf16 row pieces, every one a partial cache line.)
+constexpr int PD_CH = 40;                      // input channels per workgroup (blockIdx.z): 41 KB of accumulators
+constexpr int PD_CQ = 4;                       // thread groups per channel: group q owns column quarter q of the tile ...
+constexpr int PD_SB = PD_TL / PD_CQ;           // ... = one 32-column bucket of the entry lists (~52 entries at the benchmark shape)
+constexpr int PD_WB = 16;                      // W rows requested before the first fma (64 -- a whole bucket in one round trip -- measured slower)
+constexpr int PD_SQ = 128;                     // entries per group sorted in LDS at a time (more: further rounds, still in global rank order)
 
 __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g,
                                                             int E, int L, int ntile, int32_t *__restrict__ tile_off,
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__re
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
-        if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_TL], 1);
+        if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_SB], 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -752,10 +757,10 @@ __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__re
     for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
         if ((unsigned)l >= (unsigned)L) continue;
-        const int t = l / PD_TL;
+        const int t = l / PD_SB;
         const int p = off[t] + atomicAdd(&cnt[t], 1);
         // sort key (column, entry id); entry id = c * M + m, the consumer recovers the channel as id / M
-        ent_key[(size_t)b * E + p] = ((uint32_t)(l - t * PD_TL) << 20) | (uint32_t)e;
+        ent_key[(size_t)b * E + p] = ((uint32_t)(l - t * PD_SB) << 20) | (uint32_t)e;
         ent_val[(size_t)b * E + p] = g[(size_t)b * E + e];
     }
 }
@@ -767,110 +772,214 @@ __device__ __forceinline__ void pd_store(uint16_t *p, size_t i, float v) {     /
     p[i] = (uint16_t)(r & 0xFFFFu);
 }
 template <typename TO>
-__global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
+__global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
                                                            const float *__restrict__ ent_val, const float *__restrict__ W,
-                                                           int E, int M, int Cin, int C1, int L, int ntile,
-                                                           TO *__restrict__ gx1, TO *__restrict__ gx2)
+                                                           int E, int M, int Cin, int C1, int L, int nbucket,
+                                                           TO *__restrict__ gx1, TO *__restrict__ gx2, int abl /*experiments (variants build): 1 no stores, 2 no accumulation, 4 no sort*/)
 {
-    extern __shared__ float sm_f[];              // acc[PD_TL][Cin + 1] | keys[PD_SORT] | vals[PD_SORT] | wrow[PD_SORT]
-    const int ld = Cin + 1;
+    extern __shared__ float sm_f[];              // acc[PD_TL][PD_CH + 1] | per group: keys, vals, wrow, staged keys [PD_SQ] each
+    constexpr int ld = PD_CH + 1;
     float *acc = sm_f;
-    uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld);
-    float *vals = reinterpret_cast<float *>(keys + PD_SORT);
-    int *wrow = reinterpret_cast<int *>(vals + PD_SORT);
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
-    for (int i = tid; i < PD_TL * ld; i += nth) acc[i] = 0.f;
-    const int beg = tile_off[(size_t)b * (ntile + 1) + tile], end = tile_off[(size_t)b * (ntile + 1) + tile + 1];
-    const uint32_t *kb = ent_key + (size_t)b * E;
-    const float *vb = ent_val + (size_t)b * E;
-    for (int base = beg; base < end; base += PD_SORT) {
-        const int n = min(PD_SORT, end - base);
-        __syncthreads();
-        if (n <= 256) {
-            // the usual case (~50 entries per tile): rank sort, one barrier -- each entry counts the smaller keys (keys are distinct)
-            uint32_t mykey = 0xFFFFFFFFu;
-            float myval = 0.f;
-            if (tid < n) { mykey = kb[base + tid]; myval = vb[base + tid]; keys[PD_SORT / 2 + tid] = mykey; }
-            __syncthreads();
-            if (tid < n) {
-                int rank = 0;
-                for (int q = 0; q < n; ++q) rank += keys[PD_SORT / 2 + q] < mykey;
-                keys[rank] = mykey;
-                vals[rank] = myval;
-            }
-            __syncthreads();
-        } else {
-        int n2 = 1;
-        while (n2 < n) n2 <<= 1;
-        for (int i = tid; i < n2; i += nth) {
-            keys[i] = i < n ? kb[base + i] : 0xFFFFFFFFu;
-            vals[i] = i < n ? vb[base + i] : 0.f;
-        }
-        __syncthreads();
-        for (int k = 2; k <= n2; k <<= 1)                      // bitonic sort by (column, entry id)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < n2; i += nth) {
-                    const int p = i ^ j;
-                    if (p > i) {
-                        const bool up = (i & k) == 0;
-                        const uint32_t a = keys[i], c = keys[p];
-                        if ((a > c) == up) { keys[i] = c; keys[p] = a; const float t = vals[i]; vals[i] = vals[p]; vals[p] = t; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // Accumulate: thread i owns input channel i of every column of the tile and walks the entries in sorted (column, id) order, so
-        // the order of the fma chain of an accumulator is fixed (deterministic) and no two threads touch the same one.  The W rows of
-        // 16 entries (coalesced: the workgroup reads a whole row per entry, L2-resident) are requested before their first fma.
-        // (Round 1 gave every COLUMN to a wave: 7 columns per wave in sequence, each with two binary searches in LDS and a
-        // dependent W-row load per entry -- 50 us per workgroup for ~50 entries, 0.97 ms per training step.)
-        // (per entry, once: the W row offset and the accumulator row offset -- the division by M per (entry, thread) was half of the
-        // kernel's instructions)
-        for (int e = tid; e < n; e += nth) {
-            const uint32_t kk = keys[e];
-            wrow[e] = ((int)(kk & 0xFFFFFu) / M) * Cin;
-            keys[e] = (kk >> 20) * (uint32_t)ld;
-        }
-        __syncthreads();
-        for (int i = tid; i < Cin; i += nth) {
-            for (int e0 = 0; e0 < n; e0 += 16) {
-                float wv[16];
+    const int i = tid % PD_CH, q = tid / PD_CH;                             // channel ch0 + i, column quarter q
+    uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld) + q * 4 * PD_SQ;
+    float *vals = reinterpret_cast<float *>(keys + PD_SQ);
+    int *wrow = reinterpret_cast<int *>(keys + 2 * PD_SQ);
+    uint32_t *staged = keys + 3 * PD_SQ;
+    __shared__ int nq_all[PD_CQ];
+    const int ch0 = blockIdx.z * PD_CH, nch = min(PD_CH, Cin - ch0);        // this workgroup's input channels
+    for (int t = tid; t < PD_TL * ld; t += nth) acc[t] = 0.f;
+    const int sb = tile * PD_CQ + q;                                        // this group's bucket (32 columns)
+    const int beg = sb < nbucket ? tile_off[(size_t)b * (nbucket + 1) + sb] : 0;
+    const int nq = sb < nbucket ? tile_off[(size_t)b * (nbucket + 1) + sb + 1] - beg : 0;
+    const uint32_t *kb = ent_key + (size_t)b * E + beg;
+    const float *vb = ent_val + (size_t)b * E + beg;
+    if (i == 0) nq_all[q] = nq;
+    __syncthreads();
+    int nmax = 0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int e = e0 + q < n ? e0 + q : n - 1;
-                    wv[q] = W[(size_t)wrow[e] + i];
+    for (int t = 0; t < PD_CQ; ++t) nmax = max(nmax, nq_all[t]);
+    // Every group sorts ITS bucket by (column, entry id) -- rank sort: an entry counts the smaller keys (they are distinct) -- so the order
+    // of the fma chain of an accumulator is fixed whatever order the bucket atomics took; then thread (i, q) applies the group's entries
+    // to channel ch0 + i (no two threads touch the same accumulator).  Buckets beyond PD_SQ entries (never at the benchmark shape) go in
+    // rounds of PD_SQ consecutive RANKS, the keys compared straight from global memory: still one fixed order.
+    const bool small = nq <= PD_SQ;
+    if (small) for (int e = i; e < nq; e += PD_CH) staged[e] = kb[e];
+    for (int base = 0; base < nmax; base += PD_SQ) {
+        __syncthreads();                                                    // staged keys visible / the previous round consumed
+        const int n = min(PD_SQ, max(0, nq - base));
+        for (int e = i; e < nq; e += PD_CH) {
+            const uint32_t key = small ? staged[e] : kb[e];
+            int rank = 0;
+            if (abl & 4) rank = e;
+            else if (small) { for (int t = 0; t < nq; ++t) rank += staged[t] < key; }
+            else       { for (int t = 0; t < nq; ++t) rank += kb[t] < key; }
+            if (rank >= base && rank < base + n) {
+                // per entry, once: the W row offset and the accumulator row (the division by M per (entry, thread) was half of the
+                // kernel's instructions in round 2)
+                keys[rank - base] = (key >> 20) + (uint32_t)(q * PD_SB);    // column inside the tile
+                vals[rank - base] = vb[e];
+                wrow[rank - base] = ((int)(key & 0xFFFFFu) / M) * Cin + ch0;
+            }
+        }
+        __syncthreads();
+        if (i < nch && n > 0 && !(abl & 2)) {
+            // the W rows of PD_WB entries (the PD_CH threads of a group read 320 consecutive bytes per entry, L2-resident) are requested
+            // before their first fma
+            // The entries are sorted by column: the fma chain of a column runs in a REGISTER and is written when the column changes (an
+            // LDS read-add-write per entry serialises on the LDS latency -- hipcc cannot tell that two accumulators differ; this was most
+            // of the kernel's time).  Same chain, same order, same bits.  A column that continues from the previous round of a very
+            // large bucket resumes from the stored value.
+            int cur = (int)keys[0];
+            float sum = base > 0 ? acc[cur * ld + i] : 0.f;
+            for (int e0 = 0; e0 < n; e0 += PD_WB) {
+                float wv[PD_WB];
+#pragma unroll
+                for (int t = 0; t < PD_WB; ++t) {
+                    const int e = e0 + t < n ? e0 + t : n - 1;
+                    wv[t] = W[(size_t)wrow[e] + i];
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (e0 + q < n) {
-                        float *ac = acc + keys[e0 + q] + i;
-                        *ac = __fmaf_rn(vals[e0 + q], wv[q], *ac);
+                for (int t = 0; t < PD_WB; ++t) {
+                    if (e0 + t < n) {
+                        const int col = (int)keys[e0 + t];
+                        if (col != cur) {
+                            acc[cur * ld + i] = sum;
+                            cur = col;
+                            sum = base > 0 ? acc[cur * ld + i] : 0.f;
+                        }
+                        sum = __fmaf_rn(vals[e0 + t], wv[t], sum);
                     }
                 }
             }
+            if (n > 0) acc[cur * ld + i] = sum;
         }
     }
     __syncthreads();
+    if (abl & 1) return;
     const int l0 = tile * PD_TL;
     if (sizeof(TO) == 2 && (L & 1) == 0) {
-        // bf16 output, even L: two columns per thread, one 4-byte store (2-byte stores of single elements: 0.80 ms of the bf16 step)
-        for (int idx = tid; idx < Cin * (PD_TL / 2); idx += nth) {
-            const int i = idx / (PD_TL / 2), col = (idx - i * (PD_TL / 2)) * 2;
+        // bf16 output, even L: two columns per thread, one 4-byte store -- 64 consecutive threads write the 256 bytes of a row segment
+        for (int idx = tid; idx < nch * (PD_TL / 2); idx += nth) {
+            const int r = idx / (PD_TL / 2), col = (idx - r * (PD_TL / 2)) * 2;
             if (l0 + col >= L) continue;                        // (L even: col + 1 is inside too)
-            unsigned r;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(acc[col * ld + i]), "v"(acc[(col + 1) * ld + i]));
-            TO *dst = i < C1 ? gx1 + ((size_t)b * C1 + i) * L + l0 + col : gx2 + ((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col;
-            *reinterpret_cast<unsigned *>(dst) = r;
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(acc[col * ld + r]), "v"(acc[(col + 1) * ld + r]));
+            const int ch = ch0 + r;
+            TO *dst = ch < C1 ? gx1 + ((size_t)b * C1 + ch) * L + l0 + col : gx2 + ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col;
+            *reinterpret_cast<unsigned *>(dst) = pk;
         }
         return;
     }
-    for (int idx = tid; idx < Cin * PD_TL; idx += nth) {        // coalesced: consecutive threads along the columns of one channel
-        const int i = idx / PD_TL, col = idx - i * PD_TL;
+    for (int idx = tid; idx < nch * PD_TL; idx += nth) {        // coalesced: consecutive threads along the columns of one channel
+        const int r = idx / PD_TL, col = idx - r * PD_TL;
         if (l0 + col >= L) continue;
-        const float v = acc[col * ld + i];
-        if (i < C1) pd_store(gx1, ((size_t)b * C1 + i) * L + l0 + col, v);
-        else pd_store(gx2, ((size_t)b * (Cin - C1) + (i - C1)) * L + l0 + col, v);
+        const float v = acc[col * ld + r];
+        const int ch = ch0 + r;
+        if (ch < C1) pd_store(gx1, ((size_t)b * C1 + ch) * L + l0 + col, v);
+        else pd_store(gx2, ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col, v);
+    }
+}
+
+// ---- the same dgrad on the matrix cores (bf16 training path) -------------------------------------------------------------
+// g_x[:, tile] = W^T (320 x 384) . G (384 x 64 columns), G the tile of the never-built dense gradient: the workgroup zeroes a 48 KB
+// bf16 image of G^T in LDS, drops the tile's entries into it (in this model a (channel, column) pair occurs at most once -- node m's
+// arg-max of channel c -- so nothing depends on the order the bucket atomics took; repeated pairs add up in bf16) and runs the dense product: A =
+// the bf16 pack of W^T (the layer kernels' A-fragment order, streamed from L2 three chunks ahead), B = G^T rows from LDS.  The two
+// 32-column MFMA tiles of a wave are the even and the odd columns, so cvt_pk(acc_even, acc_odd) is the dword to store (as in
+// pointmlp_bf16.hip).  g and W are rounded to bf16 (the dense bf16 dgrad of the other layers does the same); products exact, f32
+// accumulate.  0.85 -> ... ms at 64 x 384 x 64 entries, 15000 columns (the scalar kernel above: sort 0.17 + W rows from L2 0.40 +
+// stores 0.18 + 0.10, profiles/r04w_pooled_dgrad_ablation.log).
+constexpr int PM_TL = 64;                      // columns per workgroup (two 32-column buckets)
+constexpr int PM_PITCH = 784;                  // bytes per G^T row: 384 channels x 2 + 16 (196 words = 4 mod 64 banks: 16-byte reads of 16 rows tile the banks)
+
+__device__ __forceinline__ unsigned pm_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int NMT>
+__global__ __launch_bounds__(128) void pooled_dgrad_mfma_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
+                                                                const float *__restrict__ ent_val, const uint4 *__restrict__ Wtp,
+                                                                int E, int M, int C, int KC, int C1, int C2, int L, int nbucket,
+                                                                uint16_t *__restrict__ gx1, uint16_t *__restrict__ gx2)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    extern __shared__ uint4 pm_lds[];            // Ge[32][PM_PITCH] | Go[32][PM_PITCH]: G^T of the even / odd columns, channels contiguous
+    unsigned char *Ge = reinterpret_cast<unsigned char *>(pm_lds), *Go = Ge + 32 * PM_PITCH;
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    for (int t = tid; t < 2 * 32 * PM_PITCH / 16; t += 128) pm_lds[t] = make_uint4(0u, 0u, 0u, 0u);
+    const int sb0 = tile * 2, sb1 = min(sb0 + 1, nbucket), sb2 = min(sb0 + 2, nbucket);
+    const int32_t *off = tile_off + (size_t)b * (nbucket + 1);
+    const int beg = off[sb0], mid = off[sb1], end = off[sb2];
+    // A fragments of the first chunks: on their way while the tile is built
+    const uint4 *wt = Wtp + ((size_t)(wave * NMT) * KC) * 64 + lane;
+    uint4 A[3][NMT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) A[s][mt] = wt[((size_t)mt * KC + min(s, KC - 1)) * 64];
+    __syncthreads();
+    for (int e = beg + tid; e < end; e += 128) {
+        const uint32_t key = ent_key[(size_t)b * E + e];
+        const int l = (int)(key >> 20) + (e >= mid ? 32 : 0), c = (int)(key & 0xFFFFFu) / M;
+        // (a compare-and-swap on the dword that holds the channel pair: two channels of a column share it, and a (channel, column) pair
+        //  that does occur twice -- not in this model -- adds up instead of being overwritten, in arrival order)
+        unsigned *wd = reinterpret_cast<unsigned *>(((l & 1) ? Go : Ge) + (l >> 1) * PM_PITCH + (c >> 1) * 4);
+        const int sh = (c & 1) * 16;
+        const float g = ent_val[(size_t)b * E + e];
+        unsigned old = *wd, assumed;
+        do {
+            assumed = old;
+            const float cur = __uint_as_float(((assumed >> sh) & 0xFFFFu) << 16);
+            const unsigned nb = pm_cvt_pk(cur + g, 0.f) & 0xFFFFu;
+            old = atomicCAS(wd, assumed, (assumed & ~(0xFFFFu << sh)) | (nb << sh));
+        } while (old != assumed);
+    }
+    __syncthreads();
+
+    f32x16 acc[NMT][2];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
+    const unsigned char *be = Ge + n * PM_PITCH + h * 16, *bo = Go + n * PM_PITCH + h * 16;
+#define PM_STEP(kc, s)                                                                                          \
+    if ((kc) < KC) {                                                                                            \
+        const int kn = min((kc) + 2, KC - 1);                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) A[((s) + 2) % 3][mt] = wt[((size_t)mt * KC + kn) * 64]; \
+        const bf16x8 Be = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(be + (kc) * 32));         \
+        const bf16x8 Bo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(bo + (kc) * 32));         \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) {                                                    \
+            const bf16x8 Av = __builtin_bit_cast(bf16x8, A[s][mt]);                                             \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av, Be, acc[mt][0], 0, 0, 0);                  \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av, Bo, acc[mt][1], 0, 0, 0);                  \
+        }                                                                                                       \
+    }
+    for (int kc = 0; kc < KC; kc += 3) {
+        PM_STEP(kc, 0)
+        PM_STEP(kc + 1, 1)
+        PM_STEP(kc + 2, 2)
+    }
+#undef PM_STEP
+
+    const int col = tile * PM_TL + 2 * n;                              // (L even: col + 1 is inside when col is)
+    if (col < L) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (wave * NMT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ci >= C1 + C2) continue;
+                const unsigned pk = pm_cvt_pk(acc[mt][0][r], acc[mt][1][r]);
+                uint16_t *dst = ci < C1 ? gx1 + ((size_t)b * C1 + ci) * L + col : gx2 + ((size_t)b * C2 + (ci - C1)) * L + col;
+                *reinterpret_cast<unsigned *>(dst) = pk;
+            }
+        }
     }
 }
 
@@ -879,8 +988,8 @@ __global__ __launch_bounds__(320) void pooled_dgrad_kernel(const int32_t *__rest
 extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
 {
     if (B <= 0 || C <= 0 || M <= 0 || L <= 0) return 0;
-    const size_t E = (size_t)C * M, ntile = (size_t)sonet::ceil_div(L, PD_TL);
-    return (size_t)B * (E * 8 + (ntile + 1) * 4);
+    const size_t E = (size_t)C * M, nbucket = (size_t)sonet::ceil_div(L, PD_SB);
+    return (size_t)B * (E * 8 + (nbucket + 1) * 4);
 }
 
 // Sparse wgrad of the pooled last layer: the gradient of first_pn_out exists only at the C*M gathered positions of a
@@ -990,18 +1099,19 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     SONET_REQUIRE(g_pooled && pos && W && ws && gx1, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
-    const int Cin = C1 + C2, E = C * M, ntile = sonet::ceil_div(L, PD_TL);
+    const int Cin = C1 + C2, E = C * M, ntile = sonet::ceil_div(L, PD_TL), nbucket = sonet::ceil_div(L, PD_SB);
     if ((long long)C * M >= (1 << 20) || B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C*M=%d entries per cloud (max 2^20)", what, E);
-    const size_t lds2 = ((size_t)PD_TL * (Cin + 1) + 3 * PD_SORT) * 4;
-    if (lds2 > 160 * 1024 || (size_t)(2 * ntile + 1) * 4 > 64 * 1024)
-        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cin=%d or L=%d too large for the LDS tile", what, Cin, L);
+    const size_t lds2 = ((size_t)PD_TL * (PD_CH + 1) + (size_t)PD_CQ * 4 * PD_SQ) * 4;
+    if ((size_t)(2 * nbucket + 1) * 4 > 64 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d too large for the bucket counters", what, L);
     uint32_t *ent_key = reinterpret_cast<uint32_t *>(ws);
     float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
     int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
     hipStream_t st = sonet::as_stream(stream);
-    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * ntile + 1) * 4, st, pos, g_pooled, E, L, ntile, tile_off, ent_key, ent_val);
-    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B), dim3(320), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1, L, ntile, gx1,
-                       gx2 ? gx2 : gx1);
+    int abl = 0;
+    if (const char *e = sonet::knob("SONET_PD_ABL")) abl = atoi(e);
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * nbucket + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
+    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1,
+                       L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);
 }
 
@@ -1016,6 +1126,41 @@ extern "C" int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *po
                                         int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream)
 {
     return pooled_dgrad_impl<uint16_t>("sonet_pooled_dgrad_obf16", g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream);
+}
+
+/* The same gradient on the matrix cores: wt_pack = sonet_pointmlp_bf16_pack of W^T ([C1 + C2][C], i.e. Cin = C, Cout = C1 + C2 padded
+ * to 32-row tiles); g and W rounded to bf16, f32 accumulate; L even, C a multiple of 16, (C1 + C2) / 32 tiles even and <= 12, C <= 384. */
+extern "C" int sonet_pooled_dgrad_mfma_bf16(const float *g_pooled, const int32_t *pos, const void *wt_pack, int B, int C, int M, int C1, int C2,
+                                            int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream)
+{
+    const char *what = "sonet_pooled_dgrad_mfma_bf16";
+    SONET_REQUIRE(g_pooled && pos && wt_pack && ws && gx1, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
+    const int Cin = C1 + C2, E = C * M, CT = sonet::ceil_div(Cin, 32), nbucket = sonet::ceil_div(L, PD_SB), ntile = sonet::ceil_div(L, PM_TL);
+    if ((L & 1) || C % 16 || C * 2 + 16 > PM_PITCH || (CT & 1) || CT > 12 || (long long)C * M >= (1 << 20) || B > 65535 ||
+        (size_t)(2 * nbucket + 1) * 4 > 64 * 1024 || ((reinterpret_cast<uintptr_t>(gx1) | reinterpret_cast<uintptr_t>(gx2)) & 3))
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: shape B=%d C=%d M=%d C1=%d C2=%d L=%d not supported", what, B, C, M, C1, C2, L);
+    uint32_t *ent_key = reinterpret_cast<uint32_t *>(ws);
+    float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
+    int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * nbucket + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
+    const size_t lds = (size_t)2 * 32 * PM_PITCH;
+    const uint4 *wtp = reinterpret_cast<const uint4 *>(wt_pack);
+    uint16_t *g2 = gx2 ? gx2 : gx1;
+#define PM_LAUNCH(NN) hipLaunchKernelGGL(pooled_dgrad_mfma_kernel<NN>, dim3(ntile, B), dim3(128), lds, st, tile_off, ent_key, ent_val, wtp, E, M, C, C / 16, \
+                                         C1, C2, L, nbucket, gx1, g2)
+    switch (CT / 2) {
+        case 1: PM_LAUNCH(1); break;
+        case 2: PM_LAUNCH(2); break;
+        case 3: PM_LAUNCH(3); break;
+        case 4: PM_LAUNCH(4); break;
+        case 5: PM_LAUNCH(5); break;
+        default: PM_LAUNCH(6); break;
+    }
+#undef PM_LAUNCH
+    return sonet::launched(what);
 }
 
 // ---- small-batch fully connected layer (classifier / decoder heads in eval mode) --------------------------------------

@@ -311,7 +311,14 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 # column 0 (left in the sparse kernel they would pile thousands of entries onto a single tile)
                 w = weight2d.detach().float().contiguous()
                 occ = row_max.unsqueeze(1) > 0
-                g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype)
+                wt_pack = None
+                if x1.dtype == torch.bfloat16 and _ops.pooled_dgrad_mfma_ok(w.shape[0], C1, C2, L):
+                    wt = w.t().contiguous()                                        # (C1 + C2) x C, rows padded to 32-row tiles
+                    if wt.shape[0] % 32:
+                        wt = torch.cat((wt, wt.new_zeros(32 - wt.shape[0] % 32, wt.shape[1])), dim=0)
+                    wt_pack = _ops.pointmlp_pack(wt, "bf16")
+                g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype,
+                                               wt_pack=wt_pack)
                 col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
                 g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
                 g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)

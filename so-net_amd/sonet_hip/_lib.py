@@ -104,6 +104,7 @@ SIGNATURES = {
     "sonet_pooled_wgrad_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "sonet_pooled_dgrad_obf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_pooled_dgrad_mfma_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],

@@ -1280,8 +1280,17 @@ def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     return out
 
 
-def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32):
-    """Sparse W^T . g for a gradient that exists only at the pooled positions: g_pooled, pos B x C x M -> (gx1 B x C1 x L, gx2 B x C2 x L)."""
+POOLED_DGRAD_MFMA = True        # bf16 outputs: the dense-tile product on the matrix cores (sonet_pooled_dgrad_mfma_bf16) when the shape allows
+
+
+def pooled_dgrad_mfma_ok(C, C1, C2, L):
+    ct = (C1 + C2 + 31) // 32
+    return POOLED_DGRAD_MFMA and L % 2 == 0 and C % 16 == 0 and C <= 384 and ct % 2 == 0 and ct <= 12
+
+
+def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32, wt_pack=None):
+    """Sparse W^T . g for a gradient that exists only at the pooled positions: g_pooled, pos B x C x M -> (gx1 B x C1 x L, gx2 B x C2 x L).
+    wt_pack (bf16 outputs only): pointmlp_pack(W^T, "bf16") -> the matrix-core kernel (g and W rounded to bf16)."""
     _chk(g_pooled, "g_pooled", torch.float32, 3)
     _chk(pos_i32, "pos", torch.int32, 3)
     _chk(weight2d, "weight", torch.float32, 2)
@@ -1291,6 +1300,13 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32
     ws = torch.empty((lib.sonet_pooled_dgrad_ws_size(B, C, M, int(L)),), dtype=torch.uint8, device=dev)
     gx1 = torch.empty((B, C1, int(L)), dtype=out_dtype, device=dev)
     gx2 = torch.empty((B, C2, int(L)), dtype=out_dtype, device=dev) if C2 else None
+    if wt_pack is not None and out_dtype == torch.bfloat16 and pooled_dgrad_mfma_ok(C, C1, C2, int(L)):
+        if wt_pack.dtype != torch.int16 or wt_pack.numel() != lib.sonet_pointmlp_bf16_pack_size(C, (C1 + C2 + 31) // 32 * 32) // 2:
+            raise SonetHipError("pooled_dgrad: wt_pack is not the bf16 pack of W^T")
+        with torch.cuda.device(dev), _timed("pooled_dgrad_mfma"):
+            check(lib.sonet_pooled_dgrad_mfma_bf16(ptr(g_pooled), ptr(pos_i32), ptr(wt_pack), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2),
+                                                   stream_ptr()), "sonet_pooled_dgrad_mfma_bf16")
+        return gx1, gx2
     fn = lib.sonet_pooled_dgrad_f32 if out_dtype == torch.float32 else lib.sonet_pooled_dgrad_obf16
     with torch.cuda.device(dev), _timed("pooled_dgrad"):
         check(fn(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2), stream_ptr()),

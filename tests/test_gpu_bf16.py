@@ -336,7 +336,7 @@ def test_classifier_training_step_bf16(fixture):
         loss.backward()
     names = set(n for n, _, _ in rec.records)
     assert any(n.startswith("pointmlpbf16") for n in names) and not any(n.startswith(("pointmlph3", "pointmlpx3")) for n in names), names
-    assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad", "pooled_wgrad",
+    assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad_mfma", "pooled_wgrad",
             "index_max_gather_bf16"} <= names, names
     # train-mode BatchNorm divides by batch statistics of bf16-rounded activations and the feature passes three max-pools whose
     # winners may change: bound the rms error (4e-2; measured 2.0e-2 at N=512, 3.1e-2 at N=5000) and the worst element

@@ -590,6 +590,48 @@ def test_pooled_dgrad_vs_dense():
         assert torch.equal(gx1b, gx1)                                      # deterministic
 
 
+@pytest.mark.parametrize("B,C,M,C1,C2,L", [(3, 384, 64, 64, 256, 3000), (2, 96, 8, 16, 48, 130), (2, 64, 16, 64, 0, 514), (64, 384, 64, 64, 256, 15000)])
+def test_pooled_dgrad_on_the_matrix_cores(B, C, M, C1, C2, L):
+    """sonet_pooled_dgrad_mfma_bf16 (the tile of the never-built gradient assembled in LDS, times W^T on bf16 MFMAs) against scatter_add +
+    dense matmul in float64 on the bf16-rounded operands: within bf16 output rounding; bit-identical run to run when the positions of a
+    (cloud, channel) row are distinct (the arg-max positions of different nodes are); a repeated (channel, column) pair adds up."""
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(B + C + L)
+    g = torch.randn(B, C, M, generator=gen)
+    pos = (torch.arange(M).view(1, 1, M) * (L // M) + torch.randint(0, L // M, (B, C, M), generator=gen)).to(torch.int32)
+    pos[:, 0, 2] = -1                                                  # ignored entry
+    W = torch.randn(C, C1 + C2, generator=gen) * 0.1
+    wt = W.t().contiguous()
+    if wt.shape[0] % 32:
+        wt = torch.cat((wt, wt.new_zeros(32 - wt.shape[0] % 32, C)), dim=0)
+    wtp = ops.pointmlp_pack(wt.to(DEV), "bf16")
+    assert ops.pooled_dgrad_mfma_ok(C, C1, C2, L)
+
+    def run(p):
+        gx1, gx2 = ops.pooled_dgrad(g.to(DEV), p.to(DEV), W.to(DEV), C1, C2, L, out_dtype=torch.bfloat16, wt_pack=wtp)
+        return torch.cat([gx1] + ([gx2] if C2 else []), dim=1)
+
+    def ref(p):
+        dev = DEV if B * C * L > 5e7 else "cpu"
+        gb, Wb = g.to(torch.bfloat16).double().to(dev), W.to(torch.bfloat16).double().to(dev)
+        out = []
+        for b0 in range(0, B, 8):                                       # float64 on the GPU in slices (the benchmark shape)
+            pp = p[b0:b0 + 8].to(dev)
+            G = torch.zeros(pp.shape[0], C, L + 1, dtype=torch.float64, device=dev).scatter_add_(2, torch.where(pp < 0, L, pp).long(), gb[b0:b0 + 8])[:, :, :L]
+            out.append(torch.matmul(Wb.t().unsqueeze(0), G).cpu())
+        return torch.cat(out, dim=0)
+
+    got, want = run(pos), ref(pos)
+    err = (got.cpu().double() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -8 + 1e-6 * float(want.abs().max())).all()), float(err.max())
+    assert torch.equal(run(pos), got)
+    if B <= 3:
+        dup = pos.clone()
+        dup[:, : C // 4, 1] = dup[:, : C // 4, 0]                        # the same (channel, column) twice: the two gradients add (bf16 sum)
+        got, want = run(dup), ref(dup)
+        assert float((got.cpu().double() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("node_num,sn,k,N", [(16, True, 3, 700), (64, False, 3, 900), (36, True, 2, 333), (16, False, 1, 257)])
 def test_encoder_other_configs_fast_path_vs_exact_path(node_num, sn, k, N):
     """Configurations the reference fixtures do not cover (other SOM sizes, no surface normals, other k): the default

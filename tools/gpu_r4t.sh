@@ -1,6 +1,5 @@
 #!/bin/bash
-# bf16 streaming layer kernel after the statistics-epilogue change; tests; the bf16 training step
-python tools/bench_bf16_layers.py 2>&1 | grep -v amdgpu | head -9
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "pooled" 2>&1 | tail -3
 timeout 900 python -m pytest tests/test_gpu_bf16.py -x -q 2>&1 | tail -3
 python bench.py --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
