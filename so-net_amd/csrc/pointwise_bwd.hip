@@ -1002,64 +1002,67 @@ extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
 constexpr int PW_R = 2;                                      // x rows resident in LDS at a time
 constexpr int PW_G = 8;                                      // row pairs per workgroup (the entries are loaded once for all of them)
 constexpr int PW_M = 64;                                     // entries per output channel kept in registers (M <= PW_M)
+constexpr int PW_T = 768;                                    // threads: two per output channel (C <= 384), each with half of the M entries
 template <typename TX>
-__global__ __launch_bounds__(384) void pooled_wgrad_kernel(const float *__restrict__ g, const int32_t *__restrict__ pos,
+__global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restrict__ g, const int32_t *__restrict__ pos,
                                                             const TX *__restrict__ x, int C, int M, int Ci, int L,
                                                             float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float rows[];           // [PW_R][L]
+    // rows in the storage type: bf16 rows stay bf16 in LDS (widened on the read) -- 60 KB per pair of 15000-column rows instead of 120,
+    // so two workgroups share a CU and one multiplies while the other loads (round 3 widened on the way in: one workgroup per CU,
+    // load -> barrier -> multiply -> barrier in sequence).  The multiply is instruction-bound (an LDS read and an fma per entry and
+    // row): two threads per channel, 32 entries each, the halves meet in LDS (a + b: one order).
+    extern __shared__ __attribute__((aligned(16))) unsigned char rows_raw[];           // [PW_R][L] of TX | comb[PW_T / 2][PW_R] f32
+    TX *rows = reinterpret_cast<TX *>(rows_raw);
+    float *comb = reinterpret_cast<float *>(rows_raw + (((size_t)PW_R * L * sizeof(TX) + 15) & ~(size_t)15));
     const int b = blockIdx.y;
-    const int c = threadIdx.x;                                            // C <= blockDim.x (checked by the launcher)
-    // this thread's M entries: L2 latency was the whole cost when they were re-read for every row pair
-    float gv[PW_M];
-    int pv[PW_M];
+    const int c = threadIdx.x % (PW_T / 2), half = threadIdx.x / (PW_T / 2);   // C <= PW_T / 2 (checked by the launcher)
+    constexpr int MH = PW_M / 2;
+    float gv[MH];
+    int pv[MH];
 #pragma unroll
-    for (int m = 0; m < PW_M; ++m) {
-        const bool ok = m < M && c < C;
-        gv[m] = ok ? g[((size_t)b * M + m) * C + c] : 0.f;
-        const int p = ok ? pos[((size_t)b * M + m) * C + c] : -1;
+    for (int m = 0; m < MH; ++m) {
+        const int mm = half * MH + m;
+        const bool ok = mm < M && c < C;
+        gv[m] = ok ? g[((size_t)b * M + mm) * C + c] : 0.f;
+        const int p = ok ? pos[((size_t)b * M + mm) * C + c] : -1;
         pv[m] = (unsigned)p < (unsigned)L ? p : -1;
     }
+    auto widen = [](TX v) -> float {
+        if constexpr (sizeof(TX) == 4) return v;
+        else return __uint_as_float((unsigned)v << 16);
+    };
     for (int gi = 0; gi < PW_G; ++gi) {
         const int ci0 = (blockIdx.x * PW_G + gi) * PW_R;
         if (ci0 >= Ci) break;
         const int nr = min(PW_R, Ci - ci0);
         const TX *xb = x + ((size_t)b * Ci + ci0) * L;
         __syncthreads();                                                  // the previous pair has been consumed
-        if constexpr (sizeof(TX) == 4) {
-            if ((L & 3) == 0 && ((size_t)xb & 15) == 0) {
-                const float4 *x4 = reinterpret_cast<const float4 *>(xb);
-                float4 *r4 = reinterpret_cast<float4 *>(rows);
-                for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) r4[i] = x4[i];
-            } else {
-                for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = (float)xb[i];
-            }
-        } else {                                                          // bfloat16 rows: widened on the way into LDS
-            if ((L & 3) == 0 && ((size_t)xb & 7) == 0) {
-                const uint2 *x2 = reinterpret_cast<const uint2 *>(xb);
-                float4 *r4 = reinterpret_cast<float4 *>(rows);
-                for (int i = threadIdx.x; i < nr * (L >> 2); i += blockDim.x) {
-                    const uint2 d = x2[i];
-                    r4[i] = make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xFFFF0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xFFFF0000u));
-                }
-            } else {
-                for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = __uint_as_float((unsigned)xb[i] << 16);
-            }
+        const size_t nbytes = (size_t)nr * L * sizeof(TX);
+        if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
+            const uint4 *x4 = reinterpret_cast<const uint4 *>(xb);
+            uint4 *r4 = reinterpret_cast<uint4 *>(rows);
+            for (int i = threadIdx.x; i < (int)(nbytes >> 4); i += blockDim.x) r4[i] = x4[i];
+        } else {
+            for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = xb[i];
         }
         __syncthreads();
+        float acc[PW_R];
+#pragma unroll
+        for (int r = 0; r < PW_R; ++r) acc[r] = 0.f;
         if (c < C) {
-            float acc[PW_R];
 #pragma unroll
-            for (int r = 0; r < PW_R; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < PW_M; ++m) {
+            for (int m = 0; m < MH; ++m) {
                 if (pv[m] >= 0) {
-                    acc[0] = __fmaf_rn(gv[m], rows[pv[m]], acc[0]);
-                    if (nr > 1) acc[1] = __fmaf_rn(gv[m], rows[L + pv[m]], acc[1]);
+                    acc[0] = __fmaf_rn(gv[m], widen(rows[pv[m]]), acc[0]);
+                    if (nr > 1) acc[1] = __fmaf_rn(gv[m], widen(rows[L + pv[m]]), acc[1]);
                 }
             }
-            for (int r = 0; r < nr; ++r) out[((size_t)b * C + c) * Ci + ci0 + r] = acc[r];
+            if (half == 1) { comb[c * PW_R] = acc[0]; comb[c * PW_R + 1] = acc[1]; }
         }
+        __syncthreads();
+        if (c < C && half == 0)
+            for (int r = 0; r < nr; ++r) out[((size_t)b * C + c) * Ci + ci0 + r] = acc[r] + comb[c * PW_R + r];
     }
 }
 
@@ -1070,11 +1073,11 @@ static int pooled_wgrad_impl(const char *what, const float *g_pooled, const int3
     SONET_REQUIRE(g_pooled && pos && x && gw_partial, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && Ci > 0 && L > 0 && B <= 65535, "%s: bad size B=%d C=%d M=%d Ci=%d L=%d", what, B, C, M, Ci, L);
     if (C > 384 || M > PW_M) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d > 384 or M=%d > %d", what, C, M, PW_M);
-    const size_t lds = (size_t)PW_R * L * sizeof(float);
+    const size_t lds = (((size_t)PW_R * L * sizeof(TX) + 15) & ~(size_t)15) + (size_t)(PW_T / 2) * PW_R * sizeof(float);
     if (lds > 152 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d rows do not fit LDS", what, L);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel<TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
-    hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(384), lds, sonet::as_stream(stream),
+    hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(PW_T), lds, sonet::as_stream(stream),
                        g_pooled, pos, x, C, M, Ci, L, gw_partial);
     return sonet::launched(what);
 }

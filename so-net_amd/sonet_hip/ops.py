@@ -1280,7 +1280,7 @@ def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     return out
 
 
-POOLED_DGRAD_MFMA = True        # bf16 outputs: the dense-tile product on the matrix cores (sonet_pooled_dgrad_mfma_bf16) when the shape allows
+POOLED_DGRAD_MFMA = _os.environ.get("SONET_POOLED_DGRAD_MFMA", "1") != "0"        # bf16 outputs: the dense-tile product on the matrix cores (sonet_pooled_dgrad_mfma_bf16) when the shape allows
 
 
 def pooled_dgrad_mfma_ok(C, C1, C2, L):
