@@ -300,6 +300,132 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16_kernel(
         }
 }
 
+// ---- bf16 wgrad, streaming generation: both operands through an LDS ring filled by LDS-DMA ------------------------------------------
+// The kernel above hands every lane 16-byte pieces of ITS row: a load instruction touches 32 rows x 32 bytes (2.8 TB/s on the
+// point-level shapes; hipBLASLt reaches 3.1-3.9 there).  Here a persistent workgroup (one per CU) owns a (GT x 128) x 128 block of dw
+// and a slice of the 64-column units; a unit's g rows and x rows -- (GT x 128 + 128) rows x 128 bytes -- go straight from memory
+// into one of three LDS slots (global_load_lds_dwordx4: eight lanes per row, i.e. whole 128-byte row segments per request, no VGPRs),
+// two units ahead of the MFMAs; every element is loaded once per workgroup.  16-byte piece q of row r sits at slot position
+// q ^ (r & 7) (the DMA writes lanes linearly: the lane fetches the piece that belongs at its position), so that the 16-byte fragment
+// reads of 32 rows spread over the banks.  Rows past Cout / Cin and columns past L are fetched from a zeroed 16 bytes.  One barrier
+// per unit: "my DMAs of this unit have landed" (s_waitcnt vmcnt(N_DMA): the next unit's may be in flight) + barrier = everyone's
+// have, and everyone has finished the previous unit, whose slot the next request then overwrites.  f32 partial blocks per slice,
+// summed by wgrad_reduce_kernel in a fixed order.
+constexpr int WS_UNIT = 64;
+template <int GT>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16s_kernel(const uint16_t *__restrict__ g, const uint16_t *__restrict__ x,
+                                                             const uint4 *__restrict__ zero16, float *__restrict__ partial,
+                                                             int Cout, int Cin, int L, int nL, long long units, int nsplit, int oblocks, int cblocks)
+{
+    constexpr int OBR = GT * 128, ROWS = OBR + 128, NDMA = ROWS / 32;   // DMA requests per wave and unit (64 lanes x 16 bytes = 8 rows each)
+    extern __shared__ uint4 ws_ring[];                                   // [3][ROWS][8] 16-byte pieces
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int nblk = oblocks * cblocks;
+    const int blk = blockIdx.x % nblk, sp = blockIdx.x / nblk;
+    const int ob = blk / cblocks, cb = blk - ob * cblocks;
+    const long long u0 = units * sp / nsplit, u1 = units * (sp + 1) / nsplit;
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(ws_ring);
+    const int nxt = min(4, (Cin - cb * 128 + 31) >> 5);                  // x tiles that exist
+    const bool g_any = ob * OBR + wave * GT * 32 < Cout;
+
+    f32x16 acc[GT][4];
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt)
+#pragma unroll
+        for (int xt = 0; xt < 4; ++xt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[gt][xt][r] = 0.f;
+
+    auto dma = [&](long long u, int slot) {
+        const int b = (int)(u / nL);
+        const int l0 = (int)(u - (long long)b * nL) * WS_UNIT;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int pos = (wave * NDMA + j) * 64 + lane;                // 16-byte position in the slot
+            const int row = pos >> 3, q = (pos & 7) ^ (row & 7);         // the piece that belongs there
+            const int col = l0 + 8 * q;
+            const uint16_t *src;
+            bool ok;
+            if (row < OBR) {
+                const int o = ob * OBR + row;
+                ok = o < Cout && col < L;
+                src = g + ((size_t)b * Cout + (ok ? o : 0)) * L + (ok ? col : 0);
+            } else {
+                const int c = cb * 128 + row - OBR;
+                ok = c < Cin && col < L;
+                src = x + ((size_t)b * Cin + (ok ? c : 0)) * L + (ok ? col : 0);
+            }
+            const void *addr = ok ? static_cast<const void *>(src) : static_cast<const void *>(zero16);
+            const unsigned d = lds0 + (unsigned)slot * (unsigned)(ROWS * 128) + (unsigned)(wave * NDMA + j) * 1024u;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(addr), "s"(d) : "memory");
+        }
+    };
+
+    if (u0 < u1) {
+        dma(u0, 0);
+        dma(u0 + 1 < u1 ? u0 + 1 : u1 - 1, 1);
+        int slot = 0;
+        for (long long u = u0; u < u1; ++u) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDMA) : "memory");
+            dma(u + 2 < u1 ? u + 2 : u1 - 1, slot >= 1 ? slot - 1 : 2);         // (slot + 2) % 3: the slot of unit u - 1
+            const unsigned char *sl = reinterpret_cast<const unsigned char *>(ws_ring) + (size_t)slot * (ROWS * 128);
+            if (g_any) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int pq = ((2 * ks + h) ^ (m & 7)) << 4;
+                    bf16x8 A[GT];
+#pragma unroll
+                    for (int gt = 0; gt < GT; ++gt)
+                        A[gt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sl + ((wave * GT + gt) * 32 + m) * 128 + pq));
+#pragma unroll
+                    for (int xt = 0; xt < 4; ++xt) {
+                        if (xt < nxt) {
+                            const bf16x8 Bx = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sl + (OBR + xt * 32 + m) * 128 + pq));
+#pragma unroll
+                            for (int gt = 0; gt < GT; ++gt)
+                                acc[gt][xt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[gt], Bx, acc[gt][xt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int Cpad = cblocks * 128;
+    const size_t Opad = (size_t)oblocks * OBR;
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt)
+#pragma unroll
+        for (int xt = 0; xt < 4; ++xt) {
+            float *pp = partial + ((size_t)sp * Opad + (size_t)ob * OBR + (wave * GT + gt) * 32) * Cpad + cb * 128 + xt * 32 + m;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * Cpad] = acc[gt][xt][r];
+        }
+}
+
+struct WsPlan { int gt, oblocks, cblocks, nL, nsplit; long long units; size_t part_bytes; };
+static WsPlan ws_plan(int B, int Cout, int Cin, int L)
+{
+    WsPlan p;
+    p.gt = Cout > 128 ? 2 : 1;
+    p.oblocks = sonet::ceil_div(Cout, p.gt * 128);
+    p.cblocks = sonet::ceil_div(Cin, 128);
+    p.nL = sonet::ceil_div(L, WS_UNIT);
+    p.units = (long long)B * p.nL;
+    const int nblk = p.oblocks * p.cblocks;
+    long long ns = 256 / nblk;                                  // one workgroup per CU (144 KiB of LDS)
+    if (ns > p.units / 4) ns = p.units / 4;
+    if (ns < 1) ns = 1;
+    p.nsplit = (int)ns;
+    p.part_bytes = (size_t)p.nsplit * p.oblocks * p.gt * 128 * p.cblocks * 128 * sizeof(float);
+    return p;
+}
+
 // dw[o][c] = sum over the column slices, in a fixed order: thread (element e, kq) adds slices kq, kq + 4, ... with four independent
 // chains, the four quarters meet in LDS -- 64 elements per workgroup (a 64 x 6 gradient summed over 1024 slices is 384 elements:
 // one thread per element walking all slices took 270 us of dependent loads).
@@ -379,7 +505,8 @@ extern "C" int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, voi
 extern "C" size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L)
 {
     if (B <= 0 || Cout <= 0 || Cin <= 0 || L <= 0) return 0;
-    return wg_plan(B, Cout, Cin, L, WB_UNIT).ws_bytes;
+    const size_t a = wg_plan(B, Cout, Cin, L, WB_UNIT).ws_bytes, b = 256 + ws_plan(B, Cout, Cin, L).part_bytes;
+    return a > b ? a : b;
 }
 
 extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
@@ -389,10 +516,35 @@ extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw,
     SONET_REQUIRE(B > 0 && Cout > 0 && Cin > 0 && L > 0, "%s: non-positive size", what);
     if ((double)Cout * L * 2.0 >= 8.0e9 || (double)Cin * L * 2.0 >= 8.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
     if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return sonet::fail(SONET_ERR_INVALID_ARG, "%s: g and x must be 16-byte aligned", what);
+    hipStream_t st = sonet::as_stream(stream);
+    {
+        // long reductions with 16-byte aligned 8-column groups: the streaming generation (both operands through the LDS-DMA ring)
+        bool want = (L & 7) == 0 && (long long)B * sonet::ceil_div(L, WS_UNIT) >= 2048;
+        if (const char *e = sonet::knob("SONET_WGRAD_BF16_STREAM")) want = want && atoi(e) != 0;
+        if (want) {
+            const WsPlan q = ws_plan(B, Cout, Cin, L);
+            if (hipMemsetAsync(ws, 0, 256, st) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
+            const uint4 *zero16 = reinterpret_cast<const uint4 *>(ws);
+            float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + 256);
+            const size_t lds = (size_t)3 * (q.gt * 128 + 128) * 128;
+            const dim3 grid((unsigned)(q.oblocks * q.cblocks * q.nsplit)), block(256);
+#define WS_LAUNCH(GG) do { static bool attr_set = false;                                                                              \
+                if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16s_kernel<GG>),                    \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)       \
+                                     return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
+                                 attr_set = true; }                                                                                   \
+                hipLaunchKernelGGL(wgrad_bf16s_kernel<GG>, grid, block, lds, st, g, x, zero16, part, Cout, Cin, L, q.nL, q.units, q.nsplit, q.oblocks, q.cblocks); } while (0)
+            if (q.gt == 2) WS_LAUNCH(2); else WS_LAUNCH(1);
+#undef WS_LAUNCH
+            const long long n = (long long)Cout * Cin;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, part, dw,
+                               Cout, Cin, q.nsplit, (size_t)q.oblocks * q.gt * 128, q.cblocks * 128);
+            return sonet::launched(what);
+        }
+    }
     const WgPlan p = wg_plan(B, Cout, Cin, L, WB_UNIT);
     const long long nwg = (long long)p.oblocks * p.cblocks * p.nsplit;
     if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
-    hipStream_t st = sonet::as_stream(stream);
     if (Cout % WG_BLK == 0 && Cin % WG_BLK == 0)
         hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
                            Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);

@@ -133,8 +133,13 @@ def _wgrad(g_raw, x):
                 and g_raw.shape[1] * x.shape[1] >= 256 * 128 and g_raw.shape[2] % 8 == 0):
             # node-level layers (64 columns per cloud, wide outputs): sonet_wgrad_bf16 -- one bf16 MFMA per product, f32 partial blocks,
             # fixed-order reduction -- 28 / 35 us against 73 / 79 us for the batched library GEMM + sum at 768x515 / 1024x768
-            # (tools/bench_wgrad_bf16.py).  On the point-level shapes (15000 columns per cloud) its 32-byte row segments reach 2.9 TB/s
-            # against the library's 4.1: those stay on hipBLASLt.
+            # (tools/bench_wgrad_bf16.py).
+            return _ops.wgrad_bf16(g_raw.contiguous(), x.contiguous())
+        if (_ops.WGRAD_KERNEL and g_raw.is_cuda and x.dtype == torch.bfloat16 and g_raw.shape[2] % 8 == 0
+                and g_raw.shape[0] * ((g_raw.shape[2] + 63) // 64) >= 2048 and g_raw.shape[1] + x.shape[1] >= 192):
+            # point-level layers (15000 columns per cloud): the streaming generation of sonet_wgrad_bf16 (both operands through an LDS-DMA
+            # ring, whole 128-byte row segments per request): 95 / 192 us on 128x64 / 256x128 = the library's 96 / 190 (the first
+            # generation: 128 / 260); the 64x6 gradient (70 rows in a 256-row ring slot: 80 vs 34 us) stays on hipBLASLt
             return _ops.wgrad_bf16(g_raw.contiguous(), x.contiguous())
         xt = x.transpose(1, 2)
         try:

@@ -487,7 +487,9 @@ def test_autoencoder_forward_bf16(case="autoencoder_b2_n1024"):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Cout,Cin,L", [(3, 256, 128, 1504), (2, 64, 6, 776), (4, 128, 64, 64), (1, 512, 387, 1000), (2, 1024, 768, 136),
-                                          (2, 384, 320, 3000), (3, 40, 17, 777), (1, 32, 32, 8)])
+                                          (2, 384, 320, 3000), (3, 40, 17, 777), (1, 32, 32, 8),
+                                          # >= 2048 units of 64 columns and L % 8 == 0: the streaming generation (LDS-DMA ring); partial row / column blocks, a short last unit
+                                          (16, 256, 128, 15000), (64, 128, 64, 2048), (40, 64, 6, 5000), (36, 512, 387, 4000), (33, 100, 200, 4104)])
 def test_wgrad_bf16_vs_float64(B, Cout, Cin, L):
     """sonet_wgrad_bf16 (one bf16 MFMA per product, f32 accumulation) == sum_b g[b] x[b]^T in float64 on the SAME bf16 operands, to f32
     rounding of the partial sums; ragged shapes (partial tiles, L not a multiple of 8 -> element-wise loads, short last unit)."""
