@@ -49,12 +49,19 @@ __global__ __launch_bounds__(256) void lastdim_max_bwd_kernel(const T *__restric
 __global__ __launch_bounds__(1024) void knn_inverse_kernel(const long long *__restrict__ knn_I, int M, int K, int32_t *__restrict__ off, int32_t *__restrict__ list)
 {
     __shared__ int cnt[1025];
+    extern __shared__ int Is[];                  // the cloud's E indices (out of range: -1).  Every thread walks all of them twice: straight
+                                                 // from global memory that was 1152 dependent loads per thread, 87 us of the training step
     const int b = blockIdx.x, m = threadIdx.x;
     const long long *I = knn_I + (long long)b * M * K;
     const int E = M * K;
+    for (int e = m; e < E; e += blockDim.x) {
+        const long long i = I[e];
+        Is[e] = (i >= 0 && i < M) ? (int)i : -1;
+    }
+    __syncthreads();
     int n = 0;
     if (m < M)
-        for (int e = 0; e < E; ++e) n += (I[e] == (long long)m);
+        for (int e = 0; e < E; ++e) n += (Is[e] == m);
     cnt[m] = m < M ? n : 0;
     __syncthreads();
     if (m == 0) {
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(1024) void knn_inverse_kernel(const long long *__re
         int w = cnt[m];
         int32_t *L = list + (long long)b * E;
         for (int e = 0; e < E; ++e)
-            if (I[e] == (long long)m) L[w++] = e;
+            if (Is[e] == m) L[w++] = e;
     }
 }
 
@@ -144,7 +151,8 @@ static int gather_bwd_impl(const char *what, const T *g, const int64_t *knn_I, f
     if (M > 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M=%d > 1024", what, M);
     int32_t *off = reinterpret_cast<int32_t *>(ws), *list = off + (size_t)B * (M + 1);
     hipStream_t s = sonet::as_stream(stream);
-    hipLaunchKernelGGL(knn_inverse_kernel, dim3((unsigned)B), dim3(1024), 0, s, reinterpret_cast<const long long *>(knn_I), M, K, off, list);
+    if ((size_t)M * K * 4 > 56 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: M*K=%d indices do not fit the LDS", what, M * K);
+    hipLaunchKernelGGL(knn_inverse_kernel, dim3((unsigned)B), dim3(1024), (size_t)M * K * 4, s, reinterpret_cast<const long long *>(knn_I), M, K, off, list);
     const long long total = (long long)B * C * M;
     hipLaunchKernelGGL(knn_gather_bwd_kernel<T>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, s, g, off, list, gx, C, M, K, total);
     return sonet::launched(what);

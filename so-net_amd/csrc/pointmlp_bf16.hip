@@ -838,7 +838,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         for (int ns = 1; want && ns <= CT / 2; ++ns) {
             if (CT % ns) continue;
             const int tps = CT / ns;
-            if (tps % 2 || tps * KC > 144) continue;
+            if (tps % 2 || (size_t)tps * KC * 1024 + (size_t)tps * 256 + (stats_ws ? (size_t)tps * 2048 : 0) > 158 * 1024) continue;   // W slab + affine + statistics rows
             const int cost = ns * (tps / (tps % 4 == 0 ? 4 : 2));            // times X goes through the vector memory path
             if (cost < best_cost) { best_cost = cost; best_ns = ns; }
         }

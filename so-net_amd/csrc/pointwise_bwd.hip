@@ -747,7 +747,22 @@ __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__re
         if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_SB], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (ntile <= 1024) {
+        // exclusive scan of the bucket counts by the whole workgroup (Hillis-Steele in LDS: 10 steps; one thread walking 469 buckets
+        // with an LDS round trip each was a fifth of the kernel)
+        const int t = threadIdx.x;
+        const int mine = t < ntile ? cnt[t] : 0;
+        if (t < ntile) off[t + 1] = mine;
+        if (t == 0) off[0] = 0;
+        __syncthreads();
+        for (int d = 1; d < ntile; d <<= 1) {
+            const int v = (t < ntile && t >= d) ? off[t + 1 - d] : 0;
+            __syncthreads();
+            if (t < ntile) off[t + 1] += v;
+            __syncthreads();
+        }
+        if (t < ntile) cnt[t] = 0;
+    } else if (threadIdx.x == 0) {
         int acc = 0;
         for (int t = 0; t < ntile; ++t) { off[t] = acc; acc += cnt[t]; cnt[t] = 0; }
         off[ntile] = acc;
