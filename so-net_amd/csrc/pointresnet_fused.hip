@@ -231,9 +231,12 @@ __global__ __launch_bounds__(256) void pointresnet_pack_kernel(const float *__re
                 v[z] = c < Cin ? W[(long long)(ct * 32 + i) * Cin + c] : 0.f;
             }
             range_track(wr, 32.f * v[0], 32.f * v[1]);              // (logged as 32 |w|: the fp16 range applies to that)
-            // A-side slices: 0 = fp16(32 w) = 32 wh (terms h and m), 1 = fp16(32 (w - wh)) = fp16(32 w - 32 wh) (term l)
-            const unsigned hh = cvt_pk_f16(32.f * v[0], 32.f * v[1]);
-            const unsigned ll = cvt_pk_f16(32.f * v[0] - f16_lo(hh), 32.f * v[1] - f16_hi(hh));
+            // A-side slices: 0 = fp16(32 w) = 32 wh (terms h and m), 1 = fp16(32 (w - wh)) = fp16(32 w - 32 wh) (term l).  |w| > 2047 is
+            // clamped (a finite, wrong product instead of inf - inf = NaN in the residual); the range log above has the true value
+            const float w0 = v[0] != v[0] ? v[0] : __builtin_fminf(__builtin_fmaxf(32.f * v[0], -F16_MAX32), F16_MAX32);     // (NaN stays NaN)
+            const float w1 = v[1] != v[1] ? v[1] : __builtin_fminf(__builtin_fmaxf(32.f * v[1], -F16_MAX32), F16_MAX32);
+            const unsigned hh = cvt_pk_f16(w0, w1);
+            const unsigned ll = cvt_pk_f16(w0 - f16_lo(hh), w1 - f16_hi(hh));
             w[p] = term == 0 ? hh : ll;
         }
     }
