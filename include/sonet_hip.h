@@ -398,7 +398,9 @@ size_t sonet_wgrad_x3_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
 /* bf16 twin (BASELINE configs[1] "bf16"): g [B][Cout][L], x [B][Cin][L] as bfloat16 bit patterns (16-byte aligned), one bf16 MFMA per
  * product, f32 accumulation, f32 partial blocks over the same column slices, the same fixed-order reduction -> dw [Cout][Cin] f32.
- * Replaces torch.bmm(g, x^T, out_dtype=f32).sum(0) (hipBLASLt) in the bf16 training step.  ws: sonet_wgrad_bf16_ws_size bytes. */
+ * Replaces torch.bmm(g, x^T, out_dtype=f32).sum(0) (hipBLASLt) in the bf16 training step.  ws: sonet_wgrad_bf16_ws_size bytes.
+ * Long reductions (L % 8 == 0, >= 2048 units of 64 columns in the batch) take the streaming generation: both operands through an
+ * LDS-DMA ring, one workgroup per CU, (128 or 256) x 128 blocks of dw, partial blocks per column slice summed in a fixed order. */
 size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
 

@@ -739,48 +739,73 @@ constexpr int PD_SB = PD_TL / PD_CQ;           // ... = one 32-column bucket of 
 constexpr int PD_WB = 16;                      // W rows requested before the first fma (64 -- a whole bucket in one round trip -- measured slower)
 constexpr int PD_SQ = 128;                     // entries per group sorted in LDS at a time (more: further rounds, still in global rank order)
 
+constexpr int PB_Q = 4;                        // workgroups per cloud: each owns a quarter of the bucket range (one per cloud left 3/4 of the chip idle)
 __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g,
                                                             int E, int L, int ntile, int32_t *__restrict__ tile_off,
                                                             uint32_t *__restrict__ ent_key, float *__restrict__ ent_val)
 {
-    extern __shared__ int sm_i[];                // cnt[ntile] | off[ntile + 1]
-    int *cnt = sm_i, *off = sm_i + ntile;
-    const int b = blockIdx.x;
+    extern __shared__ int sm_i[];                // cnt[nbq] | off[nbq + 1]   (nbq = buckets per workgroup)
+    __shared__ int qtot[PB_Q];
+    const int nbq = (ntile + PB_Q - 1) / PB_Q;
+    int *cnt = sm_i, *off = sm_i + nbq;
+    const int b = blockIdx.x, q = blockIdx.y;
+    const int t0 = q * nbq, nb = max(0, min(ntile, t0 + nbq) - t0);              // this workgroup's buckets [t0, t0 + nb)
     const int32_t *pb = pos + (size_t)b * E;
-    for (int t = threadIdx.x; t < ntile; t += 1024) cnt[t] = 0;
+    for (int t = threadIdx.x; t < nbq; t += 1024) cnt[t] = 0;
+    if (threadIdx.x < PB_Q) qtot[threadIdx.x] = 0;
     __syncthreads();
+    // pass 1: counts of the own buckets; entries per quarter (every workgroup counts all four: its base offset is the sum of the
+    // quarters before it -- no exchange between workgroups), a thread's four counts meet in its wave first
+    int mine[PB_Q];
+#pragma unroll
+    for (int k = 0; k < PB_Q; ++k) mine[k] = 0;
     for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
-        if ((unsigned)l < (unsigned)L) atomicAdd(&cnt[l / PD_SB], 1);
+        if ((unsigned)l >= (unsigned)L) continue;
+        const int t = l / PD_SB, qq = t / nbq;
+#pragma unroll
+        for (int k = 0; k < PB_Q; ++k) mine[k] += (qq == k);
+        if (qq == q) atomicAdd(&cnt[t - t0], 1);
+    }
+#pragma unroll
+    for (int k = 0; k < PB_Q; ++k) {
+        int v = mine[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&qtot[k], v);
     }
     __syncthreads();
-    if (ntile <= 1024) {
-        // exclusive scan of the bucket counts by the whole workgroup (Hillis-Steele in LDS: 10 steps; one thread walking 469 buckets
-        // with an LDS round trip each was a fifth of the kernel)
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < PB_Q; ++k) base += k < q ? qtot[k] : 0;
+    if (nb <= 1024) {
+        // exclusive scan of the bucket counts by the whole workgroup (Hillis-Steele in LDS; one thread walking the buckets with an LDS
+        // round trip each was a fifth of the kernel)
         const int t = threadIdx.x;
-        const int mine = t < ntile ? cnt[t] : 0;
-        if (t < ntile) off[t + 1] = mine;
+        if (t < nb) off[t + 1] = cnt[t];
         if (t == 0) off[0] = 0;
         __syncthreads();
-        for (int d = 1; d < ntile; d <<= 1) {
-            const int v = (t < ntile && t >= d) ? off[t + 1 - d] : 0;
+        for (int d = 1; d < nb; d <<= 1) {
+            const int v = (t < nb && t >= d) ? off[t + 1 - d] : 0;
             __syncthreads();
-            if (t < ntile) off[t + 1] += v;
+            if (t < nb) off[t + 1] += v;
             __syncthreads();
         }
-        if (t < ntile) cnt[t] = 0;
+        if (t < nb) cnt[t] = 0;
     } else if (threadIdx.x == 0) {
         int acc = 0;
-        for (int t = 0; t < ntile; ++t) { off[t] = acc; acc += cnt[t]; cnt[t] = 0; }
-        off[ntile] = acc;
+        for (int t = 0; t < nb; ++t) { off[t] = acc; acc += cnt[t]; cnt[t] = 0; }
+        off[nb] = acc;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t <= ntile; t += 1024) tile_off[(size_t)b * (ntile + 1) + t] = off[t];
+    for (int t = threadIdx.x; t < nb; t += 1024) tile_off[(size_t)b * (ntile + 1) + t0 + t] = base + off[t];
+    if (threadIdx.x == 0 && t0 + nb == ntile && nb > 0) tile_off[(size_t)b * (ntile + 1) + ntile] = base + off[nb];
     for (int e = threadIdx.x; e < E; e += 1024) {
         const int l = pb[e];
         if ((unsigned)l >= (unsigned)L) continue;
         const int t = l / PD_SB;
-        const int p = off[t] + atomicAdd(&cnt[t], 1);
+        if (t < t0 || t >= t0 + nb) continue;
+        const int p = base + off[t - t0] + atomicAdd(&cnt[t - t0], 1);
         // sort key (column, entry id); entry id = c * M + m, the consumer recovers the channel as id / M
         ent_key[(size_t)b * E + p] = ((uint32_t)(l - t * PD_SB) << 20) | (uint32_t)e;
         ent_val[(size_t)b * E + p] = g[(size_t)b * E + e];
@@ -921,34 +946,42 @@ __device__ __forceinline__ unsigned pm_cvt_pk(float lo, float hi) {
     return r;
 }
 
-template <int NMT>
-__global__ __launch_bounds__(128) void pooled_dgrad_mfma_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
+template <int NMT, int CH /*64-column halves per workgroup: 1 or 2*/>
+__global__ __launch_bounds__(128 * CH) void pooled_dgrad_mfma_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
                                                                 const float *__restrict__ ent_val, const uint4 *__restrict__ Wtp,
                                                                 int E, int M, int C, int KC, int C1, int C2, int L, int nbucket,
                                                                 uint16_t *__restrict__ gx1, uint16_t *__restrict__ gx2)
 {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    extern __shared__ uint4 pm_lds[];            // Ge[32][PM_PITCH] | Go[32][PM_PITCH]: G^T of the even / odd columns, channels contiguous
-    unsigned char *Ge = reinterpret_cast<unsigned char *>(pm_lds), *Go = Ge + 32 * PM_PITCH;
+    constexpr int NR = 32 * CH;                  // G^T rows (column pairs) per parity
+    extern __shared__ uint4 pm_lds[];            // Ge[NR][PM_PITCH] | Go[NR][PM_PITCH]: G^T of the even / odd columns, channels contiguous
+    unsigned char *Ge = reinterpret_cast<unsigned char *>(pm_lds), *Go = Ge + NR * PM_PITCH;
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mhalf = wave & 1, chalf = wave >> 1;                          // cin tiles [mhalf NMT, ...), columns [64 chalf, 64 chalf + 64) of the tile
     const int n = lane & 31, h = lane >> 5;
-    for (int t = tid; t < 2 * 32 * PM_PITCH / 16; t += 128) pm_lds[t] = make_uint4(0u, 0u, 0u, 0u);
-    const int sb0 = tile * 2, sb1 = min(sb0 + 1, nbucket), sb2 = min(sb0 + 2, nbucket);
+    for (int t = tid; t < 2 * NR * PM_PITCH / 16; t += 128 * CH) pm_lds[t] = make_uint4(0u, 0u, 0u, 0u);
+    const int sb0 = tile * 2 * CH;
     const int32_t *off = tile_off + (size_t)b * (nbucket + 1);
-    const int beg = off[sb0], mid = off[sb1], end = off[sb2];
-    // A fragments of the first chunks: on their way while the tile is built
-    const uint4 *wt = Wtp + ((size_t)(wave * NMT) * KC) * 64 + lane;
+    int bnd[2 * CH + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * CH; ++k) bnd[k] = off[min(sb0 + k, nbucket)];
+    // A fragments of the first chunks: on their way while the tile is built.  (With CH = 2 the two waves of a cin half request the same
+    // fragments a few hundred cycles apart: the second request is an L1 hit, and W^T crosses the L2 once per 128 columns.)
+    const uint4 *wt = Wtp + ((size_t)(mhalf * NMT) * KC) * 64 + lane;
     uint4 A[3][NMT];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) A[s][mt] = wt[((size_t)mt * KC + min(s, KC - 1)) * 64];
     __syncthreads();
-    for (int e = beg + tid; e < end; e += 128) {
+    for (int e = bnd[0] + tid; e < bnd[2 * CH]; e += 128 * CH) {
         const uint32_t key = ent_key[(size_t)b * E + e];
-        const int l = (int)(key >> 20) + (e >= mid ? 32 : 0), c = (int)(key & 0xFFFFFu) / M;
+        int bk = 0;
+#pragma unroll
+        for (int k = 1; k < 2 * CH; ++k) bk += e >= bnd[k];
+        const int l = (int)(key >> 20) + 32 * bk, c = (int)(key & 0xFFFFFu) / M;
         // (a compare-and-swap on the dword that holds the channel pair: two channels of a column share it, and a (channel, column) pair
         //  that does occur twice -- not in this model -- adds up instead of being overwritten, in arrival order)
         unsigned *wd = reinterpret_cast<unsigned *>(((l & 1) ? Go : Ge) + (l >> 1) * PM_PITCH + (c >> 1) * 4);
@@ -969,7 +1002,7 @@ __global__ __launch_bounds__(128) void pooled_dgrad_mfma_kernel(const int32_t *_
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
-    const unsigned char *be = Ge + n * PM_PITCH + h * 16, *bo = Go + n * PM_PITCH + h * 16;
+    const unsigned char *be = Ge + (32 * chalf + n) * PM_PITCH + h * 16, *bo = Go + (32 * chalf + n) * PM_PITCH + h * 16;
 #define PM_STEP(kc, s)                                                                                          \
     if ((kc) < KC) {                                                                                            \
         const int kn = min((kc) + 2, KC - 1);                                                                   \
@@ -989,19 +1022,53 @@ __global__ __launch_bounds__(128) void pooled_dgrad_mfma_kernel(const int32_t *_
     }
 #undef PM_STEP
 
-    const int col = tile * PM_TL + 2 * n;                              // (L even: col + 1 is inside when col is)
+    if constexpr (CH == 2) {
+        // 128-column tiles: the output goes through LDS (the G^T image is finished with) and leaves as 16 bytes per lane, 256-byte row
+        // segments.  (As dword stores -- 32 lanes x 4 bytes per row and instruction, every segment a partial cache line on 30000-byte
+        // rows -- the store phase ran at the ~1.6 TB/s of the staged bf16 layer kernel's epilogue.)
+        constexpr int OP = 272;                                           // bytes per output row in LDS: 128 columns x 2 + 16
+        unsigned char *ot = reinterpret_cast<unsigned char *>(pm_lds);
+        __syncthreads();                                                  // every wave has read its last B fragment
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (mhalf * NMT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                *reinterpret_cast<unsigned *>(ot + ci * OP + (64 * chalf + 2 * n) * 2) = pm_cvt_pk(acc[mt][0][r], acc[mt][1][r]);
+            }
+        __syncthreads();
+        const int l0 = tile * (PM_TL * CH);
+        const int piece = tid & 15;                                       // 8 columns
+        const bool vec = (L & 7) == 0;                                    // row starts 16-byte aligned
+        for (int ci = tid >> 4; ci < C1 + C2; ci += (128 * CH) >> 4) {
+            const int c0 = l0 + 8 * piece;
+            if (c0 >= L) continue;
+            uint16_t *dst = ci < C1 ? gx1 + ((size_t)b * C1 + ci) * L + c0 : gx2 + ((size_t)b * C2 + (ci - C1)) * L + c0;
+            const uint4 v = *reinterpret_cast<const uint4 *>(ot + ci * OP + piece * 16);
+            if (vec && c0 + 8 <= L) {
+                *reinterpret_cast<uint4 *>(dst) = v;
+            } else {                                                      // (L even: whole dwords)
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + 2 * e < L) reinterpret_cast<unsigned *>(dst)[e] = w[e];
+            }
+        }
+    } else {
+    const int col = tile * (PM_TL * CH) + 64 * chalf + 2 * n;          // (L even: col + 1 is inside when col is)
     if (col < L) {
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = (wave * NMT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ci = (mhalf * NMT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (ci >= C1 + C2) continue;
                 const unsigned pk = pm_cvt_pk(acc[mt][0][r], acc[mt][1][r]);
                 uint16_t *dst = ci < C1 ? gx1 + ((size_t)b * C1 + ci) * L + col : gx2 + ((size_t)b * C2 + (ci - C1)) * L + col;
                 *reinterpret_cast<unsigned *>(dst) = pk;
             }
         }
+    }
     }
 }
 
@@ -1134,7 +1201,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     hipStream_t st = sonet::as_stream(stream);
     int abl = 0;
     if (const char *e = sonet::knob("SONET_PD_ABL")) abl = atoi(e);
-    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * nbucket + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B, PB_Q), dim3(1024), (size_t)(2 * sonet::ceil_div(nbucket, PB_Q) + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
     hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1,
                        L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);
@@ -1162,7 +1229,7 @@ extern "C" int sonet_pooled_dgrad_mfma_bf16(const float *g_pooled, const int32_t
     SONET_REQUIRE(g_pooled && pos && wt_pack && ws && gx1, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
-    const int Cin = C1 + C2, E = C * M, CT = sonet::ceil_div(Cin, 32), nbucket = sonet::ceil_div(L, PD_SB), ntile = sonet::ceil_div(L, PM_TL);
+    const int Cin = C1 + C2, E = C * M, CT = sonet::ceil_div(Cin, 32), nbucket = sonet::ceil_div(L, PD_SB);
     if ((L & 1) || C % 16 || C * 2 + 16 > PM_PITCH || (CT & 1) || CT > 12 || (long long)C * M >= (1 << 20) || B > 65535 ||
         (size_t)(2 * nbucket + 1) * 4 > 64 * 1024 || ((reinterpret_cast<uintptr_t>(gx1) | reinterpret_cast<uintptr_t>(gx2)) & 3))
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: shape B=%d C=%d M=%d C1=%d C2=%d L=%d not supported", what, B, C, M, C1, C2, L);
@@ -1170,12 +1237,23 @@ extern "C" int sonet_pooled_dgrad_mfma_bf16(const float *g_pooled, const int32_t
     float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
     int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
     hipStream_t st = sonet::as_stream(stream);
-    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B), dim3(1024), (size_t)(2 * nbucket + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
-    const size_t lds = (size_t)2 * 32 * PM_PITCH;
+    hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B, PB_Q), dim3(1024), (size_t)(2 * sonet::ceil_div(nbucket, PB_Q) + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
+    // 128-column workgroups (four waves, one per CU: W^T crosses the L2 once per 128 columns) on big launches, 64-column ones otherwise
+    int ch = (long long)B * sonet::ceil_div(L, 2 * PM_TL) >= 2048 ? 2 : 1;
+    if (const char *e = sonet::knob("SONET_PM_CH")) { const int v = atoi(e); if (v == 1 || v == 2) ch = v; }
+    const int ntile_l = sonet::ceil_div(L, PM_TL * ch);
+    size_t lds = (size_t)2 * 32 * ch * PM_PITCH;
+    if (ch == 2 && (size_t)CT * 32 * 272 > lds) lds = (size_t)CT * 32 * 272;          // (the output tile reuses the image)
     const uint4 *wtp = reinterpret_cast<const uint4 *>(wt_pack);
     uint16_t *g2 = gx2 ? gx2 : gx1;
-#define PM_LAUNCH(NN) hipLaunchKernelGGL(pooled_dgrad_mfma_kernel<NN>, dim3(ntile, B), dim3(128), lds, st, tile_off, ent_key, ent_val, wtp, E, M, C, C / 16, \
-                                         C1, C2, L, nbucket, gx1, g2)
+#define PM_LAUNCH1(NN, CC) do { static bool attr_set = false;                                                                        \
+        if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pooled_dgrad_mfma_kernel<NN, CC>),                   \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)                \
+                             return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                           \
+                         attr_set = true; }                                                                                           \
+        hipLaunchKernelGGL((pooled_dgrad_mfma_kernel<NN, CC>), dim3(ntile_l, B), dim3(128 * CC), lds, st, tile_off, ent_key, ent_val, wtp, E, M, C, C / 16, \
+                           C1, C2, L, nbucket, gx1, g2); } while (0)
+#define PM_LAUNCH(NN) do { if (ch == 2) PM_LAUNCH1(NN, 2); else PM_LAUNCH1(NN, 1); } while (0)
     switch (CT / 2) {
         case 1: PM_LAUNCH(1); break;
         case 2: PM_LAUNCH(2); break;
@@ -1184,6 +1262,7 @@ extern "C" int sonet_pooled_dgrad_mfma_bf16(const float *g_pooled, const int32_t
         case 5: PM_LAUNCH(5); break;
         default: PM_LAUNCH(6); break;
     }
+#undef PM_LAUNCH1
 #undef PM_LAUNCH
     return sonet::launched(what);
 }
