@@ -463,6 +463,9 @@ int sonet_bn_running_update_f32(float *running_mean, float *running_var, const f
 int sonet_bn_bwd_coeffs_f32(const double *sums, const float *mean, const float *invstd, const float *gamma, double n, int C,
                             float *a, float *b, float *c0, float *g_gamma, float *g_beta, sonet_stream_t stream);
 /* y = act(x*scale[c] + shift[c]) out of place (training forward: raw stays for the backward). */
+/* Mean over the k copies of a point (segmenter head, models/networks.py:331-336): out[r][n] = c * ((h[r][n] + h[r][N + n]) + h[r][2N + n]),
+ * h [rows][k * N] f32, c = 1/3 (k = 3) / 0.5 (k = 2), k = 1: copy; the reference's order of operations (bit-identical to split + add + mul). */
+int sonet_chunk_mean_f32(const float *h, float *out, long long rows, int N, int k, sonet_stream_t stream);
 int sonet_channel_affine_act_out_f32(const float *x, const float *scale, const float *shift, int relu, float *y,
                                      int B, int C, int L, sonet_stream_t stream);
 

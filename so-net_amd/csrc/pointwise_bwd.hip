@@ -720,6 +720,53 @@ extern "C" int sonet_node_gather_lead_affine_act_bf16(const uint16_t *z, const i
     return sonet::launched(what);
 }
 
+// ---- mean over the k copies of a point (segmenter head, models/networks.py:331-336) ----------------------------------------------
+// out[r][n] = c * ((h[r][n] + h[r][N + n]) + h[r][2 N + n]),  h [rows][k N], c = 1/3 (k = 3) or 0.5 (k = 2), k = 1: copy -- the
+// reference's own order of the adds and the single multiplication, so the result is bit-identical to the three aten launches it
+// replaces (split + add + add + mul: ~0.1 ms of the segmenter's 1.9 ms at 64 x 256 x 3 x 1024).
+namespace {
+__global__ __launch_bounds__(256) void chunk_mean_kernel(const float *__restrict__ h, float *__restrict__ out, long long rows, int N, int k, float c)
+{
+    const long long r = blockIdx.y;
+    const float *hr = h + r * (long long)k * N;
+    float *orow = out + r * N;
+    const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) {
+        const float4 *h4 = reinterpret_cast<const float4 *>(hr);
+        float4 *o4 = reinterpret_cast<float4 *>(orow);
+        const int N4 = N >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < N4; i += gridDim.x * 256) {
+            float4 s = h4[i];
+            for (int kk = 1; kk < k; ++kk) {
+                const float4 v = h4[(long long)kk * N4 + i];
+                s.x = __fadd_rn(s.x, v.x); s.y = __fadd_rn(s.y, v.y); s.z = __fadd_rn(s.z, v.z); s.w = __fadd_rn(s.w, v.w);
+            }
+            if (k > 1) { s.x = __fmul_rn(c, s.x); s.y = __fmul_rn(c, s.y); s.z = __fmul_rn(c, s.z); s.w = __fmul_rn(c, s.w); }
+            o4[i] = s;
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+            float s = hr[i];
+            for (int kk = 1; kk < k; ++kk) s = __fadd_rn(s, hr[(long long)kk * N + i]);
+            orow[i] = k > 1 ? __fmul_rn(c, s) : s;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sonet_chunk_mean_f32(const float *h, float *out, long long rows, int N, int k, sonet_stream_t stream)
+{
+    const char *what = "sonet_chunk_mean_f32";
+    SONET_REQUIRE(h && out, "%s: NULL pointer", what);
+    SONET_REQUIRE(rows > 0 && N > 0 && k >= 1, "%s: bad size", what);
+    if (rows > 65535 * 32768ll || k > 3) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: rows=%lld k=%d", what, rows, k);
+    if (rows > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: more than 65535 rows", what);
+    const int gx = sonet::ceil_div(N, 1024) < 1 ? 1 : (sonet::ceil_div(N, 1024) > 8 ? 8 : sonet::ceil_div(N, 1024));
+    hipLaunchKernelGGL(chunk_mean_kernel, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, sonet::as_stream(stream), h, out, rows, N, k,
+                       k == 3 ? (float)(1.0 / 3.0) : 0.5f);
+    return sonet::launched(what);
+}
+
 // ---- sparse dgrad of the pooled last layer ---------------------------------------------------
 // In the classifier / autoencoder the only consumer of first_pn_out = W4 . [x1; x2] + b is the per-node max-pool
 // (models/networks.py:180-185), so d loss / d first_pn_out has exactly M non-zeros per (b, c) row -- at the arg-max

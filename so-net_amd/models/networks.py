@@ -221,12 +221,15 @@ class Encoder(nn.Module):
             pool = _ops.pointresnet_bf16_pool if _ops.POINTMLP_PRECISION == "bf16" else _ops.pointresnet_fused_pool
             self.first_pn_out_masked_max = pool(g, wstream, affine, M)
         else:
-            g = _ops.som_group(xd, snd, a, want_decentered=not use_sn, want_augmented=use_sn)            # :140-172
+            # (a head that reads the per-point attributes afterwards -- the segmenter -- gets them from this launch: a second som_group
+            #  launch for x_decentered / centers was 1 % of the segmenter's step)
+            per_point = bool(getattr(self, 'want_first_pn_out', False))
+            g = _ops.som_group(xd, snd, a, want_centers=per_point, want_decentered=(not use_sn) or per_point, want_augmented=use_sn)   # :140-172
             sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes
             self.som_node = sb.node
             row_max = g["row_max"]
             self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None,
-                              centers=None, x_decentered=None if use_sn else g["x_decentered"])
+                              centers=g["centers"], x_decentered=g["x_decentered"])
             pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
 
             pooled = None
@@ -418,13 +421,17 @@ class Segmenter(nn.Module):
         return self._tail(self.layer3(self.layer2(h)), k)
 
     def _tail(self, h, k):
-        chunks = torch.split(h, self.opt.input_pc_num, dim=2)
-        assert len(chunks) == k
-        h = chunks[0]
-        for c in chunks[1:]:
-            h = h + c
-        if k > 1:
-            h = (1.0 / k) * h if k == 3 else 0.5 * h          # networks.py:331-336 (k in {2, 3})
+        if (h.is_cuda and h.dtype == torch.float32 and k in (2, 3) and not torch.is_grad_enabled() and h.is_contiguous()
+                and h.shape[2] == k * self.opt.input_pc_num and h.shape[0] * h.shape[1] <= 65535):
+            h = _ops.chunk_mean(h, k)                          # one launch, the same order of operations (bit-identical)
+        else:
+            chunks = torch.split(h, self.opt.input_pc_num, dim=2)
+            assert len(chunks) == k
+            h = chunks[0]
+            for c in chunks[1:]:
+                h = h + c
+            if k > 1:
+                h = (1.0 / k) * h if k == 3 else 0.5 * h          # networks.py:331-336 (k in {2, 3})
         h = self.layer4(h)
         if self.opt.dropout > 0.1:
             h = self.drop4(h)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_chunk_mean_f32": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_stats_bf16": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_bf16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],

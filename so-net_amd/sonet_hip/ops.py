@@ -1213,6 +1213,20 @@ def channel_affine_act(x, scale, shift, relu):
     return y
 
 
+def chunk_mean(h, k):
+    """Mean over the k copies of a point: h B x C x (k N) f32 -> B x C x N = c * ((h[..., :N] + h[..., N:2N]) + h[..., 2N:]), c = 1/3 or 0.5
+    (models/networks.py:331-336, the reference's order of operations)."""
+    _chk(h, "h", torch.float32, 3)
+    B, C, L = h.shape
+    if k not in (1, 2, 3) or L % k:
+        raise SonetHipError("chunk_mean: k in {1, 2, 3} and a length divisible by k")
+    dev = _same_device(h)
+    out = torch.empty((B, C, L // k), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("chunk_mean"):
+        check(_lib.load().sonet_chunk_mean_f32(ptr(h), ptr(out), B * C, L // k, int(k), stream_ptr()), "sonet_chunk_mean_f32")
+    return out
+
+
 _CONST = {}
 
 

@@ -590,6 +590,18 @@ def test_pooled_dgrad_vs_dense():
         assert torch.equal(gx1b, gx1)                                      # deterministic
 
 
+@pytest.mark.parametrize("B,C,N,k", [(2, 256, 1024, 3), (3, 7, 333, 3), (2, 16, 130, 2), (1, 5, 8, 1), (64, 256, 1024, 3)])
+def test_chunk_mean_is_the_reference_expression_bit_for_bit(B, C, N, k):
+    """sonet_chunk_mean_f32 == (1/3) * (h0 + h1 + h2) / 0.5 * (h0 + h1) of models/networks.py:331-336 as aten evaluates it."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C + N + k)
+    h = torch.randn(B, C, k * N, generator=g).to(DEV)
+    got = ops.chunk_mean(h, k)
+    parts = torch.split(h, N, dim=2)
+    ref = parts[0] if k == 1 else 0.5 * (parts[0] + parts[1]) if k == 2 else (1.0 / 3.0) * (parts[0] + parts[1] + parts[2])
+    assert tuple(got.shape) == (B, C, N) and torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("B,C,M,C1,C2,L", [(3, 384, 64, 64, 256, 3000), (2, 96, 8, 16, 48, 130), (2, 64, 16, 64, 0, 514), (64, 384, 64, 64, 256, 15000)])
 def test_pooled_dgrad_on_the_matrix_cores(B, C, M, C1, C2, L):
     """sonet_pooled_dgrad_mfma_bf16 (the tile of the never-built gradient assembled in LDS, times W^T on bf16 MFMAs) against scatter_add +
