@@ -1135,8 +1135,9 @@ extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
 // make a direct scatter formulation uncoalesced become LDS reads), thread <-> output channel c keeps its M entries in
 // registers (g and pos come TRANSPOSED, [B][M][C], so that loading them is coalesced) and applies them to PW_G row pairs.
 // Per-cloud partials out[b][c][ci]; the caller sums over b (fixed order: deterministic).
-constexpr int PW_R = 2;                                      // x rows resident in LDS at a time
-constexpr int PW_G = 8;                                      // row pairs per workgroup (the entries are loaded once for all of them)
+constexpr int PW_ROWS = 16;                                  // x rows per workgroup (the entries are loaded once for all of them)
+template <typename TX> struct PwR { static constexpr int value = sizeof(TX) == 4 ? 1 : 2; };   // rows resident in LDS at a time: 60 KB either way at
+                                                             // 15000 columns (bf16 pairs, single f32 rows) -- two workgroups per CU
 constexpr int PW_M = 64;                                     // entries per output channel kept in registers (M <= PW_M)
 constexpr int PW_T = 768;                                    // threads: two per output channel (C <= 384), each with half of the M entries
 template <typename TX>
@@ -1148,6 +1149,7 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
     // so two workgroups share a CU and one multiplies while the other loads (round 3 widened on the way in: one workgroup per CU,
     // load -> barrier -> multiply -> barrier in sequence).  The multiply is instruction-bound (an LDS read and an fma per entry and
     // row): two threads per channel, 32 entries each, the halves meet in LDS (a + b: one order).
+    constexpr int PW_R = PwR<TX>::value, PW_G = PW_ROWS / PW_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char rows_raw[];           // [PW_R][L] of TX | comb[PW_T / 2][PW_R] f32
     TX *rows = reinterpret_cast<TX *>(rows_raw);
     float *comb = reinterpret_cast<float *>(rows_raw + (((size_t)PW_R * L * sizeof(TX) + 15) & ~(size_t)15));
@@ -1191,10 +1193,13 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
             for (int m = 0; m < MH; ++m) {
                 if (pv[m] >= 0) {
                     acc[0] = __fmaf_rn(gv[m], widen(rows[pv[m]]), acc[0]);
-                    if (nr > 1) acc[1] = __fmaf_rn(gv[m], widen(rows[L + pv[m]]), acc[1]);
+                    if constexpr (PW_R > 1) { if (nr > 1) acc[1] = __fmaf_rn(gv[m], widen(rows[L + pv[m]]), acc[1]); }
                 }
             }
-            if (half == 1) { comb[c * PW_R] = acc[0]; comb[c * PW_R + 1] = acc[1]; }
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < PW_R; ++r) comb[c * PW_R + r] = acc[r];
+            }
         }
         __syncthreads();
         if (c < C && half == 0)
@@ -1209,11 +1214,12 @@ static int pooled_wgrad_impl(const char *what, const float *g_pooled, const int3
     SONET_REQUIRE(g_pooled && pos && x && gw_partial, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && Ci > 0 && L > 0 && B <= 65535, "%s: bad size B=%d C=%d M=%d Ci=%d L=%d", what, B, C, M, Ci, L);
     if (C > 384 || M > PW_M) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d > 384 or M=%d > %d", what, C, M, PW_M);
+    constexpr int PW_R = PwR<TX>::value;
     const size_t lds = (((size_t)PW_R * L * sizeof(TX) + 15) & ~(size_t)15) + (size_t)(PW_T / 2) * PW_R * sizeof(float);
     if (lds > 152 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d rows do not fit LDS", what, L);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel<TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
-    hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_R * PW_G), (unsigned)B), dim3(PW_T), lds, sonet::as_stream(stream),
+    hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_ROWS), (unsigned)B), dim3(PW_T), lds, sonet::as_stream(stream),
                        g_pooled, pos, x, C, M, Ci, L, gw_partial);
     return sonet::launched(what);
 }
