@@ -91,6 +91,11 @@ int sonet_index_max_gather_f32(const float *data, const int32_t *index, const in
 int sonet_index_max_gather_bf16(const uint16_t *data, const int32_t *index, const int32_t *row_max,
                                 int32_t *out_idx, float *out_val, int B, int C, int Np, int K,
                                 sonet_stream_t stream);
+/* The same pool over an activation that exists only as P16 planes (sonet_p16_size(B, C, Np) bytes, layout under sonet_pointmlp_h3p):
+ * values = (form 0 + form 1) / 32 exactly, i.e. the 22-bit values the next layer multiplies; otherwise the rules of
+ * sonet_index_max_gather_f32 (models/index_max_ext/index_max_cuda.cu:10-26 + the gather of models/networks.py:185).  K <= 512. */
+int sonet_index_max_gather_p16(const void *planes, const int32_t *index, const int32_t *row_max,
+                               int32_t *out_idx, float *out_val, int B, int C, int Np, int K, sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * som_assign  -- replaces the body of BatchSOM.query_topk (and BatchSOM.query for k = 1)
@@ -282,7 +287,8 @@ int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void *wstream, c
                                 float *y, int B, int L, sonet_stream_t stream);
 /* The same launch also writes y pre-split: yp = the P16 planes of y (sonet_p16_size(B, 384, L) bytes; layout under sonet_pointmlp_h3p
  * above), the operand format of sonet_pointmlp_h3p -- the part segmenter's first layer reads first_pn_out per point copy
- * (models/networks.py:296-326, models/segmenter.py:90-109).  The largest split magnitude joins word 2 of the range log. */
+ * (models/networks.py:296-326, models/segmenter.py:90-109).  The largest split magnitude joins word 2 of the range log.
+ * y == NULL: only the planes are written (the per-node pool then runs on them: sonet_index_max_gather_p16). */
 int sonet_pointresnet_fused_p16_f32(const float *x, int Cin0, const void *wstream, const float *affine,
                                     float *y, void *yp, int B, int L, sonet_stream_t stream);
 

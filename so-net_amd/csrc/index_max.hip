@@ -169,6 +169,66 @@ int launch_index_max(const T *data, const int32_t *index, const int32_t *row_max
     return sonet::launched(what);
 }
 
+// ---- the same pool over an activation that only exists as P16 planes (csrc/pointmlp_h3p.hip) -----------------------------------------
+// P[b][kc][form][h][l][8] fp16, value = (form 0 + form 1) / 32 exactly (22 significand bits), element e of half h = channel
+// 16 kc + 4 h + (e & 3) + 8 (e >> 2).  One workgroup owns (b, kc, h) = 8 channels of a cloud: a lane's two 16-byte loads (one per
+// form, consecutive lanes = consecutive columns: 1 KiB per wave and instruction) are the 8 channel values of ONE column, and the bins
+// of the 8 rows are updated exactly as above.  The segmenter's first PointNet then need not write first_pn_out in f32 at all.
+__device__ __forceinline__ void p16_unpack(const uint4 &hi, const uint4 &mid, float (&v)[8]) {
+    const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, mw[4] = {mid.x, mid.y, mid.z, mid.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_bit_cast(h2, hw[p]), c = __builtin_bit_cast(h2, mw[p]);
+        v[2 * p] = ((float)a[0] + (float)c[0]) * 0.03125f;              // exact: the two pieces do not overlap, 1/32 is a power of two
+        v[2 * p + 1] = ((float)a[1] + (float)c[1]) * 0.03125f;
+    }
+}
+
+__global__ __launch_bounds__(IM_THREADS) void index_max_p16_kernel(const uint4 *__restrict__ planes, const int32_t *__restrict__ index,
+                                                                  const int32_t *__restrict__ row_max, int32_t *__restrict__ out_idx,
+                                                                  float *__restrict__ out_val, int C, int KC, int Np, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];  // [8][K]
+    const int tid = threadIdx.x;
+    const int grp = xcd_remap(blockIdx.x, gridDim.x);               // (b, kc, h): the 2 KC workgroups of a cloud share its id row
+    const int h = grp & 1, kc = (grp >> 1) % KC, b = (grp >> 1) / KC;
+    const uint4 *p_hi = planes + ((((size_t)b * KC + kc) * 2 + 0) * 2 + h) * (size_t)Np;
+    const uint4 *p_mid = planes + ((((size_t)b * KC + kc) * 2 + 1) * 2 + h) * (size_t)Np;
+    const int32_t *irow = index + (long long)b * Np;
+    for (int i = tid; i < 8 * K; i += IM_THREADS) bins[i] = IM_INIT_KEY;
+    __syncthreads();
+#pragma unroll 2
+    for (int n = tid; n < Np; n += IM_THREADS) {
+        const int id = irow[n];
+        float v[8];
+        p16_unpack(p_hi[n], p_mid[n], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) im_update(bins + e * K, id, K, __float_as_uint(v[e]), (unsigned)n);
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * K; i += IM_THREADS) {
+        const int e = i / K, m = i - e * K;
+        const int c = 16 * kc + 4 * h + (e & 3) + 8 * (e >> 2);
+        if (c >= C) continue;                                          // (channels of a padded last chunk)
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(bins[i] & 0xFFFFFFFFull));
+        const long long o = ((long long)b * C + c) * K + m;
+        out_idx[o] = pos;
+        if (out_val != nullptr) {
+            const unsigned okey = (unsigned)(bins[i] >> 32);
+            const bool won = bins[i] != IM_INIT_KEY && (row_max == nullptr || row_max[(long long)b * K + m] != 0);
+            float v = __uint_as_float((okey & 0x80000000u) ? (okey ^ 0x80000000u) : ~okey);
+            if (!won || v == 0.f) {                                    // element 0 of the row / the winner itself (a zero: the key holds +0 for -0)
+                float w[8];
+                const int q = won ? pos : 0;
+                p16_unpack(p_hi[q], p_mid[q], w);
+                v = w[e];
+            }
+            out_val[o] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sonet_index_max_f32(const float *data, const int32_t *index, int32_t *out_idx,
@@ -197,4 +257,23 @@ extern "C" int sonet_index_max_gather_bf16(const uint16_t *data, const int32_t *
     SONET_REQUIRE(out_val, "sonet_index_max_gather_bf16: out_val is NULL");
     return launch_index_max<uint16_t>(data, index, row_max, out_idx, out_val, B, C, Np, K, sonet::as_stream(stream),
                                       "sonet_index_max_gather_bf16");
+}
+
+/* index_max_gather over an activation given as P16 planes (sonet_p16_size(B, C, Np) bytes, the layout of sonet_pointmlp_h3p): the
+ * values are (hi + mid) / 32 exactly; same rules as sonet_index_max_gather_f32 (-1000 / position 0 for empty segments, first maximum
+ * wins, row_max masks nodes).  Np below 2^31, K <= 512. */
+extern "C" int sonet_index_max_gather_p16(const void *planes, const int32_t *index, const int32_t *row_max,
+                                          int32_t *out_idx, float *out_val, int B, int C, int Np, int K, sonet_stream_t stream)
+{
+    const char *what = "sonet_index_max_gather_p16";
+    SONET_REQUIRE(planes && index && out_idx && out_val, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C > 0 && Np > 0 && K > 0, "%s: non-positive size B=%d C=%d Np=%d K=%d", what, B, C, Np, K);
+    if (K > 512) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: K=%d > 512 bins", what, K);
+    if (reinterpret_cast<uintptr_t>(planes) & 15) return sonet::fail(SONET_ERR_INVALID_ARG, "%s: planes must be 16-byte aligned", what);
+    const int KC = sonet::ceil_div(C, 16);
+    const long long nwg = (long long)B * KC * 2;
+    if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many rows", what);
+    hipLaunchKernelGGL(index_max_p16_kernel, dim3((unsigned)nwg), dim3(IM_THREADS), (size_t)8 * K * sizeof(unsigned long long), sonet::as_stream(stream),
+                       reinterpret_cast<const uint4 *>(planes), index, row_max, out_idx, out_val, C, KC, Np, K);
+    return sonet::launched(what);
 }

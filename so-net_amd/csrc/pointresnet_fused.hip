@@ -708,8 +708,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void pointresnet_fused_kernel(
         // ---- layer 4: NPASS passes x KC4 steps of MT4 output tiles; chunks 0-3 = layer-1 output (park), 4-19 = layer 3 (a[...]) ----
         // Pass 0 carries the in-place jobs of layer 3's second tile group (one per step, steps 0-15: tile 4 + s/4, half (s/2)&1,
         // column tile s&1 -- tile 4 is complete when step 12 needs it); passes 1-3 run the same steps without jobs.
+        // (y == nullptr -- the P16-only store variant: a descriptor of zero bytes, every f32 store falls outside it and writes nothing)
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            y + b * (long long)(32 * T3) * L, 0, (int)((unsigned)(32 * T3) * rowB), 0x00020000);
+            y ? y + b * (long long)(32 * T3) * L : const_cast<float *>(x), 0, y ? (int)((unsigned)(32 * T3) * rowB) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(
             P16OUT ? static_cast<char *>(yp) + b * (long long)(2 * T3) * 64 * L : nullptr, 0, P16OUT ? (int)((unsigned)(2 * T3) * 64u * (unsigned)L) : 0, 0x00020000);
 #define ACC4(u, c) acc[u][c]
@@ -1030,13 +1031,13 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     return sonet::launched(what);
 }
 
-/* sonet_pointresnet_fused_f32 that also writes y pre-split: yp = the P16 planes of y (sonet_p16_size(B, 384, L) bytes, include/sonet_hip.h),
+/* sonet_pointresnet_fused_f32 that also (y != NULL) or only (y == NULL) writes y pre-split: yp = the P16 planes of y (sonet_p16_size(B, 384, L) bytes, include/sonet_hip.h),
  * the operand format of sonet_pointmlp_h3p -- the segmenter's first layer reads first_pn_out per point copy (models/networks.py:296-326). */
 extern "C" int sonet_pointresnet_fused_p16_f32(const float *x, int Cin0, const void *wstream, const float *affine,
                                                float *y, void *yp, int B, int L, sonet_stream_t stream)
 {
     const char *what = "sonet_pointresnet_fused_p16_f32";
-    SONET_REQUIRE(x && wstream && affine && y && yp, "%s: NULL pointer", what);
+    SONET_REQUIRE(x && wstream && affine && yp, "%s: NULL pointer", what);          // (y may be NULL: only the planes are written)
     SONET_REQUIRE(B > 0 && L > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d Cin0=%d", what, B, L, Cin0);
     if ((double)(32 * T3) * L * 4.0 >= 2.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel exceeds 2 GiB", what);
     const int tpc = sonet::ceil_div(L, TPTS);

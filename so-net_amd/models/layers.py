@@ -903,8 +903,9 @@ class PointResNet(nn.Module):
                 return _ops.pointresnet_bf16(x.float().contiguous(), wstream, affine)
             if getattr(self, "emit_p16", False) and _ops.P16_CHAINS:
                 # a caller that feeds the output to a third-generation layer (the segmenter) takes it pre-split from the same launch
-                y, self.last_p16 = _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine, want_p16=True)
-                return y
+                only = self.emit_p16 == "only" and not torch.is_grad_enabled()
+                y, self.last_p16 = _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine, want_p16="only" if only else True)
+                return y                                   # (None when only the planes were written)
             return _ops.pointresnet_fused(_FusedPointwise._prep(x).float(), wstream, affine)
         n = len(self.out_channels_list)
         skip = self.layers[0](x, epoch)

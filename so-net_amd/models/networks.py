@@ -143,6 +143,8 @@ class Encoder(nn.Module):
     def first_pn_out(self):
         """B x 384 x kN output of the first PointNet.  On the fused no-grad path it is never written during
         forward (only its per-node max is needed); it is materialised here if a caller (the segmenter) reads it."""
+        if self._first_pn_out is None and self._lazy is not None and self._lazy.get("first_p16") is not None:
+            self._first_pn_out = self._lazy["first_p16"].float()
         if self._first_pn_out is None and self._lazy is not None:
             st = self._lazy
             g = _ops.som_group(st["x"], st["sn"], st["a"], want_augmented=st["sn"] is not None, want_decentered=st["sn"] is None)
@@ -240,7 +242,12 @@ class Encoder(nn.Module):
                 self.first_pn_out, self.first_pn_out_masked_max, _ = pooled
             else:
                 self.first_pn_out = self.first_pointnet(pn_in, epoch)        # :175-178  B x 384 x kN
-                if torch.is_grad_enabled() and self.first_pn_out.requires_grad:
+                if self._first_pn_out is None:
+                    # the fused first PointNet wrote only the P16 planes (emit_p16 = "only"): the pool runs on them, first_pn_out is
+                    # decoded on demand (property)
+                    self._lazy["first_p16"] = self.first_pointnet.last_p16
+                    _, self.first_pn_out_masked_max = _ops.index_max_gather_p16(self.first_pointnet.last_p16, a.min_idx_i32, M, row_max)
+                elif torch.is_grad_enabled() and self.first_pn_out.requires_grad:
                     gather_index = _ops.index_max(self.first_pn_out.detach(), a.min_idx_i32, M).long()   # :180-184
                     self.first_pn_out_masked_max = self.first_pn_out.gather(
                         dim=2, index=gather_index * row_max.unsqueeze(1).long())                         # :185
@@ -397,9 +404,13 @@ class Segmenter(nn.Module):
         zn = _ops.pointmlp(torch.cat([t_.to(sdt) for t_ in node_in], dim=1).contiguous(), wp_node, ones, zeros, False, Cout)
         z = (zn.float() + zg.unsqueeze(2)).contiguous()
         x2 = torch.cat(small, dim=1).to(sdt).contiguous()
-        first_pn_out = first_pn_out.to(sdt)
-        if (wp_point.dtype == torch.int8 and lyr._p16_ok() and self.layer2._p16_ok() and self.layer3._p16_ok()
-                and first_pn_out.shape[1] % 16 == 0):
+        c_first = first_pn_out_p16.C if first_pn_out_p16 is not None else first_pn_out.shape[1]
+        p16_chain = (wp_point.dtype == torch.int8 and lyr._p16_ok() and self.layer2._p16_ok() and self.layer3._p16_ok() and c_first % 16 == 0)
+        if first_pn_out is None:                       # the first PointNet wrote only the P16 planes (segmentation_forward)
+            first_pn_out = None if p16_chain else first_pn_out_p16.float()
+        if first_pn_out is not None:
+            first_pn_out = first_pn_out.to(sdt)
+        if p16_chain:
             # third-generation layers: the three kN-column layers hand their activations on pre-split (P16), the split of layer 1's
             # input is one pass over first_pn_out; the per-node block is added in layer 1's epilogue from LDS
             def wsel():
@@ -452,6 +463,10 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
     # ... pre-split when the head runs its third-generation chain (the fused first PointNet then writes the P16 planes itself)
     encoder.first_pointnet.emit_p16 = bool(segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True) and segmenter.layer1._p16_ok()
                                            and segmenter.layer2._p16_ok() and segmenter.layer3._p16_ok())
+    if encoder.first_pointnet.emit_p16 and _ops.P16_ONLY and _ops.POINTMLP_PRECISION == "h3":
+        # ... and ONLY pre-split: the per-node pool runs on the planes, first_pn_out is decoded to f32 if somebody reads it (0.3 GB of
+        # writes less at 64 x 1024 points)
+        encoder.first_pointnet.emit_p16 = "only"
     feature = encoder(pc, sn, node, node_knn_I, is_train, epoch)
     head = lambda: _segmentation_head(encoder, segmenter, pc, sn, label, feature)      # noqa: E731
     if torch.is_grad_enabled() and not segmenter.training and getattr(encoder, "_infer_tag", False):
@@ -463,10 +478,12 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
 def _segmentation_head(encoder, segmenter, pc, sn, label, feature):
     st = encoder._lazy
     if segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True):
-        return segmenter.forward_nodewise(encoder.x_decentered, pc, sn, label, encoder.first_pn_out, encoder.som_node,
+        p16 = getattr(encoder.first_pointnet, "last_p16", None)
+        first = None if (p16 is not None and encoder._first_pn_out is None) else encoder.first_pn_out      # (P16-only: not decoded to f32)
+        return segmenter.forward_nodewise(encoder.x_decentered, pc, sn, label, first, encoder.som_node,
                                           encoder.first_pn_out_masked_max.contiguous(), encoder.knn_feature_1.contiguous(),
                                           encoder.final_pn_out.contiguous(), feature, st["a"].min_idx_i32,
-                                          first_pn_out_p16=getattr(encoder.first_pointnet, "last_p16", None))
+                                          first_pn_out_p16=p16)
     need_grad = torch.is_grad_enabled() and encoder.first_pn_out_masked_max.requires_grad
     if need_grad:
         idx = encoder.min_idx.unsqueeze(1)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sonet_pointmlp_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_gather": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_index_max_gather_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_index_max_gather_p16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_node_gather_lead_affine_act_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "sonet_node_gather_lead_affine_act_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "sonet_pointmlp_stats_ws_size": [_i, _i, _i],

@@ -120,6 +120,24 @@ def index_max_gather(data, index, K, row_max=None):
     return idx, val
 
 
+def index_max_gather_p16(planes, index, K, row_max=None):
+    """index_max_gather on an activation that exists only as P16 planes (``P16``): values (hi + mid) / 32, the 22-bit values the next
+    layer multiplies -> (idx i32, val f32) B x C x K."""
+    _chk(index, "index", torch.int32, 2)
+    B, C, Np = planes.shape
+    if tuple(index.shape) != (B, Np):
+        raise SonetHipError("index must be B x N' = %s, got %s" % ((B, Np), tuple(index.shape)))
+    if row_max is not None:
+        _chk(row_max, "row_max", torch.int32, 2)
+    dev = _same_device(planes.data, index, row_max)
+    idx = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
+    val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("index_max_gather_p16"):
+        check(_lib.load().sonet_index_max_gather_p16(ptr(planes.data), ptr(index), ptr(row_max), ptr(idx), ptr(val), B, C, Np, int(K), stream_ptr()),
+              "sonet_index_max_gather_p16")
+    return idx, val
+
+
 # ------------------------------------------------------------------------------------------ SOM
 class SomAssignment:
     """Result of som_assign: node ids per point copy plus the per-node count / sum state."""
@@ -1089,12 +1107,13 @@ def pointresnet_fused(x, wstream, affine, want_p16=False):
         raise SonetHipError("affine must be 832 x 2 (scale, shift)")
     dev = _same_device(x, wstream, affine)
     B, Cin0, L = x.shape
-    y = torch.empty((B, 384, L), dtype=torch.float32, device=dev)
+    only = want_p16 == "only"                   # -> (None, planes): y is never written in f32 (P16.float() decodes the planes)
+    y = None if only else torch.empty((B, 384, L), dtype=torch.float32, device=dev)
     yp = p16_empty(B, 384, L, dev) if want_p16 else None
-    if y.numel() == 0:
+    if B * L == 0:
         return (y, yp) if want_p16 else y
     _range_arm("pointresnet_fused_L%d" % L)
-    with torch.cuda.device(dev), _timed("pointresnet_fused%s_L%d" % ("_p16" if want_p16 else "", L)):
+    with torch.cuda.device(dev), _timed("pointresnet_fused%s_L%d" % ("_p16only" if only else "_p16" if want_p16 else "", L)):
         if want_p16:
             check(_lib.load().sonet_pointresnet_fused_p16_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), ptr(yp.data), B, L, stream_ptr()),
                   "sonet_pointresnet_fused_p16_f32")
@@ -1294,6 +1313,7 @@ def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     return out
 
 
+P16_ONLY = _os.environ.get("SONET_P16_ONLY", "1") != "0"        # segmenter: the fused first PointNet writes only the P16 planes of first_pn_out
 POOLED_DGRAD_MFMA = _os.environ.get("SONET_POOLED_DGRAD_MFMA", "1") != "0"        # bf16 outputs: the dense-tile product on the matrix cores (sonet_pooled_dgrad_mfma_bf16) when the shape allows
 
 

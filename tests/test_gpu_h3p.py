@@ -229,3 +229,69 @@ def test_pointmlp_h3p_output_range_is_logged():
     with ops.range_scope(torch.device(DEV)) as rs:           # weights beyond the fp16(32 w) range
         ops.pointmlp_h3p(x, ops.pointmlp_h3p_pack(W * 4000.0), one, zero, True, 128, out="f32")
     assert rs.violations()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,L,M", [(2, 384, 3072, 64), (3, 40, 777, 7), (1, 16, 64, 64), (64, 384, 3072, 64)])
+def test_index_max_gather_on_p16_planes_equals_the_f32_kernel_on_the_decoded_values(B, C, L, M):
+    """sonet_index_max_gather_p16 (the per-node arg-max pool straight on P16 planes) == sonet_index_max_gather_f32 on p16_to_f32 of the same
+    planes, bit for bit (positions and values), incl. empty nodes (position 0), masked nodes, out-of-range ids, ties, +-0, a padded last chunk."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C + L)
+    x = torch.randn(B, C, L, generator=g)
+    x[:, :, 5] = x[:, :, 3]                                     # ties: the first wins
+    x[0, 0, :] = 0.0
+    x[0, 1, ::2] = -0.0
+    idx = torch.randint(0, M, (B, L), generator=g, dtype=torch.int32)
+    if M > 3:
+        idx[idx == 2] = 3                                       # node 2 is empty
+        idx[0, :10] = M + 5                                     # ids nobody owns
+    row_max = torch.ones(B, M, dtype=torch.int32)
+    row_max[:, 1 % M] = 0                                       # a masked node gathers position 0
+    p = ops.p16_from_f32(x.to(DEV))
+    dec = ops.p16_to_f32(p)
+    i0, v0 = ops.index_max_gather(dec, idx.to(DEV), M, row_max.to(DEV))
+    i1, v1 = ops.index_max_gather_p16(p, idx.to(DEV), M, row_max.to(DEV))
+    assert torch.equal(i0, i1)
+    assert torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_fused_first_pointnet_p16_only_equals_the_variant_that_also_stores_f32():
+    """sonet_pointresnet_fused_p16_f32 with y == NULL writes the same planes as with y, and the segmenter's forward through them (P16-only
+    first PointNet + index_max_gather_p16) stays within 1e-5 of the path that stores first_pn_out in f32."""
+    from argparse import Namespace
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 4, 1024
+    opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024, activation="relu",
+                    normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="center", bn_momentum=0.1,
+                    bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=50)
+    enc, seg = NW.Encoder(opt), NW.Segmenter(opt)
+    synth.fill_state_dict_(enc.state_dict(), 1)
+    synth.fill_state_dict_(seg.state_dict(), 2)
+    enc.to(DEV).eval()
+    seg.to(DEV).eval()
+    inp = synth.make_inputs(B, N, seed=3, device=torch.device(DEV))
+    label = torch.randint(0, 16, (B,), device=DEV)
+    outs, names = {}, {}
+    for only in (True, False):
+        ops.P16_ONLY = only
+        try:
+            with torch.no_grad(), ops.kernel_timing() as rec:
+                outs[only] = NW.segmentation_forward(enc, seg, inp["pc"], inp["sn"], label, inp["node"], inp["node_knn_I"]).clone()
+                planes = enc.first_pointnet.last_p16.data.clone()
+                first = enc.first_pn_out.clone()                # (decoded from the planes when only they were written)
+                pooled = enc.first_pn_out_masked_max.clone()
+        finally:
+            ops.P16_ONLY = True
+        names[only] = set(n for n, _, _ in rec.records)
+        outs[(only, "planes")], outs[(only, "first")], outs[(only, "pooled")] = planes, first, pooled
+    assert any(n.startswith("pointresnet_fused_p16only") for n in names[True]) and "index_max_gather_p16" in names[True]
+    assert any(n.startswith("pointresnet_fused_p16_") for n in names[False]) and "index_max_gather" in names[False]
+    assert torch.equal(outs[(True, "planes")], outs[(False, "planes")])
+    scale = float(outs[(False, "first")].abs().max())
+    assert float((outs[(True, "first")] - outs[(False, "first")]).abs().max()) <= 2.0 ** -21 * scale        # 22-bit planes vs the f32 store
+    assert float((outs[(True, "pooled")] - outs[(False, "pooled")]).abs().max()) <= 2.0 ** -21 * scale
+    ref = outs[False]
+    assert float((outs[True] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
