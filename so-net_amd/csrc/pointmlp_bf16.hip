@@ -877,16 +877,19 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
                            else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, false>), BF_ARGS); } } while (0)
     if (MT == 12) S = 1;                                      // (12 slices per chunk already: one chunk per stage)
-    // big launches (HBM-bound: the wave needs ~8 KiB of X in flight to cover the memory latency): X two stages ahead
-    int nxb = (paired && S == 2 && (MT == 4 || MT == 2) && KC >= 6 && nwg_x >= 1024) ? 3 : 2;
+#ifdef SONET_VARIANTS
+    // X and W two stages ahead (NXB = 3): measured 1-5 % SLOWER than one stage ahead on every shape (profiles/r04s_bf16_layers_ablation.log
+    // and docs/findings.md R4.8: the staged kernel is bound by the serialisation of a pass, not by its look-ahead) -- kept as the record
+    // of the experiment, selectable in the variants build only
     if (const char *e = sonet::knob("SONET_BF16_NXB")) {
-        const int want = atoi(e);
-        if (want == 2 || (want == 3 && paired && S == 2 && (MT == 4 || MT == 2))) nxb = want;
+        if (atoi(e) == 3 && paired && S == 2 && (MT == 4 || MT == 2)) {
+            if (MT == 4) hipLaunchKernelGGL((pointmlp_bf16_kernel<4, 2, true, 3>), BF_ARGS);
+            else         hipLaunchKernelGGL((pointmlp_bf16_kernel<2, 2, true, 3>), BF_ARGS);
+            if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
+            return sonet::launched(what);
+        }
     }
-    if (nxb == 3) {
-        if (MT == 4) hipLaunchKernelGGL((pointmlp_bf16_kernel<4, 2, true, 3>), BF_ARGS);
-        else         hipLaunchKernelGGL((pointmlp_bf16_kernel<2, 2, true, 3>), BF_ARGS);
-    } else
+#endif
     switch (MT) {
         case 12: BF_LAUNCH(12); break;
         case 6: BF_LAUNCH(6); break;
