@@ -265,6 +265,15 @@ def _encoder_parity(enc, inp, P=2, tol=1e-5, **kw):
     return res
 
 
+def make_adam(module):
+    """The reference's optimizer (models/classifier.py:45-49: Adam, lr 1e-3, betas (0.9, 0.999)) -- as sonet_hip.optim.FusedAdam, the same
+    update in one launch (tests/test_gpu_optim.py pins it against torch.optim.Adam); SONET_TORCH_ADAM=1 times torch.optim.Adam itself."""
+    if os.environ.get("SONET_TORCH_ADAM", "0") == "1":
+        return torch.optim.Adam(module.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    from sonet_hip.optim import FusedAdam
+    return FusedAdam(module.parameters(), lr=1e-3, betas=(0.9, 0.999))
+
+
 def _windows(fn, steps, n=3, dev=None, collective=False):
     """n timed windows of `steps` calls.  collective (a job of several ranks): a barrier on both sides of every window and the MAX over
     ranks, as for the headline; returns (seconds per step of the job, seconds per step of this rank)."""
@@ -325,8 +334,7 @@ def other_configs(args, dev, world=1, rank=0):
             inp = synth.make_inputs(B, N, seed=100 + rank, device=dev)     # this rank's shard of the global batch
             dp.init_distributed(force=True)                       # (world 1: a one-rank RCCL group, the same bucketed exchange as the 8-GPU job)
             dp.broadcast_parameters([enc, cls])
-            opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
-            opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
+            opt_e, opt_c = make_adam(enc), make_adam(cls)
             reducer = dp.GradientAllReducer([enc, cls], always_reduce=True)
             state = {}
 
@@ -509,8 +517,7 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
     enc.train()
     cls.train()
     dp.broadcast_parameters([enc, cls])
-    opt_e = torch.optim.Adam(enc.parameters(), lr=1e-3, betas=(0.9, 0.999))
-    opt_c = torch.optim.Adam(cls.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt_e, opt_c = make_adam(enc), make_adam(cls)
     # always_reduce: the RCCL collectives run even in a single-rank group, so the 1-GPU line exercises (and prices) the same
     # hook-driven bucketed exchange the 8-GPU job uses
     reducer = dp.GradientAllReducer([enc, cls], always_reduce=torch.distributed.is_initialized())

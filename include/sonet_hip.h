@@ -513,6 +513,17 @@ int sonet_chamfer_nn2_f32(const float *a, const float *b, int32_t *nn_ab, int32_
                           sonet_stream_t stream);
 #endif /* SONET_VARIANTS */
 
+/* torch.optim.Adam's update (models/classifier.py:45-49; amsgrad = False, weight_decay = 0) for all f32 parameters of an optimizer in
+ * ONE launch.  tensors: device table, 32 bytes per tensor: {float *param; const float *grad; float *exp_avg; float *exp_avg_sq}
+ * (grad NULL: skipped, the tensor's step count does not advance); step_size[t] = lr / (1 - beta1^step_t), bc2_sqrt[t] = sqrt(1 -
+ * beta2^step_t); chunk table: chunk j covers sonet_adam_chunk() elements of tensor chunk_tensor[j] from chunk_off[j]; sizes[t] =
+ * element counts; one_minus_beta1/2 = 1 - beta rounded from double (as torch's Python floats are).
+ * m <- lerp(m, g, 1 - beta1); v <- v beta2 + (1 - beta2) g g; p <- p - step_size m / (sqrt(v) / bc2_sqrt + eps). */
+int sonet_adam_chunk(void);
+int sonet_adam_multi_f32(const void *tensors, const float *step_size, const float *bc2_sqrt, const int32_t *chunk_tensor,
+                         const long long *chunk_off, const long long *sizes, int nchunks, float beta1, float beta2,
+                         float one_minus_beta1, float one_minus_beta2, float eps, sonet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

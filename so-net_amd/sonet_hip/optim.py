@@ -1,0 +1,125 @@
+"""``FusedAdam`` -- ``torch.optim.Adam`` (models/classifier.py:45-49: lr, betas, no weight decay, no amsgrad) with ONE launch per step.
+
+The reference steps two Adam optimizers per iteration; PyTorch's foreach implementation costs about a dozen multi-tensor launches for
+them (0.25 ms of a 5.7 ms training step at B = 64).  Here all parameters of the optimizer -- pass the parameters of several modules to one
+optimizer, or use two: one launch each -- are updated by ``sonet_adam_multi_f32`` from a chunk table.  Same state layout as torch
+(``state[p]["step"]``, ``["exp_avg"]``, ``["exp_avg_sq"]``), same arithmetic in the same order (f32, the step-dependent scalars in double
+on the host), a parameter without a gradient is skipped and keeps its step count.  CUDA f32 parameters only; anything else raises.
+
+    opt = FusedAdam(list(encoder.parameters()) + list(classifier.parameters()), lr=1e-3, betas=(0.9, 0.999))
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import SonetHipError, check, ptr, stream_ptr
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("FusedAdam: bad hyper-parameters lr=%r betas=%r eps=%r" % (lr, betas, eps))
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self._plans = {}                              # group index -> launch plan (built at the first step)
+
+    def _plan(self, gi, group):
+        plan = self._plans.get(gi)
+        if plan is not None:
+            return plan
+        ps = [p for p in group["params"] if p.requires_grad]
+        if not ps:
+            return None
+        dev = ps[0].device
+        for p in ps:
+            if not p.is_cuda or p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
+                raise SonetHipError("FusedAdam: contiguous float32 CUDA parameters on one device only")
+        lib = _lib.load()
+        chunk = int(lib.sonet_adam_chunk())
+        total = sum(p.numel() for p in ps)
+        flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off, chunk_tensor, chunk_off = 0, [], []
+        for t, p in enumerate(ps):
+            st = self.state[p]
+            n = p.numel()
+            if "exp_avg" in st:                        # resumed from a state_dict: keep the loaded moments
+                flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            st["exp_avg"], st["exp_avg_sq"] = flat_m[off:off + n].view_as(p), flat_v[off:off + n].view_as(p)
+            st["step"] = float(st.get("step", 0.0))
+            for c0 in range(0, n, chunk):
+                chunk_tensor.append(t)
+                chunk_off.append(c0)
+            off += n
+        T = len(ps)
+        # static device tables; the gradient pointers and the step-dependent scalars travel through ONE pinned buffer per step:
+        # [T records of 4 pointers (32 bytes)] [T step sizes f32] [T sqrt(bc2) f32]
+        rec_bytes = 32 * T
+        host = torch.zeros(rec_bytes + 8 * T, dtype=torch.uint8).pin_memory()
+        devbuf = torch.zeros(rec_bytes + 8 * T, dtype=torch.uint8, device=dev)
+        hnp = host.numpy()                             # (shares the pinned memory)
+        rec = hnp[:rec_bytes].view(np.int64).reshape(T, 4)
+        for t, p in enumerate(ps):
+            st = self.state[p]
+            rec[t, 0], rec[t, 2], rec[t, 3] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        plan = dict(ps=ps, T=T, host=host, dev=devbuf, rec=rec, scal=hnp[rec_bytes:].view(np.float32).reshape(2, T),
+                    dev_scal=devbuf[rec_bytes:].view(torch.float32).view(2, T), ptrs=[p.data_ptr() for p in ps],
+                    chunk_tensor=torch.tensor(chunk_tensor, dtype=torch.int32, device=dev),
+                    chunk_off=torch.tensor(chunk_off, dtype=torch.int64, device=dev),
+                    sizes=torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev), flat=(flat_m, flat_v),
+                    event=None)
+        self._plans[gi] = plan
+        return plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            plan = self._plan(gi, group)
+            if plan is None:
+                continue
+            lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+            if plan["event"] is not None:
+                plan["event"].synchronize()           # the previous step's copy out of the pinned buffer is done (it always is)
+            keep, updated, gp, ss, bs = [], [], [0] * plan["T"], [1.0] * plan["T"], [1.0] * plan["T"]
+            for t, p in enumerate(plan["ps"]):
+                if p.data_ptr() != plan["ptrs"][t]:
+                    raise SonetHipError("FusedAdam: a parameter's storage moved (module.to(...) after the first step?)")
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != torch.float32 or g.device != p.device or g.is_sparse:
+                    raise SonetHipError("FusedAdam: float32 dense gradients on the parameter's device only")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                keep.append(g)
+                updated.append(p)
+                st = self.state[p]
+                st["step"] += 1.0
+                gp[t] = g.data_ptr()
+                ss[t] = lr / (1.0 - b1 ** st["step"])
+                bs[t] = math.sqrt(1.0 - b2 ** st["step"])
+            plan["rec"][:, 1] = gp                     # (three vector assignments into the pinned buffer)
+            plan["scal"][0, :] = ss
+            plan["scal"][1, :] = bs
+            if not keep:
+                continue
+            dev = plan["dev"]
+            with torch.cuda.device(dev.device):
+                dev.copy_(plan["host"], non_blocking=True)
+                plan["event"] = torch.cuda.Event()
+                plan["event"].record()
+                check(lib.sonet_adam_multi_f32(ptr(dev), ptr(plan["dev_scal"][0]), ptr(plan["dev_scal"][1]), ptr(plan["chunk_tensor"]),
+                                               ptr(plan["chunk_off"]), ptr(plan["sizes"]), int(plan["chunk_tensor"].numel()),
+                                               float(b1), float(b2), float(1.0 - b1), float(1.0 - b2), float(eps), stream_ptr()), "sonet_adam_multi_f32")
+            # the kernel wrote through raw pointers: tell autograd and every cache keyed on ``_version`` (the packed weights of the layer
+            # kernels, the h3 weight-range verdicts) that the parameters changed, as an in-place aten op would
+            for p in updated:
+                torch.autograd.graph.increment_version(p)
+        return loss
