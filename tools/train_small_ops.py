@@ -24,8 +24,7 @@ with ops.precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"):
     enc.to(dev).train()
     cls.to(dev).train()
     inp = synth.make_inputs(B, N, seed=100, device=dev)
-    oe = torch.optim.Adam(enc.parameters(), lr=1e-3)
-    oc = torch.optim.Adam(cls.parameters(), lr=1e-3)
+    oe, oc = bench.make_adam(enc), bench.make_adam(cls)
 
     def step():
         feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
@@ -39,17 +38,18 @@ with ops.precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         step()
     torch.cuda.synchronize()
-want = ("aten::zeros", "aten::zero_", "aten::fill_", "aten::copy_", "aten::contiguous", "aten::sum", "aten::to", "aten::clone", "aten::cat",
-        "aten::empty_like", "aten::add", "aten::mul", "aten::where", "aten::full_like", "aten::ones_like", "aten::zeros_like", "aten::_to_copy")
+want = ("aten::zero_", "aten::fill_", "aten::copy_")
 cnt = collections.Counter()
-for ev in prof.key_averages(group_by_stack_n=12):
+for ev in prof.key_averages(group_by_stack_n=20):
     if ev.key in want:
         st = list(ev.stack or [])
-        fr = [f for f in st if "/so-net_amd/" in f or "bench.py" in f or "/tools/" in f]
-        where = fr[0].split("/so-net_amd/")[-1] if fr else "(torch: %s)" % (st[0][-70:] if st else "no stack")
+        fr = [f for f in st if any(k in f for k in ("layers.py", "networks.py", "ops.py", "operations.py", "dp.py", "optim.py", "som.py", "graph.py"))]
+        leaf = " | ".join(x.split("/")[-1][-48:] for x in st[:3])
+        where = (" <- ".join(f.split("/")[-1] for f in fr[:3]) if fr else "(no repo frame)") + "   [" + leaf + "]"
         cnt[(ev.key, where)] += ev.count
 for (name, where), n in cnt.most_common(80):
     print("%3d  %-18s %s" % (n, name, where))
