@@ -189,6 +189,8 @@ class _PointwiseFn(torch.autograd.Function):
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, sh, raw, mean, invstd, gamma,
                                   zeros)
             ctx.mark_non_differentiable(mean, var)
+        # (without this autograd hands backward freshly zero-filled "gradients" of mean and var: two fill launches per layer and step)
+        ctx.set_materialize_grads(False)
         ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
         if mode == 'affine':
             return y
@@ -196,6 +198,8 @@ class _PointwiseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
+        if gy is None:                                                    # (the output was not used)
+            return (None,) * 12
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
         gy = gy.contiguous()
