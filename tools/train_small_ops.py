@@ -42,14 +42,18 @@ with ops.precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"):
                  experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         step()
     torch.cuda.synchronize()
-want = ("aten::zero_", "aten::fill_", "aten::copy_")
-cnt = collections.Counter()
-for ev in prof.key_averages(group_by_stack_n=20):
-    if ev.key in want:
-        st = list(ev.stack or [])
-        fr = [f for f in st if any(k in f for k in ("layers.py", "networks.py", "ops.py", "operations.py", "dp.py", "optim.py", "som.py", "graph.py"))]
-        leaf = " | ".join(x.split("/")[-1][-48:] for x in st[:3])
-        where = (" <- ".join(f.split("/")[-1] for f in fr[:3]) if fr else "(no repo frame)") + "   [" + leaf + "]"
-        cnt[(ev.key, where)] += ev.count
-for (name, where), n in cnt.most_common(80):
-    print("%3d  %-18s %s" % (n, name, where))
+launching = ("aten::zeros", "aten::zero_", "aten::fill_", "aten::copy_", "aten::clone", "aten::contiguous", "aten::sum", "aten::cat", "aten::add", "aten::add_",
+             "aten::mul", "aten::mul_", "aten::where", "aten::to", "aten::_to_copy", "aten::full", "aten::full_like", "aten::ones_like", "aten::zeros_like",
+             "aten::bmm", "aten::mm", "aten::matmul", "aten::addmm", "aten::gather", "aten::scatter_add_", "aten::index", "aten::sub", "aten::div", "aten::rsqrt",
+             "aten::bitwise_not", "aten::lt", "aten::gt", "aten::eq", "aten::max", "aten::amax", "aten::mean", "aten::linear", "aten::batch_norm", "aten::dropout",
+             "aten::relu", "aten::threshold_backward", "aten::native_batch_norm_backward", "aten::log_softmax", "aten::nll_loss_forward", "aten::transpose_copy")
+evs = sorted([e for e in prof.events() if e.name.startswith("aten::")], key=lambda e: e.time_range.start)
+top, end = [], -1
+for e in evs:                                   # top-level operators only (nested ones are their implementation)
+    if e.time_range.start >= end:
+        top.append(e)
+        end = e.time_range.end
+cnt = collections.Counter((e.name, str(e.input_shapes)[:90]) for e in top if e.name in launching)
+for (name, shp), n in sorted(cnt.items(), key=lambda kv: (-kv[1], kv[0])):
+    print("%3d  %-22s %s" % (n, name, shp))
+print(sum(cnt.values()), "launching aten operators per step")
