@@ -513,6 +513,17 @@ int sonet_chamfer_nn2_f32(const float *a, const float *b, int32_t *nn_ab, int32_
                           sonet_stream_t stream);
 #endif /* SONET_VARIANTS */
 
+/* Packs of a matrix given by element strides: element (o, c) = W[o * row_stride + c * col_stride] for o < rows, c < Cin; rows in
+ * [rows, Cout) pack as zeros (callers pad Cout to a friendly tile count).  With (row_stride, col_stride) = (1, ld) and W advanced by a
+ * column offset: the pack of a column block of W TRANSPOSED -- the dgrad's weights (W^T g of models/layers.py:282-296's conv) -- read
+ * along W's own rows, without a transposed copy.  Same pack sizes / layouts as sonet_pointmlp_{x3,h3,bf16}_pack(Cin, Cout). */
+int sonet_pointmlp_x3_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp3, int Cin, int Cout, int rows,
+                                   sonet_stream_t stream);
+int sonet_pointmlp_h3_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp3, int Cin, int Cout, int rows,
+                                   sonet_stream_t stream);
+int sonet_pointmlp_bf16_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp, int Cin, int Cout, int rows,
+                                     sonet_stream_t stream);
+
 /* torch.optim.Adam's update (models/classifier.py:45-49; amsgrad = False, weight_decay = 0) for all f32 parameters of an optimizer in
  * ONE launch.  tensors: device table, 32 bytes per tensor: {float *param; const float *grad; float *exp_avg; float *exp_avg_sq}
  * (grad NULL: skipped, the tensor's step count does not advance); step_size[t] = lr / (1 - beta1^step_t), bc2_sqrt[t] = sqrt(1 -

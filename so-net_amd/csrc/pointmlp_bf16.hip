@@ -39,7 +39,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {       // r
 }
 
 // Wp[ct][kc][lane] (uint4 = 8 bf16):  W[ct*32 + (lane&31)][kc*16 + 8*(lane>>5) + t], t = 0..7, zero padded
-__global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp, int Cin, int Cout, int KC, long long total)
+__global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp, int Cin, int Cout, int KC, long long total,
+                                                         long long rs /*element (o, c) = W[o * rs + c * cs]*/, long long cs)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict_
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = c0 + 2 * p;
-        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
-        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
+        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * rs + (long long)c * cs] : 0.f;
+        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * rs + (long long)(c + 1) * cs] : 0.f;
         w[p] = cvt_pk_bf16(w0, w1);
     }
     Wp[t] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -725,16 +726,28 @@ extern "C" size_t sonet_pointmlp_bf16_pack_size(int Cin, int Cout)
     return (size_t)sonet::ceil_div(Cout, 32) * sonet::ceil_div(Cin, 16) * 64 * 16;     // bytes
 }
 
-extern "C" int sonet_pointmlp_bf16_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream)
+static int bf16_pack_impl(const char *what, const float *W, void *Wp, int Cin, int Cout, int rows, long long rs, long long cs, sonet_stream_t stream)
 {
-    const char *what = "sonet_pointmlp_bf16_pack";
     SONET_REQUIRE(W && Wp, "%s: NULL pointer", what);
-    SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
+    SONET_REQUIRE(Cin > 0 && Cout > 0 && rows > 0 && rows <= Cout, "%s: bad size Cin=%d Cout=%d rows=%d", what, Cin, Cout, rows);
     const int KC = sonet::ceil_div(Cin, 16);
     const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
     hipLaunchKernelGGL(bf16_pack_kernel, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                       W, reinterpret_cast<uint4 *>(Wp), Cin, Cout, KC, total);
+                       W, reinterpret_cast<uint4 *>(Wp), Cin, rows, KC, total, rs, cs);
     return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_bf16_pack(const float *W, void *Wp, int Cin, int Cout, sonet_stream_t stream)
+{
+    return bf16_pack_impl("sonet_pointmlp_bf16_pack", W, Wp, Cin, Cout, Cout, Cin, 1, stream);
+}
+
+/* The bf16 pack of a matrix given by element strides (see sonet_pointmlp_x3_pack_strided): element (o, c) = W[o * row_stride + c *
+ * col_stride] for o < rows, zeros for rows <= o < Cout. */
+extern "C" int sonet_pointmlp_bf16_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp, int Cin, int Cout, int rows,
+                                                sonet_stream_t stream)
+{
+    return bf16_pack_impl("sonet_pointmlp_bf16_pack_strided", W, Wp, Cin, Cout, rows, row_stride, col_stride, stream);
 }
 
 static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,

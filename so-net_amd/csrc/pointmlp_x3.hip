@@ -96,7 +96,8 @@ __device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsig
 constexpr int H3_KPAD = 8;
 template <bool F16>
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
-                                                       int Cin, int Cout, int KC /*fp16: KCP*/, long long total, unsigned *__restrict__ trailer)
+                                                       int Cin, int Cout, int KC /*fp16: KCP*/, long long total, unsigned *__restrict__ trailer,
+                                                       long long rs /*element (o, c) = W[o * rs + c * cs]*/, long long cs)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
     if (t >= total) return;                                              // (total is a multiple of 64: whole waves leave)
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = c0 + 2 * p;
-        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * Cin + c] : 0.f;
-        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * Cin + c + 1] : 0.f;
+        const float w0 = (o < Cout && c < Cin) ? W[(long long)o * rs + (long long)c * cs] : 0.f;
+        const float w1 = (o < Cout && c + 1 < Cin) ? W[(long long)o * rs + (long long)(c + 1) * cs] : 0.f;
         range_track(wr, w0, w1);
         if constexpr (F16) {
             unsigned hh, res;
@@ -787,19 +788,41 @@ extern "C" size_t sonet_pointmlp_x3_pack_size(int Cin, int Cout)
     return (size_t)sonet::ceil_div(Cout, 32) * per_tile * 1024 + 64;     // bytes
 }
 
-static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
+// rows: the rows of W that exist (o >= rows packs zeros: callers pad Cout to a friendly tile count); (rs, cs): element strides of W
+static int x3_pack_impl(const char *what, bool f16, const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream,
+                        int rows = -1, long long rs = 0, long long cs = 1)
 {
     SONET_REQUIRE(W && Wp3, "%s: NULL pointer", what);
     SONET_REQUIRE(Cin > 0 && Cout > 0, "%s: non-positive size", what);
+    if (rows < 0) { rows = Cout; rs = Cin; cs = 1; }
+    SONET_REQUIRE(rows <= Cout, "%s: rows=%d > Cout=%d", what, rows, Cout);
     const int KC = f16 ? sonet::ceil_div(Cin, 16 * H3_KPAD) * H3_KPAD : sonet::ceil_div(Cin, 16);
     const long long total = (long long)sonet::ceil_div(Cout, 32) * KC * 64;
     unsigned *trailer = reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(Wp3) + total * (f16 ? 2 : 3));
     if (hipMemsetAsync(trailer, 0, 64, sonet::as_stream(stream)) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: memset failed", what);
+    // (the kernel packs ceil(Cout / 32) tiles and zero-fills rows >= its Cout argument: pass the rows that exist)
     if (f16) hipLaunchKernelGGL(x3_pack_kernel<true>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total, trailer);
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, rows, KC, total, trailer, rs, cs);
     else     hipLaunchKernelGGL(x3_pack_kernel<false>, dim3((unsigned)sonet::ceil_div64(total, 256)), dim3(256), 0, sonet::as_stream(stream),
-                                W, reinterpret_cast<uint4 *>(Wp3), Cin, Cout, KC, total, trailer);
+                                W, reinterpret_cast<uint4 *>(Wp3), Cin, rows, KC, total, trailer, rs, cs);
     return sonet::launched(what);
+}
+
+/* The pack of a matrix given by element strides: element (o, c), o < rows, c < Cin, is W[o * row_stride + c * col_stride]; rows
+ * [rows, Cout) pack as zeros.  With (row_stride, col_stride) = (1, ld) and W advanced by a column offset this is the pack of a column
+ * block of W TRANSPOSED -- the dgrad's weights -- read along W's own rows (coalesced), without a transposed copy. */
+extern "C" int sonet_pointmlp_x3_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp3, int Cin, int Cout, int rows,
+                                              sonet_stream_t stream)
+{
+    SONET_REQUIRE(rows > 0, "sonet_pointmlp_x3_pack_strided: rows must be positive");
+    return x3_pack_impl("sonet_pointmlp_x3_pack_strided", false, W, Wp3, Cin, Cout, stream, rows, row_stride, col_stride);
+}
+
+extern "C" int sonet_pointmlp_h3_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp3, int Cin, int Cout, int rows,
+                                              sonet_stream_t stream)
+{
+    SONET_REQUIRE(rows > 0, "sonet_pointmlp_h3_pack_strided: rows must be positive");
+    return x3_pack_impl("sonet_pointmlp_h3_pack_strided", true, W, Wp3, Cin, Cout, stream, rows, row_stride, col_stride);
 }
 
 extern "C" int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)

@@ -97,7 +97,7 @@ def _pack_transposed(weight2d, C1, C2):
         if Ci == 0:
             out.append(None)
             continue
-        wt = weight2d[:, lo:lo + Ci].t().contiguous().float()                  # Ci x Cout
+        Cout = weight2d.shape[0]
         Cp = Ci
         if mode != "f32" and Ci % 32 != 0 and Ci > 32:
             # the split-operand kernels want 32-row output tiles: pad with zero rows and drop them afterwards (387 and 515
@@ -106,9 +106,17 @@ def _pack_transposed(weight2d, C1, C2):
             if (Cp // 32) % 2 == 1 and Cp >= 256:
                 # an odd tile count runs one 32-row tile per wave (MT = 1: 2x slower per tile than MT = 4): 13 -> 16, 17 -> 20
                 Cp = (Ci + 127) // 128 * 128
-            wt = torch.cat((wt, wt.new_zeros(Cp - Ci, wt.shape[1])), dim=0)
-        m = mode if (mode == "f32" or _ops.x3_supported(wt.shape[1], 0, Cp)) else "f32"
-        out.append((_ops.pointmlp_pack(wt, m), Ci, Cp))
+        m = mode if (mode == "f32" or _ops.x3_supported(Cout, 0, Cp)) else "f32"
+        if (m in ("x3", "h3", "bf16") and weight2d.is_cuda and weight2d.dtype == torch.float32 and weight2d.is_contiguous()
+                and (m == "bf16" or Cp % 32 == 0)):
+            # packed straight from W (lanes along W's rows, rows Ci .. Cp as zeros): no transposed copy, no padding cat -- the
+            # transposed copy + the pack's 32-byte row reads were 0.3 ms of the f32-class training step (six packs per step)
+            out.append((_ops.pointmlp_pack_transposed(weight2d.detach(), lo, Ci, Cp, m), Ci, Cp))
+        else:
+            wt = weight2d[:, lo:lo + Ci].t().contiguous().float()              # Ci x Cout
+            if Cp != Ci:
+                wt = torch.cat((wt, wt.new_zeros(Cp - Ci, wt.shape[1])), dim=0)
+            out.append((_ops.pointmlp_pack(wt, m), Ci, Cp))
         lo += Ci
     return out
 

@@ -110,6 +110,9 @@ SIGNATURES = {
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_channel_affine_act_out_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_chunk_mean_f32": [_vp, _vp, ctypes.c_longlong, _i, _i, _vp],
+    "sonet_pointmlp_x3_pack_strided": [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_h3_pack_strided": [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_pack_strided": [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _i, _i, _vp],
     "sonet_adam_chunk": [],
     "sonet_adam_multi_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -781,6 +781,29 @@ def pointmlp_pack(weight2d, mode="f32"):
     return wp
 
 
+def pointmlp_pack_transposed(weight2d, lo, Ci, Cp, mode):
+    """The pack of W[:, lo:lo + Ci]^T (Ci x Cout, zero rows up to Cp) -- the dgrad's weights -- read from ``weight2d`` (Cout x Cin f32,
+    contiguous) in place: no transposed copy, and the pack kernel's lanes run along W's rows.  mode "x3" / "h3" / "bf16"."""
+    _chk(weight2d, "weight", torch.float32, 2)
+    dev = _same_device(weight2d)
+    Cout, Cin = weight2d.shape
+    if not (0 <= lo and lo + Ci <= Cin and Ci <= Cp):
+        raise SonetHipError("pointmlp_pack_transposed: bad block lo=%d Ci=%d Cp=%d of %d columns" % (lo, Ci, Cp, Cin))
+    lib = _lib.load()
+    src = weight2d.data_ptr() + 4 * lo
+    with torch.cuda.device(dev):
+        if mode == "bf16":
+            wp = torch.empty((lib.sonet_pointmlp_bf16_pack_size(Cout, Cp) // 2,), dtype=torch.int16, device=dev)
+            check(lib.sonet_pointmlp_bf16_pack_strided(src, 1, Cin, ptr(wp), Cout, Cp, Ci, stream_ptr()), "sonet_pointmlp_bf16_pack_strided")
+        elif mode in ("x3", "h3"):
+            wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cout, Cp),), dtype=torch.uint8 if mode == "x3" else torch.int8, device=dev)
+            fn = lib.sonet_pointmlp_x3_pack_strided if mode == "x3" else lib.sonet_pointmlp_h3_pack_strided
+            check(fn(src, 1, Cin, ptr(wp), Cout, Cp, Ci, stream_ptr()), "sonet_pointmlp_x3_pack_strided")
+        else:
+            raise SonetHipError("pointmlp_pack_transposed: mode %r" % (mode,))
+    return wp
+
+
 def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``.
     ``gidx`` (B x L i32, h3 packs only): column l of x1 (B x C1 x L1) is taken from x1[:, :, gidx[b, l]] -- zeros when the

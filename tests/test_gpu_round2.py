@@ -646,3 +646,21 @@ def test_h3_per_channel_range_case():
     print("raw h3 on the adversarial operands: worst err / (1e-5 max(|ref|, rms)) = %.2f" % float((np.abs(raw - ref) / (1e-5 * np.maximum(np.abs(ref), rms))).max()))
     # ordinary weights pass the column test (and keep the fp16 split)
     assert ops.h3_weight_ok(torch.randn(256, 128, generator=g).to(DEV) * 0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["x3", "h3", "bf16"])
+@pytest.mark.parametrize("Cout,Cin,lo,Ci,Cp", [(512, 387, 0, 387, 512), (384, 320, 64, 256, 256), (384, 320, 0, 64, 64), (1024, 768, 0, 768, 768),
+                                              (768, 515, 0, 515, 640), (128, 64, 0, 64, 64)])
+def test_transposed_pack_read_in_place_equals_the_pack_of_the_transposed_copy(mode, Cout, Cin, lo, Ci, Cp):
+    """sonet_pointmlp_{x3,h3,bf16}_pack_strided on W (the dgrad's weights W[:, lo:lo+Ci]^T, zero rows up to Cp) == the pack of the
+    materialised transposed, padded copy: byte for byte (range trailer included)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(Cout + Cin + lo)
+    W = (torch.randn(Cout, Cin, generator=g) * 0.2).to(DEV)
+    wt = W[:, lo:lo + Ci].t().contiguous()
+    if Cp != Ci:
+        wt = torch.cat((wt, wt.new_zeros(Cp - Ci, Cout)), dim=0)
+    ref = ops.pointmlp_pack(wt, mode)
+    got = ops.pointmlp_pack_transposed(W, lo, Ci, Cp, mode)
+    assert got.dtype == ref.dtype and got.numel() == ref.numel() and torch.equal(got, ref)
