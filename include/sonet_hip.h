@@ -535,6 +535,23 @@ int sonet_adam_multi_f32(const void *tensors, const float *step_size, const floa
                          const long long *chunk_off, const long long *sizes, int nchunks, float beta1, float beta2,
                          float one_minus_beta1, float one_minus_beta2, float eps, sonet_stream_t stream);
 
+/* The B x C fully connected layers of the heads in TRAINING (models/layers.py:123-166: Linear + BatchNorm1d + ReLU, stacked by
+ * models/networks.py:202-227): one forward launch, two backward launches per layer instead of aten's addmm / batch_norm / relu /
+ * threshold_backward / batch_norm_backward / mm / mm / sum.  f32, B <= sonet_fc_max_rows() rows, Cin % 4 == 0, Cout % 4 == 0.
+ * forward: y = act(BN(x W^T + bias)); gamma == NULL: no normalisation; gamma != NULL: batch statistics (B >= 2, biased variance for the
+ * output), running_mean / running_var (either may be NULL) updated in place with `momentum` (unbiased variance), xhat [B][Cout] and
+ * invstd [Cout] kept for the backward.
+ * backward: gy -> dz [B][Cout] (ReLU mask from y, BatchNorm backward from xhat / invstd / gamma), dW [Cout][Cin] = dz^T x, dbias = column
+ * sums of dz (dW, dbias may be NULL), dgamma, dbeta;  sonet_fc_dx_f32: dx [B][Cin] = dz W. */
+int sonet_fc_max_rows(void);
+int sonet_fc_bn_act_fwd_f32(const float *x, const float *W, const float *bias, const float *gamma, const float *beta,
+                            float *running_mean, float *running_var, float momentum, float eps, int relu, int B, int Cin, int Cout,
+                            float *y, float *xhat, float *invstd, sonet_stream_t stream);
+int sonet_fc_bn_act_bwd_f32(const float *gy, const float *y, const float *xhat, const float *invstd, const float *gamma, const float *x,
+                            int relu, int B, int Cin, int Cout, float *dz, float *dW, float *dbias, float *dgamma, float *dbeta,
+                            sonet_stream_t stream);
+int sonet_fc_dx_f32(const float *dz, const float *W, int B, int Cin, int Cout, float *dx, sonet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -598,8 +598,42 @@ class EquivariantLayer(_FusedPointwise):
         return y
 
 
+class _FcFn(torch.autograd.Function):
+    """Linear + BatchNorm1d (batch statistics) + ReLU of a B x C head layer in training as one forward and two backward launches
+    (``sonet_fc_bn_act_fwd_f32`` / ``_bwd_f32`` / ``sonet_fc_dx_f32``; models/layers.py:123-166).  ``bn`` is the BatchNorm module (its
+    running statistics are updated in place by the forward kernel, as F.batch_norm does) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, bn, relu):
+        x, weight = x.contiguous(), weight.contiguous()
+        if bn is not None:
+            if x.shape[0] < 2:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            rm, rv = bn.running_mean, bn.running_var
+            if not all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == x.device) for t in (rm, rv)):
+                raise _ops.SonetHipError("MyLinear: the BatchNorm running statistics must be contiguous float32 tensors on the input's device")
+            y, xhat, invstd = _ops.fc_bn_act_fwd(x, weight, bias, gamma.contiguous(), beta.contiguous(), rm, rv, bn.momentum, bn.eps, relu)
+        else:
+            y, xhat, invstd = _ops.fc_bn_act_fwd(x, weight, bias, None, None, None, None, 0.0, 0.0, relu)
+        ctx.relu, ctx.has_bn, ctx.has_bias = bool(relu), bn is not None, bias is not None
+        empty = x.new_empty(0)
+        ctx.save_for_backward(x, weight, y if relu else empty, xhat if xhat is not None else empty, invstd if invstd is not None else empty,
+                              gamma.detach() if gamma is not None else empty)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y, xhat, invstd, gamma = ctx.saved_tensors
+        bn = ctx.has_bn
+        dz, dW, db, dgamma, dbeta = _ops.fc_bn_act_bwd(gy.contiguous(), y if ctx.relu else None, xhat if bn else None, invstd if bn else None,
+                                                      gamma if bn else None, x, ctx.relu, want_dw=ctx.needs_input_grad[1])
+        dx = _ops.fc_dx(dz, weight) if ctx.needs_input_grad[0] else None
+        return dx, dW, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), dgamma, dbeta, None, None
+
+
 class MyLinear(nn.Module):
-    """FC + BN + act (models/layers.py:123-166).  Classifier-head layer: B x C only, stays on aten."""
+    """FC + BN + act (models/layers.py:123-166).  Classifier-head layer, B x C only: eval / no-grad on ``sonet_linear_act_f32``,
+    training on the ``sonet_fc_*`` kernels (``_FcFn``); other norms / activations / wide batches stay on aten."""
 
     def __init__(self, in_features, out_features, activation=None, normalization=None, momentum=0.1,
                  bn_momentum_decay_step=None, bn_momentum_decay=1):
@@ -649,6 +683,15 @@ class MyLinear(nn.Module):
         if fast:                                         # eval / no-grad: Linear + BN + ReLU as one kernel
             scale, shift = self._eval_affine()
             return _ops.linear_act(x.contiguous(), self.linear.weight.detach().contiguous(), scale, shift, self.activation == 'relu')
+        bn = self.norm if self.normalization == 'batch' else None
+        if (torch.is_grad_enabled() and self.normalization in (None, 'batch') and self.activation in (None, 'relu')
+                and (bn is None or (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None))
+                and _ops.fc_head_ok(x, self.linear.weight) and (bn is None or x.shape[0] >= 2)):
+            # training: Linear + BatchNorm1d (batch statistics) + ReLU in one launch, two for the backward
+            if bn is not None:
+                bn.decay_momentum(epoch)
+            return _FcFn.apply(x, self.linear.weight, self.linear.bias, bn.weight if bn is not None else None,
+                               bn.bias if bn is not None else None, bn, self.activation == 'relu')
         x = self.linear(x)
         if self.normalization == 'batch':
             x = self.norm(x, epoch)

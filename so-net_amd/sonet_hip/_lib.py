@@ -114,6 +114,10 @@ SIGNATURES = {
     "sonet_pointmlp_h3_pack_strided": [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_pack_strided": [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _i, _i, _vp],
     "sonet_adam_chunk": [],
+    "sonet_fc_max_rows": [],
+    "sonet_fc_bn_act_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_fc_bn_act_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sonet_fc_dx_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "sonet_adam_multi_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp],
     "sonet_channel_stats_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_channel_stats_bf16": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],

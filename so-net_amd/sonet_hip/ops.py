@@ -1402,6 +1402,63 @@ def linear_act(x, weight, scale, shift, relu):
     return y
 
 
+FC_HEAD = _os.environ.get("SONET_FC_HEAD", "1") != "0"          # training: the heads' B x C layers on sonet_fc_* (one forward, two backward launches per layer)
+
+
+def fc_head_ok(x, weight):
+    """The training kernels of the heads' FC layers take this (x B x Cin, weight Cout x Cin)?"""
+    return (FC_HEAD and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_cuda
+            and 1 <= x.shape[0] <= 128 and x.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0 and x.shape[1] >= 4 and weight.shape[0] >= 4)
+
+
+def fc_bn_act_fwd(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    """Linear + BatchNorm1d (batch statistics; gamma None: no normalisation) + ReLU, training forward: -> (y, xhat, invstd); the running
+    statistics are updated in place (models/layers.py:123-166)."""
+    _chk(x, "x", torch.float32, 2)
+    _chk(weight, "weight", torch.float32, 2)
+    dev = _same_device(x, weight)
+    B, Cin = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+    xhat = torch.empty((B, Cout), dtype=torch.float32, device=dev) if gamma is not None else None
+    invstd = torch.empty((Cout,), dtype=torch.float32, device=dev) if gamma is not None else None
+    with torch.cuda.device(dev), _timed("fc_bn_act_fwd_%dx%d" % (Cin, Cout)):
+        check(_lib.load().sonet_fc_bn_act_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                  float(momentum), float(eps), int(bool(relu)), B, Cin, Cout, ptr(y), ptr(xhat), ptr(invstd),
+                                                  stream_ptr()), "sonet_fc_bn_act_fwd_f32")
+    return y, xhat, invstd
+
+
+def fc_bn_act_bwd(gy, y, xhat, invstd, gamma, x, relu, want_dw=True):
+    """-> (dz, dW, dbias, dgamma, dbeta): the layer's backward up to its own parameters (dgamma / dbeta None without a norm)."""
+    _chk(gy, "gy", torch.float32, 2)
+    dev = _same_device(gy, x)
+    B, Cout = gy.shape
+    Cin = x.shape[1]
+    dz = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+    dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev) if want_dw else None
+    vec = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+    has_bn = gamma is not None
+    with torch.cuda.device(dev), _timed("fc_bn_act_bwd_%dx%d" % (Cin, Cout)):
+        check(_lib.load().sonet_fc_bn_act_bwd_f32(ptr(gy), ptr(y), ptr(xhat), ptr(invstd), ptr(gamma), ptr(x), int(bool(relu)), B, Cin, Cout,
+                                                  ptr(dz), ptr(dW), ptr(vec[0]), ptr(vec[1]) if has_bn else None, ptr(vec[2]) if has_bn else None,
+                                                  stream_ptr()), "sonet_fc_bn_act_bwd_f32")
+    return dz, dW, vec[0], (vec[1] if has_bn else None), (vec[2] if has_bn else None)
+
+
+def fc_dx(dz, weight):
+    """dx B x Cin = dz (B x Cout) . weight (Cout x Cin)."""
+    _chk(dz, "dz", torch.float32, 2)
+    _chk(weight, "weight", torch.float32, 2)
+    dev = _same_device(dz, weight)
+    B, Cout = dz.shape
+    Cin = weight.shape[1]
+    dx = torch.empty((B, Cin), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("fc_dx_%dx%d" % (Cin, Cout)):
+        check(_lib.load().sonet_fc_dx_f32(ptr(dz), ptr(weight), B, Cin, Cout, ptr(dx), stream_ptr()), "sonet_fc_dx_f32")
+    return dx
+
+
 def chamfer_nn(q, db):
     """q B x 3 x Nq, db B x 3 x Nd -> B x Nq i32 nearest database index."""
     _chk(q, "q", torch.float32, 3)
