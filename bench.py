@@ -7,7 +7,10 @@ head, eval mode) over one batch of synthetic clouds already resident in HBM: B c
 5000 points, 8x8 SOM, k=3, som_k=9, surface normals on (BASELINE.json configs[1] shape; forward is
 the metric).  The batch is sharded over ranks with no data-path collective ("weak" scaling: per-GPU
 work fixed).  W untimed warm-up steps, then exactly K steps bracketed by barrier +
-torch.cuda.synchronize(); the time is the MAX over ranks; rank 0 prints ONE JSON line.
+torch.cuda.synchronize(); the time is the MAX over ranks; rank 0 prints ONE JSON line.  Before the W warm-up steps every
+timed region runs --spin-up seconds (default 1 s, reported as `spin_up`) of untimed steps: an idle MI355X sits at 94 MHz
+and reaches its clocks after 0.3-0.5 s of load (profiles/r04y_first_process.log: 3 % on a 20-step window, 40 % on the
+first 40 training steps of a fresh box).
 
 Extra objects on the line (task contract (4)):
   roofline      -- for the dominant kernel of the step (largest share of kernel time): algorithmic
@@ -65,6 +68,9 @@ def parse():
                     help="skip the other BASELINE.json configs (training step bf16 / f32-class, segmenter, autoencoder + Chamfer) under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps per window of each `other_configs` entry")
     ap.add_argument("--windows", type=int, default=3, help="timed windows of K steps of the headline (the first one is `value`)")
+    ap.add_argument("--spin-up", type=float, default=1.0,
+                    help="seconds of untimed steps before the W warm-up steps of a timed region: an idle MI355X sits at 94 MHz and needs "
+                         "0.3-0.5 s of load to reach its clocks (tools/first_process.py); 0 = none")
     return ap.parse_args()
 
 
@@ -298,6 +304,18 @@ def _windows(fn, steps, n=3, dev=None, collective=False):
     return ts, mine
 
 
+def _spin_up(fn, seconds, chunk=16):
+    """Untimed calls of `fn` for `seconds` of wall time (device drained every `chunk` calls): clocks up before a timed region.
+    Returns the number of calls."""
+    n, t0 = 0, time.perf_counter()
+    while seconds > 0 and time.perf_counter() - t0 < seconds:
+        for _ in range(chunk):
+            fn()
+        torch.cuda.synchronize()
+        n += chunk
+    return n
+
+
 def other_configs(args, dev, world=1, rank=0):
     """world > 1 (the driver's --gpus N command, EVERY rank calls this): BASELINE configs[4] -- the data-parallel training step, global
     batch 64 x N, bucketed RCCL gradient all-reduce -- in bf16 and in the f32-class arithmetic, timed like the headline (barrier on both
@@ -357,6 +375,7 @@ def other_configs(args, dev, world=1, rank=0):
                     enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
                 par = _encoder_parity(enc, inp, 2, tol=BF16_TOL if precision == "bf16" else 1e-5)
                 enc.train()
+            _spin_up(step, 0.5 * args.spin_up, chunk=8)
             for _ in range(5):
                 step()
             ts, mine = _windows(step, K, dev=dev, collective=world > 1)
@@ -429,6 +448,7 @@ def other_configs(args, dev, world=1, rank=0):
             call = lambda: g(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"])     # noqa: E731
             for _ in range(3):
                 call()
+            _spin_up(call, 0.5 * args.spin_up)
             ts, _ = _windows(call, K)
             bad = g.range_violations()
             for _ in range(2):
@@ -535,6 +555,7 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         opt_c.step()
         return loss, nbytes
 
+    _spin_up(step, args.spin_up, chunk=8)
     for _ in range(max(1, args.warmup)):
         loss, nbytes = step()
     dp.barrier()
@@ -635,6 +656,7 @@ def main():
                 return o
         else:
             run_many = lambda n, first=0: [step() for _ in range(n)][-1]            # noqa: E731
+        spin_calls = _spin_up(lambda: run_many(P), args.spin_up) * P
         run_many(args.warmup)
         dp.barrier()
         torch.cuda.synchronize()
@@ -829,6 +851,9 @@ def main():
                     "min": round(world * B * args.steps / max(window_s), 1),
                     "median": round(world * B * args.steps / sorted(window_s)[len(window_s) // 2], 1),
                     "what": "whole-job clouds/s of every timed window (max over ranks each); `value` is the first"},
+        "spin_up": {"seconds": args.spin_up, "untimed_steps": spin_calls,
+                    "what": "untimed replays before the W warm-up steps: an idle MI355X sits at its lowest clock and needs 0.3-0.5 s of load to "
+                            "leave it (tools/first_process.py, profiles/r04y_first_process.log); --spin-up 0 = none"},
         "ranks": ranks,
         "in_flight": P, "single_stream": single, "replay_among_others_equals_replay_alone": overlap_ok,
         "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,
