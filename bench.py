@@ -68,6 +68,8 @@ def parse():
                     help="skip the other BASELINE.json configs (training step bf16 / f32-class, segmenter, autoencoder + Chamfer) under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps per window of each `other_configs` entry")
     ap.add_argument("--windows", type=int, default=3, help="timed windows of K steps of the headline (the first one is `value`)")
+    ap.add_argument("--range-check-every", type=int, default=None,
+                    help="period (replays) of the non-blocking operand-range check of the replayed graphs (default: sonet_hip.graph.CHECK_EVERY; 0 = off)")
     ap.add_argument("--spin-up", type=float, default=1.0,
                     help="seconds of untimed steps before the W warm-up steps of a timed region: an idle MI355X sits at 94 MHz and needs "
                          "0.3-0.5 s of load to reach its clocks (tools/first_process.py); 0 = none")
@@ -640,7 +642,10 @@ def main():
     fwd = lambda pc, sn, node, knn: cls(enc(pc, sn, node, knn, is_train=False))      # noqa: E731
     with torch.no_grad():
         if use_graph:
+            from sonet_hip import graph as _graph
             from sonet_hip.graph import GraphedForward
+            if args.range_check_every is not None:
+                _graph.CHECK_EVERY = max(0, args.range_check_every)
             inps = [inp] + [synth.make_inputs(B, N, seed=100 + rank + 1000 * q, device=dev) for q in range(1, P)]
             graphs = [GraphedForward(fwd, (i_["pc"], i_["sn"], i_["node"], i_["node_knn_I"]), warmup=max(1, args.warmup)) for i_ in inps]
             streams = [torch.cuda.Stream(device=dev) for _ in range(P)]

@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from sonet_hip import ops as _ops
 from util import som
-from .layers import EquivariantLayer, KNNModule, MyLinear, PointNet, PointResNet  # noqa: F401
+from .layers import EquivariantLayer, KNNModule, MyLinear, PointNet, PointResNet, _PlainAttrs  # noqa: F401
 
 
 def _head_inference(fn):
@@ -89,7 +89,7 @@ class Transformer(nn.Module):
         return torch.tanh(self.fc3(self.fc2_out, epoch))
 
 
-class Encoder(nn.Module):
+class Encoder(_PlainAttrs, nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
@@ -272,7 +272,7 @@ class Encoder(nn.Module):
         return self.feature
 
 
-class Classifier(nn.Module):
+class Classifier(_PlainAttrs, nn.Module):
     """feature_num -> 512 -> 256 -> classes (models/networks.py:202-227).  Three B x C FC layers:
     not part of the hot path, plain PyTorch-ROCm."""
 
@@ -298,7 +298,7 @@ class Classifier(nn.Module):
         return self.fc3(self.fc2_out, epoch)
 
 
-class Segmenter(nn.Module):
+class Segmenter(_PlainAttrs, nn.Module):
     """Per-point part-segmentation head (models/networks.py:230-344): five EquivariantLayers on the
     3356-channel concat of per-point, per-node (broadcast back) and global features; the k copies of a
     point are averaged after layer 3.  All layers run on the fused point-wise kernels."""

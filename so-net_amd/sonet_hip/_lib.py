@@ -203,7 +203,10 @@ _device_ok = {}
 
 
 def require_device(device):
-    """The ops run only on an MI355X: fail loudly otherwise."""
+    """The ops run only on an MI355X: fail loudly otherwise.  (Checked once per device: torch.cuda.is_available() alone costs 2-3 us per
+    call -- an environment lookup -- and an op wrapper runs a hundred times per training step.)"""
+    if device.index in _device_ok:
+        return
     if not torch.cuda.is_available():
         raise SonetHipError("sonet_hip needs an MI355X (gfx950) GPU; torch.cuda.is_available() is False "
                             "and there is no CPU fallback")
@@ -216,7 +219,25 @@ def require_device(device):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device (what torch.cuda.current_stream().cuda_stream returns, without building a Stream
+    object: 10 us -> 0.4 us, 100 calls per training step)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class on_device:
+    """``with torch.cuda.device(dev)`` for a ``torch.device`` that is known to be a CUDA device, without the argument parsing
+    (4-5 us per use, 50 uses per training step)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index if dev.index is not None else -1
+
+    def __enter__(self):
+        self.prev = torch.cuda._exchange_device(self.idx)
+
+    def __exit__(self, *exc):
+        torch.cuda._maybe_exchange_device(self.prev)
+        return False
 
 
 def ptr(t):

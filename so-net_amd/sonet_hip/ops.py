@@ -93,7 +93,7 @@ def index_max(data, index, K):
     if out.numel() == 0 or Np == 0:
         return out.zero_()
     lib = _lib.load()
-    with torch.cuda.device(dev), _timed("index_max"):
+    with _lib.on_device(dev), _timed("index_max"):
         fn = lib.sonet_index_max_f32 if data.dtype == torch.float32 else lib.sonet_index_max_bf16
         check(fn(ptr(data), ptr(index), ptr(out), B, C, Np, int(K), stream_ptr()), "sonet_index_max")
     return out
@@ -115,7 +115,7 @@ def index_max_gather(data, index, K, row_max=None):
     val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
     lib = _lib.load()
     fn = lib.sonet_index_max_gather_f32 if data.dtype == torch.float32 else lib.sonet_index_max_gather_bf16
-    with torch.cuda.device(dev), _timed("index_max_gather" if data.dtype == torch.float32 else "index_max_gather_bf16"):
+    with _lib.on_device(dev), _timed("index_max_gather" if data.dtype == torch.float32 else "index_max_gather_bf16"):
         check(fn(ptr(data), ptr(index), ptr(row_max), ptr(idx), ptr(val), B, C, Np, int(K), stream_ptr()), "sonet_index_max_gather")
     return idx, val
 
@@ -132,7 +132,7 @@ def index_max_gather_p16(planes, index, K, row_max=None):
     dev = _same_device(planes.data, index, row_max)
     idx = torch.empty((B, C, int(K)), dtype=torch.int32, device=dev)
     val = torch.empty((B, C, int(K)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("index_max_gather_p16"):
+    with _lib.on_device(dev), _timed("index_max_gather_p16"):
         check(_lib.load().sonet_index_max_gather_p16(ptr(planes.data), ptr(index), ptr(row_max), ptr(idx), ptr(val), B, C, Np, int(K), stream_ptr()),
               "sonet_index_max_gather_p16")
     return idx, val
@@ -160,7 +160,7 @@ def som_assign(x, node, k, want_i64=False):
     ws = torch.empty((B * 3 * M * 8 + B * M * 4,), dtype=torch.uint8, device=dev)
     r.sum_ws = ws[:B * 3 * M * 8].view(torch.float64).view(B, 3, M)
     r.count = ws[B * 3 * M * 8:].view(torch.int32).view(B, M)
-    with torch.cuda.device(dev), _timed("som_assign"):
+    with _lib.on_device(dev), _timed("som_assign"):
         check(_lib.load().sonet_som_assign_f32(ptr(x), ptr(node), B, N, M, r.k, ptr(r.min_idx_i32), ptr(r.min_idx_i64),
                                                ptr(r.count), ptr(r.sum_ws), stream_ptr()), "sonet_som_assign_f32")
     return r
@@ -181,7 +181,7 @@ def som_group(x, sn, a, want_centers=False, want_decentered=False, want_augmente
     out["centers"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_centers else None
     out["x_decentered"] = torch.empty((B, 3, kN), dtype=torch.float32, device=dev) if want_decentered else None
     out["x_augmented"] = torch.empty((B, 6, kN), dtype=torch.float32, device=dev) if want_augmented else None
-    with torch.cuda.device(dev), _timed("som_group"):
+    with _lib.on_device(dev), _timed("som_group"):
         check(_lib.load().sonet_som_group_f32(ptr(x), ptr(sn), ptr(a.min_idx_i32), ptr(a.count), ptr(a.sum_ws),
                                               B, N, M, k, ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["centers"]),
                                               ptr(out["x_decentered"]), ptr(out["x_augmented"]), stream_ptr()),
@@ -203,7 +203,7 @@ def som_sort_group(x, sn, a):
                pos0=torch.empty((B,), dtype=torch.int32, device=dev),
                node_off=torch.empty((B, M), dtype=torch.int32, device=dev), count=a.count)
     cursor = torch.empty((B, M), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), _timed("som_sort_group"):
+    with _lib.on_device(dev), _timed("som_sort_group"):
         check(_lib.load().sonet_som_sort_group_f32(ptr(x), ptr(sn), ptr(a.min_idx_i32), ptr(a.count), ptr(a.sum_ws), B, N, M, k,
                                                    ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
                                                    ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(cursor), stream_ptr()),
@@ -238,7 +238,7 @@ def som_assign_sort(x, sn, node, k, want_i64=False):
                pos0=torch.empty((B,), dtype=torch.int32, device=dev),
                node_off=torch.empty((B, M), dtype=torch.int32, device=dev), count=r.count)
     ws = torch.empty((lib.sonet_som_assign_sort_ws_size(B, N, M, k),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev), _timed("som_assign_sort"):
+    with _lib.on_device(dev), _timed("som_assign_sort"):
         check(lib.sonet_som_assign_sort_f32(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
                                             ptr(r.sum_ws), ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
                                             ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(ws), stream_ptr()),
@@ -251,7 +251,7 @@ def som_mask(min_idx_i32, M):
     dev = _same_device(min_idx_i32)
     B, kN = min_idx_i32.shape
     mask = torch.empty((B, kN, int(M)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), _timed("som_mask"):
+    with _lib.on_device(dev), _timed("som_mask"):
         check(_lib.load().sonet_som_mask_i32(ptr(min_idx_i32), ptr(mask), B, kN, int(M), stream_ptr()), "sonet_som_mask_i32")
     return mask
 
@@ -264,7 +264,7 @@ def node_gather(feat, min_idx_i32):
     B, C, M = feat.shape
     kN = min_idx_i32.shape[1]
     out = torch.empty((B, C, kN), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("node_gather"):
+    with _lib.on_device(dev), _timed("node_gather"):
         check(_lib.load().sonet_node_gather_f32(ptr(feat), ptr(min_idx_i32), ptr(out), B, C, M, kN, stream_ptr()),
               "sonet_node_gather_f32")
     return out
@@ -279,7 +279,7 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     B, C, L = t.shape
     if z.shape[0] != B or z.shape[1] != C or min_idx_i32.shape != (B, L):
         raise SonetHipError("z must be B x C x M and min_idx B x L")
-    with torch.cuda.device(dev), _timed("node_add_affine_act"):
+    with _lib.on_device(dev), _timed("node_add_affine_act"):
         check(_lib.load().sonet_node_add_affine_act_f32(ptr(t), ptr(z), ptr(min_idx_i32), ptr(scale), ptr(shift), int(bool(relu)),
                                                         B, C, L, z.shape[2], stream_ptr()), "sonet_node_add_affine_act_f32")
     return t
@@ -299,7 +299,7 @@ def wgrad_x3(g, x):
     if g.numel() == 0 or x.numel() == 0:
         return dw.zero_()
     ws = torch.empty((lib.sonet_wgrad_x3_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev), _timed("wgradx3_%dx%d_L%d" % (Cout, Cin, L)):
+    with _lib.on_device(dev), _timed("wgradx3_%dx%d_L%d" % (Cout, Cin, L)):
         check(lib.sonet_wgrad_x3_f32(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_x3_f32")
     return dw
 
@@ -319,7 +319,7 @@ def wgrad_bf16(g, x):
     if g.numel() == 0 or x.numel() == 0:
         return dw.zero_()
     ws = torch.empty((lib.sonet_wgrad_bf16_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev), _timed("wgradbf16_%dx%d_L%d" % (Cout, Cin, L)):
+    with _lib.on_device(dev), _timed("wgradbf16_%dx%d_L%d" % (Cout, Cin, L)):
         check(lib.sonet_wgrad_bf16(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_bf16")
     return dw
 
@@ -341,7 +341,7 @@ def node_gather_lead_affine_act(z, gidx, lead, wl, scale, shift, relu):
     out = torch.empty((B, C, L), dtype=z.dtype, device=dev)
     lib = _lib.load()
     fn = lib.sonet_node_gather_lead_affine_act_f32 if z.dtype == torch.float32 else lib.sonet_node_gather_lead_affine_act_bf16
-    with torch.cuda.device(dev), _timed("node_gather_lead%s_%dx%d_L%d" % ("" if z.dtype == torch.float32 else "bf16", NL, C, L)):
+    with _lib.on_device(dev), _timed("node_gather_lead%s_%dx%d_L%d" % ("" if z.dtype == torch.float32 else "bf16", NL, C, L)):
         check(fn(ptr(z), ptr(gidx), ptr(lead), ptr(wl), ptr(scale), ptr(shift), int(bool(relu)), ptr(out), B, C, L, M, NL, stream_ptr()),
               "sonet_node_gather_lead_affine_act")
     return out
@@ -353,7 +353,7 @@ def knn_self(node, K):
     dev = _same_device(node)
     B, _, M = node.shape
     out = torch.empty((B, M, int(K)), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev), _timed("knn_self"):
+    with _lib.on_device(dev), _timed("knn_self"):
         check(_lib.load().sonet_knn_self_f32(ptr(node), ptr(out), B, M, int(K), stream_ptr()), "sonet_knn_self_f32")
     return out
 
@@ -368,7 +368,7 @@ def knn_group(coord, feat, knn_I, center_avg):
     K = knn_I.shape[2]
     center = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
     out = torch.empty((B, 3 + C, M, K), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("knn_group"):
+    with _lib.on_device(dev), _timed("knn_group"):
         check(_lib.load().sonet_knn_group_f32(ptr(coord), ptr(feat), ptr(knn_I), B, C, M, K, int(bool(center_avg)), ptr(center), ptr(out),
                                               stream_ptr()), "sonet_knn_group_f32")
     return center, out
@@ -385,7 +385,7 @@ def lastdim_max(x):
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=dev)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(dev), _timed("lastdim_max"):
+    with _lib.on_device(dev), _timed("lastdim_max"):
         check(_lib.load().sonet_lastdim_max_f32(ptr(x), ptr(out), out.numel(), K, stream_ptr()), "sonet_lastdim_max_f32")
     return out
 
@@ -400,7 +400,7 @@ def knn_gather(x, knn_I):
     K = knn_I.shape[2]
     dev = _same_device(x, knn_I)
     out = torch.empty((B, C, M, K), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("knn_gather"):
+    with _lib.on_device(dev), _timed("knn_gather"):
         check(_lib.load().sonet_knn_gather_f32(ptr(x), ptr(knn_I), ptr(out), B, C, M, K, stream_ptr()), "sonet_knn_gather_f32")
     return out
 
@@ -419,7 +419,7 @@ def knn_gather_bwd(g, knn_I, M):
     gx = torch.empty((B, C, M), dtype=torch.float32, device=dev)
     ws = torch.empty((lib.sonet_knn_gather_bwd_ws_size(B, M, K),), dtype=torch.uint8, device=dev)
     fn = lib.sonet_knn_gather_bwd_bf16 if g.dtype == torch.bfloat16 else lib.sonet_knn_gather_bwd_f32
-    with torch.cuda.device(dev), _timed("knn_gather_bwd"):
+    with _lib.on_device(dev), _timed("knn_gather_bwd"):
         check(fn(ptr(g), ptr(knn_I), ptr(gx), ptr(ws), B, C, M, K, stream_ptr()), "sonet_knn_gather_bwd")
     return gx
 
@@ -437,7 +437,7 @@ class _LastDimMax(torch.autograd.Function):
         idx = torch.empty(xc.shape[:-1], dtype=torch.int32, device=xc.device)
         lib = _lib.load()
         fn = lib.sonet_lastdim_argmax_bf16 if xc.dtype == torch.bfloat16 else lib.sonet_lastdim_argmax_f32
-        with torch.cuda.device(xc.device), _timed("lastdim_argmax"):
+        with _lib.on_device(xc.device), _timed("lastdim_argmax"):
             check(fn(ptr(xc), ptr(out), ptr(idx), rows, K, stream_ptr()), "sonet_lastdim_argmax")
         ctx.save_for_backward(idx)
         ctx.K = K
@@ -450,7 +450,7 @@ class _LastDimMax(torch.autograd.Function):
         gx = torch.empty(tuple(gc.shape) + (ctx.K,), dtype=gc.dtype, device=gc.device)
         lib = _lib.load()
         fn = lib.sonet_lastdim_max_bwd_bf16 if gc.dtype == torch.bfloat16 else lib.sonet_lastdim_max_bwd_f32
-        with torch.cuda.device(gc.device), _timed("lastdim_max_bwd"):
+        with _lib.on_device(gc.device), _timed("lastdim_max_bwd"):
             check(fn(ptr(gc), ptr(idx), ptr(gx), gc.numel(), ctx.K, stream_ptr()), "sonet_lastdim_max_bwd")
         return gx
 
@@ -765,7 +765,7 @@ def pointmlp_pack(weight2d, mode="f32"):
     dev = _same_device(weight2d)
     Cout, Cin = weight2d.shape
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if mode == "x3":
             wp = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin, Cout),), dtype=torch.uint8, device=dev)
             check(lib.sonet_pointmlp_x3_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_x3_pack")
@@ -791,7 +791,7 @@ def pointmlp_pack_transposed(weight2d, lo, Ci, Cp, mode):
         raise SonetHipError("pointmlp_pack_transposed: bad block lo=%d Ci=%d Cp=%d of %d columns" % (lo, Ci, Cp, Cin))
     lib = _lib.load()
     src = weight2d.data_ptr() + 4 * lo
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if mode == "bf16":
             wp = torch.empty((lib.sonet_pointmlp_bf16_pack_size(Cout, Cp) // 2,), dtype=torch.int16, device=dev)
             check(lib.sonet_pointmlp_bf16_pack_strided(src, 1, Cin, ptr(wp), Cout, Cp, Ci, stream_ptr()), "sonet_pointmlp_bf16_pack_strided")
@@ -840,7 +840,7 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     if bf16:
         if y.dtype != torch.bfloat16:
             raise SonetHipError("pointmlp: a bf16 pack writes a bfloat16 output")
-        with torch.cuda.device(dev), _timed("pointmlpbf16_%dx%d_L%d" % (C1 + C2, Cout, L)):
+        with _lib.on_device(dev), _timed("pointmlpbf16_%dx%d_L%d" % (C1 + C2, Cout, L)):
             if gidx is not None:
                 check(lib.sonet_pointmlp_bf16_gather(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
                                                      ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_bf16_gather")
@@ -852,7 +852,7 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     name = "pointmlp%s_%dx%d_L%d" % ("h3" if h3 else "x3" if x3 else "", C1 + C2, Cout, L)
     if h3:
         _range_arm(name)
-    with torch.cuda.device(dev), _timed(name):
+    with _lib.on_device(dev), _timed(name):
         if gidx is not None:
             check(lib.sonet_pointmlp_h3_gather_f32(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
                                                    ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_h3_gather_f32")
@@ -884,7 +884,7 @@ def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
     y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
     name = "pointmlph3_nodeadd_%dx%d_L%d" % (C1 + C2, Cout, L)
     _range_arm(name)
-    with torch.cuda.device(dev), _timed(name):
+    with _lib.on_device(dev), _timed(name):
         check(lib.sonet_pointmlp_h3_nodeadd_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
                                                 ptr(z), ptr(zidx), z.shape[2], stream_ptr()), "sonet_pointmlp_h3_nodeadd_f32")
     return y
@@ -962,7 +962,7 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
     var = torch.empty((Cout,), dtype=torch.float32, device=dev)
     if bf16:
         ws = torch.empty((lib.sonet_pointmlp_bf16_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
+        with _lib.on_device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
             check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
                                                 ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
         return y, mean, var
@@ -971,7 +971,7 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
     if h3:
         _range_arm(name)
     fn = lib.sonet_pointmlp_h3_stats_f32 if h3 else lib.sonet_pointmlp_x3_stats_f32
-    with torch.cuda.device(dev), _timed(name):
+    with _lib.on_device(dev), _timed(name):
         check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
                  stream_ptr()), "sonet_pointmlp_stats")
     return y, mean, var
@@ -1019,7 +1019,7 @@ def p16_from_f32(x, scale=None, shift=None, relu=False):
         _chk(shift, "shift", torch.float32, 1)
     name = "p16_from_f32_%d_L%d" % (C, L)
     _range_arm(name)
-    with torch.cuda.device(dev), _timed(name):
+    with _lib.on_device(dev), _timed(name):
         check(_lib.load().sonet_p16_from_f32(ptr(x), ptr(out.data), B, C, L, ptr(scale), ptr(shift), int(bool(relu)), stream_ptr()),
               "sonet_p16_from_f32")
     return out
@@ -1028,7 +1028,7 @@ def p16_from_f32(x, scale=None, shift=None, relu=False):
 def p16_to_f32(p):
     x = torch.empty((p.B, p.C, p.L), dtype=torch.float32, device=p.device)
     if x.numel():
-        with torch.cuda.device(p.device), _timed("p16_to_f32"):
+        with _lib.on_device(p.device), _timed("p16_to_f32"):
             check(_lib.load().sonet_p16_to_f32(ptr(p.data), ptr(x), p.B, p.C, p.L, stream_ptr()), "sonet_p16_to_f32")
     return x
 
@@ -1039,7 +1039,7 @@ def pointmlp_h3p_pack(weight2d):
     dev = _same_device(weight2d)
     Cout, Cin = weight2d.shape
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         wp = torch.empty((lib.sonet_pointmlp_h3p_pack_size(Cin, Cout) // 4,), dtype=torch.int32, device=dev)
         check(lib.sonet_pointmlp_h3p_pack(ptr(weight2d), ptr(wp), Cin, Cout, stream_ptr()), "sonet_pointmlp_h3p_pack")
     return wp
@@ -1097,7 +1097,7 @@ def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None
     if B * L * Cout != 0:
         name = "pointmlph3p%s_%dx%d_L%d" % ("_nodeadd" if z is not None else "_stats" if stats else "", C1 + C2, Cout, L)
         _range_arm(name)
-        with torch.cuda.device(dev), _timed(name):
+        with _lib.on_device(dev), _timed(name):
             check(lib.sonet_pointmlp_h3p(ptr(x1.data), C1, L1, ptr(gidx), ptr(x2.data) if x2 is not None else None, C2, ptr(wp), ptr(scale), ptr(shift),
                                          int(bool(relu)), ptr(y), ptr(yp.data) if yp is not None else None, B, Cout, L, ptr(z), ptr(zidx), ZM,
                                          ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_h3p")
@@ -1115,7 +1115,7 @@ def pointresnet_pack(w1, w2, w3, w4):
     dev = _same_device(w1, w2, w3, w4)
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pointresnet_pack_size(),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         check(lib.sonet_pointresnet_pack(ptr(w1), ptr(w2), ptr(w3), ptr(w4), w1.shape[1], ptr(ws), stream_ptr()),
               "sonet_pointresnet_pack")
     return ws
@@ -1136,7 +1136,7 @@ def pointresnet_fused(x, wstream, affine, want_p16=False):
     if B * L == 0:
         return (y, yp) if want_p16 else y
     _range_arm("pointresnet_fused_L%d" % L)
-    with torch.cuda.device(dev), _timed("pointresnet_fused%s_L%d" % ("_p16only" if only else "_p16" if want_p16 else "", L)):
+    with _lib.on_device(dev), _timed("pointresnet_fused%s_L%d" % ("_p16only" if only else "_p16" if want_p16 else "", L)):
         if want_p16:
             check(_lib.load().sonet_pointresnet_fused_p16_f32(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), ptr(yp.data), B, L, stream_ptr()),
                   "sonet_pointresnet_fused_p16_f32")
@@ -1158,7 +1158,7 @@ def pointresnet_fused_pool(sg, wstream, affine, M):
     ws = torch.empty((lib.sonet_pointresnet_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
     out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
     _range_arm("pointresnet_fused_pool_L%d" % L)
-    with torch.cuda.device(dev), _timed("pointresnet_fused_pool_L%d" % L):
+    with _lib.on_device(dev), _timed("pointresnet_fused_pool_L%d" % L):
         check(lib.sonet_pointresnet_fused_pool_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
                                                    ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
               "sonet_pointresnet_fused_pool_f32")
@@ -1174,7 +1174,7 @@ def pointresnet_bf16_pack(w1, w2, w3, w4):
     dev = _same_device(w1, w2, w3, w4)
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pointresnet_bf16_pack_size(),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         check(lib.sonet_pointresnet_bf16_pack(ptr(w1), ptr(w2), ptr(w3), ptr(w4), w1.shape[1], ptr(ws), stream_ptr()),
               "sonet_pointresnet_bf16_pack")
     return ws
@@ -1191,7 +1191,7 @@ def pointresnet_bf16(x, wstream, affine):
     y = torch.empty((B, 384, L), dtype=torch.bfloat16, device=dev)
     if y.numel() == 0:
         return y
-    with torch.cuda.device(dev), _timed("pointresnet_bf16_L%d" % L):
+    with _lib.on_device(dev), _timed("pointresnet_bf16_L%d" % L):
         check(_lib.load().sonet_pointresnet_bf16(ptr(x), Cin0, ptr(wstream), ptr(affine), ptr(y), B, L, stream_ptr()),
               "sonet_pointresnet_bf16")
     return y
@@ -1208,7 +1208,7 @@ def pointresnet_bf16_pool(sg, wstream, affine, M):
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pointresnet_bf16_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
     out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("pointresnet_bf16_pool_L%d" % L):
+    with _lib.on_device(dev), _timed("pointresnet_bf16_pool_L%d" % L):
         check(lib.sonet_pointresnet_bf16_pool(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
                                               ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
               "sonet_pointresnet_bf16_pool")
@@ -1227,7 +1227,7 @@ def channel_stats(y):
     var = torch.empty((C,), dtype=torch.float32, device=dev)
     lib = _lib.load()
     fn = lib.sonet_channel_stats_f32 if y.dtype == torch.float32 else lib.sonet_channel_stats_bf16
-    with torch.cuda.device(dev), _timed("channel_stats" if y.dtype == torch.float32 else "channel_stats_bf16"):
+    with _lib.on_device(dev), _timed("channel_stats" if y.dtype == torch.float32 else "channel_stats_bf16"):
         check(fn(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_channel_stats")
     return mean, var
 
@@ -1236,7 +1236,7 @@ def channel_affine_act_(y, scale, shift, relu):
     _chk(y, "y", torch.float32, 3)
     dev = _same_device(y, scale, shift)
     B, C, L = y.shape
-    with torch.cuda.device(dev), _timed("channel_affine_act"):
+    with _lib.on_device(dev), _timed("channel_affine_act"):
         check(_lib.load().sonet_channel_affine_act_f32(ptr(y), ptr(scale), ptr(shift), int(bool(relu)), B, C, L, stream_ptr()),
               "sonet_channel_affine_act_f32")
     return y
@@ -1250,7 +1250,7 @@ def channel_affine_act(x, scale, shift, relu):
     y = torch.empty_like(x)
     lib = _lib.load()
     fn = lib.sonet_channel_affine_act_out_f32 if x.dtype == torch.float32 else lib.sonet_channel_affine_act_out_bf16
-    with torch.cuda.device(dev), _timed("channel_affine_act" if x.dtype == torch.float32 else "channel_affine_act_bf16"):
+    with _lib.on_device(dev), _timed("channel_affine_act" if x.dtype == torch.float32 else "channel_affine_act_bf16"):
         check(fn(ptr(x), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, C, L, stream_ptr()), "sonet_channel_affine_act_out")
     return y
 
@@ -1264,7 +1264,7 @@ def chunk_mean(h, k):
         raise SonetHipError("chunk_mean: k in {1, 2, 3} and a length divisible by k")
     dev = _same_device(h)
     out = torch.empty((B, C, L // k), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("chunk_mean"):
+    with _lib.on_device(dev), _timed("chunk_mean"):
         check(_lib.load().sonet_chunk_mean_f32(ptr(h), ptr(out), B * C, L // k, int(k), stream_ptr()), "sonet_chunk_mean_f32")
     return out
 
@@ -1287,7 +1287,7 @@ def bn_fwd_coeffs(mean, var, gamma, beta, eps):
     dev = _same_device(mean, var, gamma, beta)
     C = mean.numel()
     out = torch.empty((3, C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         check(_lib.load().sonet_bn_fwd_coeffs_f32(ptr(mean), ptr(var), ptr(gamma.detach().contiguous()), ptr(beta.detach().contiguous()),
                                                   float(eps), C, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "sonet_bn_fwd_coeffs_f32")
     return out[0], out[1], out[2]
@@ -1298,7 +1298,7 @@ def bn_bwd_coeffs(sums, mean, invstd, gamma, n):
     dev = _same_device(sums, mean, invstd, gamma)
     C = mean.numel()
     out = torch.empty((5, C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         check(_lib.load().sonet_bn_bwd_coeffs_f32(ptr(sums), ptr(mean), ptr(invstd), ptr(gamma.detach().contiguous()), float(n), C,
                                                   ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), stream_ptr()),
               "sonet_bn_bwd_coeffs_f32")
@@ -1314,7 +1314,7 @@ def pointwise_bwd_stats(gy, raw, scale, shift, relu, want_sums=False):
     sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
     lib = _lib.load()
     fn = lib.sonet_pointwise_bwd_stats_f32 if gy.dtype == torch.float32 else lib.sonet_pointwise_bwd_stats_bf16
-    with torch.cuda.device(dev), _timed("pointwise_bwd_stats" if gy.dtype == torch.float32 else "pointwise_bwd_stats_bf16"):
+    with _lib.on_device(dev), _timed("pointwise_bwd_stats" if gy.dtype == torch.float32 else "pointwise_bwd_stats_bf16"):
         check(fn(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), B, C, L, ptr(sums), stream_ptr()), "sonet_pointwise_bwd_stats")
     if want_sums:
         return sums
@@ -1330,7 +1330,7 @@ def pointwise_bwd_apply(gy, raw, scale, shift, relu, a, b, c0):
     out = torch.empty_like(gy)
     lib = _lib.load()
     fn = lib.sonet_pointwise_bwd_apply_f32 if gy.dtype == torch.float32 else lib.sonet_pointwise_bwd_apply_bf16
-    with torch.cuda.device(dev), _timed("pointwise_bwd_apply" if gy.dtype == torch.float32 else "pointwise_bwd_apply_bf16"):
+    with _lib.on_device(dev), _timed("pointwise_bwd_apply" if gy.dtype == torch.float32 else "pointwise_bwd_apply_bf16"):
         check(fn(ptr(gy), ptr(raw), ptr(scale), ptr(shift), int(bool(relu)), ptr(a), ptr(b), ptr(c0), ptr(out), B, C, L, stream_ptr()),
               "sonet_pointwise_bwd_apply")
     return out
@@ -1360,12 +1360,12 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32
     if wt_pack is not None and out_dtype == torch.bfloat16 and pooled_dgrad_mfma_ok(C, C1, C2, int(L)):
         if wt_pack.dtype != torch.int16 or wt_pack.numel() != lib.sonet_pointmlp_bf16_pack_size(C, (C1 + C2 + 31) // 32 * 32) // 2:
             raise SonetHipError("pooled_dgrad: wt_pack is not the bf16 pack of W^T")
-        with torch.cuda.device(dev), _timed("pooled_dgrad_mfma"):
+        with _lib.on_device(dev), _timed("pooled_dgrad_mfma"):
             check(lib.sonet_pooled_dgrad_mfma_bf16(ptr(g_pooled), ptr(pos_i32), ptr(wt_pack), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2),
                                                    stream_ptr()), "sonet_pooled_dgrad_mfma_bf16")
         return gx1, gx2
     fn = lib.sonet_pooled_dgrad_f32 if out_dtype == torch.float32 else lib.sonet_pooled_dgrad_obf16
-    with torch.cuda.device(dev), _timed("pooled_dgrad"):
+    with _lib.on_device(dev), _timed("pooled_dgrad"):
         check(fn(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2), stream_ptr()),
               "sonet_pooled_dgrad")
     return gx1, gx2
@@ -1383,7 +1383,7 @@ def pooled_wgrad(g_pooled_t, pos_i32_t, x):
     part = torch.empty((B, C, Ci), dtype=torch.float32, device=dev)
     lib = _lib.load()
     fn = lib.sonet_pooled_wgrad_f32 if x.dtype == torch.float32 else lib.sonet_pooled_wgrad_xbf16
-    with torch.cuda.device(dev), _timed("pooled_wgrad"):
+    with _lib.on_device(dev), _timed("pooled_wgrad"):
         check(fn(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()), "sonet_pooled_wgrad")
     return part.sum(0)
 
@@ -1396,7 +1396,7 @@ def linear_act(x, weight, scale, shift, relu):
     B, Cin = x.shape
     Cout = weight.shape[0]
     y = torch.empty((B, Cout), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("linear_act_%dx%d" % (Cin, Cout)):
+    with _lib.on_device(dev), _timed("linear_act_%dx%d" % (Cin, Cout)):
         check(_lib.load().sonet_linear_act_f32(ptr(x), ptr(weight), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cin, Cout, stream_ptr()),
               "sonet_linear_act_f32")
     return y
@@ -1422,7 +1422,7 @@ def fc_bn_act_fwd(x, weight, bias, gamma, beta, running_mean, running_var, momen
     y = torch.empty((B, Cout), dtype=torch.float32, device=dev)
     xhat = torch.empty((B, Cout), dtype=torch.float32, device=dev) if gamma is not None else None
     invstd = torch.empty((Cout,), dtype=torch.float32, device=dev) if gamma is not None else None
-    with torch.cuda.device(dev), _timed("fc_bn_act_fwd_%dx%d" % (Cin, Cout)):
+    with _lib.on_device(dev), _timed("fc_bn_act_fwd_%dx%d" % (Cin, Cout)):
         check(_lib.load().sonet_fc_bn_act_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                   float(momentum), float(eps), int(bool(relu)), B, Cin, Cout, ptr(y), ptr(xhat), ptr(invstd),
                                                   stream_ptr()), "sonet_fc_bn_act_fwd_f32")
@@ -1439,7 +1439,7 @@ def fc_bn_act_bwd(gy, y, xhat, invstd, gamma, x, relu, want_dw=True):
     dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev) if want_dw else None
     vec = torch.empty((3, Cout), dtype=torch.float32, device=dev)
     has_bn = gamma is not None
-    with torch.cuda.device(dev), _timed("fc_bn_act_bwd_%dx%d" % (Cin, Cout)):
+    with _lib.on_device(dev), _timed("fc_bn_act_bwd_%dx%d" % (Cin, Cout)):
         check(_lib.load().sonet_fc_bn_act_bwd_f32(ptr(gy), ptr(y), ptr(xhat), ptr(invstd), ptr(gamma), ptr(x), int(bool(relu)), B, Cin, Cout,
                                                   ptr(dz), ptr(dW), ptr(vec[0]), ptr(vec[1]) if has_bn else None, ptr(vec[2]) if has_bn else None,
                                                   stream_ptr()), "sonet_fc_bn_act_bwd_f32")
@@ -1454,7 +1454,7 @@ def fc_dx(dz, weight):
     B, Cout = dz.shape
     Cin = weight.shape[1]
     dx = torch.empty((B, Cin), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("fc_dx_%dx%d" % (Cin, Cout)):
+    with _lib.on_device(dev), _timed("fc_dx_%dx%d" % (Cin, Cout)):
         check(_lib.load().sonet_fc_dx_f32(ptr(dz), ptr(weight), B, Cin, Cout, ptr(dx), stream_ptr()), "sonet_fc_dx_f32")
     return dx
 
@@ -1467,7 +1467,7 @@ def chamfer_nn(q, db):
     B, _, Nq = q.shape
     Nd = db.shape[2]
     nn = torch.empty((B, Nq), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), _timed("chamfer_nn"):
+    with _lib.on_device(dev), _timed("chamfer_nn"):
         check(_lib.load().sonet_chamfer_nn_f32(ptr(q), ptr(db), ptr(nn), B, Nq, Nd, stream_ptr()), "sonet_chamfer_nn_f32")
     return nn
 
@@ -1478,7 +1478,7 @@ def mfma_f16_sustained_rate(random_operands=True, iters=4000, device=None):
     import ctypes
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.require_device(dev)
         check(_lib.load().sonet_diag_mfma_f16_rate(1 if random_operands else 0, int(iters), ctypes.byref(tf), ctypes.byref(ghz), stream_ptr()),
               "sonet_diag_mfma_f16_rate")
@@ -1498,7 +1498,7 @@ def knn_prepare(coord, knn_I, center_avg):
     center = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
     dec = torch.empty((B, 3, K * M), dtype=torch.float32, device=dev)
     gidx = torch.empty((B, K * M), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), _timed("knn_prepare"):
+    with _lib.on_device(dev), _timed("knn_prepare"):
         check(_lib.load().sonet_knn_prepare_f32(ptr(coord), ptr(knn_I), B, M, K, int(bool(center_avg)), ptr(center), ptr(dec), ptr(gidx),
                                                 stream_ptr()), "sonet_knn_prepare_f32")
     return center, dec, gidx
@@ -1517,7 +1517,7 @@ def planes_max(x, K):
     out = torch.empty((B, C, L // K), dtype=torch.float32, device=dev)
     if out.numel() == 0:
         return out
-    with torch.cuda.device(dev), _timed("planes_max"):
+    with _lib.on_device(dev), _timed("planes_max"):
         check(_lib.load().sonet_planes_max_f32(ptr(x), ptr(out), B * C, K, L // K, stream_ptr()), "sonet_planes_max_f32")
     return out
 
@@ -1527,6 +1527,6 @@ def bn_running_update_(running_mean, running_var, mean, var, momentum, unbias):
     for t, n in ((running_mean, "running_mean"), (running_var, "running_var"), (mean, "mean"), (var, "var")):
         _chk(t, n, torch.float32, 1)
     dev = _same_device(running_mean, running_var, mean, var)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         check(_lib.load().sonet_bn_running_update_f32(ptr(running_mean), ptr(running_var), ptr(mean), ptr(var), float(momentum), float(unbias),
                                                       running_mean.numel(), stream_ptr()), "sonet_bn_running_update_f32")

@@ -111,7 +111,7 @@ class FusedAdam(torch.optim.Optimizer):
             if not keep:
                 continue
             dev = plan["dev"]
-            with torch.cuda.device(dev.device):
+            with _lib.on_device(dev.device):
                 dev.copy_(plan["host"], non_blocking=True)
                 plan["event"] = torch.cuda.Event()
                 plan["event"].record()
