@@ -308,7 +308,10 @@ def _windows(fn, steps, n=3, dev=None, collective=False):
 
 def _spin_up(fn, seconds, chunk=16):
     """Untimed calls of `fn` for `seconds` of wall time (device drained every `chunk` calls): clocks up before a timed region.
-    Returns the number of calls."""
+    Returns the number of calls.  Also: sonet_hip.host.freeze_gc() -- a generation-2 pass of CPython's cyclic collector over the ~270,000
+    objects of a torch process takes 70 ms, more than three 20-step windows of the headline (profiles/r04y_gc_pause.log)."""
+    from sonet_hip import host
+    host.freeze_gc()
     n, t0 = 0, time.perf_counter()
     while seconds > 0 and time.perf_counter() - t0 < seconds:
         for _ in range(chunk):
@@ -858,7 +861,8 @@ def main():
                     "what": "whole-job clouds/s of every timed window (max over ranks each); `value` is the first"},
         "spin_up": {"seconds": args.spin_up, "untimed_steps": spin_calls,
                     "what": "untimed replays before the W warm-up steps: an idle MI355X sits at its lowest clock and needs 0.3-0.5 s of load to "
-                            "leave it (tools/first_process.py, profiles/r04y_first_process.log); --spin-up 0 = none"},
+                            "leave it (tools/first_process.py, profiles/r04y_first_process.log); --spin-up 0 = none.  Before every timed region "
+                            "sonet_hip.host.freeze_gc() (gc.collect + gc.freeze: no 70 ms generation-2 pause of the Python collector inside a window)"},
         "ranks": ranks,
         "in_flight": P, "single_stream": single, "replay_among_others_equals_replay_alone": overlap_ok,
         "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,

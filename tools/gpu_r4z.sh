@@ -3,11 +3,14 @@
 # bench train) + the bf16 / h3 training lines, rocprofv3 of the bf16 training step, the micro-benchmarks of this round's kernels.
 TAG=${1:-r04z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-SKIP="6 7" bash tools/gpu_round.sh $TAG
+SKIP="${SKIP:-6 7}" bash tools/gpu_round.sh $TAG
 P=$R/gpurun_out/$TAG/profiles; export TMPDIR=/tmp
 for p in bf16 h3; do timeout 300 python bench.py --mode train --precision $p --steps 40 --warmup 8 2> /dev/null | tail -1 > $P/${TAG}_bench_train_$p.json; head -c 200 $P/${TAG}_bench_train_$p.json; echo; done
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_${TAG}_train -o tr -- python $R/bench.py --mode train --precision bf16 --steps 10 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/rocprof_train.err < /dev/null)
 f=$(find /tmp/rp_${TAG}_train -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $P/${TAG}_kernel_stats_train_bf16.csv
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_${TAG}_train_h3 -o tr -- python $R/bench.py --mode train --precision h3 --steps 10 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/rocprof_train_h3.err < /dev/null)
+f=$(find /tmp/rp_${TAG}_train_h3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $P/${TAG}_kernel_stats_train_h3.csv
+timeout 200 python tools/train_cpu_time.py bf16 2>&1 | grep -v amdgpu > $P/${TAG}_train_host_time.log; timeout 200 python tools/train_cpu_time.py h3 2>&1 | grep -v amdgpu >> $P/${TAG}_train_host_time.log
 { echo "== tools/bench_bf16_layers.py"; timeout 300 python tools/bench_bf16_layers.py 2>&1 | grep -v amdgpu
   echo "== tools/bench_pooled.py"; timeout 300 python tools/bench_pooled.py 2>&1 | grep -v amdgpu
   echo "== tools/bench_wgrad_bf16.py"; timeout 300 python tools/bench_wgrad_bf16.py 2>&1 | grep -v amdgpu

@@ -49,6 +49,8 @@ with ops.precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"):
     for _ in range(8):
         step(False)
     torch.cuda.synchronize()
+    from sonet_hip import host
+    host.freeze_gc()
     # (a) host only: one step at a time, the device drained before each (nothing to wait for, no queue limit)
     n = 10
     for _ in range(n):
