@@ -308,12 +308,15 @@ def _windows(fn, steps, n=3, dev=None, collective=False):
 
 def _spin_up(fn, seconds, chunk=16):
     """Untimed calls of `fn` for `seconds` of wall time (device drained every `chunk` calls): clocks up before a timed region.
-    Returns the number of calls.  Also: sonet_hip.host.freeze_gc() -- a generation-2 pass of CPython's cyclic collector over the ~270,000
+    Returns the number of calls.  In a job of several ranks `fn` may contain collectives (the gradient all-reduce of the training step):
+    every rank must make the SAME number of calls, so the decision to go on is taken on the MAX of the ranks' clocks (one small
+    all-reduce per chunk).  Also: sonet_hip.host.freeze_gc() -- a generation-2 pass of CPython's cyclic collector over the ~270,000
     objects of a torch process takes 70 ms, more than three 20-step windows of the headline (profiles/r04y_gc_pause.log)."""
-    from sonet_hip import host
+    from sonet_hip import dp, host
     host.freeze_gc()
     n, t0 = 0, time.perf_counter()
-    while seconds > 0 and time.perf_counter() - t0 < seconds:
+    dev = torch.device("cuda", torch.cuda.current_device())
+    while seconds > 0 and dp.all_reduce_max(time.perf_counter() - t0, dev) < seconds:
         for _ in range(chunk):
             fn()
         torch.cuda.synchronize()
