@@ -439,7 +439,7 @@ def other_configs(args, dev, world=1, rank=0):
                     "allreduce": {"backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
                                   "bytes_per_step": state["nbytes"], "buckets": len(reducer.buckets), "exposed_us_per_step": round(exposed_us, 1)},
                     "top_kernels": top, "roofline": roof,
-                    "loss_after": round(float(state["loss"]), 5),
+                    "loss_after": round(float(state["loss"].detach()), 5),
                     "parity_checked": dict(par, what="eval forward of the timed batch with the weights the timed steps start from vs the oracle; "
                                                 "training gradients are pinned by tests/golden/train_step_* (tests/test_gpu_parity.py, tests/test_gpu_bf16.py)")}
 
