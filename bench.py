@@ -306,7 +306,7 @@ def _windows(fn, steps, n=3, dev=None, collective=False):
     return ts, mine
 
 
-def _spin_up(fn, seconds, chunk=16):
+def _spin_up(fn, seconds, chunk=16, dev=None, sync=None):
     """Untimed calls of `fn` for `seconds` of wall time (device drained every `chunk` calls): clocks up before a timed region.
     Returns the number of calls.  In a job of several ranks `fn` may contain collectives (the gradient all-reduce of the training step):
     every rank must make the SAME number of calls, so the decision to go on is taken on the MAX of the ranks' clocks (one small
@@ -315,11 +315,12 @@ def _spin_up(fn, seconds, chunk=16):
     from sonet_hip import dp, host
     host.freeze_gc()
     n, t0 = 0, time.perf_counter()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev     # (dev / sync: the gloo test of the rank agreement)
+    sync = torch.cuda.synchronize if sync is None else sync
     while seconds > 0 and dp.all_reduce_max(time.perf_counter() - t0, dev) < seconds:
         for _ in range(chunk):
             fn()
-        torch.cuda.synchronize()
+        sync()
         n += chunk
     return n
 

@@ -124,6 +124,51 @@ def test_dp_helpers_world_size_2_gloo():
     assert got == [(0, "ok"), (1, "ok")]
 
 
+def _spin_worker(rank, world, port, q):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "so-net_amd"))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import bench
+    from sonet_hip import dp
+    dp.init_distributed(backend="gloo")
+    calls = [0]
+
+    def step():                                                   # a step with a collective in it; rank 1 is four times slower
+        time.sleep(0.002 if rank == 0 else 0.008)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        calls[0] += 1
+    n = bench._spin_up(step, 0.3, chunk=4, dev=torch.device("cpu"), sync=lambda: None)
+    assert n == calls[0] and n >= 4
+    counts = [None] * world
+    dist.all_gather_object(counts, n)
+    assert counts[0] == counts[1], counts                        # the same number of calls on every rank (or the job hangs)
+    dp.barrier()
+    dist.destroy_process_group()
+    q.put((rank, n))
+
+
+@pytest.mark.timeout(180)
+def test_bench_spin_up_makes_the_same_number_of_calls_on_every_rank():
+    """bench.py's untimed spin-up runs for a wall-clock time, and in the training regions its step contains the gradient all-reduce: ranks
+    with different clocks must still agree on the number of calls."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_spin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got[0][1] == got[1][1]
+
+
 def test_single_process_is_a_no_op():
     import torch.nn as nn
     from sonet_hip import dp
