@@ -627,6 +627,11 @@ class _FcFn(torch.autograd.Function):
             if not all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == x.device) for t in (rm, rv)):
                 raise _ops.SonetHipError("MyLinear: the BatchNorm running statistics must be contiguous float32 tensors on the input's device")
             y, xhat, invstd = _ops.fc_bn_act_fwd(x, weight, bias, gamma.contiguous(), beta.contiguous(), rm, rv, bn.momentum, bn.eps, relu)
+            # the kernel wrote the running statistics through raw pointers: move their version counters as an in-place aten op would
+            # (the folded eval-mode affine of MyLinear._eval_affine is keyed on them)
+            for t in (rm, rv):
+                if t is not None:
+                    torch.autograd.graph.increment_version(t)
         else:
             y, xhat, invstd = _ops.fc_bn_act_fwd(x, weight, bias, None, None, None, None, 0.0, 0.0, relu)
         ctx.relu, ctx.has_bn, ctx.has_bias = bool(relu), bn is not None, bias is not None

@@ -38,6 +38,10 @@ def test_fc_layer_training_kernels_vs_aten_and_float64(B, Cin, Cout, norm, act):
     gy = torch.randn(B, Cout, device=DEV)
     xa, xb, xc = x.clone().requires_grad_(True), x.clone().requires_grad_(True), x.double().requires_grad_(True)
     assert ops.fc_head_ok(xa, own.linear.weight)
+    own.eval()
+    with torch.no_grad():
+        own(x, 0)                                                   # (fills the folded eval-mode affine: it must not survive the training step)
+    own.train()
     with ops.kernel_timing() as rec:
         ya = own(xa, 0)
         (ya * gy).sum().backward()
@@ -68,6 +72,13 @@ def test_fc_layer_training_kernels_vs_aten_and_float64(B, Cin, Cout, norm, act):
         assert float(own.linear.bias.grad.abs().max()) <= 1e-4 * float(gy.abs().sum(0).max())
     else:
         chk(own.linear.bias.grad, ref.linear.bias.grad, r64.linear.bias.grad, "dbias")
+    # eval after the training step: the folded affine must see the running statistics the kernel just wrote
+    if norm:
+        own.eval(), ref.eval()
+        with torch.no_grad():
+            ea, eb = own(x, 0), ref(x, 0)
+        assert _rel(ea, eb) <= 1e-5, _rel(ea, eb)
+        own.train(), ref.train()
     # deterministic
     own.zero_grad(set_to_none=True)
     xa2 = x.clone().requires_grad_(True)
