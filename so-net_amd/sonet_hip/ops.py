@@ -1530,3 +1530,6 @@ def bn_running_update_(running_mean, running_var, mean, var, momentum, unbias):
     with _lib.on_device(dev):
         check(_lib.load().sonet_bn_running_update_f32(ptr(running_mean), ptr(running_var), ptr(mean), ptr(var), float(momentum), float(unbias),
                                                       running_mean.numel(), stream_ptr()), "sonet_bn_running_update_f32")
+    # written through raw pointers: move the version counters as an in-place aten op would (caches keyed on versions must notice)
+    torch.autograd.graph.increment_version(running_mean)
+    torch.autograd.graph.increment_version(running_var)
