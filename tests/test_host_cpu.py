@@ -202,3 +202,59 @@ def test_fused_kernel_build_leaves_the_accumulation_registers_alone():
     for name, k in fused.items():
         assert k["mfma"] == 1224, (name, k)
         assert k["accvgpr_by_compiler"] == 0 and k["scratch"] == 0 and k["early_reads"] == 0, (name, k)
+
+
+def test_plain_attribute_fast_path_keeps_module_semantics():
+    """models.layers._PlainAttrs sends re-assignments of plain attributes past nn.Module.__setattr__; parameters, buffers, sub-modules,
+    first assignments and properties must behave exactly as on a plain nn.Module."""
+    import torch.nn as nn
+    from models.layers import EquivariantLayer, MyLinear, _PlainAttrs
+
+    class M(_PlainAttrs, nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(2, 2)
+            self.register_buffer("buf", torch.zeros(2))
+            self.cache = None
+            self._seen = []
+
+        @property
+        def prop(self):
+            return self._seen
+
+        @prop.setter
+        def prop(self, v):
+            self._seen = self._seen + [v]
+
+    m = M()
+    m.cache = torch.ones(3)                                        # plain attribute, re-assigned: the fast path
+    assert "cache" in m.__dict__ and torch.equal(m.cache, torch.ones(3))
+    m.cache = nn.Parameter(torch.ones(1))                          # a Parameter under an existing plain name: registered, as nn.Module does
+    assert "cache" in dict(m.named_parameters()) and "cache" not in m.__dict__
+    m.buf = torch.ones(2)                                          # a buffer stays a buffer
+    assert "buf" in dict(m.named_buffers()) and torch.equal(m.state_dict()["buf"], torch.ones(2))
+    m.lin = nn.Linear(3, 3)                                        # a sub-module stays registered
+    assert dict(m.named_modules())["lin"].in_features == 3
+    m.prop = 1
+    m.prop = 2
+    assert m.prop == [1, 2]                                        # property setters are honoured
+    m.fresh = 5                                                    # first assignment: the normal path
+    m.fresh = 6
+    assert m.fresh == 6
+    # the product modules carry the mixin and still expose the reference's parameters
+    lay, fc = EquivariantLayer(4, 8, activation="relu", normalization="batch"), MyLinear(8, 4, activation="relu", normalization="batch")
+    assert isinstance(lay, _PlainAttrs) and isinstance(fc, _PlainAttrs)
+    assert sorted(k for k, _ in lay.named_parameters()) == ["conv.bias", "conv.weight", "norm.bias", "norm.weight"]
+    lay._wp_key = ("a",)
+    lay._wp_key = ("b",)
+    assert lay._wp_key == ("b",) and "_wp_key" not in lay.state_dict()
+
+
+def test_freeze_gc_freezes_and_unfreezes():
+    import gc
+    from sonet_hip import host
+    before = gc.get_freeze_count()
+    n = host.freeze_gc()
+    assert n >= before and n > 1000 and gc.get_freeze_count() == n   # (a Python process tracks far more than a thousand objects)
+    host.unfreeze_gc()
+    assert gc.get_freeze_count() == 0
