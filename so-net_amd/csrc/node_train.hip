@@ -70,7 +70,8 @@ __global__ __launch_bounds__(1024) void knn_inverse_kernel(const long long *__re
         cnt[M] = acc;
     }
     __syncthreads();
-    if (m <= M) off[(long long)b * (M + 1) + m] = cnt[m];
+    // (M + 1 offsets from at most 1024 threads: at M == 1024 thread 0 also writes the closing one)
+    for (int i = m; i <= M; i += blockDim.x) off[(long long)b * (M + 1) + i] = cnt[i];
     if (m < M) {
         int w = cnt[m];
         int32_t *L = list + (long long)b * E;

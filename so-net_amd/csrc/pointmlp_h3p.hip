@@ -672,7 +672,9 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     }
 #endif
 
-    if (a.rlog != nullptr && ct_begin == 0) {
+    if (a.rlog != nullptr) {
+        // (every output slab publishes the range of the planes IT wrote -- slabs hold different channels; only the weight trailer is
+        // a per-launch constant and goes through one thread)
         if (a.yp) {
             // (after a ReLU only the positive side -- and a NaN of either sign -- can leave the range)
             const unsigned pos = yr.mp > 0 ? (unsigned)yr.mp : 0u, nan_neg = yr.mn > 0xFF800000u ? (yr.mn & 0x7FFFFFFFu) : 0u;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
             if constexpr (OUT == 2) bits = bits > (5u << 23) ? bits - (5u << 23) : 0u;       // (32 x was tracked: take the factor out of the exponent)
             range_publish(a.rlog + 2, bits, lane);
         }
-        if (wg_col == 0 && threadIdx.x == 0)
+        if (ct_begin == 0 && wg_col == 0 && threadIdx.x == 0)
             atomicMax(a.rlog + 1, reinterpret_cast<const unsigned *>(wp + (size_t)a.CT * a.KCP * 2048u)[0]);
     }
 }

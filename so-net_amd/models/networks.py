@@ -463,7 +463,8 @@ def segmentation_forward(encoder, segmenter, pc, sn, label, node, node_knn_I, is
     # ... pre-split when the head runs its third-generation chain (the fused first PointNet then writes the P16 planes itself)
     encoder.first_pointnet.emit_p16 = bool(segmenter._nodewise_ok() and getattr(segmenter, "nodewise", True) and segmenter.layer1._p16_ok()
                                            and segmenter.layer2._p16_ok() and segmenter.layer3._p16_ok())
-    if encoder.first_pointnet.emit_p16 and _ops.P16_ONLY and _ops.POINTMLP_PRECISION == "h3":
+    if encoder.first_pointnet.emit_p16 and _ops.P16_ONLY and _ops.POINTMLP_PRECISION == "h3" and node.size()[2] <= 512:
+        # (the pool on the planes -- sonet_index_max_gather_p16 -- holds <= 512 node bins; wider SOMs keep the f32 pool)
         # ... and ONLY pre-split: the per-node pool runs on the planes, first_pn_out is decoded to f32 if somebody reads it (0.3 GB of
         # writes less at 64 x 1024 points)
         encoder.first_pointnet.emit_p16 = "only"

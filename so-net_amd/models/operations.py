@@ -20,8 +20,9 @@ class _KnnGather(torch.autograd.Function):
     def backward(ctx, g):
         (knn_I,) = ctx.saved_tensors
         B, C, M, K = g.shape
-        if g.is_cuda and g.dtype in (torch.float32, torch.bfloat16) and M == ctx.M and M <= 1024:
-            # gather over per-cloud inverse neighbour lists: fixed summation order, no index expansion, no fill
+        if g.is_cuda and g.dtype in (torch.float32, torch.bfloat16) and M == ctx.M and M <= 1024 and M * K <= 14336:
+            # gather over per-cloud inverse neighbour lists: fixed summation order, no index expansion, no fill (the kernel's limits: one
+            # thread per node, the cloud's M * K indices in 56 KiB of LDS; anything larger takes scatter_add below)
             return _ops.knn_gather_bwd(g.contiguous(), knn_I.contiguous(), ctx.M).to(g.dtype), None
         idx = knn_I.reshape(B, 1, M * K).expand(B, C, M * K)
         gx = torch.zeros((B, C, ctx.M), dtype=g.dtype, device=g.device)

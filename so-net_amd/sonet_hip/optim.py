@@ -24,6 +24,17 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self._plans = {}                              # group index -> launch plan (built at the first step)
 
+    def load_state_dict(self, state_dict):
+        """``Optimizer.load_state_dict`` swaps in new state tensors: the launch plans (device pointers into the flat moment buffers the
+        OLD state tensors were views of) are dropped and rebuilt at the next step, which copies the loaded moments in."""
+        super().load_state_dict(state_dict)
+        self._plans = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_plans"):                   # (the base constructor adds the initial groups before __init__ creates _plans)
+            self._plans = {}
+
     def _plan(self, gi, group):
         plan = self._plans.get(gi)
         if plan is not None:
@@ -66,6 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
             rec[t, 0], rec[t, 2], rec[t, 3] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
         plan = dict(ps=ps, T=T, host=host, dev=devbuf, rec=rec, scal=hnp[rec_bytes:].view(np.float32).reshape(2, T),
                     dev_scal=devbuf[rec_bytes:].view(torch.float32).view(2, T), ptrs=[p.data_ptr() for p in ps],
+                    mptrs=[self.state[p]["exp_avg"].data_ptr() for p in ps],
                     chunk_tensor=torch.tensor(chunk_tensor, dtype=torch.int32, device=dev),
                     chunk_off=torch.tensor(chunk_off, dtype=torch.int64, device=dev),
                     sizes=torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev), flat=(flat_m, flat_v),
@@ -98,9 +110,14 @@ class FusedAdam(torch.optim.Optimizer):
                     raise SonetHipError("FusedAdam: float32 dense gradients on the parameter's device only")
                 if not g.is_contiguous():
                     g = g.contiguous()
+                st = self.state[p]
+                if st["exp_avg"].data_ptr() != plan["mptrs"][t]:
+                    # the state was replaced behind the plan (``opt.state[p] = ...``, a hand-rolled restore): never update buffers
+                    # nobody reads -- say so (load_state_dict / add_param_group drop the plans themselves)
+                    raise SonetHipError("FusedAdam: state[p]['exp_avg'] was replaced after the first step; use load_state_dict(), or "
+                                        "clear opt._plans after editing the state by hand")
                 keep.append(g)
                 updated.append(p)
-                st = self.state[p]
                 st["step"] += 1.0
                 gp[t] = g.data_ptr()
                 ss[t] = lr / (1.0 - b1 ** st["step"])

@@ -232,6 +232,27 @@ def test_pointmlp_h3p_output_range_is_logged():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cout,L,row", [(512, 500, 500), (1024, 3072, 1000), (512, 3072, 200)])
+def test_pointmlp_h3p_output_range_is_logged_from_every_output_slab(Cout, L, row):
+    """The production layers split Cout over several output slabs (one workgroup set per slab): an out-of-range value in a HIGH
+    channel -- a slab other than slab 0 -- must reach the range log as well (only slab 0 used to publish)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = ops.p16_from_f32(cu(torch.randn(2, 64, L, generator=g)))
+    W = cu(torch.randn(Cout, 64, generator=g))
+    one, zero = cu(torch.ones(Cout)), cu(torch.zeros(Cout))
+    with ops.range_scope(torch.device(DEV)) as rs:
+        ops.pointmlp_h3p(x, ops.pointmlp_h3p_pack(W), one, zero, True, Cout, out="p16")
+    assert rs.violations() == []
+    sc = one.clone()
+    sc[row] = 1000.0                                         # only this channel leaves +-2047
+    with ops.range_scope(torch.device(DEV)) as rs:
+        ops.pointmlp_h3p(x, ops.pointmlp_h3p_pack(W), sc, zero, True, Cout, out="p16")
+    bad = rs.violations()
+    assert bad and "2047" in bad[0][1]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C,L,M", [(2, 384, 3072, 64), (3, 40, 777, 7), (1, 16, 64, 64), (64, 384, 3072, 64)])
 def test_index_max_gather_on_p16_planes_equals_the_f32_kernel_on_the_decoded_values(B, C, L, M):
     """sonet_index_max_gather_p16 (the per-node arg-max pool straight on P16 planes) == sonet_index_max_gather_f32 on p16_to_f32 of the same

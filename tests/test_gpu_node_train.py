@@ -40,7 +40,7 @@ def test_lastdim_max_autograd_nan_wins_like_torch():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,C,M,K", [(4, 384, 64, 9), (2, 3, 64, 9), (3, 17, 30, 5), (1, 8, 1000, 4)])
+@pytest.mark.parametrize("B,C,M,K", [(4, 384, 64, 9), (2, 3, 64, 9), (3, 17, 30, 5), (1, 8, 1000, 4), (2, 5, 1024, 3), (1, 4, 1024, 14)])
 def test_knn_gather_backward_equals_scatter_add(B, C, M, K, dtype):
     from models import operations
     from sonet_hip import ops
@@ -58,3 +58,18 @@ def test_knn_gather_backward_equals_scatter_add(B, C, M, K, dtype):
     if dtype == torch.float32:
         y.backward(gy)
         assert torch.equal(x.grad, got)
+
+
+def test_knn_gather_backward_beyond_the_kernel_limits_takes_scatter_add():
+    """M * K above the inverse-list kernel's LDS budget (56 KiB of indices): the autograd node falls back to scatter_add instead of raising."""
+    from models import operations
+    B, C, M, K = 1, 3, 512, 32
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, M, generator=g).to(DEV).requires_grad_(True)
+    I = torch.randint(0, M, (B, M, K), generator=g).to(DEV)
+    y = operations.knn_gather_by_indexing(x, I)
+    gy = torch.randn(B, C, M, K, generator=g).to(DEV)
+    y.backward(gy)
+    ref = torch.zeros(B, C, M, dtype=torch.float64, device=DEV)
+    ref.scatter_add_(2, I.reshape(B, 1, M * K).expand(B, C, M * K), gy.double().reshape(B, C, M * K))
+    assert float((x.grad.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

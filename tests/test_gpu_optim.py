@@ -73,3 +73,63 @@ def test_fused_adam_state_dict_round_trip_and_errors():
     pa[0].grad = torch.ones_like(pa[0])
     o1.step()
     assert pa[0]._version > v0                   # caches keyed on the version (packed weights) see the update
+
+
+def test_fused_adam_load_state_dict_after_a_step_takes_the_loaded_moments():
+    """the launch plan (pointers into the flat moment buffers) is built at the first step; a load_state_dict() AFTER a step
+    must drop it, or the kernel keeps updating buffers nobody reads and state_dict() returns stale moments."""
+    import copy
+    from sonet_hip.optim import FusedAdam
+    from sonet_hip.ops import SonetHipError
+    pa = _params(11, DEV)
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = torch.optim.Adam(pa, lr=1e-3), FusedAdam(pb, lr=1e-3)
+    g = torch.Generator().manual_seed(2)
+
+    def grads():
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+    for _ in range(3):
+        grads()
+        oa.step()
+        ob.step()
+    snap_a, snap_b = copy.deepcopy(oa.state_dict()), copy.deepcopy(ob.state_dict())
+    snap_p = [p.detach().clone() for p in pb]
+    for _ in range(2):                                        # move on, then go back to the snapshot
+        grads()
+        oa.step()
+        ob.step()
+    oa.load_state_dict(snap_a)
+    ob.load_state_dict(snap_b)
+    with torch.no_grad():
+        for a, b, s in zip(pa, pb, snap_p):
+            a.copy_(s)
+            b.copy_(s)
+    grads()
+    oa.step()
+    ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(a.detach().abs().max()))
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 4.0
+        assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 5e-6 * max(1e-6, float(sa["exp_avg"].abs().max()))
+    # the moments state_dict() hands out are the ones the kernel updates
+    grads()
+    before = ob.state_dict()["state"][0]["exp_avg"].clone()
+    ob.step()
+    assert not torch.equal(before, ob.state_dict()["state"][0]["exp_avg"])
+    # a state edited by hand behind the plan is an error, not a silent no-op
+    ob.state[pb[0]]["exp_avg"] = torch.zeros_like(pb[0])
+    with pytest.raises(SonetHipError):
+        ob.step()
+    # add_param_group after a step: the new group is stepped too
+    extra = torch.nn.Parameter(torch.ones(7, device=DEV))
+    oc = FusedAdam([pb[1]], lr=1e-2)
+    pb[1].grad = torch.ones_like(pb[1])
+    oc.step()
+    oc.add_param_group({"params": [extra]})
+    extra.grad = torch.ones_like(extra)
+    pb[1].grad = torch.ones_like(pb[1])
+    oc.step()
+    assert float(extra.detach().max()) < 1.0
