@@ -240,6 +240,37 @@ int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t *gidx, con
                        const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
                        sonet_stream_t stream);
 
+/* No-grad node-level stage on the third-generation layer (so-net_amd/csrc/node_stage.hip, pointmlp_h3p.hip): KNNModule + the final
+ * PointNet + the global max (models/layers.py:313-367,384-387, models/networks.py:187-197) on a FLAT column axis -- ONE "cloud" whose
+ * columns are the B x M nodes of the batch (column b M + m; the axis is padded with zero columns to Lm = sonet_node_stage_columns(B, M),
+ * a multiple of 128, which is the column count of every M-level tensor below), so that 64 clouds x 64 nodes fill a launch.
+ * sonet_pointresnet_fused_pool_p16_f32 (below) hands the pooled map over as such planes; a sonet_pointmlp_h3p launch (B = 1, L = B M, f32
+ * out) applies the 384-channel block of KNNModule's first layer ONCE per node: z (the layer is linear; models/layers.py:351).
+ * The rest of that layer per neighbour copy (models/layers.py:319-352),
+ *   h1[c][n, k] = act(scale[c] (z[c][b M + I[b][m][k]] + wl[c][0..2] . (coord[b][:, I[b][m][k]] - center[b][:, m])) + shift[c]),
+ * as P16 planes of a 1 x C x Lp activation, Lp = sonet_knn_stage_columns(B, M, K): every 128-column block holds G = min(16, 128 / K) nodes, the K
+ * neighbour copies of a node next to each other (column 128 i + g K + k = neighbour k of node i G + g), zero padding behind them, in two launches:
+ * sonet_knn_stage_prepare_f32 (needs the node coordinates only) writes rec [Lp] int4 = (source column b M + I on the flat axis -- -1: index
+ *   outside [0, M), features read as zeros as in sonet_knn_group_f32; -2: padding column --, the three de-centred coordinates as f32 bits),
+ *   center [B][3][M] f32 = mean of the K neighbour coordinates (center_avg) or the node (KNNModule's first output) and center_p16 = the same as a
+ *   one-chunk P16 panel (sonet_p16_size(1, 3, Lm) bytes: the 3 leading channels of the final PointNet's input); knn_I [B][M][KI] i64, first K used;
+ * sonet_knn_stage_input_p16: z_p16 = P16 planes of the 1 x C x Lm map z (sonet_pointmlp_h3p, yp output), wl [C][3] -> h1_p16.  Largest |h1| -> word 2
+ *   of the range log.
+ * sonet_pointmlp_h3p_gmax: the layer followed by a max over groups of GK consecutive columns in ONE launch (L % 128 == 0, one cloud):
+ * every 128-column block holds G groups (G GK <= 128), group g of block i is output column i G + g (< ngout).  Exactly one output:
+ * yp = P16 planes (Lout >= ngout columns, the first ngout written) of the maxima (KNNModule's max over the neighbours, models/layers.py:365; G <= 16) or y = f32
+ * [ngout][Cout] (the global max over a cloud's M nodes = the feature vector, models/networks.py:197; G <= 2, GK % 4 == 0).  NaN wins.
+ * sonet_p16_flat_to_bcm_f32: planes of a flat 1 x C x (B M) activation -> f32 [B][C][M] (an intermediate map a caller asks for). */
+size_t sonet_knn_stage_columns(int B, int M, int K);
+size_t sonet_node_stage_columns(int B, int M);
+int sonet_knn_stage_prepare_f32(const float *coord, const int64_t *knn_I, int KI, int center_avg, int B, int M, int K,
+                                float *center, void *center_p16, void *rec, sonet_stream_t stream);
+int sonet_knn_stage_input_p16(const void *rec, const void *z_p16, const float *wl, const float *scale, const float *shift, int relu,
+                              int B, int M, int K, int C, void *h1_p16, sonet_stream_t stream);
+int sonet_pointmlp_h3p_gmax(const void *x1p, int C1, const void *x2p, int C2, const void *Wp, const float *scale, const float *shift,
+                            int relu, int Cout, int L, int GK, int G, int ngout, int Lout, float *y, void *yp, sonet_stream_t stream);
+int sonet_p16_flat_to_bcm_f32(const void *p16, float *x, int B, int C, int M, sonet_stream_t stream);
+
 /* Node-level pieces of the training step (so-net_amd/csrc/node_train.hip).
  * sonet_lastdim_argmax_*: out[r] = max over the K contiguous values of row r, idx[r] = index of the FIRST maximum (a NaN wins) -- torch.max
  *   over the K' neighbours of KNNModule (models/layers.py:350-365) and over the M nodes (models/networks.py:197) with the routing its
@@ -322,6 +353,12 @@ size_t sonet_pointresnet_pool_ws_size(int B, int L, int M);
 int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
                                      const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
                                      const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream);
+/* The same, and the decode pass also writes the pooled map pre-split on the flat column axis of the node-level stage: out_p16 = P16
+ * planes of a 1 x 384 x Lm activation (Lm = sonet_node_stage_columns(B, M), column b M + m; the pad columns are not written); largest pooled magnitude -> word 2 of
+ * the range log (its consumers cannot check the clamp any more). */
+int sonet_pointresnet_fused_pool_p16_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                         const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                         const int32_t *count, void *ws, float *out, void *out_p16, int B, int L, int M, sonet_stream_t stream);
 /* The SOM stage of the no-grad pooled path in TWO launches: sonet_som_assign_f32 + sonet_som_sort_group_f32 in one call
  * (util/som.py:237-269 + models/networks.py:128-172).  Same outputs -- min_idx_i32 [B][k*N] (k-major; min_idx_i64 optional),
  * count [B][M], sum_ws [B][3][M] f64 (optional), som_node [B][3][M], row_max [B][M] (both optional), x_aug_sorted [B][6][kN],
@@ -334,6 +371,15 @@ int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node
                               int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
                               float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
                               int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream);
+/* ... whose second launch also does sonet_knn_stage_prepare_f32 (below) on the cluster means it computes: center [B][3][M], center_p16 and rec
+ * are bit-identical to the separate launch on som_node, and the no-grad forward needs no launch for KNNModule's index / coordinate side
+ * (models/layers.py:319-350). */
+int sonet_som_assign_sort_knn_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                  int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                  float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                  int32_t *pos0, int32_t *node_off, void *ws,
+                                  const int64_t *knn_I, int KI, int K, int center_avg, float *center, void *center_p16, void *rec,
+                                  sonet_stream_t stream);
 /* som_sort_group: som_group with the kN point copies of every cloud counting-sorted by node id.
  * x_aug_sorted [B][6][kN], ids_sorted [B][kN], pos0 [B], node_off [B][M]; cursor_ws: B*M i32 (zeroed by the callee). */
 int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,

@@ -103,3 +103,17 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 __device__ __forceinline__ void range_publish(unsigned *word, unsigned wave_max_bits, int lane) {
     if (lane == 0 && wave_max_bits > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, wave_max_bits);
 }
+
+// ---- P16 planes (include/sonet_hip.h): a value pair clamped to the fp16-split range, scaled by 32, as packed fp16 hi + packed fp16 residual
+// (the residual is exact in f32 before it is rounded) -- the arithmetic of split_act in pointmlp_h3p.hip, for the producers outside it
+__device__ __forceinline__ void p16_split_pair(float x0, float x1, unsigned &h, unsigned &m) {
+    typedef _Float16 sonet_h2_t __attribute__((ext_vector_type(2)));
+    typedef float sonet_f2_t __attribute__((ext_vector_type(2)));
+    const sonet_f2_t X = {32.f * __builtin_amdgcn_fmed3f(x0, -2047.f, 2047.f), 32.f * __builtin_amdgcn_fmed3f(x1, -2047.f, 2047.f)};
+    const sonet_h2_t hv = __builtin_convertvector(X, sonet_h2_t);
+    const sonet_f2_t R = {X[0] - (float)hv[0], X[1] - (float)hv[1]};
+    h = __builtin_bit_cast(unsigned, hv);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(R, sonet_h2_t));
+}
+// groups (nodes) per 128-column block of the K-level tensor of the flat node-level stage (node_stage.hip): as many as fit, at most 16
+static inline int knn_stage_groups(int K) { const int g = 128 / K; return g > 16 ? 16 : g; }

@@ -195,6 +195,10 @@ struct H3pArgs {
     unsigned long long *prof;             // (variants build) phase cycle counters: [0] workgroups, [1] prologue, [2] chunk loops, [3] epilogues, [4] whole
     long long ngroups;                    // B * gpc
     int KC1, KC2, L1, L, Cout, CT, KC, KCr, KCP, ct_per_y, nslab, ncol, gpc, relu, ZM;
+    // (EPI 4 / 5: group-max epilogues of the node-level stage) every workgroup's 128 columns hold G groups of GK consecutive columns
+    // (columns G GK .. 127 are padding); the max over a group goes to output column wg_col G + g (< ngout) of yp (P16, Lout = ngout
+    // columns; EPI 4) or to y[group][Cout] (f32; EPI 5)
+    int GK, G, ngout, Lout;                // (Lout >= ngout: column count = plane stride of yp)
 };
 
 __device__ __forceinline__ i32x4_t make_rsrc(const void *base, unsigned bytes) {
@@ -250,10 +254,19 @@ __device__ __forceinline__ void sched_pair() {
 // (A transposed orientation -- X as the MFMA's A operand, so that a lane holds 16 points of one channel and the f32 rows leave as 16-byte
 // stores -- was built and dropped: its stores write 32-byte pieces of 32 rows per instruction and measured 12 % slower than two full
 // 128-byte lines per dword store, docs/findings.md R4.2.)
+// EPI 4 / 5 (NC = 1, one cloud = the flat column axis of the node-level stage): the max over groups of GK consecutive columns instead of
+// the columns themselves -- KNNModule's max over the K neighbours of a node (models/layers.py:365; EPI 4: P16 planes out) and the global
+// max over a cloud's M nodes (models/networks.py:197; EPI 5: f32 [cloud][Cout]).  A tile's 32 x 128 post-activation values pass through
+// LDS (17 KiB) one tile at a time; NaN wins like torch.max.
+constexpr int GM_STRIDE = 136;                                 // floats per staged row: 128 columns + 8 (rows 4 apart land 32 banks apart)
+__device__ __forceinline__ float nan_max(float m, float v) { return (v > m || v != v) ? v : m; }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int MT, int NC, int OCC, int EPI, int OUT>
 __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pArgs a)
 {
     static_assert(OUT >= 1 && OUT <= 3 && (EPI != 2 || (OUT & 1)), "output mode");
+    static_assert(EPI < 4 || (NC == 1 && ((EPI == 4 && OUT == 2) || (EPI == 5 && OUT == 1))), "group-max epilogues: 32-column waves, P16 (4) or f32 (5) out");
     static_assert(MT % 2 == 0 && (NC == 1 || NC == 2), "tile shape");
     // X look-ahead: 3 chunks (2 measured 3-5 % slower on the 64-column tiles); 2 for the 64-column tiles with the addend rows in LDS at two
     // workgroups per CU: 16 registers less, that instantiation sits at the 256-register limit
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
         float aff[EPI == 1 ? 1024 : 2048];
         float2 red[EPI == 2 ? 4 : 1][EPI == 2 ? MT * 32 : 1];
         float zl[EPI == 1 ? MT * 32 : 1][EPI == 1 ? 64 : 1];      // (EPI 1) the pass's rows of the per-node addend, when the workgroup sits in one cloud
+        float gm[EPI >= 4 ? 32 : 1][EPI >= 4 ? GM_STRIDE : 1];    // (EPI 4 / 5) one output tile x the workgroup's 128 columns, post-activation
     };
     __shared__ __attribute__((aligned(16))) Lds lds;
 
@@ -417,6 +431,68 @@ __global__ __launch_bounds__(P_THREADS, OCC) void pointmlp_h3p_kernel(const H3pA
     // epilogue of one pass: tiles ct0 .. ct0 + MT - 1, one (tile, column tile) at a time (a scheduling barrier in between: left alone,
     // hipcc lifts all 16 MT NC accumulator registers out of the accumulation file at once and spills)
     auto epilogue = [&](int ct0) {
+        if constexpr (EPI >= 4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if ((ct0 + mt) * 32 >= a.Cout) continue;          // (uniform over the workgroup: the barriers below are safe)
+                float asc16[16], ash16[16];
+                {
+                    const float4 *t4 = reinterpret_cast<const float4 *>(lds.aff + (ct0 - ct_begin + mt) * 64 + h * 32);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 s4 = t4[u], h4 = t4[4 + u];
+                        asc16[4 * u] = s4.x; asc16[4 * u + 1] = s4.y; asc16[4 * u + 2] = s4.z; asc16[4 * u + 3] = s4.w;
+                        ash16[4 * u] = h4.x; ash16[4 * u + 1] = h4.y; ash16[4 * u + 2] = h4.z; ash16[4 * u + 3] = h4.w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = __fmaf_rn(acc[mt][0][r], asc16[r], ash16[r]);
+                    lds.gm[(r & 3) + 8 * (r >> 2) + 4 * h][32 * wave + j] = v < relu_thr ? 0.f : v;
+                }
+                lds_barrier();
+                const int t = (int)threadIdx.x;
+                if constexpr (EPI == 4) {
+                    // thread = (element pair p of a P16 half, group g, 16-row chunk qq and half h2 of the tile): two rows x GK columns
+                    const int p = t & 3, u = t >> 2;
+                    const int g = u % a.G, qh = u / a.G;
+                    if (qh < 4) {
+                        const int qq = qh >> 1, h2 = qh & 1;
+                        const float *r0 = &lds.gm[16 * qq + 4 * h2 + 2 * (p & 1) + 8 * (p >> 1)][g * a.GK];
+                        float m0 = r0[0], m1 = r0[GM_STRIDE];
+                        for (int k = 1; k < a.GK; ++k) {
+                            m0 = nan_max(m0, r0[k]);
+                            m1 = nan_max(m1, r0[GM_STRIDE + k]);
+                        }
+                        const long long n_out = (long long)wg_col * a.G + g;
+                        if (n_out < a.ngout) {
+                            range_track(yr, m0, m1);
+                            unsigned hv, mv;
+                            // (OUT == 2: the affine table made the values 32 x already, like the plain P16 epilogue)
+                            split2(__builtin_amdgcn_fmed3f(m0, split_lo * 32.f, 65504.f), __builtin_amdgcn_fmed3f(m1, split_lo * 32.f, 65504.f), hv, mv);
+                            unsigned *dst = reinterpret_cast<unsigned *>(static_cast<char *>(a.yp)
+                                + ((((size_t)((ct0 + mt) * 2 + qq) * 2) * 2 + h2) * (size_t)a.Lout + (size_t)n_out) * 16) + p;
+                            dst[0] = hv;
+                            dst[(size_t)a.Lout * 8] = mv;                  // form 1: two half planes (2 x Lout x 16 bytes) further
+                        }
+                    }
+                } else {
+                    // thread = (quarter of the group's columns, row, group): GK / 4 values, then the four quarters meet in a quad
+                    const int seg = t & 3, row = (t >> 2) & 31, g = t >> 7;
+                    const int cols = a.GK >> 2;
+                    const float *r0 = &lds.gm[row][(g < a.G ? g : 0) * a.GK + seg * cols];
+                    float m = r0[0];
+                    for (int k = 1; k < cols; ++k) m = nan_max(m, r0[k]);
+                    m = nan_max(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+                    m = nan_max(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+                    const long long n_out = (long long)wg_col * a.G + g;
+                    if (seg == 0 && g < a.G && n_out < a.ngout) a.y[(size_t)n_out * a.Cout + (size_t)(ct0 + mt) * 32 + row] = m;
+                }
+                lds_barrier();
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if ((ct0 + mt) * 32 >= a.Cout) continue;              // (the zero tile behind an odd tile count)
@@ -769,21 +845,19 @@ int launch_shape(int epi, int out, unsigned nwg, hipStream_t st, const H3pArgs &
     else if (epi == 0 && out == 1) H3P_GO(0, 1);
     else if (epi == 0 && out == 2) H3P_GO(0, 2);
     else if (epi == 0 && out == 3) H3P_GO(0, 3);
+    else if (epi == 4 && out == 2) { if constexpr (NC == 1) H3P_GO(4, 2); else return 1; }
+    else if (epi == 5 && out == 1) { if constexpr (NC == 1) H3P_GO(5, 1); else return 1; }
     else return 1;
 #undef H3P_GO
     return 0;
 }
 }  // namespace
 
-/* y = act((W . cat(x1, x2) [+ zadd[b][o][zidx[b][l]]]) * scale + shift) on P16 inputs; outputs: y (f32 [B][Cout][L]) and / or yp (P16).
- * x1: B x C1 channels x L1 columns (C1 % 16 == 0 when x2 is given), read through gidx [B][L] when given; x2: B x C2 x L.
- * stats_ws / mean / var: training forward (batch statistics of y from the epilogue; needs y). */
-extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t *gidx, const void *x2p, int C2, const void *Wp,
-                                  const float *scale, const float *shift, int relu, float *y, void *yp, int B, int Cout, int L,
-                                  const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
-                                  sonet_stream_t stream)
+static int h3p_launch(const char *what, const void *x1p, int C1, int L1, const int32_t *gidx, const void *x2p, int C2, const void *Wp,
+                      const float *scale, const float *shift, int relu, float *y, void *yp, int B, int Cout, int L,
+                      const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
+                      int GK, int G, int ngout, int Lout, sonet_stream_t stream)
 {
-    const char *what = "sonet_pointmlp_h3p";
     if (!gidx) L1 = L;
     SONET_REQUIRE(x1p && Wp && scale && shift && (y || yp), "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0 && L1 > 0, "%s: non-positive size", what);
@@ -803,7 +877,7 @@ extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t
     // per wave when the launch still fills the chip that way, 32 otherwise (node-level launches); 2-tile passes for Cout % 128 != 0.
     // (8 x 2 and 6 x 2 tiles with one workgroup per CU measured within 3 % of 4 x 2 on the large layers and 2-4 x slower on the small
     // ones: they exist in the variants build only.)
-    Shape sh = (CT % 4 == 0) ? (cols >= 131072 ? Shape{4, 2, 2} : Shape{4, 1, 2}) : Shape{2, 1, 2};
+    Shape sh = (CT % 4 == 0) ? ((cols >= 131072 && GK == 0) ? Shape{4, 2, 2} : Shape{4, 1, 2}) : Shape{2, 1, 2};
 #ifdef SONET_VARIANTS
     if (const char *e = sonet::knob("SONET_H3P_SHAPE")) {       // "MT,NC,OCC" (tools/bench_h3p.py)
         int m = 0, n = 0, o = 0;
@@ -839,9 +913,11 @@ extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t
 #endif
     a.KC1 = KC1; a.KC2 = KC2; a.L1 = L1; a.L = L; a.Cout = Cout; a.CT = CT; a.KC = KC; a.KCr = KCr; a.KCP = KCP; a.ct_per_y = CT / nslab;
     a.nslab = nslab; a.ncol = (int)ncol; a.gpc = gpc; a.relu = relu; a.ZM = ZM;
+    a.GK = GK; a.G = G; a.ngout = ngout; a.Lout = Lout;
     hipStream_t st = sonet::as_stream(stream);
     // (addend rows through LDS: the four waves of a workgroup in one cloud, 256-byte rows, slabs of <= 16 tiles)
-    const int epi = stats_ws ? 2 : zadd ? ((ZM == 64 && gpc % 4 == 0 && CT / nslab <= 16 && Cout % 64 == 0) ? 1 : 3) : 0;
+    const int epi = GK ? (yp ? 4 : 5)
+                       : stats_ws ? 2 : zadd ? ((ZM == 64 && gpc % 4 == 0 && CT / nslab <= 16 && Cout % 64 == 0) ? 1 : 3) : 0;
     const unsigned g = (unsigned)nwg;
     const int out = (y ? 1 : 0) | (yp ? 2 : 0);
     int miss = 1;
@@ -856,4 +932,36 @@ extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t
     if (miss) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: no kernel for tile shape %d x %d with epilogue %d and outputs %d", what, sh.MT, sh.NC, epi, out);
     if (stats_ws) sonet::launch_stats_finalize(reinterpret_cast<const double *>(stats_ws), (int)ncol, Cout, 1.0 / ((double)B * L), mean, var, st);
     return sonet::launched(what);
+}
+
+/* y = act((W . cat(x1, x2) [+ zadd[b][o][zidx[b][l]]]) * scale + shift) on P16 inputs; outputs: y (f32 [B][Cout][L]) and / or yp (P16).
+ * x1: B x C1 channels x L1 columns (C1 % 16 == 0 when x2 is given), read through gidx [B][L] when given; x2: B x C2 x L.
+ * stats_ws / mean / var: training forward (batch statistics of y from the epilogue; needs y). */
+extern "C" int sonet_pointmlp_h3p(const void *x1p, int C1, int L1, const int32_t *gidx, const void *x2p, int C2, const void *Wp,
+                                  const float *scale, const float *shift, int relu, float *y, void *yp, int B, int Cout, int L,
+                                  const float *zadd, const int32_t *zidx, int ZM, void *stats_ws, float *mean, float *var,
+                                  sonet_stream_t stream)
+{
+    return h3p_launch("sonet_pointmlp_h3p", x1p, C1, L1, gidx, x2p, C2, Wp, scale, shift, relu, y, yp, B, Cout, L, zadd, zidx, ZM, stats_ws, mean, var,
+                      0, 0, 0, 0, stream);
+}
+
+/* The layer followed by a max over groups of columns, in one launch (node-level stage, flat column axis: ONE cloud of L columns, L % 128 == 0).
+ * Every 128-column block holds G groups of GK consecutive columns (G GK <= 128; the columns behind them are padding and take no part);
+ * group g of block i is output column i G + g, ngout of them.  Exactly one output: yp = P16 planes of a 1 x Cout x Lout activation (Lout >= ngout;
+ * the columns from ngout on are not written)
+ * (KNNModule's max over the K neighbours, models/layers.py:365), or y = f32 [ngout][Cout] (the global max over a cloud's nodes,
+ * models/networks.py:197).  NaN wins, as in torch.max. */
+extern "C" int sonet_pointmlp_h3p_gmax(const void *x1p, int C1, const void *x2p, int C2, const void *Wp, const float *scale, const float *shift,
+                                       int relu, int Cout, int L, int GK, int G, int ngout, int Lout, float *y, void *yp, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_h3p_gmax";
+    SONET_REQUIRE((y == nullptr) != (yp == nullptr), "%s: exactly one of y (f32 [ngout][Cout]) and yp (P16 planes)", what);
+    SONET_REQUIRE(L > 0 && L % 128 == 0, "%s: L=%d must be a positive multiple of 128", what, L);
+    SONET_REQUIRE(GK >= 1 && G >= 1 && G * GK <= 128 && ngout >= 1 && (long long)ngout <= (long long)(L / 128) * G, "%s: bad grouping GK=%d G=%d ngout=%d", what, GK, G, ngout);
+    SONET_REQUIRE(!yp || Lout >= ngout, "%s: Lout=%d (the planes' column count) below ngout=%d", what, Lout, ngout);
+    if (yp) { if (G > 16) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: at most 16 groups per 128 columns for P16 output (G=%d)", what, G); }
+    else if (G > 2 || GK % 4 != 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: f32 output takes G <= 2 groups of GK %% 4 == 0 columns (G=%d GK=%d)", what, G, GK);
+    return h3p_launch(what, x1p, C1, L, nullptr, x2p, C2, Wp, scale, shift, relu, y, yp, 1, Cout, L, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                      GK, G, ngout, Lout, stream);
 }

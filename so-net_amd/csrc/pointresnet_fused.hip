@@ -949,7 +949,8 @@ __global__ __launch_bounds__(256) void pooled_init_kernel(unsigned *__restrict__
 __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__restrict__ pooled, const unsigned *__restrict__ partial,
                                                              const int32_t *__restrict__ ids_sorted, const int32_t *__restrict__ node_off,
                                                              const int32_t *__restrict__ count, const float *__restrict__ v0,
-                                                             float *__restrict__ out, int M, int L, int tpc)
+                                                             float *__restrict__ out, int M, int L, int tpc,
+                                                             uint4 *__restrict__ out_p16, unsigned *__restrict__ rlog)
 {
     constexpr int C = 32 * T3;
     __shared__ float tile[32][33];
@@ -985,6 +986,37 @@ __global__ __launch_bounds__(256) void pooled_decode_kernel(const unsigned *__re
     for (int i = 0; i < 4; ++i) {
         const int cc = c0 + ly + 8 * i, m = m0 + lx;
         if (m < M) out[(b * C + cc) * M + m] = tile[lx][ly + 8 * i];
+    }
+    if (out_p16 != nullptr && threadIdx.x < 128) {
+        // the same values pre-split, on the FLAT column axis of the node-level stage (P16 planes of a 1 x 384 x (B M) activation, column
+        // b M + m: node_stage.hip): the operand of KNNModule's first layer.  Thread = (node, 16-channel chunk qq of the 32, half hh).
+        const int node = threadIdx.x & 31, qq = (threadIdx.x >> 6) & 1, hh = (threadIdx.x >> 5) & 1;
+        const int m = m0 + node;
+        RangeAcc xr = {0, 0u};
+        if (m < M) {
+            const long long BM = ((long long)gridDim.z * M + 127) / 128 * 128, l = b * M + m;      // (plane stride: the flat axis padded to 128 columns)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[node][16 * qq + 4 * hh + (e & 3) + 8 * (e >> 2)];
+            unsigned hv[4], mv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                range_track(xr, v[2 * q], v[2 * q + 1]);
+                const float X0 = 32.f * __builtin_amdgcn_fmed3f(v[2 * q], -2047.f, 2047.f), X1 = 32.f * __builtin_amdgcn_fmed3f(v[2 * q + 1], -2047.f, 2047.f);
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                typedef float f2_t __attribute__((ext_vector_type(2)));
+                const f2_t xv = {X0, X1};
+                const h2_t hp = __builtin_convertvector(xv, h2_t);
+                const f2_t rv = {X0 - (float)hp[0], X1 - (float)hp[1]};
+                hv[q] = __builtin_bit_cast(unsigned, hp);
+                mv[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, h2_t));
+            }
+            const int kc = c0 / 16 + qq;
+            out_p16[((long long)(kc * 2 + 0) * 2 + hh) * BM + l] = make_uint4(hv[0], hv[1], hv[2], hv[3]);
+            out_p16[((long long)(kc * 2 + 1) * 2 + hh) * BM + l] = make_uint4(mv[0], mv[1], mv[2], mv[3]);
+        }
+        // (the planes' consumers cannot check the clamp any more: the largest pooled magnitude goes to word 2 of the launch's range slot)
+        if (rlog != nullptr) range_publish(rlog + 2, wave_umax(range_amax_bits(xr)), (int)(threadIdx.x & 63));
     }
 }
 
@@ -1057,11 +1089,10 @@ extern "C" size_t sonet_pointresnet_pool_ws_size(int B, int L, int M)
     return (size_t)((long long)B * M * (32 * T3) + ntiles * NPASS * SEG_SLOTS * PCH) * 4 + (size_t)B * (32 * T3) * 4;
 }
 
-extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
-                                                const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
-                                                const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream)
+static int fused_pool_impl(const char *what, const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                           const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                           const int32_t *count, void *ws, float *out, void *out_p16, int B, int L, int M, sonet_stream_t stream)
 {
-    const char *what = "sonet_pointresnet_fused_pool_f32";
     SONET_REQUIRE(x_sorted && wstream && affine && ids_sorted && pos0 && node_off && count && ws && out, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && L > 0 && M > 0 && Cin0 >= 1 && Cin0 <= 16, "%s: bad size B=%d L=%d M=%d Cin0=%d", what, B, L, M, Cin0);
     if (B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: B=%d > 65535", what, B);
@@ -1079,8 +1110,27 @@ extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0,
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log());
     hipLaunchKernelGGL(pooled_decode_kernel, dim3((unsigned)(32 * T3 / 32), (unsigned)sonet::ceil_div(M, 32), (unsigned)B), dim3(256), 0, st,
-                       pooled_ws, partial_ws, ids_sorted, node_off, count, v0_ws, out, M, L, tpc);
+                       pooled_ws, partial_ws, ids_sorted, node_off, count, v0_ws, out, M, L, tpc, reinterpret_cast<uint4 *>(out_p16), sonet::range_log());
     return sonet::launched(what);
+}
+
+extern "C" int sonet_pointresnet_fused_pool_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                                const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                                const int32_t *count, void *ws, float *out, int B, int L, int M, sonet_stream_t stream)
+{
+    return fused_pool_impl("sonet_pointresnet_fused_pool_f32", x_sorted, Cin0, wstream, affine, ids_sorted, pos0, node_off, count, ws, out, nullptr, B, L, M, stream);
+}
+
+/* The same launches; the decode pass also writes the pooled map pre-split on the flat column axis of the node-level stage: out_p16 =
+ * P16 planes of a 1 x 384 x (B M) activation (sonet_p16_size(1, 384, B * M) bytes, column b M + m), the operand of KNNModule's first layer
+ * (sonet_pointmlp_h3p); the largest pooled magnitude goes to word 2 of the range log. */
+extern "C" int sonet_pointresnet_fused_pool_p16_f32(const float *x_sorted, int Cin0, const void *wstream, const float *affine,
+                                                    const int32_t *ids_sorted, const int32_t *pos0, const int32_t *node_off,
+                                                    const int32_t *count, void *ws, float *out, void *out_p16, int B, int L, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointresnet_fused_pool_p16_f32";
+    SONET_REQUIRE(out_p16, "%s: NULL pointer", what);
+    return fused_pool_impl(what, x_sorted, Cin0, wstream, affine, ids_sorted, pos0, node_off, count, ws, out, out_p16, B, L, M, stream);
 }
 
 #ifdef SONET_PROF

@@ -736,11 +736,24 @@ __global__ __launch_bounds__(SP_THREADS) void som_assign_rank_kernel(
 
 // LDS (dynamic): double tsum[3][M] | float mean[3][M] | int noff[M] | int base[M] | int lstart[M] | int tot[M] | int mine[M]
 //                | int gpos[k * SP_T] | float buf[7][k * SP_T]
+// Optional rider of som_sort_fill2_kernel: the index / coordinate side of KNNModule on the flat column axis of the node-level stage
+// (node_stage.hip, knn_stage_prepare_kernel -- same records, same arithmetic), computed by the cloud's last workgroup from the cluster
+// means it already holds in LDS: the no-grad forward needs no launch for it.
+struct KnnPrep {
+    const int64_t *I;                     // [B][M][KI] neighbour table (NULL: no rider)
+    int KI, K, avg, G;
+    long long BM, Lm;
+    float *center;                        // [B][3][M]
+    uint4 *center_p16;                    // one-chunk P16 panel, Lm columns
+    int4 *rec;                            // [Lp] (source column | -1 | -2, three de-centred coordinates)
+};
+
 __global__ __launch_bounds__(SP_THREADS) void som_sort_fill2_kernel(
     const float *__restrict__ x, const float *__restrict__ sn, const int32_t *__restrict__ min32, const uint16_t *__restrict__ rank16,
     const int32_t *__restrict__ cnt_part, const double *__restrict__ sum_part, int N, int M, int k, int nW,
     int32_t *__restrict__ count, double *__restrict__ sum_ws, float *__restrict__ som_node, int32_t *__restrict__ row_max,
-    float *__restrict__ x_aug_sorted, int32_t *__restrict__ ids_sorted, int32_t *__restrict__ pos0, int32_t *__restrict__ node_off)
+    float *__restrict__ x_aug_sorted, int32_t *__restrict__ ids_sorted, int32_t *__restrict__ pos0, int32_t *__restrict__ node_off,
+    const KnnPrep kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     double *tsum = reinterpret_cast<double *>(smem2);
@@ -751,6 +764,23 @@ __global__ __launch_bounds__(SP_THREADS) void som_sort_fill2_kernel(
     int *gpos = mine + M;
     float *buf = reinterpret_cast<float *>(gpos + cap);
     const int tid = threadIdx.x, w = blockIdx.x, b = blockIdx.y;
+    // (rider) the cloud's M K neighbour items are spread over its workgroups, one per thread; the item's K table entries are requested
+    // HERE, ahead of everything else, so that their round trip is over by the time the means exist
+    constexpr int KP_MAXK = 16;
+    int kidx[KP_MAXK];
+    const int kp_stride = nW * SP_THREADS;
+    if (kp.I != nullptr && kp.K <= KP_MAXK) {
+        const int t = w * SP_THREADS + tid;
+        if (t < M * kp.K) {
+            const int64_t *Ib = kp.I + ((size_t)b * M + t / kp.K) * kp.KI;
+#pragma unroll
+            for (int q = 0; q < KP_MAXK; ++q) {
+                long long v = -1;
+                if (q < kp.K) v = Ib[q];
+                kidx[q] = ((unsigned long long)v < (unsigned long long)M) ? (int)v : -1;
+            }
+        }
+    }
     // totals over the cloud's workgroups, one thread per (quantity, node): quantity 0 = count (+ this workgroup's run start), 1-3 = sums
     for (int t = tid; t < 4 * M; t += SP_THREADS) {
         const int q = t / M, m = t - q * M;
@@ -788,6 +818,63 @@ __global__ __launch_bounds__(SP_THREADS) void som_sort_fill2_kernel(
     if (tid >= 64 && tid < 128) lds_exclusive_scan(mine, lstart, M, tid - 64);   // this workgroup's local node order (second wave)
     __syncthreads();
     if (w == 0) for (int m = tid; m < M; m += SP_THREADS) node_off[(size_t)b * M + m] = noff[m];
+    if (kp.I != nullptr) {
+        // KNNModule's neighbourhood centres and de-centred neighbour coordinates (models/layers.py:319-350) from the means in LDS
+        const int K = kp.K, MK = M * K;
+        bool first = K <= KP_MAXK;
+        for (int t = w * SP_THREADS + tid; t < MK; t += kp_stride, first = false) {
+            const int m = t / K, kk = t - m * K;
+            const int64_t *Ib = kp.I + ((size_t)b * M + m) * kp.KI;
+            int id = -1;
+            if (first) {
+#pragma unroll
+                for (int q = 0; q < KP_MAXK; ++q) id = q == kk ? kidx[q] : id;
+            } else {
+                const long long v = Ib[kk];
+                id = ((unsigned long long)v < (unsigned long long)M) ? (int)v : -1;
+            }
+            const bool ok = id >= 0;
+            float d[3], ctr[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *src = mean + c * M;
+                if (kp.avg) {
+                    float sum = 0.f;
+                    if (first) {
+#pragma unroll
+                        for (int q = 0; q < KP_MAXK; ++q)
+                            if (q < K) sum += kidx[q] >= 0 ? src[kidx[q]] : 0.f;
+                    } else {
+                        for (int q = 0; q < K; ++q) {
+                            const long long ik = Ib[q];
+                            sum += ((unsigned long long)ik < (unsigned long long)M) ? src[ik] : 0.f;
+                        }
+                    }
+                    ctr[c] = sum / (float)K;
+                } else {
+                    ctr[c] = src[m];
+                }
+                d[c] = (ok ? src[id] : 0.f) - ctr[c];
+            }
+            const long long n = (long long)b * M + m, blk = n / kp.G;
+            const int g = (int)(n - blk * kp.G);
+            kp.rec[blk * 128 + g * K + kk] = make_int4(ok ? (int)((long long)b * M + id) : -1, __float_as_int(d[0]), __float_as_int(d[1]), __float_as_int(d[2]));
+            if (kk == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) kp.center[((size_t)b * 3 + c) * M + m] = ctr[c];
+                unsigned h0, m0, h1v, m1;
+                p16_split_pair(ctr[0], ctr[1], h0, m0);
+                p16_split_pair(ctr[2], 0.f, h1v, m1);
+                kp.center_p16[0 * kp.Lm + n] = make_uint4(h0, h1v, 0u, 0u);
+                kp.center_p16[1 * kp.Lm + n] = make_uint4(0u, 0u, 0u, 0u);
+                kp.center_p16[2 * kp.Lm + n] = make_uint4(m0, m1, 0u, 0u);
+                kp.center_p16[3 * kp.Lm + n] = make_uint4(0u, 0u, 0u, 0u);
+                // the padding columns of a block: behind its last node, or behind the very last node of the batch
+                if (g == kp.G - 1 || n == kp.BM - 1)
+                    for (int col = (g + 1) * K; col < 128; ++col) kp.rec[blk * 128 + col] = make_int4(-2, 0, 0, 0);
+            }
+        }
+    }
     const size_t kN = (size_t)k * N;
     const float *xb = x + (size_t)b * 3 * N;
     const float *snb = sn + (size_t)b * 3 * N;
@@ -833,12 +920,11 @@ extern "C" size_t sonet_som_assign_sort_ws_size(int B, int N, int M, int k)
     return (size_t)B * nW * 3 * M * 8 + (((size_t)B * nW * M * 4 + 7) & ~(size_t)7) + (((size_t)B * k * N * 2 + 7) & ~(size_t)7);
 }
 
-extern "C" int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
-                                         int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
-                                         float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
-                                         int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream)
+static int som_assign_sort_impl(const char *what, const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                int32_t *pos0, int32_t *node_off, void *ws, const KnnPrep &kp, sonet_stream_t stream)
 {
-    const char *what = "sonet_som_assign_sort_f32";
     SONET_REQUIRE(x && sn && node && min_idx_i32 && count && x_aug_sorted && ids_sorted && pos0 && node_off && ws, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && N > 0 && M > 0, "%s: non-positive size B=%d N=%d M=%d", what, B, N, M);
     SONET_REQUIRE(k >= 1 && k <= SP_KMAX && k <= M, "%s: k=%d must be in [1, min(4, M=%d)]", what, k, M);
@@ -862,8 +948,40 @@ extern "C" int sonet_som_assign_sort_f32(const float *x, const float *sn, const 
     if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_sort_fill2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
         return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what);
     hipLaunchKernelGGL(som_sort_fill2_kernel, grid, block, lds2, st, x, sn, min_idx_i32, rank16, cnt_part, sum_part, N, M, k, nW,
-                       count, sum_ws, som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off);
+                       count, sum_ws, som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off, kp);
     return sonet::launched(what);
+}
+
+extern "C" int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                         int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                         float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                         int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream)
+{
+    KnnPrep kp;
+    kp.I = nullptr; kp.KI = kp.K = kp.avg = kp.G = 0; kp.BM = kp.Lm = 0; kp.center = nullptr; kp.center_p16 = nullptr; kp.rec = nullptr;
+    return som_assign_sort_impl("sonet_som_assign_sort_f32", x, sn, node, B, N, M, k, min_idx_i32, min_idx_i64, count, sum_ws, som_node, row_max,
+                                x_aug_sorted, ids_sorted, pos0, node_off, ws, kp, stream);
+}
+
+/* sonet_som_assign_sort_f32 whose second launch also does sonet_knn_stage_prepare_f32 on the cluster means it computes (KNNModule's index /
+ * coordinate side on the flat column axis of the node-level stage, include/sonet_hip.h): same outputs center [B][3][M], center_p16, rec --
+ * bit-identical to the separate launch on som_node. */
+extern "C" int sonet_som_assign_sort_knn_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                             int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                             float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                             int32_t *pos0, int32_t *node_off, void *ws,
+                                             const int64_t *knn_I, int KI, int K, int center_avg, float *center, void *center_p16, void *rec,
+                                             sonet_stream_t stream)
+{
+    const char *what = "sonet_som_assign_sort_knn_f32";
+    SONET_REQUIRE(knn_I && center && center_p16 && rec, "%s: NULL pointer", what);
+    SONET_REQUIRE(K >= 1 && K <= 128 && KI >= K, "%s: bad neighbour count K=%d (of %d)", what, K, KI);
+    KnnPrep kp;
+    kp.I = knn_I; kp.KI = KI; kp.K = K; kp.avg = center_avg; kp.G = knn_stage_groups(K);
+    kp.BM = (long long)B * M; kp.Lm = (kp.BM + 127) / 128 * 128;
+    kp.center = center; kp.center_p16 = reinterpret_cast<uint4 *>(center_p16); kp.rec = reinterpret_cast<int4 *>(rec);
+    return som_assign_sort_impl(what, x, sn, node, B, N, M, k, min_idx_i32, min_idx_i64, count, sum_ws, som_node, row_max,
+                                x_aug_sorted, ids_sorted, pos0, node_off, ws, kp, stream);
 }
 
 extern "C" int sonet_som_sort_group_f32(const float *x, const float *sn, const int32_t *min_idx_i32, const int32_t *count,

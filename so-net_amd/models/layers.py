@@ -475,6 +475,16 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
                 cache[tag] = (key, _ops.pointmlp_h3p_pack(src.contiguous().float()))
         return cache[tag][1]
 
+    def _lead_cols(self, lead):
+        """W[:, :lead] as a contiguous Cout x lead f32 matrix (the coordinate channels of KNNModule's first layer), cached per weight version."""
+        w = self.conv.weight
+        key = (w._version, w.data_ptr(), w.device, lead)
+        if getattr(self, '_wlead_key', None) != key:
+            with torch.no_grad():
+                self._wlead = self._weight2d().detach()[:, :lead].float().contiguous()
+            self._wlead_key = key
+        return self._wlead
+
     def _p16_ok(self):
         """Eval-mode, no-grad, h3: this layer can run on pre-split (P16) operands and hand its output on in that form."""
         return (_ops.POINTMLP_PRECISION == "h3" and _ops.P16_CHAINS and not torch.is_grad_enabled() and self.conv.weight.is_cuda

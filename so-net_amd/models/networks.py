@@ -158,6 +158,41 @@ class Encoder(_PlainAttrs, nn.Module):
     def first_pn_out(self, v):
         self._first_pn_out = v
 
+    # (the flat node-level stage keeps its intermediate maps pre-split; the f32 tensors the reference leaves on the module are built
+    #  when somebody reads them)
+    def _stage_map(self, name):
+        v = self.__dict__.get("_" + name)
+        st = self.__dict__.get("_stage")
+        if v is None and st is not None:
+            with torch.no_grad():
+                if name == "knn_feature_1":
+                    v = _ops.p16_flat_to_bcm(st["knn_p16"], st["B"], st["M"])
+                else:                                   # final_pn_out: the last layer once more, this time with its columns written
+                    lyr = self.final_pointnet.layers[1]
+                    sc, sh = lyr._eval_affine()
+                    y = _ops.pointmlp_h3p(st["h3_p16"], lyr._packed_p16(), sc, sh, lyr.activation == 'relu', lyr.conv.out_channels, out="f32")
+                    v = y[0, :, :st["B"] * st["M"]].reshape(-1, st["B"], st["M"]).permute(1, 0, 2).contiguous()
+            if getattr(self, "_infer_tag", False):
+                _ops.mark_inference(v)
+            self.__dict__["_" + name] = v
+        return v
+
+    @property
+    def knn_feature_1(self):
+        return self._stage_map("knn_feature_1")
+
+    @knn_feature_1.setter
+    def knn_feature_1(self, v):
+        self.__dict__["_knn_feature_1"] = v
+
+    @property
+    def final_pn_out(self):
+        return self._stage_map("final_pn_out")
+
+    @final_pn_out.setter
+    def final_pn_out(self, v):
+        self.__dict__["_final_pn_out"] = v
+
     @property
     def centers(self):
         return self._per_point("centers")
@@ -184,9 +219,62 @@ class Encoder(_PlainAttrs, nn.Module):
             out = self._forward_guarded(x, sn, node, node_knn_I, is_train, epoch)
         self._infer_tag = (not torch.is_grad_enabled()) or infer
         if self._infer_tag:
-            for t in (out, self.first_pn_out_masked_max, self.final_pn_out, self.som_node, getattr(self, "knn_feature_1", None)):
+            # (the raw slots, not the properties: a map the flat node-level stage kept pre-split is decoded -- and tagged -- when it is read)
+            for t in (out, self.first_pn_out_masked_max, self.__dict__.get("_final_pn_out"), self.som_node, self.__dict__.get("_knn_feature_1")):
                 _ops.mark_inference(t)
         return out
+
+    # ---- no-grad node-level stage on the flat column axis (csrc/node_stage.hip) ---------------------------------------------------
+    def _node_stage_ok(self, B, M, node_knn_I):
+        """KNNModule + final PointNet + global max as five launches on pre-split activations: eval, no autograd, h3 arithmetic, the
+        standard two-layer modules, 64 or 128 nodes (a cloud's nodes = one or half a 128-column block)."""
+        opt = self.opt
+        if not (_ops.NODE_STAGE_P16 and _ops.GATHER_NODE_STAGE and _ops.P16_CHAINS and _ops.POINTMLP_PRECISION == "h3" and opt.som_k >= 2) \
+                or torch.is_grad_enabled():
+            return False
+        if getattr(self, 'want_first_pn_out', False):           # (a head that reads the intermediate maps densely: the segmenter)
+            return False
+        if M not in (64, 128) or node_knn_I is None or node_knn_I.dim() != 3 or node_knn_I.dtype != torch.int64 \
+                or node_knn_I.shape[2] < opt.som_k or opt.som_k > 128 or opt.som_k_type not in ('avg', 'center'):
+            return False
+        if not isinstance(self.final_pointnet, PointNet) or len(self.knnlayer.layers) != 2 or len(self.final_pointnet.layers) != 2:
+            return False
+        k1, k2 = self.knnlayer.layers
+        f1, f2 = self.final_pointnet.layers
+        if k1.conv.in_channels != 3 + 384 or k2.conv.in_channels != k1.conv.out_channels or k1.conv.out_channels % 16 != 0 \
+                or f1.conv.in_channels != 3 + k2.conv.out_channels or k2.conv.out_channels % 16 != 0 or f2.conv.in_channels != f1.conv.out_channels:
+            return False
+        return all(l._p16_ok() for l in (k1, k2, f1, f2))
+
+    def _node_stage(self, xp, prep, B, M):
+        """xp: ``P16`` 1 x 384 x Lm (the pooled map from the fused first PointNet's decode pass), prep: ``knn_stage_prepare`` of the
+        nodes (launched before the first PointNet: it needs the coordinates only) -> feature B x feature_num."""
+        K, G = prep["K"], prep["G"]
+        k1, k2 = self.knnlayer.layers
+        f1, f2 = self.final_pointnet.layers
+        dev = xp.device
+        C1 = k1.conv.out_channels
+        # KNNModule layer 1 = (its 384-channel block once per node) + (gather + the 3 coordinate channels per neighbour copy)
+        z = _ops.pointmlp_h3p(xp, k1._packed_p16(lambda: k1._weight2d().detach()[:, 3:], "feat"), _ops.const_vec(C1, 1.0, dev),
+                              _ops.const_vec(C1, 0.0, dev), False, C1, out="p16", tag="flat")
+        s1, t1 = k1._eval_affine()
+        h1 = _ops.knn_stage_input(prep, z, k1._lead_cols(3), s1, t1, k1.activation == 'relu')
+        center, cp = prep["center"], prep["center_p16"]
+        # layer 2 + max over the K neighbours (models/layers.py:352-365)
+        s2, t2 = k2._eval_affine()
+        knn = _ops.pointmlp_h3p_gmax(h1, k2._packed_p16(), s2, t2, k2.activation == 'relu', k2.conv.out_channels, K, G, B * M, out="p16", Lout=xp.L)
+        # final PointNet on cat(center, knn feature) (models/networks.py:191-196): the 3 centre channels as the second panel
+        s3, t3 = f1._eval_affine()
+        h3 = _ops.pointmlp_h3p(knn, f1._packed_p16(lambda: torch.cat((f1._weight2d().detach()[:, 3:], f1._weight2d().detach()[:, :3]), dim=1), "rot3"),
+                               s3, t3, f1.activation == 'relu', f1.conv.out_channels, x2=cp, out="p16", tag="flat")
+        # last layer + max over the cloud's M nodes (models/networks.py:197)
+        s4, t4 = f2._eval_affine()
+        feature = _ops.pointmlp_h3p_gmax(h3, f2._packed_p16(), s4, t4, f2.activation == 'relu', f2.conv.out_channels, M, 128 // M, B, out="f32")
+        self.knn_center_1 = center
+        self.__dict__["_stage"] = dict(knn_p16=knn, h3_p16=h3, B=B, M=M)
+        self.__dict__["_knn_feature_1"] = None
+        self.__dict__["_final_pn_out"] = None
+        return feature
 
     def _forward_guarded(self, x, sn, node, node_knn_I, is_train, epoch):
         """The forward inside an operand-range scope of the fp16-split arithmetic (sonet_hip/ops.py ``run_guarded``):
@@ -207,7 +295,11 @@ class Encoder(_PlainAttrs, nn.Module):
         fused_pool = (use_sn and _ops.FUSE_POOL and not getattr(self, 'want_first_pn_out', False)
                       and not torch.is_grad_enabled() and self.first_pointnet._fusable_eval(xd)
                       and int(opt.k) * xd.shape[2] * 384 * 4 < 4e9)
-        fast = sb.assign_sort(xd, snd, opt.k) if fused_pool else None   # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
+        # the flat node-level stage (KNNModule + final PointNet + global max on pre-split activations): its index / coordinate side needs
+        # the cluster means only and rides on the SOM stage's second launch
+        stage = fused_pool and _ops.POINTMLP_PRECISION == "h3" and self._node_stage_ok(xd.shape[0], M, node_knn_I)
+        knn = (node_knn_I.contiguous(), int(opt.som_k), opt.som_k_type == 'avg') if stage else None
+        fast = sb.assign_sort(xd, snd, opt.k, knn=knn) if fused_pool else None   # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
         if fast is not None:
             a, g = fast
         else:
@@ -220,9 +312,19 @@ class Encoder(_PlainAttrs, nn.Module):
             self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None, centers=None, x_decentered=None)
             self._first_pn_out = None                                    # lazy (property)
             wstream, affine = self.first_pointnet._fused_state()
+            self.__dict__["_stage"] = None
+            if stage:
+                # ... -> KNNModule + final PointNet + global max on the flat column axis, pre-split activations end to end (:187-197)
+                prep = g.get("knn_prep")
+                if prep is None:                                # (the two-launch SOM stage did not take the batch: a launch of its own)
+                    prep = _ops.knn_stage_prepare(self.som_node, knn[0], knn[1], knn[2])
+                self.first_pn_out_masked_max, xp = _ops.pointresnet_fused_pool(g, wstream, affine, M, want_p16=True)
+                self.feature = self._node_stage(xp, prep, xd.shape[0], M)
+                return self.feature
             pool = _ops.pointresnet_bf16_pool if _ops.POINTMLP_PRECISION == "bf16" else _ops.pointresnet_fused_pool
             self.first_pn_out_masked_max = pool(g, wstream, affine, M)
         else:
+            self.__dict__["_stage"] = None
             # (a head that reads the per-point attributes afterwards -- the segmenter -- gets them from this launch: a second som_group
             #  launch for x_decentered / centers was 1 % of the segmenter's step)
             per_point = bool(getattr(self, 'want_first_pn_out', False))

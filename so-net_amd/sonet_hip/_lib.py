@@ -38,6 +38,8 @@ SIGNATURES = {
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_ws_size": [_i, _i, _i, _i],
     "sonet_som_assign_sort_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sonet_som_assign_sort_knn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_mask_i32": [_vp, _vp, _i, _i, _i, _vp],
     "sonet_node_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -96,6 +98,13 @@ SIGNATURES = {
     "sonet_pointresnet_fused_p16_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "sonet_pointresnet_pool_ws_size": [_i, _i, _i],
     "sonet_pointresnet_fused_pool_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_pointresnet_fused_pool_p16_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_knn_stage_columns": [_i, _i, _i],
+    "sonet_knn_stage_prepare_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_knn_stage_input_p16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "sonet_pointmlp_h3p_gmax": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "sonet_node_stage_columns": [_i, _i],
+    "sonet_p16_flat_to_bcm_f32": [_vp, _vp, _i, _i, _i, _vp],
     "sonet_som_sort_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_pointwise_bwd_stats_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "sonet_pointwise_bwd_apply_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -137,6 +146,8 @@ _RESTYPES = {
     "sonet_wgrad_bf16_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_x3_pack_size": ctypes.c_size_t,
     "sonet_p16_size": ctypes.c_size_t,
+    "sonet_knn_stage_columns": ctypes.c_size_t,
+    "sonet_node_stage_columns": ctypes.c_size_t,
     "sonet_knn_gather_bwd_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_h3p_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_h3p_stats_ws_size": ctypes.c_size_t,

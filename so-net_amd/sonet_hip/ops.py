@@ -211,9 +211,11 @@ def som_sort_group(x, sn, a):
     return out
 
 
-def som_assign_sort(x, sn, node, k, want_i64=False):
+def som_assign_sort(x, sn, node, k, want_i64=False, knn=None):
     """som_assign + som_sort_group of the no-grad pooled path in two launches (``sonet_som_assign_sort_f32``): -> (SomAssignment,
-    dict(som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off, count)).  Node ids / counts bit-identical to the separate calls."""
+    dict(som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off, count)).  Node ids / counts bit-identical to the separate calls.
+    knn = (knn_I B x M x KI int64, K, center_avg): the second launch also does ``knn_stage_prepare`` on the cluster means
+    (``sonet_som_assign_sort_knn_f32``); its result is the dict's "knn_prep"."""
     _chk(x, "x", torch.float32, 3)
     _chk(sn, "sn", torch.float32, 3)
     _chk(node, "node", torch.float32, 3)
@@ -238,6 +240,25 @@ def som_assign_sort(x, sn, node, k, want_i64=False):
                pos0=torch.empty((B,), dtype=torch.int32, device=dev),
                node_off=torch.empty((B, M), dtype=torch.int32, device=dev), count=r.count)
     ws = torch.empty((lib.sonet_som_assign_sort_ws_size(B, N, M, k),), dtype=torch.uint8, device=dev)
+    if knn is not None:
+        knn_I, K, avg = knn
+        _chk(knn_I, "knn_I", torch.int64, 3)
+        KI = knn_I.shape[2]
+        if tuple(knn_I.shape[:2]) != (B, M) or KI < K or not 1 <= K <= 128:
+            raise SonetHipError("som_assign_sort: knn_I B x M x (>= K), 1 <= K <= 128")
+        _same_device(x, knn_I)
+        Lm = node_stage_columns(B, M)
+        Lp = int(lib.sonet_knn_stage_columns(B, M, int(K)))
+        prep = dict(center=torch.empty((B, 3, M), dtype=torch.float32, device=dev), center_p16=p16_flat(3, Lm, B * M, dev),
+                    rec=torch.empty((Lp, 4), dtype=torch.int32, device=dev), B=B, M=M, K=int(K), G=min(16, 128 // int(K)), Lp=Lp)
+        with _lib.on_device(dev), _timed("som_assign_sort"):
+            check(lib.sonet_som_assign_sort_knn_f32(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
+                                                    ptr(r.sum_ws), ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
+                                                    ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(ws),
+                                                    ptr(knn_I), KI, int(K), int(bool(avg)), ptr(prep["center"]), ptr(prep["center_p16"].data), ptr(prep["rec"]),
+                                                    stream_ptr()), "sonet_som_assign_sort_knn_f32")
+        out["knn_prep"] = prep
+        return r, out
     with _lib.on_device(dev), _timed("som_assign_sort"):
         check(lib.sonet_som_assign_sort_f32(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
                                             ptr(r.sum_ws), ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
@@ -488,6 +509,9 @@ GATHER_NODE_STAGE = _os.environ.get("SONET_GATHER_NODE_STAGE", "1") != "0"
 NODE_LINEAR_SPLIT = _os.environ.get("SONET_NODE_LINEAR_SPLIT", "1") != "0"
 # no-grad h3 chains of point-wise layers hand their activations on pre-split (P16 planes, csrc/pointmlp_h3p.hip) instead of as f32
 P16_CHAINS = _os.environ.get("SONET_P16_CHAINS", "1") != "0"
+# no-grad node-level stage (KNNModule + final PointNet + global max) on the third-generation layer, flat column axis, max-over-group
+# epilogues (csrc/node_stage.hip): 5 launches instead of 8.  0 = the round-4 stage (second-generation layers + planes_max / lastdim_max)
+NODE_STAGE_P16 = _os.environ.get("SONET_NODE_STAGE_P16", "1") != "0"
 WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 
@@ -1045,7 +1069,7 @@ def pointmlp_h3p_pack(weight2d):
     return wp
 
 
-def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None, z=None, zidx=None, stats=False):
+def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None, z=None, zidx=None, stats=False, tag=None):
     """y = act((W . cat(x1, x2) [+ z[:, :, zidx]]) * scale + shift) on P16 inputs (x1, x2: ``P16``).
     out: "f32" -> B x Cout x L f32 tensor, "p16" -> ``P16``, "both" -> (f32, P16).  gidx (B x L i32): column l of x1 is x1[:, :, gidx[b, l]].
     stats=True (out "f32" only): also the per-channel (mean, biased var) of y over (B, L) -> (y, mean, var)."""
@@ -1095,7 +1119,7 @@ def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None
         var = torch.empty((Cout,), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.sonet_pointmlp_h3p_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
     if B * L * Cout != 0:
-        name = "pointmlph3p%s_%dx%d_L%d" % ("_nodeadd" if z is not None else "_stats" if stats else "", C1 + C2, Cout, L)
+        name = "pointmlph3p%s_%dx%d_L%d" % ("_nodeadd" if z is not None else "_stats" if stats else ("_" + tag) if tag else "", C1 + C2, Cout, L)
         _range_arm(name)
         with _lib.on_device(dev), _timed(name):
             check(lib.sonet_pointmlp_h3p(ptr(x1.data), C1, L1, ptr(gidx), ptr(x2.data) if x2 is not None else None, C2, ptr(wp), ptr(scale), ptr(shift),
@@ -1104,6 +1128,108 @@ def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None
     if stats:
         return y, mean, var
     return y if out == "f32" else yp if out == "p16" else (y, yp)
+
+
+def node_stage_columns(B, M):
+    """Column count Lm of the M-level tensors of the flat node-level stage: B * M rounded up to a multiple of 128."""
+    return (B * M + 127) // 128 * 128
+
+
+def p16_flat(C, L, nvalid, device):
+    """P16 planes of a flat 1 x C x L activation whose first ``nvalid`` columns a kernel will write: the pad columns must read as zeros
+    (garbage there would reach the range log), so a padded axis starts zero-filled."""
+    if nvalid == L:
+        return p16_empty(1, C, L, device)
+    n = _lib.load().sonet_p16_size(1, C, L)
+    return P16(torch.zeros((n,), dtype=torch.uint8, device=device), 1, C, L)
+
+
+def pointmlp_h3p_gmax(x1, wp, scale, shift, relu, Cout, GK, G, ngout, x2=None, out="p16", Lout=None):
+    """The layer followed by a max over groups of GK consecutive columns, one launch (``sonet_pointmlp_h3p_gmax``): x1 (x2) ``P16`` with
+    B == 1 and L % 128 == 0, G groups per 128-column block.  out "p16" -> ``P16`` 1 x Cout x Lout (Lout >= ngout columns, default ngout;
+    pad columns zero), "f32" -> f32 tensor ngout x Cout."""
+    if not isinstance(x1, P16) or (x2 is not None and not isinstance(x2, P16)):
+        raise SonetHipError("pointmlp_h3p_gmax: P16 inputs")
+    if wp.dtype != torch.int32:
+        raise SonetHipError("pointmlp_h3p_gmax: an h3p pack (ops.pointmlp_h3p_pack)")
+    if x1.B != 1 or (x2 is not None and (x2.B != 1 or x2.L != x1.L)):
+        raise SonetHipError("pointmlp_h3p_gmax: one flat cloud (B == 1), x2 with the columns of x1")
+    if out not in ("p16", "f32"):
+        raise SonetHipError("pointmlp_h3p_gmax: out is 'p16' or 'f32'")
+    C1, L = x1.C, x1.L
+    C2 = x2.C if x2 is not None else 0
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    dev = _same_device(x1.data, x2.data if x2 is not None else None, wp, scale, shift)
+    lib = _lib.load()
+    if wp.numel() * 4 != lib.sonet_pointmlp_h3p_pack_size(C1 + C2, Cout):
+        raise SonetHipError("packed weight has %d bytes, expected %d for Cin=%d Cout=%d"
+                            % (wp.numel() * 4, lib.sonet_pointmlp_h3p_pack_size(C1 + C2, Cout), C1 + C2, Cout))
+    Lout = int(ngout if Lout is None else Lout)
+    y = torch.empty((ngout, Cout), dtype=torch.float32, device=dev) if out == "f32" else None
+    yp = p16_flat(Cout, Lout, ngout, dev) if out == "p16" else None
+    name = "pointmlph3p_gmax%d_%dx%d_L%d" % (GK, C1 + C2, Cout, int(ngout) * int(GK))      # (the columns that count: without the blocks' padding)
+    _range_arm(name)
+    with _lib.on_device(dev), _timed(name):
+        check(lib.sonet_pointmlp_h3p_gmax(ptr(x1.data), C1, ptr(x2.data) if x2 is not None else None, C2, ptr(wp), ptr(scale), ptr(shift),
+                                          int(bool(relu)), Cout, L, int(GK), int(G), int(ngout), Lout, ptr(y), ptr(yp.data) if yp is not None else None,
+                                          stream_ptr()), "sonet_pointmlp_h3p_gmax")
+    return y if out == "f32" else yp
+
+
+def knn_stage_prepare(coord, knn_I, K, center_avg):
+    """Index / coordinate side of KNNModule on the flat column axis (``sonet_knn_stage_prepare_f32``; needs only the node coordinates):
+    coord B x 3 x M f32, knn_I B x M x KI int64 (first K columns used) -> dict(center B x 3 x M f32, center_p16 ``P16`` 1 x 3 x Lm,
+    rec int32 Lp x 4, B, M, K, G) with G = min(16, 128 // K) nodes per 128-column block of the K-level tensor."""
+    _chk(coord, "coord", torch.float32, 3)
+    _chk(knn_I, "knn_I", torch.int64, 3)
+    B, three, M = coord.shape
+    KI = knn_I.shape[2]
+    if three != 3 or tuple(knn_I.shape[:2]) != (B, M) or KI < K or not 1 <= K <= 128:
+        raise SonetHipError("knn_stage_prepare: coord B x 3 x M, knn_I B x M x (>= K), 1 <= K <= 128")
+    dev = _same_device(coord, knn_I)
+    lib = _lib.load()
+    Lm = node_stage_columns(B, M)
+    Lp = int(lib.sonet_knn_stage_columns(B, M, int(K)))
+    center = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
+    cp = p16_flat(3, Lm, B * M, dev)
+    rec = torch.empty((Lp, 4), dtype=torch.int32, device=dev)
+    _range_arm("knn_stage_prepare")
+    with _lib.on_device(dev), _timed("knn_stage_prepare"):
+        check(lib.sonet_knn_stage_prepare_f32(ptr(coord), ptr(knn_I), KI, int(bool(center_avg)), B, M, int(K), ptr(center), ptr(cp.data), ptr(rec),
+                                              stream_ptr()), "sonet_knn_stage_prepare_f32")
+    return dict(center=center, center_p16=cp, rec=rec, B=B, M=M, K=int(K), G=min(16, 128 // int(K)), Lp=Lp)
+
+
+def knn_stage_input(prep, z, wl, scale, shift, relu):
+    """KNNModule's first layer per neighbour copy (``sonet_knn_stage_input_p16``): prep from ``knn_stage_prepare``, z ``P16`` 1 x C x Lm
+    (the layer's feature block applied per node), wl C x 3 -> h1 ``P16`` 1 x C x Lp."""
+    if not isinstance(z, P16) or z.B != 1 or z.L != node_stage_columns(prep["B"], prep["M"]):
+        raise SonetHipError("knn_stage_input: z is a P16 1 x C x Lm activation")
+    _chk(wl, "wl", torch.float32, 2)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    C = z.C
+    if tuple(wl.shape) != (C, 3) or scale.numel() != C or shift.numel() != C:
+        raise SonetHipError("knn_stage_input: wl C x 3, scale / shift C")
+    dev = _same_device(prep["rec"], z.data, wl, scale, shift)
+    h1 = p16_empty(1, C, prep["Lp"], dev)            # (every column is written: pad columns as zeros)
+    name = "knn_stage_input_%dx%d" % (C, prep["B"] * prep["M"] * prep["K"])
+    _range_arm(name)
+    with _lib.on_device(dev), _timed(name):
+        check(_lib.load().sonet_knn_stage_input_p16(ptr(prep["rec"]), ptr(z.data), ptr(wl), ptr(scale), ptr(shift), int(bool(relu)),
+                                                    prep["B"], prep["M"], prep["K"], C, ptr(h1.data), stream_ptr()), "sonet_knn_stage_input_p16")
+    return h1
+
+
+def p16_flat_to_bcm(p, B, M):
+    """``P16`` 1 x C x Lm on the flat column axis of the node-level stage -> f32 B x C x M."""
+    if p.B != 1 or p.L != node_stage_columns(B, M):
+        raise SonetHipError("p16_flat_to_bcm: a 1 x C x (B M) activation")
+    x = torch.empty((B, p.C, M), dtype=torch.float32, device=p.device)
+    with _lib.on_device(p.device), _timed("p16_flat_to_bcm"):
+        check(_lib.load().sonet_p16_flat_to_bcm_f32(ptr(p.data), ptr(x), B, p.C, M, stream_ptr()), "sonet_p16_flat_to_bcm_f32")
+    return x
 
 
 def pointresnet_pack(w1, w2, w3, w4):
@@ -1146,9 +1272,9 @@ def pointresnet_fused(x, wstream, affine, want_p16=False):
     return (y, yp) if want_p16 else y
 
 
-def pointresnet_fused_pool(sg, wstream, affine, M):
+def pointresnet_fused_pool(sg, wstream, affine, M, want_p16=False):
     """First PointNet + per-node max-pool in one pass over node-sorted points (``sg`` = som_sort_group result)
-    -> B x 384 x M f32."""
+    -> B x 384 x M f32.  want_p16: -> (that, ``P16`` 1 x 384 x Lm): the same map pre-split on the flat column axis of the node-level stage."""
     x_sorted = sg["x_aug_sorted"]
     _chk(x_sorted, "x_sorted", torch.float32, 3)
     _chk(affine, "affine", torch.float32, 2)
@@ -1157,12 +1283,18 @@ def pointresnet_fused_pool(sg, wstream, affine, M):
     lib = _lib.load()
     ws = torch.empty((lib.sonet_pointresnet_pool_ws_size(B, L, int(M)),), dtype=torch.uint8, device=dev)
     out = torch.empty((B, 384, int(M)), dtype=torch.float32, device=dev)
+    outp = p16_flat(384, node_stage_columns(B, int(M)), B * int(M), dev) if want_p16 else None
     _range_arm("pointresnet_fused_pool_L%d" % L)
     with _lib.on_device(dev), _timed("pointresnet_fused_pool_L%d" % L):
-        check(lib.sonet_pointresnet_fused_pool_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
-                                                   ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
-              "sonet_pointresnet_fused_pool_f32")
-    return out
+        if want_p16:
+            check(lib.sonet_pointresnet_fused_pool_p16_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
+                                                           ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), ptr(outp.data), B, L, int(M),
+                                                           stream_ptr()), "sonet_pointresnet_fused_pool_p16_f32")
+        else:
+            check(lib.sonet_pointresnet_fused_pool_f32(ptr(x_sorted), Cin0, ptr(wstream), ptr(affine), ptr(sg["ids_sorted"]), ptr(sg["pos0"]),
+                                                       ptr(sg["node_off"]), ptr(sg["count"]), ptr(ws), ptr(out), B, L, int(M), stream_ptr()),
+                  "sonet_pointresnet_fused_pool_f32")
+    return (out, outp) if want_p16 else out
 
 
 def pointresnet_bf16_pack(w1, w2, w3, w4):

@@ -97,7 +97,7 @@ class BatchSOM():
         self.last_assignment = a
         return a
 
-    def assign_sort(self, x, sn, k):
+    def assign_sort(self, x, sn, k, knn=None):
         """Assignment + node-sorted grouping in two launches (the no-grad pooled path of the level-2 Encoder): -> (assignment,
         grouping dict), or None when the batch is outside what the fused launches take (B > 65535, M > 1024, k > 4) -- the caller
         then uses assign() + som_sort_group."""
@@ -107,7 +107,8 @@ class BatchSOM():
         M = node.shape[2]
         if x.shape[0] > 65535 or M > 1024 or not (1 <= int(k) <= min(4, M)):
             return None
-        a, g = _ops.som_assign_sort(x.contiguous(), sn, node, int(k))
+        # (knn = (node_knn_I, K, center_avg): KNNModule's index / coordinate side rides on the second launch -- grouping dict "knn_prep")
+        a, g = _ops.som_assign_sort(x.contiguous(), sn, node, int(k), knn=knn)
         self.last_assignment = a
         return a, g
 

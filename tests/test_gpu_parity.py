@@ -1027,8 +1027,10 @@ def test_encoder_node_stage_gather_matches_materialised_path():
     enc.to(DEV).eval()
     args = (cu(g["pc"]), cu(g["sn"]), cu(g["node"]), cu(g["node_knn_I"]))
     old = ops.GATHER_NODE_STAGE, ops.POINTMLP_PRECISION
+    old_flat = ops.NODE_STAGE_P16
     try:
         ops.POINTMLP_PRECISION = "h3"
+        ops.NODE_STAGE_P16 = False               # (the flat stage of round 5 has its own comparison: tests/test_gpu_node_stage.py)
         outs = {}
         for flag in (True, False):
             ops.GATHER_NODE_STAGE = flag
@@ -1041,6 +1043,7 @@ def test_encoder_node_stage_gather_matches_materialised_path():
             assert_close_rms(a.cpu().numpy(), b.cpu().numpy(), 5e-6, "gathering node stage vs materialised")   # the split itself: ~3e-6
     finally:
         ops.GATHER_NODE_STAGE, ops.POINTMLP_PRECISION = old
+        ops.NODE_STAGE_P16 = old_flat
 
 
 def test_pooled_wgrad_matches_dense_scatter_gemm():
