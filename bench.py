@@ -100,6 +100,7 @@ BF16_TOL = 5e-2     # bf16 storage: worst element within 5e-2 * max(|ref|, rms(r
 def parity_check(args, enc, cls, inp, out, enc_sd, cls_sd, n_clouds=4):
     """The oracle on the first clouds of the TIMED batch vs what the timed path produced for them: node ids bit-exact,
     feature / score within 1e-5 * max(|ref|, rms(ref)) -- so the number on the line belongs to results that were checked."""
+    _assert_untimed('parity_check')
     import numpy as np
     from oracle import cpu_oracle as O
     P = min(n_clouds, args.batch)
@@ -174,6 +175,7 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
 
 def cpu_baseline(args, enc_sd, cls_sd):
     """Oracle forward on the host cores, bounded sample (about 10-30 s)."""
+    _assert_untimed('cpu_baseline')
     from oracle import cpu_oracle as O
     from sonet_hip import synth
     ncpu = os.cpu_count() or 1
@@ -260,6 +262,7 @@ def _kernel_top(rec, steps, B, N, n=5):
 
 def _encoder_parity(enc, inp, P=2, tol=1e-5, **kw):
     """The encoder stage of a timed batch against the oracle on its first P clouds (node ids bit-exact, feature within tol)."""
+    _assert_untimed('_encoder_parity')
     import numpy as np
     from oracle import cpu_oracle as O
     sd = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
@@ -284,6 +287,42 @@ def make_adam(module):
     return FusedAdam(module.parameters(), lr=1e-3, betas=(0.9, 0.999))
 
 
+_TIMED = [0]          # > 0 while a timed window is open on this rank: the CPU oracle (32 threads on rank 0) must never run then
+
+
+class _timed_region:
+    def __enter__(self):
+        _TIMED[0] += 1
+
+    def __exit__(self, *exc):
+        _TIMED[0] -= 1
+        return False
+
+
+def _assert_untimed(what):
+    if _TIMED[0]:
+        raise SystemExit("bench.py: %s (CPU oracle) called inside a timed window" % what)
+
+
+def pin_host_threads(world, local_rank):
+    """A job of several ranks shares one host: give every rank its own contiguous block of the cores this process may use (contiguous =
+    NUMA-local on the two-socket boxes) and size torch's intra-op pool to it, so that one rank's host work -- rank 0's oracle legs
+    between the timed windows, the Python enqueue loop of the training step -- cannot land on another rank's launch thread."""
+    if world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // world
+    if per < 1:
+        return None
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(32, per)))
+    return {"cpus_per_rank": per, "first": mine[0], "last": mine[-1], "torch_threads": torch.get_num_threads()}
+
+
 def _windows(fn, steps, n=3, dev=None, collective=False):
     """n timed windows of `steps` calls.  collective (a job of several ranks): a barrier on both sides of every window and the MAX over
     ranks, as for the headline; returns (seconds per step of the job, seconds per step of this rank)."""
@@ -294,9 +333,10 @@ def _windows(fn, steps, n=3, dev=None, collective=False):
             dp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
+        with _timed_region():
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
         me = (time.perf_counter() - t0) / steps
         if collective:
             dp.barrier()
@@ -422,14 +462,19 @@ def other_configs(args, dev, world=1, rank=0):
                     enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
                 ref32 = _encoder_parity(enc, inp, 2, tol=1e-5)
                 ratio = (after["feature_err_over_bound"] * tol) / max(ref32["feature_err_over_bound"] * 1e-5, 1e-12)
+                # REPORTED, NOT GATED: the figure is the bf16 feature error on weights ~100 Adam steps on random labels left behind -- a
+                # worse-conditioned network (the first layer's folded BatchNorm scale 2 -> 5.7, running variances 0.5 -> 0.06:
+                # tools/bf16_drift.py), on which the f32-class arithmetic is further from the oracle too.  A ratio to that error is an
+                # explanation, not a bound (a 14 % feature error would pass a 2^14 ratio), so no pass/fail is derived from it: the gate
+                # of this entry is the node ids (bit-exact) plus the `before` check above on the fixtures' weights at the stated tolerance.
                 gate.update(f32_class_same_weights_err_over_1e5_bound=ref32["feature_err_over_bound"], bf16_over_f32_class_error=round(ratio, 1),
-                            ok=bool(after["min_idx_bit_exact"] and ratio <= 16384.0))
+                            gated=False, ok=bool(after["min_idx_bit_exact"]))
             else:
-                gate.update(ok=bool(after["min_idx_bit_exact"] and after["feature_err_over_bound"] <= 4.0))
+                gate.update(gated=True, ok=bool(after["min_idx_bit_exact"] and after["feature_err_over_bound"] <= 4.0))
             gate["what"] = ("the same check with the weights and BatchNorm running statistics the timed Adam steps left behind (random labels, %d steps: "
-                            "a worse-conditioned network, see tools/bf16_drift.py).  Gate: node ids bit-exact and -- bf16 -- an error within 2^14 x the "
-                            "f32-class arithmetic's on the same weights (unit roundoffs 2^-9 vs 2^-22); f32-class: within 4 x the fixtures' bound"
-                            % (5 + 3 * K + 3))
+                            "a worse-conditioned network, see tools/bf16_drift.py).  f32-class: gated at node ids bit-exact and features within 4 x the "
+                            "fixtures' bound.  bf16: node ids bit-exact is the gate; the feature error is REPORTED UNGATED (with the f32-class error on the "
+                            "same weights beside it) -- no bound on it is claimed" % (5 + 3 * K + 3))
             par["after_the_timed_steps"] = gate
             par["ok"] = bool(par["ok"] and gate["ok"])
             med = sorted(ts)[len(ts) // 2]
@@ -572,10 +617,11 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, nbytes = step()
-    dp.barrier()
-    torch.cuda.synchronize()
+    with _timed_region():
+        for _ in range(args.steps):
+            loss, nbytes = step()
+        dp.barrier()
+        torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t0
     elapsed = dp.all_reduce_max(my_elapsed, dev)
     assert torch.isfinite(loss)
@@ -590,8 +636,10 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "value": round(world * B * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("bf16 (bf16 storage of activations and gradients, one bf16 MFMA per product, f32 accumulate, f32 master weights; "
-                                       "wgrad: hipBLASLt bf16 -> f32)" if ops.POINTMLP_PRECISION == "bf16"
-                                       else "f32 (%s forward, x3 dgrad; wgrad GEMMs on hipBLASLt f32)" % ops.POINTMLP_PRECISION), "data": "synthetic",
+                                       "weight gradients: sonet_wgrad_bf16, bf16 operands -> f32, fixed-order reduction; the two KNN-level ones and 64 x 6 on hipBLASLt)"
+                                       if ops.POINTMLP_PRECISION == "bf16"
+                                       else "f32 (%s forward, x3 dgrad; weight gradients: sonet_wgrad_x3, 3 x bf16 split of both operands, fixed-order "
+                                            "reduction; narrow ones on hipBLASLt f32)" % ops.POINTMLP_PRECISION), "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
                                   % (world, nbytes, max(1, len(reducer.buckets)))},
@@ -619,6 +667,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    host_pin = pin_host_threads(world, local_rank)
 
     B, N = args.batch, args.points
     opt = make_opt(dev, B, N)
@@ -675,9 +724,10 @@ def main():
         dp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = run_many(args.steps)
-        dp.barrier()
-        torch.cuda.synchronize()
+        with _timed_region():
+            out = run_many(args.steps)
+            dp.barrier()
+            torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert torch.isfinite(out).all()
         # further windows of the same K steps (`value` is the FIRST window, as the contract says; the spread is on the line)
@@ -686,9 +736,10 @@ def main():
             dp.barrier()
             torch.cuda.synchronize()
             tw = time.perf_counter()
-            run_many(args.steps)
-            dp.barrier()
-            torch.cuda.synchronize()
+            with _timed_region():
+                run_many(args.steps)
+                dp.barrier()
+                torch.cuda.synchronize()
             window_s.append(time.perf_counter() - tw)
         single = None
         overlap_ok = None
@@ -854,6 +905,9 @@ def main():
         "metric": "point-clouds/sec forward, ModelNet40 5k-pt 8x8 SOM",
         "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # (`value` is the FIRST timed window, as the contract says; the windows of one process spread by several per cent -- clocks --, so
+        #  the median of all of them is printed next to it)
+        "value_median": round(world * B * args.steps / sorted(window_s)[len(window_s) // 2], 2),
         "dtype": dtype, "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier forward (level-2 Encoder + Classifier head, eval), %d pts, 8x8 SOM, "
                                "k=3, som_k=9, surface normals" % N,
@@ -870,6 +924,7 @@ def main():
                             "leave it (tools/first_process.py, profiles/r04y_first_process.log); --spin-up 0 = none.  Before every timed region "
                             "sonet_hip.host.freeze_gc() (gc.collect + gc.freeze: no 70 ms generation-2 pause of the Python collector inside a window)"},
         "ranks": ranks,
+        "host_threads": host_pin if host_pin is not None else {"pinned": False, "what": "one rank: the process keeps the host's cores (the CPU oracle legs run outside every timed window: asserted)"},
         "in_flight": P, "single_stream": single, "replay_among_others_equals_replay_alone": overlap_ok,
         "arithmetic": ops.POINTMLP_PRECISION, "other_arithmetics": other,
         "range_guard": {"enabled": bool(ops.RANGE_GUARD), "violations": len(range_bad)},

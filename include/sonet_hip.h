@@ -455,7 +455,6 @@ int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int 
  * LDS-DMA ring, one workgroup per CU, (128 or 256) x 128 blocks of dw, partial blocks per column slice summed in a fixed order. */
 size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
-
 /* out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_{i<NL} wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]);  z [B][C][M] = the
  * layer applied to the M node features once (sonet_pointmlp_h3_f32 with unit scale), gidx [B][L] i32 (out of range: 0),
  * lead [B][NL][L] the per-column channels (NL <= 4: the 3 de-centred coordinates), wl [C][NL] their weight columns, exact f32
@@ -512,6 +511,13 @@ int sonet_bn_fwd_coeffs_f32(const float *mean, const float *var, const float *ga
  * running = running*(1 - momentum) + momentum*stat, the variance entering as var*unbias (unbias = n/(n-1)); in place, [C]. */
 int sonet_bn_running_update_f32(float *running_mean, float *running_var, const float *mean, const float *var,
                                 float momentum, float unbias, int C, sonet_stream_t stream);
+/* "BatchNorm rider" of the training forward: registers, for the calling thread, what the NEXT statistics finalize -- the one inside
+ * sonet_pointmlp_*_stats_*, sonet_pointmlp_h3p (statistics epilogue) or sonet_channel_stats_* -- also computes per channel from the batch
+ * statistics it produces: (invstd, scale, shift) as sonet_bn_fwd_coeffs_f32 and, when running_mean / running_var are given, their update
+ * as sonet_bn_running_update_f32 -- the same arithmetic in the same order, one launch instead of three per BatchNorm layer and step
+ * (models/layers.py:60-70).  Consumed (and cleared) by that launch; gamma == NULL clears it. */
+int sonet_bn_rider_set(const float *gamma, const float *beta, float eps, float momentum, float unbias,
+                       float *running_mean, float *running_var, float *invstd, float *scale, float *shift);
 int sonet_bn_bwd_coeffs_f32(const double *sums, const float *mean, const float *invstd, const float *gamma, double n, int C,
                             float *a, float *b, float *c0, float *g_gamma, float *g_beta, sonet_stream_t stream);
 /* y = act(x*scale[c] + shift[c]) out of place (training forward: raw stays for the backward). */
@@ -567,6 +573,16 @@ int sonet_pointmlp_x3_pack_strided(const float *W, long long row_stride, long lo
                                    sonet_stream_t stream);
 int sonet_pointmlp_h3_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp3, int Cin, int Cout, int rows,
                                    sonet_stream_t stream);
+/* Refresh many weight packs in one launch (+ one that clears the max-|w| trailers): the optimizer changes every weight once per training step
+ * (models/classifier.py:93-99), and a launch per layer and pack flavour was fifteen launches and fifteen 64-byte memsets per step.
+ * table: n_entries records of 72 bytes on the device,
+ *   { const float *W; void *Wp; int64 rs, cs, total; int32 Cin, rows, KC, flavour, blk0, nblk; int64 pad }
+ * -- entry i packs the matrix with element (o, c) = W[o rs + c cs], o < rows, c < Cin, into Wp exactly as sonet_pointmlp_bf16_pack_strided
+ * (flavour 0), sonet_pointmlp_x3_pack_strided (1) or sonet_pointmlp_h3_pack_strided (2) would; KC = sonet_pack_multi_kc(flavour, Cin),
+ * total = 64 x ceil(Cout_pack / 32) x KC, the entry owns workgroups blk0 .. blk0 + nblk - 1, nblk = ceil(total / 256), blk0 ascending;
+ * total_blocks = their sum. */
+int sonet_pack_multi(const void *table, int n_entries, int total_blocks, sonet_stream_t stream);
+int sonet_pack_multi_kc(int flavour, int Cin);
 int sonet_pointmlp_bf16_pack_strided(const float *W, long long row_stride, long long col_stride, void *Wp, int Cin, int Cout, int rows,
                                      sonet_stream_t stream);
 

@@ -39,6 +39,25 @@ uint32_t *range_log() { return g_range_log; }
 
 extern "C" int sonet_range_log_set(uint32_t *slot) { sonet::g_range_log = slot; return SONET_OK; }
 
+namespace sonet {
+static thread_local BnRider g_bn_rider = {nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr};
+BnRider take_bn_rider() {
+    const BnRider r = g_bn_rider;
+    g_bn_rider.gamma = nullptr;
+    return r;
+}
+}  // namespace sonet
+
+extern "C" int sonet_bn_rider_set(const float *gamma, const float *beta, float eps, float momentum, float unbias,
+                                  float *running_mean, float *running_var, float *invstd, float *scale, float *shift)
+{
+    if (gamma == nullptr) { sonet::g_bn_rider.gamma = nullptr; return SONET_OK; }
+    SONET_REQUIRE(beta && invstd && scale && shift, "sonet_bn_rider_set: NULL pointer");
+    SONET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sonet_bn_rider_set: running_mean and running_var come together");
+    sonet::g_bn_rider = sonet::BnRider{gamma, beta, eps, momentum, unbias, running_mean, running_var, invstd, scale, shift};
+    return SONET_OK;
+}
+
 extern "C" int sonet_abi_version(void) { return 1; }
 extern "C" const char *sonet_build_arch(void) { return "gfx950"; }
 extern "C" const char *sonet_last_error(void) { return sonet::err_buf(); }

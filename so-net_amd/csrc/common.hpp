@@ -57,6 +57,18 @@ int zero_words(void *p, size_t bytes, hipStream_t st);
 // [nwg][C][2] (f64), fixed order.  Defined in pointmlp_x3.hip.
 int launch_stats_finalize(const double *partial, int nwg, int C, double inv_n, float *mean, float *var, hipStream_t st);
 
+// "BatchNorm rider" of the training forward (sonet_bn_rider_set, include/sonet_hip.h): what the NEXT statistics finalize of this thread
+// also computes per channel -- the normalisation coefficients (sonet_bn_fwd_coeffs_f32) and F.batch_norm's running-statistics update
+// (sonet_bn_running_update_f32), same arithmetic in the same order -- instead of two more C-element launches per BatchNorm layer and step.
+// take_bn_rider() hands it out once and clears it.  Defined in api.hip.
+struct BnRider {
+    const float *gamma, *beta;            // NULL gamma: no rider
+    float eps, momentum, unbias;
+    float *rmean, *rvar;                  // running statistics, updated in place (may be NULL)
+    float *invstd, *sc, *sh;              // outputs [C]
+};
+BnRider take_bn_rider();
+
 }  // namespace sonet
 
 // sum over the 32 lanes of a half wave, result in every lane (all lanes must be active): xor-1, xor-2 inside a quad, mirror inside

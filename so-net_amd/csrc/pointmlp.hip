@@ -549,7 +549,7 @@ __global__ __launch_bounds__(ST_THREADS) void channel_stats_kernel(const float *
 }
 
 __global__ __launch_bounds__(256) void channel_stats_finalize_kernel(const double *__restrict__ stat_ws, int C, double inv_n,
-                                                                      float *__restrict__ mean, float *__restrict__ var)
+                                                                      float *__restrict__ mean, float *__restrict__ var, const sonet::BnRider rd)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -558,6 +558,19 @@ __global__ __launch_bounds__(256) void channel_stats_finalize_kernel(const doubl
     if (v < 0.0) v = 0.0;
     mean[c] = (float)m;
     var[c] = (float)v;
+    if (rd.gamma != nullptr) {                                  // (BatchNorm rider, common.hpp: coefficients + running update, operation for operation)
+        const float mf = (float)m, vf = (float)v;
+        const float is = 1.0f / __fsqrt_rn(vf + rd.eps);
+        const float s_ = rd.gamma[c] * is;
+        rd.invstd[c] = is;
+        rd.sc[c] = s_;
+        rd.sh[c] = rd.beta[c] - mf * s_;
+        if (rd.rmean != nullptr) {
+            const float mo = rd.momentum;
+            rd.rmean[c] = __fmaf_rn(mf, mo, __fmul_rn(rd.rmean[c], 1.0f - mo));
+            rd.rvar[c] = __fmaf_rn(__fmul_rn(vf, rd.unbias), mo, __fmul_rn(rd.rvar[c], 1.0f - mo));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void channel_affine_act_kernel(float *__restrict__ y, const float *__restrict__ scale,
@@ -701,7 +714,7 @@ extern "C" int sonet_channel_stats_f32(const float *y, int B, int C, int L, doub
     if (chunks > 64) chunks = 64;
     hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks, C), dim3(ST_THREADS), 0, st, y, B, C, L, stat_ws);
     hipLaunchKernelGGL(channel_stats_finalize_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, st,
-                       stat_ws, C, 1.0 / (double)per_c, mean, var_biased);
+                       stat_ws, C, 1.0 / (double)per_c, mean, var_biased, sonet::take_bn_rider());
     return sonet::launched(what);
 }
 

@@ -95,12 +95,9 @@ __device__ __forceinline__ void split16_w(float w0, float w1, unsigned &h, unsig
 // consecutive bytes -- one LDS-DMA base with four instruction offsets -- and a K tail needs no special case.
 constexpr int H3_KPAD = 8;
 template <bool F16>
-__global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
-                                                       int Cin, int Cout, int KC /*fp16: KCP*/, long long total, unsigned *__restrict__ trailer,
-                                                       long long rs /*element (o, c) = W[o * rs + c * cs]*/, long long cs)
+__device__ __forceinline__ void x3_pack_body(const float *__restrict__ W, uint4 *__restrict__ Wp3, int Cin, int Cout, int KC, long long t,
+                                             unsigned *__restrict__ trailer, long long rs, long long cs)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
-    if (t >= total) return;                                              // (total is a multiple of 64: whole waves leave)
     RangeAcc wr = {0, 0u};
     const int lane = (int)(t & 63);
     const long long r = t >> 6;
@@ -135,30 +132,117 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ 
     range_publish(trailer, wave_umax(range_amax_bits(wr)), lane);         // max |w| of the layer (range log, word 1 of a launch)
 }
 
-// mean / biased variance from the per-workgroup partial sums of the statistics epilogue: 4 channels x 64 slices per workgroup, fixed
-// order (deterministic)
-__global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const double *__restrict__ partial, int nwg, int C, double inv_n,
-                                                                     float *__restrict__ mean, float *__restrict__ var)
+template <bool F16>
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp3,
+                                                       int Cin, int Cout, int KC /*fp16: KCP*/, long long total, unsigned *__restrict__ trailer,
+                                                       long long rs /*element (o, c) = W[o * rs + c * cs]*/, long long cs)
 {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int k = ln; k < nwg; k += 64) {
-            const double *p = partial + ((size_t)k * C + c) * 2;
-            s1 += p[0];
-            s2 += p[1];
-        }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s1 += __shfl_down(s1, off, 64);
-        s2 += __shfl_down(s2, off, 64);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (ct*KC + kc)*64 + lane
+    if (t >= total) return;                                              // (total is a multiple of 64: whole waves leave)
+    x3_pack_body<F16>(W, Wp3, Cin, Cout, KC, t, trailer, rs, cs);
+}
+
+// ---- every weight pack of a training step in ONE launch (sonet_pack_multi): a device table of the packs to refresh -- the layers' forward
+// packs and the transposed packs of their dgrads, any flavour -- and one workgroup range per entry.  The optimizer changes every weight
+// once per step; fifteen pack launches (+ fifteen 64-byte trailer memsets) per step were 0.1 ms of device time and as many host calls.
+struct PackEntry {
+    const float *W;                       // source: element (o, c) = W[o * rs + c * cs]
+    void *Wp;                             // destination pack
+    long long rs, cs, total;              // total = 64 x (32-row tiles) x (K chunks) work items
+    int Cin, rows, KC, flavour;           // flavour 0 = bf16, 1 = x3 (three bf16 pieces), 2 = h3 (fp16 + residual)
+    int blk0, nblk;                       // this entry's workgroups: blk0 .. blk0 + nblk - 1
+    long long pad_;
+};
+static_assert(sizeof(PackEntry) == 72, "PackEntry layout is part of the C ABI (sonet_pack_multi)");
+
+__device__ __forceinline__ unsigned *pack_trailer(const PackEntry &e) {
+    return reinterpret_cast<unsigned *>(reinterpret_cast<uint4 *>(e.Wp) + e.total * (e.flavour == 2 ? 2 : 3));
+}
+
+__global__ __launch_bounds__(64) void pack_multi_zero_kernel(const PackEntry *__restrict__ tab, int n)
+{
+    const int e = blockIdx.x, w = threadIdx.x;
+    if (e < n && tab[e].flavour != 0 && w < 16) pack_trailer(tab[e])[w] = 0u;
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackEntry *__restrict__ tab, int n)
+{
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int e = 0;
+        while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].blk0) ++e;
+        which = e;
     }
-    if (ln == 0 && c < C) {
-        const double m = s1 * inv_n;
-        double v = s2 * inv_n - m * m;
+    __syncthreads();
+    const PackEntry e = tab[which];
+    const long long t = (long long)((int)blockIdx.x - e.blk0) * 256 + threadIdx.x;
+    if (t >= e.total) return;
+    if (e.flavour == 1) x3_pack_body<false>(e.W, reinterpret_cast<uint4 *>(e.Wp), e.Cin, e.rows, e.KC, t, pack_trailer(e), e.rs, e.cs);
+    else if (e.flavour == 2) x3_pack_body<true>(e.W, reinterpret_cast<uint4 *>(e.Wp), e.Cin, e.rows, e.KC, t, pack_trailer(e), e.rs, e.cs);
+    else {
+        // (the body of bf16_pack_kernel, pointmlp_bf16.hip)
+        const int lane = (int)(t & 63);
+        const long long r = t >> 6;
+        const int kc = (int)(r % e.KC), ct = (int)(r / e.KC);
+        const int o = ct * 32 + (lane & 31);
+        const int c0 = kc * 16 + 8 * (lane >> 5);
+        unsigned w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = c0 + 2 * p;
+            const float w0 = (o < e.rows && c < e.Cin) ? e.W[(long long)o * e.rs + (long long)c * e.cs] : 0.f;
+            const float w1 = (o < e.rows && c + 1 < e.Cin) ? e.W[(long long)o * e.rs + (long long)(c + 1) * e.cs] : 0.f;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[p]) : "v"(w0), "v"(w1));
+        }
+        reinterpret_cast<uint4 *>(e.Wp)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// mean / biased variance from the per-workgroup partial sums of the statistics epilogue: one workgroup per channel, thread i adds the
+// partials i, i + 256, ... in order, the 256 sums meet in a fixed tree (deterministic).  (Four channels per workgroup and 64 lanes per
+// channel took 40 us on the 7,500 partials of a point-level f32 layer.)  With a rider (common.hpp) the same thread goes on to the
+// normalisation coefficients and the running-statistics update -- the arithmetic of bn_fwd_coeffs_kernel / bn_running_update_kernel
+// (pointwise_bwd.hip), operation for operation.
+__device__ __forceinline__ void bn_rider_apply(const sonet::BnRider &rd, int c, float mean, float var) {
+    if (rd.gamma == nullptr) return;
+    const float is = 1.0f / __fsqrt_rn(var + rd.eps);
+    const float s_ = rd.gamma[c] * is;
+    rd.invstd[c] = is;
+    rd.sc[c] = s_;
+    rd.sh[c] = rd.beta[c] - mean * s_;
+    if (rd.rmean != nullptr) {
+        const float m = rd.momentum;
+        rd.rmean[c] = __fmaf_rn(mean, m, __fmul_rn(rd.rmean[c], 1.0f - m));
+        rd.rvar[c] = __fmaf_rn(__fmul_rn(var, rd.unbias), m, __fmul_rn(rd.rvar[c], 1.0f - m));
+    }
+}
+
+__global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const double *__restrict__ partial, int nwg, int C, double inv_n,
+                                                                     float *__restrict__ mean, float *__restrict__ var, const sonet::BnRider rd)
+{
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = t; k < nwg; k += 256) {
+        const double *p = partial + ((size_t)k * C + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+    r1[t] = s1;
+    r2[t] = s2;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { r1[t] += r1[t + off]; r2[t] += r2[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double m = r1[0] * inv_n;
+        double v = r2[0] * inv_n - m * m;
         if (v < 0.0) v = 0.0;
         mean[c] = (float)m;
         var[c] = (float)v;
+        bn_rider_apply(rd, c, (float)m, (float)v);
     }
 }
 
@@ -773,7 +857,7 @@ __global__ __launch_bounds__(X3_THREADS, NC == 1 ? 2 : 1) void pointmlp_h3r_kern
 // (shared with pointmlp_bf16.hip)
 int sonet::launch_stats_finalize(const double *partial, int nwg, int C, double inv_n, float *mean, float *var, hipStream_t st)
 {
-    hipLaunchKernelGGL(stats_partial_finalize_kernel, dim3((unsigned)sonet::ceil_div(C, 4)), dim3(256), 0, st, partial, nwg, C, inv_n, mean, var);
+    hipLaunchKernelGGL(stats_partial_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, nwg, C, inv_n, mean, var, sonet::take_bn_rider());
     return 0;
 }
 
@@ -833,6 +917,29 @@ extern "C" int sonet_pointmlp_x3_pack(const float *W, void *Wp3, int Cin, int Co
 extern "C" int sonet_pointmlp_h3_pack(const float *W, void *Wp3, int Cin, int Cout, sonet_stream_t stream)
 {
     return x3_pack_impl("sonet_pointmlp_h3_pack", true, W, Wp3, Cin, Cout, stream);
+}
+
+/* Refresh many weight packs in one launch (+ one that clears the max-|w| trailers).  table: n_entries records of 72 bytes on the device,
+ *   { const float *W; void *Wp; int64 rs, cs, total; int32 Cin, rows, KC, flavour, blk0, nblk; int64 pad }
+ * -- entry i packs the matrix with element (o, c) = W[o rs + c cs], o < rows, c < Cin (rows beyond `rows` up to the pack's tile count as zeros)
+ * into Wp exactly as sonet_pointmlp_bf16_pack_strided (flavour 0), sonet_pointmlp_x3_pack_strided (1) or sonet_pointmlp_h3_pack_strided (2)
+ * would; KC = the flavour's chunk count of Cin, total = 64 x tiles x KC, and the entry owns workgroups blk0 .. blk0 + nblk - 1 with
+ * nblk = ceil(total / 256), blk0 ascending; total_blocks = their sum. */
+extern "C" int sonet_pack_multi(const void *table, int n_entries, int total_blocks, sonet_stream_t stream)
+{
+    const char *what = "sonet_pack_multi";
+    SONET_REQUIRE(table, "%s: NULL pointer", what);
+    SONET_REQUIRE(n_entries > 0 && total_blocks > 0, "%s: empty table", what);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(pack_multi_zero_kernel, dim3((unsigned)n_entries), dim3(64), 0, st, reinterpret_cast<const PackEntry *>(table), n_entries);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, reinterpret_cast<const PackEntry *>(table), n_entries);
+    return sonet::launched(what);
+}
+
+/* chunk count (KC) a flavour's pack uses for Cin input channels: what the table's KC field must hold */
+extern "C" int sonet_pack_multi_kc(int flavour, int Cin)
+{
+    return flavour == 2 ? sonet::ceil_div(Cin, 16 * H3_KPAD) * H3_KPAD : sonet::ceil_div(Cin, 16);
 }
 
 static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, const float *x2, int C2, const void *Wp3,

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void rowwise_bf16_kernel(const uint16_t *__res
 }
 
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const double *__restrict__ ws, int C, double inv_n,
-                                                             float *__restrict__ mean, float *__restrict__ var)
+                                                             float *__restrict__ mean, float *__restrict__ var, const sonet::BnRider rd)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -366,6 +366,19 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const double *__res
     if (v < 0.0) v = 0.0;
     mean[c] = (float)m;
     var[c] = (float)v;
+    if (rd.gamma != nullptr) {                                  // (BatchNorm rider: bn_fwd_coeffs_kernel + bn_running_update_kernel below, operation for operation)
+        const float mf = (float)m, vf = (float)v;
+        const float is = 1.0f / __fsqrt_rn(vf + rd.eps);
+        const float s_ = rd.gamma[c] * is;
+        rd.invstd[c] = is;
+        rd.sc[c] = s_;
+        rd.sh[c] = rd.beta[c] - mf * s_;
+        if (rd.rmean != nullptr) {
+            const float mo = rd.momentum;
+            rd.rmean[c] = __fmaf_rn(mf, mo, __fmul_rn(rd.rmean[c], 1.0f - mo));
+            rd.rvar[c] = __fmaf_rn(__fmul_rn(vf, rd.unbias), mo, __fmul_rn(rd.rvar[c], 1.0f - mo));
+        }
+    }
 }
 
 }  // namespace
@@ -560,7 +573,7 @@ extern "C" int sonet_channel_stats_bf16(const uint16_t *y, int B, int C, int L, 
     if (vec_ok(L, 2, y, nullptr, nullptr) && B <= 65535) launch_stats_vec<true>(y, nullptr, nullptr, nullptr, 0, B, C, L, sums, st);
     else if (bf_pair_ok(L, y, nullptr, nullptr)) hipLaunchKernelGGL(bwd_stats_bf16_kernel<true>, dim3(chunks, C), dim3(BW_THREADS), 0, st, y, (const uint16_t *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, B, C, L, sums);
     else hipLaunchKernelGGL(bwd_stats_bf16_kernel<false>, dim3(chunks, C), dim3(BW_THREADS), 0, st, y, (const uint16_t *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, B, C, L, sums);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, st, sums, C, 1.0 / ((double)B * L), mean, var);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(sonet::ceil_div(C, 256)), dim3(256), 0, st, sums, C, 1.0 / ((double)B * L), mean, var, sonet::take_bn_rider());
     return sonet::launched(what);
 }
 

@@ -125,7 +125,10 @@ def _pack_transposed(weight2d, C1, C2):
                 and (m == "bf16" or Cp % 32 == 0)):
             # packed straight from W (lanes along W's rows, rows Ci .. Cp as zeros): no transposed copy, no padding cat -- the
             # transposed copy + the pack's 32-byte row reads were 0.3 ms of the f32-class training step (six packs per step)
-            out.append((_ops.pointmlp_pack_transposed(weight2d.detach(), lo, Ci, Cp, m), Ci, Cp))
+            if _ops.PACK_REGISTRY:
+                out.append((_ops.packs.get(weight2d, ("t", m, lo, Ci, Cp)), Ci, Cp))     # (refreshed with every other stale pack in one launch)
+            else:
+                out.append((_ops.pointmlp_pack_transposed(weight2d.detach(), lo, Ci, Cp, m), Ci, Cp))
         else:
             wt = weight2d[:, lo:lo + Ci].t().contiguous().float()              # Ci x Cout
             if Cp != Ci:
@@ -187,7 +190,7 @@ class _PointwiseFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps):
+    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps, bn_run=None):
         Cout = weight2d.shape[0]
         dev = x1.device
         ones, zeros = _ops.const_vec(Cout, 1.0, dev), _ops.const_vec(Cout, 0.0, dev)
@@ -197,16 +200,21 @@ class _PointwiseFn(torch.autograd.Function):
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, scale, y if relu else x1.new_empty(0),
                                   ones, zeros)
         else:
-            if (_ops.STATS_EPILOGUE and Cout % 32 == 0 and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)
-                    and ((wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32)
-                         or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16))):
+            # bn_run = (running_mean, running_var, momentum, unbias) or None: the statistics launch below also writes the normalisation
+            # coefficients and updates the running statistics (``ops.bn_rider``: one launch instead of three per layer and step)
+            epi = (_ops.STATS_EPILOGUE and Cout % 32 == 0 and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)
+                   and ((wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32)
+                        or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16)))
+            if not epi:
+                raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
+            rm, rv, mom, unb = bn_run if bn_run is not None else (None, None, 0.0, 1.0)
+            invstd, sc, sh = _ops.bn_rider(gamma, beta, eps, rm, rv, mom, unb)
+            if epi:
                 # batch statistics out of the layer kernel's epilogue (one pass over raw less; big tensors: the small node-level
                 # ones keep the second-generation kernel, which has no statistics epilogue)
                 raw, mean, var = _ops.pointmlp_stats(x1, wp, ones, bias, False, Cout, x2=x2)
             else:
-                raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
                 mean, var = _ops.channel_stats(raw)
-            invstd, sc, sh = _ops.bn_fwd_coeffs(mean, var, gamma, beta, eps)
             y = _ops.channel_affine_act(raw, sc, sh, relu)
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, sh, raw, mean, invstd, gamma,
                                   zeros)
@@ -221,7 +229,7 @@ class _PointwiseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *unused):
         if gy is None:                                                    # (the output was not used)
-            return (None,) * 12
+            return (None,) * 13
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
         gy = gy.contiguous()
@@ -262,7 +270,7 @@ class _PointwiseFn(torch.autograd.Function):
         if need1 or need2:
             Cout = weight2d.shape[0]
             ones_i = None
-            packs = _pack_transposed(weight2d.detach(), x1.shape[1], x2.shape[1] if ctx.has_x2 else 0)
+            packs = _pack_transposed(weight2d, x1.shape[1], x2.shape[1] if ctx.has_x2 else 0)
             outs = []
             for need, pk in ((need1, packs[0]), (need2, packs[1])):
                 if not need or pk is None:
@@ -272,7 +280,7 @@ class _PointwiseFn(torch.autograd.Function):
             g_x1, g_x2 = outs
         if ss is not None:
             ss.join()
-        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None
+        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None
 
 
 class _PooledLastLayerFn(torch.autograd.Function):
@@ -344,17 +352,21 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 occ = row_max.unsqueeze(1) > 0
                 wt_pack = None
                 if x1.dtype == torch.bfloat16 and _ops.pooled_dgrad_mfma_ok(w.shape[0], C1, C2, L):
-                    wt = w.t().contiguous()                                        # (C1 + C2) x C, rows padded to 32-row tiles
-                    if wt.shape[0] % 32:
-                        wt = torch.cat((wt, wt.new_zeros(32 - wt.shape[0] % 32, wt.shape[1])), dim=0)
-                    wt_pack = _ops.pointmlp_pack(wt, "bf16")
+                    Cp = (C1 + C2 + 31) // 32 * 32                                 # (C1 + C2) x C, rows padded to 32-row tiles
+                    if _ops.PACK_REGISTRY and weight2d.is_contiguous() and weight2d.dtype == torch.float32:
+                        wt_pack = _ops.packs.get(weight2d, ("t", "bf16", 0, C1 + C2, Cp))
+                    else:
+                        wt = w.t().contiguous()
+                        if wt.shape[0] % 32:
+                            wt = torch.cat((wt, wt.new_zeros(32 - wt.shape[0] % 32, wt.shape[1])), dim=0)
+                        wt_pack = _ops.pointmlp_pack(wt, "bf16")
                 g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype,
                                                wt_pack=wt_pack)
                 col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
                 g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
                 g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)
             else:
-                packs = _pack_transposed(weight2d.detach(), C1, C2)
+                packs = _pack_transposed(weight2d, C1, C2)
                 outs = []
                 for pk in packs:
                     outs.append(_dgrad(G, pk))
@@ -422,6 +434,9 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             mode = "x3"
         if mode in ("x3", "h3", "bf16") and not _ops.x3_supported(w.shape[1] if C1 is None else C1, C2, w.shape[0]):
             mode = "f32"
+        if _ops.PACK_REGISTRY and mode != "f32" and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous():
+            # one launch refreshes every stale pack of the step (forward and transposed, all layers): sonet_hip.ops.packs
+            return _ops.packs.get(self._weight2d(), ("fwd", mode))
         key = (w._version, w.data_ptr(), w.device, mode)
         if getattr(self, '_wp_key', None) != key:
             with torch.no_grad():
@@ -543,14 +558,17 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
         if x2 is not None and x2.dtype != want:
             x2 = x2.to(want)
         if train_bn:
+            n = x1.shape[0] * x1.shape[2]
+            m = bn.momentum
+            # F.batch_norm's running-statistics update rides on the statistics launch of the forward (``ops.bn_rider``) when the buffers allow
+            ride = (bn.track_running_stats and m is not None and bn.running_mean is not None and bn.running_mean.is_contiguous()
+                    and bn.running_var.is_contiguous() and bn.running_mean.dtype == torch.float32 and bn.running_mean.device == x1.device)
             y, mean, var = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
-                                              fuse_act, 'batch', bn.eps)
+                                              fuse_act, 'batch', bn.eps, (bn.running_mean, bn.running_var, m, n / max(n - 1, 1)) if ride else None)
             with torch.no_grad():                                       # F.batch_norm running-stat update
-                n = y.shape[0] * y.shape[2]
-                m = bn.momentum
-                if bn.running_mean.is_contiguous() and bn.running_var.is_contiguous() and bn.running_mean.dtype == torch.float32:
-                    _ops.bn_running_update_(bn.running_mean, bn.running_var, mean.contiguous(), var.contiguous(), m, n / max(n - 1, 1))
-                else:
+                if ride:
+                    pass
+                elif bn.running_mean is not None and m is not None:
                     bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
                     bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
                 # the kernel writes the buffers through raw pointers: their _version does not move, so the folded eval

@@ -828,6 +828,113 @@ def pointmlp_pack_transposed(weight2d, lo, Ci, Cp, mode):
     return wp
 
 
+# ---- every stale weight pack of a step in one launch -------------------------------------------------------------------------------
+PACK_REGISTRY = _os.environ.get("SONET_PACK_REGISTRY", "1") != "0"     # 0: a pack launch per layer and flavour (the round-4 behaviour)
+
+
+class _PackRegistry:
+    """The packed copies of the layers' weights (``pointmlp_pack`` / ``pointmlp_pack_transposed`` results), keyed on (weight storage,
+    what is packed).  ``get`` returns the current pack; when the weight has changed since it was built (``_version``: the optimizer bumps
+    it once per step) EVERY stale pack of that device is refreshed by one ``sonet_pack_multi`` launch -- the layers' forward packs and
+    the transposed packs of their dgrads alike -- into the buffers the entries already own.  Entries die with their weight tensor."""
+
+    def __init__(self):
+        self.entries = {}            # key -> dict(ref, version, buf, rec)
+        self.tables = {}             # device -> (tuple of keys, device table, total blocks)
+
+    @staticmethod
+    def _spec(w2d, what):
+        """-> (flavour, byte offset into w2d, rs, cs, Cin_pack, rows, Cout_pack) of ("fwd", mode) or ("t", mode, lo, Ci, Cp)."""
+        Cout, Cin = w2d.shape
+        fl = {"bf16": 0, "x3": 1, "h3": 2}[what[1]]
+        if what[0] == "fwd":
+            return fl, 0, Cin, 1, Cin, Cout, Cout
+        _, _, lo, Ci, Cp = what
+        if not (0 <= lo and lo + Ci <= Cin and Ci <= Cp):
+            raise SonetHipError("pack registry: bad block lo=%d Ci=%d Cp=%d of %d columns" % (lo, Ci, Cp, Cin))
+        return fl, 4 * lo, 1, Cin, Cout, Ci, Cp                       # W[:, lo:lo + Ci]^T: element (o, c) = W[c][lo + o]
+
+    def get(self, w2d, what):
+        """w2d: the layer's weight as a contiguous Cout x Cin f32 CUDA tensor (a view of the parameter: same version counter)."""
+        key = (w2d.data_ptr(), w2d.device.index, tuple(w2d.shape), what)
+        e = self.entries.get(key)
+        if e is not None and e["ref"]() is None:                       # the storage was recycled by another tensor
+            e = None
+        if e is None:
+            e = self._create(key, w2d, what)
+        elif e["version"] != w2d._version:
+            self.refresh(w2d.device)
+        return e["buf"]
+
+    def _create(self, key, w2d, what):
+        import weakref
+        _chk(w2d, "weight", torch.float32, 2)
+        lib = _lib.load()
+        fl, off, rs, cs, Cin_p, rows, Cout_p = self._spec(w2d, what)
+        dev = w2d.device
+        with _lib.on_device(dev):
+            if fl == 0:
+                buf = torch.empty((lib.sonet_pointmlp_bf16_pack_size(Cin_p, Cout_p) // 2,), dtype=torch.int16, device=dev)
+                check(lib.sonet_pointmlp_bf16_pack_strided(w2d.data_ptr() + off, rs, cs, ptr(buf), Cin_p, Cout_p, rows, stream_ptr()), "sonet_pointmlp_bf16_pack_strided")
+            else:
+                buf = torch.empty((lib.sonet_pointmlp_x3_pack_size(Cin_p, Cout_p),), dtype=torch.uint8 if fl == 1 else torch.int8, device=dev)
+                fn = lib.sonet_pointmlp_x3_pack_strided if fl == 1 else lib.sonet_pointmlp_h3_pack_strided
+                check(fn(w2d.data_ptr() + off, rs, cs, ptr(buf), Cin_p, Cout_p, rows, stream_ptr()), "sonet_pointmlp_x3_pack_strided")
+        KC = int(lib.sonet_pack_multi_kc(fl, Cin_p))
+        total = 64 * ((Cout_p + 31) // 32) * KC
+        # (the weakref is to the view's base when there is one: views come and go, the parameter stays)
+        base = w2d._base if w2d._base is not None else w2d
+        e = dict(ref=weakref.ref(base), src=w2d, version=w2d._version, buf=buf,
+                 rec=(w2d.data_ptr() + off, buf.data_ptr(), rs, cs, total, Cin_p, rows, KC, fl))
+        e["src"] = None                                                 # (no strong reference to the weight: only its address and its weakref)
+        self.entries[key] = e
+        self.tables.pop(dev.index, None)
+        return e
+
+    def refresh(self, device):
+        """One ``sonet_pack_multi`` launch over every stale entry of ``device``."""
+        import numpy as np
+        di = device.index
+        live, dead = [], []
+        for key, e in self.entries.items():
+            if key[1] != di:
+                continue
+            t = e["ref"]()
+            if t is None:
+                dead.append(key)
+            elif e["version"] != t._version:
+                live.append((key, e, t))
+        for key in dead:
+            del self.entries[key]
+        if dead:
+            self.tables.pop(di, None)
+        if not live:
+            return
+        keys = tuple(k for k, _, _ in live)
+        tab = self.tables.get(di)
+        if tab is None or tab[0] != keys:
+            rec = np.zeros((len(live), 9), dtype=np.int64)              # 72 bytes per entry
+            blk = 0
+            for i, (_, e, _) in enumerate(live):
+                src, dst, rs, cs, total, Cin_p, rows, KC, fl = e["rec"]
+                nblk = (total + 255) // 256
+                rec[i, 0], rec[i, 1], rec[i, 2], rec[i, 3], rec[i, 4] = src, dst, rs, cs, total
+                rec[i, 5] = (Cin_p & 0xFFFFFFFF) | (rows << 32)
+                rec[i, 6] = (KC & 0xFFFFFFFF) | (fl << 32)
+                rec[i, 7] = (blk & 0xFFFFFFFF) | (nblk << 32)
+                blk += nblk
+            with _lib.on_device(device):
+                tab = (keys, torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(device), blk)
+            self.tables[di] = tab
+        with _lib.on_device(device), _timed("pack_multi_%d" % len(live)):
+            check(_lib.load().sonet_pack_multi(ptr(tab[1]), len(live), tab[2], stream_ptr()), "sonet_pack_multi")
+        for _, e, t in live:
+            e["version"] = t._version
+
+
+packs = _PackRegistry()
+
+
 def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``.
     ``gidx`` (B x L i32, h3 packs only): column l of x1 (B x C1 x L1) is taken from x1[:, :, gidx[b, l]] -- zeros when the
@@ -986,18 +1093,24 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
     var = torch.empty((Cout,), dtype=torch.float32, device=dev)
     if bf16:
         ws = torch.empty((lib.sonet_pointmlp_bf16_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
-        with _lib.on_device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
-            check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
-                                                ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
+        try:
+            with _lib.on_device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
+                check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                    ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
+        finally:
+            _rider_done()
         return y, mean, var
     ws = torch.empty((lib.sonet_pointmlp_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
     name = "pointmlp%s_stats_%dx%d_L%d" % ("h3" if h3 else "x3", C1 + C2, Cout, L)
     if h3:
         _range_arm(name)
     fn = lib.sonet_pointmlp_h3_stats_f32 if h3 else lib.sonet_pointmlp_x3_stats_f32
-    with _lib.on_device(dev), _timed(name):
-        check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
-                 stream_ptr()), "sonet_pointmlp_stats")
+    try:
+        with _lib.on_device(dev), _timed(name):
+            check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
+                     stream_ptr()), "sonet_pointmlp_stats")
+    finally:
+        _rider_done()
     return y, mean, var
 
 
@@ -1359,8 +1472,11 @@ def channel_stats(y):
     var = torch.empty((C,), dtype=torch.float32, device=dev)
     lib = _lib.load()
     fn = lib.sonet_channel_stats_f32 if y.dtype == torch.float32 else lib.sonet_channel_stats_bf16
-    with _lib.on_device(dev), _timed("channel_stats" if y.dtype == torch.float32 else "channel_stats_bf16"):
-        check(fn(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_channel_stats")
+    try:
+        with _lib.on_device(dev), _timed("channel_stats" if y.dtype == torch.float32 else "channel_stats_bf16"):
+            check(fn(ptr(y), B, C, L, ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_channel_stats")
+    finally:
+        _rider_done()
     return mean, var
 
 
@@ -1412,6 +1528,41 @@ def const_vec(C, value, device):
         t = torch.full((int(C),), float(value), dtype=torch.float32, device=device)
         _CONST[key] = t
     return t
+
+
+_rider_armed = None
+
+
+def _rider_done():
+    """After a statistics-producing call: the rider was consumed by its finalize launch -- or, if the call failed before launching,
+    must not linger for an unrelated later launch."""
+    global _rider_armed
+    if _rider_armed is not None:
+        _lib.load().sonet_bn_rider_set(None, None, 0.0, 0.0, 0.0, None, None, None, None, None)
+        _rider_armed = None
+
+
+def bn_rider(gamma, beta, eps, running_mean=None, running_var=None, momentum=0.0, unbias=1.0):
+    """Arm the "BatchNorm rider" (``sonet_bn_rider_set``) for the NEXT statistics-producing call of this thread (``pointmlp_stats``,
+    ``pointmlp_h3p(stats=True)``, ``channel_stats``): its finalize launch also writes (invstd, scale, shift) -- ``bn_fwd_coeffs`` -- and,
+    given the running statistics, updates them in place -- ``bn_running_update_`` --, operation for operation.  -> (invstd, scale, shift)
+    tensors that call will fill."""
+    dev = _same_device(gamma, beta, running_mean, running_var)
+    C = gamma.numel()
+    out = torch.empty((3, C), dtype=torch.float32, device=dev)
+    if running_mean is not None:
+        for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
+            _chk(t, n, torch.float32, 1)
+    global _rider_armed
+    g_, b_ = gamma.detach().contiguous(), beta.detach().contiguous()
+    check(_lib.load().sonet_bn_rider_set(ptr(g_), ptr(b_), float(eps), float(momentum), float(unbias),
+                                         ptr(running_mean), ptr(running_var), ptr(out[0]), ptr(out[1]), ptr(out[2])), "sonet_bn_rider_set")
+    _rider_armed = (g_, b_, out)                      # (keeps the operands alive until the statistics call has consumed the rider)
+    if running_mean is not None:
+        # written through raw pointers by the coming launch: move the version counters as an in-place aten op would
+        torch.autograd.graph.increment_version(running_mean)
+        torch.autograd.graph.increment_version(running_var)
+    return out[0], out[1], out[2]
 
 
 def bn_fwd_coeffs(mean, var, gamma, beta, eps):
