@@ -441,6 +441,15 @@ size_t sonet_pointmlp_bf16_stats_ws_size(int B, int Cout, int L);
 int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
                               const float *scale, const float *shift, int relu, uint16_t *y,
                               int B, int Cout, int L, void *stats_ws, float *mean, float *var, sonet_stream_t stream);
+/* The bf16 layer and the per-node arg-max pool of its output in ONE launch; the output itself is never written: the last (norm-free) layer
+ * of the first PointNet in training when only the pooled map is consumed -- classifier, autoencoder -- (models/layers.py:431 +
+ * models/networks.py:180-185, models/index_max_ext/index_max_cuda.cu:10-26).  out_idx [B][Cout][M] = what sonet_index_max_bf16 reports on the
+ * tensor sonet_pointmlp_bf16 would have written (first maximum above -1000 in column order, else 0), out_val [B][Cout][M] f32 = that tensor's
+ * value at out_idx * row_max (sonet_index_max_gather_bf16): bit for bit.  ids [B][L] i32 = node of every column, row_max [B][M] i32 or NULL.
+ * Needs: even L < 65535, 4-byte aligned rows, (C1 + C2) % 64 == 0, Cout % 32 == 0, M <= 255; SONET_ERR_UNSUPPORTED otherwise. */
+int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                             const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                             int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream);
 
 /* Weight gradient of a point-wise layer: dw[o][c] = sum_b sum_l g[b][o][l] * x[b][c][l]  (g [B][Cout][L], x [B][Cin][L], dw
  * [Cout][Cin], f32) -- what autograd computes for the nn.Conv1d / nn.Conv2d(1x1) weights of models/layers.py:282-296.  Both

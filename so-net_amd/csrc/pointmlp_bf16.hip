@@ -349,7 +349,32 @@ struct BfrArgs {
     int C1, C2, Cout, L, gpc, relu, KC, KC1, tps /*cout tiles per slab*/, nslab, nstream /*column streams = workgroups per slab*/;
     int ngroups;                          // B * gpc
     int sync;                             // workgroup barriers (rows that are not cache-line aligned): 1 per column group, 2 + per four chunks
+    // (POOL) the layer's output is never stored: a workgroup = (cloud, output slab) keeps the per-node arg-max bins of its rows in LDS
+    // (models/networks.py:180-185: index_max + the masked gather), ids = node of every column [B][L] i32, M <= 256 nodes
+    const int32_t *ids, *row_max;         // row_max [B][M] (NULL: nothing masked)
+    int32_t *out_idx;                     // [B][Cout][M] winning column (0 where nothing beat -1000, as the reference)
+    float *out_val;                       // [B][Cout][M] the stored (bf16) value at out_idx * row_max
+    int M;
 };
+
+// (POOL) the order of the keys is that of index_max.hip -- bigger value wins, equal values: the smaller column wins, -0 counts as +0, a NaN never
+// wins, bins start at "value -1000 at column 0" -- so the launch reports exactly what sonet_index_max_gather_bf16 reports on the tensor the
+// storing launch would have written.  The values are bf16 and a cloud has < 65536 columns: a key is 32 bits, (orderable(bf16) << 16) |
+// (0xFFFF - column), a bin one LDS word, "this element beats the running maximum" one ds_read_b32 + one compare per value.
+constexpr unsigned BFP_INIT_KEY = (0x3B85u << 16) | 0xFFFFu;                 // ord(bf16(-1000)) = ~0xC47A, column 0
+static_assert((0xC47Au ^ 0xFFFFu) == 0x3B85u, "ord(-1000) check");
+// the two orderable 16-bit patterns of a packed bf16 pair (lo | hi << 16), in place
+__device__ __forceinline__ unsigned bfp_ord2(unsigned pk) {
+    // -0 -> +0
+    pk = (pk & 0xFFFFu) == 0x8000u ? (pk & 0xFFFF0000u) : pk;
+    pk = (pk >> 16) == 0x8000u ? (pk & 0x0000FFFFu) : pk;
+    // negative: all bits flipped; positive: the sign bit set
+    const unsigned neg = (pk >> 15) & 0x00010001u;                          // 1 per negative half
+    const unsigned o = pk ^ (neg * 0x7FFFu | 0x80008000u);
+    // NaN -> 0 (never wins)
+    const unsigned mlo = pk & 0x7FFFu, mhi = (pk >> 16) & 0x7FFFu;
+    return (mlo > 0x7F80u ? 0u : (o & 0xFFFFu)) | (mhi > 0x7F80u ? 0u : (o & 0xFFFF0000u));
+}
 
 __device__ __forceinline__ i32x4_t_ bfr_rsrc(const void *base, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(base);
@@ -376,13 +401,18 @@ __device__ __forceinline__ void bfr_wait_perm(const unsigned (&x)[8], unsigned (
                  : "memory");
 }
 
-template <int MT, bool STATS>
+template <int MT, bool STATS, bool POOL = false>
 __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
 {
+    static_assert(!(STATS && POOL), "statistics belong to BatchNorm layers, the pool to the last (norm-free) layer");
     extern __shared__ uint4 bfr_lds[];
     uint4 *wl = bfr_lds;                                                       // [tps][KC][64]
     float2 *aff = reinterpret_cast<float2 *>(wl + (size_t)a.tps * a.KC * 64);  // [tps * 32]
     float2 *stl = aff + a.tps * 32;                                            // STATS: [8 waves][tps * 32] (sum, sum of squares)
+    // POOL: bins [tps * 32][M] (one word each), the value at column 0 of every row (what a bin nothing beat gathers), the cloud's node ids as bytes
+    unsigned *bins = reinterpret_cast<unsigned *>(aff + a.tps * 32);
+    unsigned *v0s = bins + (size_t)a.tps * 32 * (POOL ? a.M : 0);
+    unsigned char *idb = reinterpret_cast<unsigned char *>(v0s + a.tps * 32);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -390,13 +420,14 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
     // workgroup -> (slab, column stream): the nslab workgroups of one stream read the same X, they sit on the same XCD (ids 8 apart)
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
     const int slab = kq % a.nslab, stream = xcd + 8 * (kq / a.nslab);
+    if constexpr (POOL) { if (stream * a.gpc >= a.ngroups) return; }      // (the stream is the cloud: the grid is rounded up to whole XCD rows)
     const int ct_begin = slab * a.tps;
     const int KC = a.KC, L = a.L;
     const unsigned rowB = (unsigned)L * 2u;
 
     {
         const uint4 *src = a.Wp + (size_t)ct_begin * KC * 64;
-        const int n = a.tps * KC * 64;                          // a multiple of 512 (tps even, KC a multiple of 4)
+        const int n = a.tps * KC * 64;                          // (tps tiles x KC chunks x 64 lanes; KC a multiple of 4)
         int i0 = 0;
         for (; i0 + 512 * 8 <= n; i0 += 512 * 8) {              // eight requests per thread in flight, then the eight LDS writes
             const uint4 *sp = src + i0 + (int)threadIdx.x;
@@ -404,17 +435,31 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
             const uint4 t0 = sp[0], t1 = sp[512], t2 = sp[1024], t3 = sp[1536], t4 = sp[2048], t5 = sp[2560], t6 = sp[3072], t7 = sp[3584];
             dp[0] = t0; dp[512] = t1; dp[1024] = t2; dp[1536] = t3; dp[2048] = t4; dp[2560] = t5; dp[3072] = t6; dp[3584] = t7;
         }
-        for (; i0 < n; i0 += 512) wl[i0 + (int)threadIdx.x] = src[i0 + (int)threadIdx.x];
+        for (; i0 < n; i0 += 512)                               // (n is a multiple of 256: a multiple of 512 only for an even slab)
+            if (i0 + (int)threadIdx.x < n) wl[i0 + (int)threadIdx.x] = src[i0 + (int)threadIdx.x];
         for (int o = threadIdx.x; o < a.tps * 32; o += 512) aff[o] = make_float2(a.scale[ct_begin * 32 + o], a.shift[ct_begin * 32 + o]);
         if constexpr (STATS)
             for (int o = threadIdx.x; o < 8 * a.tps * 32; o += 512) stl[o] = make_float2(0.f, 0.f);
+        if constexpr (POOL) {
+            // (the stream IS the cloud: every column group of cloud `stream` passes through this workgroup)
+            for (int o = threadIdx.x; o < a.tps * 32 * a.M; o += 512) bins[o] = BFP_INIT_KEY;
+            for (int o = threadIdx.x; o < a.tps * 32; o += 512) v0s[o] = 0u;
+            const int32_t *idr = a.ids + (size_t)stream * L;
+            for (int o = threadIdx.x; o < L; o += 512) {
+                const int v = idr[o];
+                idb[o] = (unsigned)v < (unsigned)a.M ? (unsigned char)v : (unsigned char)255;      // (255 >= M: nobody's column; M <= 255 here)
+            }
+        }
     }
     __syncthreads();
 
     const int npass = a.tps / MT;
-    const int wv = stream * 8 + wave, stride = a.nstream * 8;
-    const int ngw = wv < a.ngroups ? (a.ngroups - wv + stride - 1) / stride : 0;     // this wave's column groups: wv, wv + stride, ...
-    const int ngw_wg = stream * 8 < a.ngroups ? (a.ngroups - stream * 8 + stride - 1) / stride : 0;   // ... and those of the workgroup's wave 0 (the most)
+    // this wave's column groups: wv, wv + stride, ... -- round-robin over the whole batch, or (POOL) over the workgroup's own cloud
+    const int wv = POOL ? stream * a.gpc + wave : stream * 8 + wave, stride = POOL ? 8 : a.nstream * 8;
+    const int gend = POOL ? (stream + 1) * a.gpc : a.ngroups;
+    const int ngw = wv < gend ? (gend - wv + stride - 1) / stride : 0;
+    const int wv0 = POOL ? stream * a.gpc : stream * 8;                               // ... and those of the workgroup's wave 0 (the most)
+    const int ngw_wg = wv0 < gend ? (gend - wv0 + stride - 1) / stride : 0;
 
     // ---- load side: a cursor (group, chunk) that runs 4 chunks ahead of the multiplications
     int lg = 0, lkc = 0, lrep = 0;                  // index into this wave's groups / chunk / pass counter (X is re-read per pass)
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
         // 16 MT stores that land nowhere (offset outside the buffer): the first unit then starts behind the same queue as every other
         // one -- four chunks of loads, then an epilogue's stores -- and ONE wait count serves the first four chunks of every unit.  (Two
         // counts selected by a branch made hipcc hand the wait statements COPIES of the ring registers, taken before the wait.)
-        {
+        if constexpr (!POOL) {                                 // (POOL: no stores anywhere in the loop -- the queue holds loads only)
             const i32x4_t_ r0 = bfr_rsrc(a.y, 4);              // (asm: as builtins hipcc folds the identical stores into one)
             const unsigned oob = 0x7FFFFF00u, zero = 0u;
 #pragma unroll
@@ -471,6 +516,20 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
             const int b = g / a.gpc;
             const int ca = (g - b * a.gpc) * 64 + 2 * j;
             const bool pva = ca < L;
+            // (POOL) the nodes of this lane's two columns (byte table in LDS; a column nobody owns -- padding, id outside [0, M) -- reads bin 0
+            // and never updates), 0xFFFF - column
+            unsigned ida_s = 0u, idb_s = 0u, npa = 0u;
+            bool oka = false, okb = false;
+            if constexpr (POOL) {
+                if (pva) {
+                    const unsigned idpair = *reinterpret_cast<const unsigned short *>(idb + ca);
+                    oka = (idpair & 0xFFu) < (unsigned)a.M;
+                    okb = (idpair >> 8) < (unsigned)a.M;
+                    ida_s = oka ? (idpair & 0xFFu) : 0u;
+                    idb_s = okb ? (idpair >> 8) : 0u;
+                }
+                npa = 0xFFFFu - (unsigned)ca;
+            }
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * L, 0, (int)((unsigned)a.Cout * rowB), 0x00020000);
             const unsigned voya = pva ? (unsigned)(4 * h * L + ca) * 2u : 0x7FFFFF00u;       // padded columns: the store falls outside the buffer
 
@@ -485,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
 #define BFR_BODY(q, kc, FIRST4)                                                                         \
                 {                                                                                       \
                     unsigned ba[4], bb[4];                                                              \
-                    bfr_wait_perm<(FIRST4 ? (24 + 16 * MT > 63 ? 63 : 24 + 16 * MT) : 24)>(X[q], ba, bb); \
+                    bfr_wait_perm<((FIRST4 && !POOL) ? (24 + 16 * MT > 63 ? 63 : 24 + 16 * MT) : 24)>(X[q], ba, bb); \
                     issue(X[q]);                                                                        \
                     const bf16x8 Ba = __builtin_bit_cast(bf16x8, make_uint4(ba[0], ba[1], ba[2], ba[3])); \
                     const bf16x8 Bb = __builtin_bit_cast(bf16x8, make_uint4(bb[0], bb[1], bb[2], bb[3])); \
@@ -511,6 +570,33 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
                     const unsigned so_tile = (unsigned)((ct_begin + tl) * 32) * rowB;
                     const float2 *af = aff + tl * 32 + 4 * h;
                     float mine = 0.f;
+                    if constexpr (POOL) {
+                        // The two stored values of this lane per register (columns ca, ca + 1 of row tl * 32 + orow + 4 h) against their nodes'
+                        // bins.  All 32 bin reads of the tile FIRST (one wait for the lot: a read - wait - compare - branch chain per value
+                        // cost an LDS round trip 96 times a pass), then the compares; only a record breaker issues an LDS atomic.
+                        const unsigned *bb0 = bins + (size_t)(tl * 32 + 4 * h) * a.M;
+                        unsigned cura[16], curb[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int orow = (r & 3) + 8 * (r >> 2);
+                            cura[r] = bb0[orow * a.M + (int)ida_s];
+                            curb[r] = bb0[orow * a.M + (int)idb_s];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int orow = (r & 3) + 8 * (r >> 2);
+                            const float2 ss = af[orow];
+                            const float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
+                            const unsigned pk = cvt_pk_bf16(va, vb);
+                            const unsigned o2 = bfp_ord2(pk);
+                            const unsigned ka = (o2 << 16) | npa, kb = (o2 & 0xFFFF0000u) | (npa - 1u);
+                            unsigned *bb = bins + (size_t)(tl * 32 + orow + 4 * h) * a.M;
+                            if (oka && ka > cura[r]) atomicMax(bb + ida_s, ka);
+                            if (okb && kb > curb[r]) atomicMax(bb + idb_s, kb);
+                            if (ca == 0) v0s[tl * 32 + orow + 4 * h] = pk << 16;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int orow = (r & 3) + 8 * (r >> 2);
@@ -539,6 +625,23 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
     } else if (a.sync) {
         const int nb = a.sync == 2 ? 1 + npass * (KC / 4) : 1;
         for (int gi = 0; gi < ngw_wg * nb; ++gi) __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (POOL) {
+        // every column of the cloud has been through: the bins ARE the result (the epilogue of index_max_kernel, index_max.hip)
+        __syncthreads();
+        const int b = stream;
+        for (int i = threadIdx.x; i < a.tps * 32 * a.M; i += 512) {
+            const int rl = i / a.M, m = i - rl * a.M;
+            const unsigned key = bins[i];
+            const int pos = (int)(0xFFFFu - (key & 0xFFFFu));
+            const size_t o = ((size_t)b * a.Cout + (size_t)ct_begin * 32 + rl) * a.M + m;
+            a.out_idx[o] = pos;
+            const unsigned okey = key >> 16;
+            const bool won = key != BFP_INIT_KEY && (a.row_max == nullptr || a.row_max[(size_t)b * a.M + m] != 0);
+            float v = __uint_as_float(((okey & 0x8000u) ? (okey ^ 0x8000u) : (~okey & 0xFFFFu)) << 16);
+            if (!won) v = __uint_as_float(v0s[rl]);             // position 0: the value the storing launch would have written there
+            a.out_val[o] = v;
+        }
     }
     if constexpr (STATS) {
         __syncthreads();
@@ -931,6 +1034,79 @@ extern "C" int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint1
     SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_bf16_stats: NULL pointer");
     return bf16_run_impl("sonet_pointmlp_bf16_stats", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
                          reinterpret_cast<double *>(stats_ws), mean, var);
+}
+
+/* The layer and the per-node arg-max pool of its output in ONE launch; the output itself is never written (the last layer of the first
+ * PointNet in training, when only the pooled map is consumed: models/layers.py:431 + models/networks.py:180-185).
+ * out_idx [B][Cout][M] = what sonet_index_max_bf16 reports on the tensor sonet_pointmlp_bf16 would have written (first maximum above -1000 in
+ * column order, else 0), out_val [B][Cout][M] f32 = that tensor's value at out_idx * row_max (sonet_index_max_gather_bf16): bit for bit.
+ * A workgroup = (cloud, slab of output tiles) on the streaming kernel: W slab, the cloud's node ids (bytes) and the bins of its rows x M
+ * nodes live in LDS, every column group of the cloud passes through it once.  ids [B][L] i32, row_max [B][M] i32 or NULL.
+ * Needs: L even and < 65535 (a key holds the column in 16 bits), 4-byte aligned rows, (C1 + C2) % 64 == 0, Cout % 32 == 0 with a slab shape that fits the LDS, M <= 255. */
+extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                        const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                                        int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_pool";
+    SONET_REQUIRE(x1 && Wp && scale && shift && ids && out_idx && out_val, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0 && M > 0, "%s: non-positive size", what);
+    SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
+    SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
+    const int Cin = C1 + C2;
+    if (Cout % 32 != 0 || Cin % 64 != 0 || L % 2 != 0 || L > 65534 || M > 255 || B > 65535 ||
+        ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2)) & 3) != 0)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout %% 32, Cin %% 64, even L, M <= 255, 4-byte aligned rows (Cout=%d Cin=%d L=%d M=%d)", what, Cout, Cin, L, M);
+    const int CT = Cout / 32, KC = Cin / 16, gpc = sonet::ceil_div(L, 64);
+    if ((double)C1 * L * 2.0 >= 2.0e9 || (double)C2 * L * 2.0 >= 2.0e9 || (long long)B * gpc >= 0x7FFFFFFFll)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
+    int cus = 256;
+    {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) cus = v;
+    }
+    // output slabs: one workgroup per (cloud, slab) and CU -- the slab count whose B x nslab workgroups need the fewest rounds of tile passes
+    int best_ns = 0, best_mt = 0;
+    long long best_cost = 0;
+    size_t best_lds = 0;
+    for (int ns = 1; ns <= CT; ++ns) {
+        if (CT % ns) continue;
+        const int tps = CT / ns;
+        const int mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
+        if (mt == 0) continue;
+        const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 4 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+        if (lds > 158 * 1024) continue;
+        const long long cost = sonet::ceil_div64((long long)B * ns, cus) * tps;
+        if (best_ns == 0 || cost < best_cost) { best_ns = ns; best_mt = mt; best_cost = cost; best_lds = lds; }
+    }
+#ifdef SONET_VARIANTS
+    if (const char *e = sonet::knob("SONET_BF16_POOL_NS")) {       // (tools/bench_pool_epilogue.py: a slab count by hand)
+        const int ns = atoi(e);
+        if (ns >= 1 && CT % ns == 0) {
+            const int tps = CT / ns, mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
+            const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 4 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+            if (mt && lds <= 158 * 1024) { best_ns = ns; best_mt = mt; best_lds = lds; }
+        }
+    }
+#endif
+    if (best_ns == 0) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: no slab shape fits the LDS (Cin=%d Cout=%d M=%d L=%d)", what, Cin, Cout, M, L);
+    BfrArgs a;
+    a.x1 = x1; a.x2 = x2; a.Wp = reinterpret_cast<const uint4 *>(Wp); a.scale = scale; a.shift = shift; a.y = nullptr; a.stats_partial = nullptr;
+    a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.L = L; a.gpc = gpc; a.relu = relu & 1; a.KC = KC; a.KC1 = C2 > 0 ? (C1 >> 4) : KC;
+    a.tps = CT / best_ns; a.nslab = best_ns; a.nstream = (B + 7) / 8 * 8; a.ngroups = B * gpc;
+    a.sync = ((unsigned)L * 2u) % 128u != 0 ? 2 : 0;
+    a.ids = ids; a.row_max = row_max; a.out_idx = out_idx; a.out_val = out_val; a.M = M;
+    hipStream_t st = sonet::as_stream(stream);
+    // (workgroup -> (slab, stream) as in the storing launch: the slabs of a cloud on one XCD; streams >= B leave at once)
+    const dim3 gridr((unsigned)(a.nstream * best_ns)), blockr(512);
+#define BFP_LAUNCH(MM) do { static bool attr_set = false;                                                                             \
+        if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pointmlp_bf16r_kernel<MM, false, true>),            \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
+                             return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                           \
+                         attr_set = true; }                                                                                           \
+        hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, false, true>), gridr, blockr, best_lds, st, a); } while (0)
+    if (best_mt == 4) BFP_LAUNCH(4); else if (best_mt == 3) BFP_LAUNCH(3); else BFP_LAUNCH(2);
+#undef BFP_LAUNCH
+    return sonet::launched(what);
 }
 
 extern "C" int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,

@@ -292,11 +292,19 @@ class _PooledLastLayerFn(torch.autograd.Function):
     scatter-added into it -- exactly what the reference's gather backward does."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M):
+    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M, need_dense=True):
         Cout = weight2d.shape[0]
         ones = _ops.const_vec(Cout, 1.0, x1.device)
-        y = _ops.pointmlp(x1, wp, ones, bias.detach().float().contiguous(), False, Cout, x2=x2)
-        idx, val = _ops.index_max_gather(y, min_idx_i32, M, row_max)
+        b = bias.detach().float().contiguous()
+        if not need_dense and wp.dtype == torch.int16 and _ops.pointmlp_bf16_pool_ok(x1, x2, Cout, M):
+            # nobody reads first_pn_out itself (classifier, autoencoder): the layer's epilogue IS the pool -- the B x 384 x kN tensor is
+            # neither written nor read back (0.74 GB of HBM traffic each way at B = 64) and the index_max launch is gone; positions and
+            # values are those of index_max_gather on the tensor the storing launch would have written, bit for bit
+            y = None
+            idx, val = _ops.pointmlp_bf16_pool(x1, wp, ones, b, False, Cout, min_idx_i32, M, row_max, x2=x2)
+        else:
+            y = _ops.pointmlp(x1, wp, ones, b, False, Cout, x2=x2)
+            idx, val = _ops.index_max_gather(y, min_idx_i32, M, row_max)
         gi = idx * row_max.unsqueeze(1)                                   # networks.py:185: empty nodes gather position 0
         ctx.save_for_backward(x1, x2, weight2d, gi, row_max)
         ctx.set_materialize_grads(False)
@@ -309,7 +317,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
         B, C1, L = x1.shape
         C2 = x2.shape[1]
         if g_y is None and g_mm is None:
-            return (None,) * 8
+            return (None,) * 9
         sparse = g_y is None
         G = None
         ss = None
@@ -373,7 +381,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 g_x1, g_x2 = outs
         if ss is not None:
             ss.join()
-        return g_x1, g_x2, g_w, g_bias, None, None, None, None
+        return g_x1, g_x2, g_w, g_bias, None, None, None, None, None
 
 
 class _FusedPointwise(_PlainAttrs, nn.Module):
@@ -981,9 +989,11 @@ class PointResNet(nn.Module):
             self._fused_akey = akey
         return self._fused_w, self._fused_aff
 
-    def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None):
+    def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None, need_dense=True):
         """Training path of the encoder: hidden layers as usual, then the last layer and the per-node arg-max pool as one
-        autograd node -> (first_pn_out, first_pn_out_masked_max, gather_index) or None when the layout does not allow it."""
+        autograd node -> (first_pn_out, first_pn_out_masked_max, gather_index) or None when the layout does not allow it.
+        need_dense=False (nobody reads first_pn_out: classifier, autoencoder): where the arithmetic has the kernel for it (bf16) the
+        first element is None -- the tensor is never written."""
         n = len(self.out_channels_list)
         last = self.layers[n - 1]
         if n < 3 or last.normalization is not None or last.activation is not None or not last._fusable():
@@ -995,7 +1005,7 @@ class PointResNet(nn.Module):
         for l in range(1, n - 1):
             t = self.layers[l](t, epoch)
         wp = last._packed(skip.shape[1], t.shape[1])
-        return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M)
+        return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, bool(need_dense))
 
     def forward(self, x, epoch=None):
         self.last_p16 = None

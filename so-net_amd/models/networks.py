@@ -145,6 +145,9 @@ class Encoder(_PlainAttrs, nn.Module):
         forward (only its per-node max is needed); it is materialised here if a caller (the segmenter) reads it."""
         if self._first_pn_out is None and self._lazy is not None and self._lazy.get("first_p16") is not None:
             self._first_pn_out = self._lazy["first_p16"].float()
+        if self._first_pn_out is None and self._lazy is not None and self._lazy.get("not_materialised"):
+            raise AttributeError("Encoder.first_pn_out was not materialised by this training forward (only its per-node maximum is consumed: the "
+                                 "pool ran in the last layer's epilogue); set encoder.want_first_pn_out = True before the forward to keep it")
         if self._first_pn_out is None and self._lazy is not None:
             st = self._lazy
             g = _ops.som_group(st["x"], st["sn"], st["a"], want_augmented=st["sn"] is not None, want_decentered=st["sn"] is None)
@@ -339,9 +342,14 @@ class Encoder(_PlainAttrs, nn.Module):
             pooled = None
             if torch.is_grad_enabled() and isinstance(self.first_pointnet, PointResNet) and getattr(self, "pooled_backward", True):
                 # training: last layer + arg-max pool as one autograd node (sparse dgrad when only the pooled output is consumed)
-                pooled = self.first_pointnet.forward_pooled(pn_in, a.min_idx_i32, row_max, M, epoch)
+                # (a head that reads first_pn_out densely -- the segmenter -- sets want_first_pn_out; otherwise the tensor is not needed and,
+                #  where the arithmetic has the kernel for it, never written: the pool is the last layer's epilogue)
+                pooled = self.first_pointnet.forward_pooled(pn_in, a.min_idx_i32, row_max, M, epoch,
+                                                            need_dense=bool(getattr(self, 'want_first_pn_out', False)) or not _ops.POOLED_TRAIN_EPILOGUE)
             if pooled is not None:
                 self.first_pn_out, self.first_pn_out_masked_max, _ = pooled
+                if self._first_pn_out is None:
+                    self._lazy["not_materialised"] = True         # (training: recomputing it would run the BatchNorm updates twice)
             else:
                 self.first_pn_out = self.first_pointnet(pn_in, epoch)        # :175-178  B x 384 x kN
                 if self._first_pn_out is None:

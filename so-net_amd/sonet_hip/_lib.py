@@ -37,6 +37,7 @@ SIGNATURES = {
     "sonet_index_max_gather_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_ws_size": [_i, _i, _i, _i],
+    "sonet_pointmlp_bf16_pool": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_pack_multi": [_vp, _i, _i, _vp],
     "sonet_pack_multi_kc": [_i, _i],
     "sonet_bn_rider_set": [_vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],

@@ -120,6 +120,59 @@ def index_max_gather(data, index, K, row_max=None):
     return idx, val
 
 
+def pointmlp_bf16_pool_ok(x1, x2, Cout, M):
+    """The shapes ``pointmlp_bf16_pool`` takes (the rest raise SONET_ERR_UNSUPPORTED): bf16 CUDA inputs, even L, (C1 + C2) % 64 == 0,
+    C1 % 16 == 0 with a second input, Cout % 32 == 0, M <= 255, and the LDS budget of a (cloud, slab) workgroup."""
+    if not (POOLED_TRAIN_EPILOGUE and x1.is_cuda and x1.dtype == torch.bfloat16 and (x2 is None or x2.dtype == torch.bfloat16)):
+        return False
+    B, C1, L = x1.shape
+    C2 = x2.shape[1] if x2 is not None else 0
+    if L % 2 or L > 65534 or (C1 + C2) % 64 or (C2 and C1 % 16) or Cout % 32 or not 0 < M <= 255 or B > 65535:
+        return False
+    KC, CT = (C1 + C2) // 16, Cout // 32
+    for ns in range(1, CT + 1):                       # (the launcher's slab search: any slab whose W rows + bins + ids fit 158 KiB)
+        if CT % ns:
+            continue
+        tps = CT // ns
+        if tps % 2 and tps % 3:
+            continue
+        if tps * KC * 1024 + tps * 32 * 8 + tps * 32 * M * 4 + tps * 32 * 4 + ((L + 15) & ~15) <= 158 * 1024:
+            return True
+    return False
+
+
+def pointmlp_bf16_pool(x1, wp, scale, shift, relu, Cout, ids, M, row_max=None, x2=None):
+    """The bf16 layer and the per-node arg-max pool of its output in one launch (``sonet_pointmlp_bf16_pool``); the B x Cout x L output is
+    never written.  -> (idx i32, val f32) B x Cout x M: exactly ``index_max_gather(pointmlp(...), ids, M, row_max)``."""
+    _chk(x1, "x", torch.bfloat16, 3)
+    B, C1, L = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2", torch.bfloat16, 3)
+        if x2.shape[0] != B or x2.shape[2] != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.shape[1]
+    if wp.dtype != torch.int16:
+        raise SonetHipError("pointmlp_bf16_pool: a bf16 pack")
+    _chk(ids, "ids", torch.int32, 2)
+    if tuple(ids.shape) != (B, L):
+        raise SonetHipError("ids must be B x L")
+    if row_max is not None:
+        _chk(row_max, "row_max", torch.int32, 2)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    dev = _same_device(x1, x2, wp, scale, shift, ids, row_max)
+    lib = _lib.load()
+    if wp.numel() != lib.sonet_pointmlp_bf16_pack_size(C1 + C2, Cout) // 2:
+        raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C1 + C2, Cout))
+    idx = torch.empty((B, Cout, int(M)), dtype=torch.int32, device=dev)
+    val = torch.empty((B, Cout, int(M)), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev), _timed("pointmlpbf16_pool_%dx%d_L%d" % (C1 + C2, Cout, L)):
+        check(lib.sonet_pointmlp_bf16_pool(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(ids), ptr(row_max),
+                                           ptr(idx), ptr(val), B, Cout, L, int(M), stream_ptr()), "sonet_pointmlp_bf16_pool")
+    return idx, val
+
+
 def index_max_gather_p16(planes, index, K, row_max=None):
     """index_max_gather on an activation that exists only as P16 planes (``P16``): values (hi + mid) / 32, the 22-bit values the next
     layer multiplies -> (idx i32, val f32) B x C x K."""
@@ -512,6 +565,8 @@ P16_CHAINS = _os.environ.get("SONET_P16_CHAINS", "1") != "0"
 # no-grad node-level stage (KNNModule + final PointNet + global max) on the third-generation layer, flat column axis, max-over-group
 # epilogues (csrc/node_stage.hip): 5 launches instead of 8.  0 = the round-4 stage (second-generation layers + planes_max / lastdim_max)
 NODE_STAGE_P16 = _os.environ.get("SONET_NODE_STAGE_P16", "1") != "0"
+# bf16 training: the last layer of the first PointNet + the per-node arg-max pool in one launch, first_pn_out never written (0 = store + index_max)
+POOLED_TRAIN_EPILOGUE = _os.environ.get("SONET_POOLED_TRAIN_EPILOGUE", "1") != "0"
 WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 

@@ -336,8 +336,9 @@ def test_classifier_training_step_bf16(fixture):
         loss.backward()
     names = set(n for n, _, _ in rec.records)
     assert any(n.startswith("pointmlpbf16") for n in names) and not any(n.startswith(("pointmlph3", "pointmlpx3")) for n in names), names
-    assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad_mfma", "pooled_wgrad",
-            "index_max_gather_bf16"} <= names, names
+    assert {"pointwise_bwd_stats_bf16", "pointwise_bwd_apply_bf16", "channel_stats_bf16", "channel_affine_act_bf16", "pooled_dgrad_mfma", "pooled_wgrad"} <= names, names
+    # the pool of the first PointNet's output: the last layer's epilogue (first_pn_out never written), or index_max on the stored tensor
+    assert any(n.startswith("pointmlpbf16_pool") for n in names) or "index_max_gather_bf16" in names, names
     # train-mode BatchNorm divides by batch statistics of bf16-rounded activations and the feature passes three max-pools whose
     # winners may change: bound the rms error (4e-2; measured 2.0e-2 at N=512, 3.1e-2 at N=5000) and the worst element
     f_got, f_ref = feat.detach().cpu().double().numpy(), g["feature"].astype(np.float64)
@@ -502,3 +503,87 @@ def test_wgrad_bf16_vs_float64(B, Cout, Cin, L):
     assert tuple(got.shape) == (Cout, Cin)
     assert_close_rms(got.cpu().numpy(), ref.cpu().numpy(), 2e-5, "wgrad bf16")
     assert torch.equal(got, ops.wgrad_bf16(gg, xx))               # deterministic (fixed-order reduction)
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L,M", [(64, 64, 256, 384, 15000, 64), (3, 64, 256, 384, 1000, 64), (2, 128, 0, 96, 130, 7),
+                                               (5, 64, 0, 64, 2, 3), (2, 64, 64, 128, 4098, 255)])
+def test_bf16_layer_with_pool_epilogue_equals_layer_then_index_max_gather(B, C1, C2, Cout, L, M):
+    """sonet_pointmlp_bf16_pool (the layer's output pooled per node in its epilogue, never written) == sonet_pointmlp_bf16 followed by
+    sonet_index_max_gather_bf16 on the stored tensor: positions and values bit for bit, incl. masked nodes, empty nodes, ids nobody owns,
+    channels that never beat -1000 (position 0 and the value stored there) and ties (the first column wins)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C1 + Cout + L + M)
+    x1 = torch.randn(B, C1, L, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(torch.bfloat16).to(DEV) if C2 else None
+    if L >= 8:
+        x1[:, :, 5] = x1[:, :, 3]                                 # ties between columns 3 and 5
+        if x2 is not None:
+            x2[:, :, 5] = x2[:, :, 3]
+    W = (torch.randn(Cout, C1 + C2, generator=g) * (C1 + C2) ** -0.5).to(DEV)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    bias[1 % Cout] = -3000.0                                      # a channel that never beats -1000: position 0, the value stored there
+    ids = torch.randint(0, M, (B, L), generator=g, dtype=torch.int32)
+    if M > 3:
+        ids[ids == 2] = 3                                          # node 2 is empty
+    if L >= 8:
+        ids[0, 5] = ids[0, 3]                                      # the tie inside one node
+        ids[B - 1, :2] = torch.tensor([M + 5, -1], dtype=torch.int32)[:2]   # ids nobody owns
+    ids = ids.to(DEV)
+    row_max = torch.ones(B, M, dtype=torch.int32)
+    row_max[:, 1 % M] = 0                                          # a masked node gathers position 0
+    row_max = row_max.to(DEV)
+    wp = ops.pointmlp_pack(W, "bf16")
+    one = ops.const_vec(Cout, 1.0, DEV)
+    assert ops.pointmlp_bf16_pool_ok(x1, x2, Cout, M)
+    for rm in (row_max, None):
+        idx, val = ops.pointmlp_bf16_pool(x1, wp, one, bias, False, Cout, ids, M, rm, x2=x2)
+        y = ops.pointmlp(x1, wp, one, bias, False, Cout, x2=x2)
+        idx_ref, val_ref = ops.index_max_gather(y, ids, M, rm)
+        assert torch.equal(idx, idx_ref)
+        assert torch.equal(val, val_ref)
+    assert int((idx[:, 1 % Cout] != 0).sum()) == 0               # the -3000 channel: nothing beat -1000
+
+
+def test_training_step_with_pool_epilogue_equals_the_storing_path():
+    """The bf16 training step with the pool in the last layer's epilogue (first_pn_out never written) == the step that stores it and runs
+    index_max on it: loss, every gradient, the updated BatchNorm statistics -- bit for bit (same positions, same values, same backward)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 4, 1500
+    res = {}
+    with ops.precision("bf16"):
+        for flag in (True, False):
+            old = ops.POOLED_TRAIN_EPILOGUE
+            ops.POOLED_TRAIN_EPILOGUE = flag
+            try:
+                opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True,
+                                                                   feature_num=1024, activation="relu", normalization="batch", dropout=0.0, node_num=64, k=3,
+                                                                   som_k=9, som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None,
+                                                                   bn_momentum_decay=0.6, classes=40)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward()
+                names = [n for n, _, _ in rec.records]
+                assert any(n.startswith("pointmlpbf16_pool") for n in names) == flag
+                assert any(n.startswith("index_max") for n in names) == (not flag)
+                if flag:
+                    with pytest.raises(AttributeError):
+                        enc.first_pn_out
+                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone())
+            finally:
+                ops.POOLED_TRAIN_EPILOGUE = old
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][3], res[False][3])
+    assert res[True][1].keys() == res[False][1].keys()
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k

@@ -69,9 +69,29 @@ def audit(txt):
                     problems.append('%s: line %d touches in-flight %s: %s' % (name, n, sorted(regs_of(ops[1]) & inflight), l))
             n += 1
         mt = int(re.search(r'pointmlp_bf16r_kernelILi(\d+)E', parts[i]).group(1))
+        pool = re.search(r'pointmlp_bf16r_kernelILi\d+ELb[01]ELb1E', parts[i]) is not None
         nst = sum(1 for l in lines if l.startswith('buffer_store_dword'))
-        if nst != 32 * mt:              # the wait counts assume 16 MT stores per epilogue and as many in the prologue
-            problems.append('%s: %d buffer_store_dword (expected %d)' % (name, nst, 32 * mt))
+        # the wait counts assume 16 MT stores per epilogue and as many in the prologue -- or (the pooling variant, which writes its
+        # result after the closing vmcnt(0)) NO vector-memory operation but the X loads anywhere in the loop
+        want = 0 if pool else 32 * mt
+        if nst != want:
+            problems.append('%s: %d buffer_store_dword (expected %d)' % (name, nst, want))
+        if pool:
+            # (the loop ends at the kernel's OWN closing wait -- the asm statement; what hipcc emits behind it is the result's write-out)
+            last0 = max((k for k, l in enumerate(lines) if l.startswith('s_waitcnt vmcnt(0)') and k > 0 and lines[k - 1].startswith(';;#ASMSTART')), default=-1)
+            # (vector-memory instructions hipcc emitted itself inside the loop would sit between asm blocks: count them by position)
+            inasm, vm_in_loop, seen_first_load = False, 0, False
+            for l in lines[:last0 if last0 >= 0 else len(lines)]:
+                if l.startswith(';;#ASMSTART'):
+                    inasm = True
+                elif l.startswith(';;#ASMEND'):
+                    inasm = False
+                elif inasm and l.startswith('buffer_load_dword'):
+                    seen_first_load = True
+                elif not inasm and seen_first_load and l.startswith(('global_', 'buffer_', 'flat_', 'scratch_')):
+                    vm_in_loop += 1
+            if vm_in_loop:
+                problems.append('%s: %d compiler-emitted vector-memory instructions inside the loop of the pooling variant' % (name, vm_in_loop))
         if loads < 64 or waits < 8:
             problems.append('%s: %d asm loads / %d waits found (the kernel changed shape?)' % (name, loads, waits))
         m = re.search(r'; ScratchSize: (\d+)', parts[i + 1])
@@ -92,8 +112,8 @@ def main():
                                   stderr=subprocess.DEVNULL)
             txt = open(out).read()
     found, problems = audit(txt)
-    if found != 4:
-        problems.append('%d instantiations of pointmlp_bf16r_kernel (expected 4)' % found)
+    if found != 7:
+        problems.append('%d instantiations of pointmlp_bf16r_kernel (expected 7: four storing, three pooling)' % found)
     for p in problems[:20]:
         print('PROBLEM', p)
     print('check_bf16r_asm: %d kernels, %d problems' % (found, len(problems)))
