@@ -355,6 +355,7 @@ struct BfrArgs {
     int32_t *out_idx;                     // [B][Cout][M] winning column (0 where nothing beat -1000, as the reference)
     float *out_val;                       // [B][Cout][M] the stored (bf16) value at out_idx * row_max
     int M;
+    int abl;                              // (variants build, POOL) 1: no epilogue at all, 2: no bin reads / updates (the arithmetic stays)
 };
 
 // (POOL) the order of the keys is that of index_max.hip -- bigger value wins, equal values: the smaller column wins, -0 counts as +0, a NaN never
@@ -411,7 +412,10 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
     float2 *stl = aff + a.tps * 32;                                            // STATS: [8 waves][tps * 32] (sum, sum of squares)
     // POOL: bins [tps * 32][M] (one word each), the value at column 0 of every row (what a bin nothing beat gathers), the cloud's node ids as bytes
     unsigned *bins = reinterpret_cast<unsigned *>(aff + a.tps * 32);
-    unsigned *v0s = bins + (size_t)a.tps * 32 * (POOL ? a.M : 0);
+    // ... and a float shadow of every bin's value (never above it): "can this element matter at all" is one LDS read and one float compare;
+    // the orderable key, its compare and the LDS atomic are paid by the few that pass (about ln n per bin)
+    float *shadow = reinterpret_cast<float *>(bins + (size_t)a.tps * 32 * (POOL ? a.M : 0));
+    unsigned *v0s = reinterpret_cast<unsigned *>(shadow + (size_t)a.tps * 32 * (POOL ? a.M : 0));
     unsigned char *idb = reinterpret_cast<unsigned char *>(v0s + a.tps * 32);
 
     const int lane = threadIdx.x & 63;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
             for (int o = threadIdx.x; o < 8 * a.tps * 32; o += 512) stl[o] = make_float2(0.f, 0.f);
         if constexpr (POOL) {
             // (the stream IS the cloud: every column group of cloud `stream` passes through this workgroup)
-            for (int o = threadIdx.x; o < a.tps * 32 * a.M; o += 512) bins[o] = BFP_INIT_KEY;
+            for (int o = threadIdx.x; o < a.tps * 32 * a.M; o += 512) { bins[o] = BFP_INIT_KEY; shadow[o] = -1000.f; }
             for (int o = threadIdx.x; o < a.tps * 32; o += 512) v0s[o] = 0u;
             const int32_t *idr = a.ids + (size_t)stream * L;
             for (int o = threadIdx.x; o < L; o += 512) {
@@ -571,16 +575,19 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
                     const float2 *af = aff + tl * 32 + 4 * h;
                     float mine = 0.f;
                     if constexpr (POOL) {
+#ifdef SONET_VARIANTS
+                        if (a.abl == 1) continue;
+#endif
                         // The two stored values of this lane per register (columns ca, ca + 1 of row tl * 32 + orow + 4 h) against their nodes'
                         // bins.  All 32 bin reads of the tile FIRST (one wait for the lot: a read - wait - compare - branch chain per value
                         // cost an LDS round trip 96 times a pass), then the compares; only a record breaker issues an LDS atomic.
-                        const unsigned *bb0 = bins + (size_t)(tl * 32 + 4 * h) * a.M;
-                        unsigned cura[16], curb[16];
+                        const float *sh0 = shadow + (size_t)(tl * 32 + 4 * h) * a.M;
+                        float cura[16], curb[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int orow = (r & 3) + 8 * (r >> 2);
-                            cura[r] = bb0[orow * a.M + (int)ida_s];
-                            curb[r] = bb0[orow * a.M + (int)idb_s];
+                            cura[r] = sh0[orow * a.M + (int)ida_s];
+                            curb[r] = sh0[orow * a.M + (int)idb_s];
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -588,11 +595,18 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
                             const float2 ss = af[orow];
                             const float va = __fmaf_rn(acc[mt][0][r], ss.x, ss.y), vb = __fmaf_rn(acc[mt][1][r], ss.x, ss.y);
                             const unsigned pk = cvt_pk_bf16(va, vb);
-                            const unsigned o2 = bfp_ord2(pk);
-                            const unsigned ka = (o2 << 16) | npa, kb = (o2 & 0xFFFF0000u) | (npa - 1u);
-                            unsigned *bb = bins + (size_t)(tl * 32 + orow + 4 * h) * a.M;
-                            if (oka && ka > cura[r]) atomicMax(bb + ida_s, ka);
-                            if (okb && kb > curb[r]) atomicMax(bb + idb_s, kb);
+                            const float sa = __uint_as_float(pk << 16), sb = __uint_as_float(pk & 0xFFFF0000u);     // the STORED values
+                            // (>=: an equal value at a smaller column still wins; a NaN fails the compare, as it never wins)
+                            bool ca_ = oka && sa >= cura[r], cb_ = okb && sb >= curb[r];
+#ifdef SONET_VARIANTS
+                            if (a.abl == 2) { ca_ = sa == 12345.f; cb_ = sb == 12345.f; }
+#endif
+                            if (ca_ || cb_) {
+                                const unsigned o2 = bfp_ord2(pk);
+                                const int row = tl * 32 + orow + 4 * h;
+                                if (ca_) { atomicMax(bins + (size_t)row * a.M + ida_s, (o2 << 16) | npa); shadow[(size_t)row * a.M + ida_s] = sa; }
+                                if (cb_) { atomicMax(bins + (size_t)row * a.M + idb_s, (o2 & 0xFFFF0000u) | (npa - 1u)); shadow[(size_t)row * a.M + idb_s] = sb; }
+                            }
                             if (ca == 0) v0s[tl * 32 + orow + 4 * h] = pk << 16;
                         }
                         continue;
@@ -966,7 +980,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
         const int spx = best_ns > 0 ? (cus / 8) / best_ns : 0;            // column streams per XCD
         if (want && best_ns > 0 && spx > 0) {
             BfrArgs a;
-            a.x1 = x1; a.x2 = x2; a.Wp = wp; a.scale = scale; a.shift = shift; a.y = y; a.stats_partial = stats_ws;
+            a.x1 = x1; a.x2 = x2; a.Wp = wp; a.scale = scale; a.shift = shift; a.y = y; a.stats_partial = stats_ws; a.abl = 0;
             a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.L = L; a.gpc = gpc; a.relu = relu & 1; a.KC = KC; a.KC1 = C2 > 0 ? (C1 >> 4) : KC;
             a.tps = CT / best_ns; a.nslab = best_ns; a.nstream = 8 * spx; a.ngroups = (int)ngroups;
             a.sync = ((unsigned)L * 2u) % 128u != 0 ? 2 : 0;
@@ -1073,7 +1087,7 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
         const int tps = CT / ns;
         const int mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
         if (mt == 0) continue;
-        const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 4 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+        const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
         if (lds > 158 * 1024) continue;
         const long long cost = sonet::ceil_div64((long long)B * ns, cus) * tps;
         if (best_ns == 0 || cost < best_cost) { best_ns = ns; best_mt = mt; best_cost = cost; best_lds = lds; }
@@ -1083,7 +1097,7 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
         const int ns = atoi(e);
         if (ns >= 1 && CT % ns == 0) {
             const int tps = CT / ns, mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
-            const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 4 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+            const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
             if (mt && lds <= 158 * 1024) { best_ns = ns; best_mt = mt; best_lds = lds; }
         }
     }
@@ -1093,8 +1107,15 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
     a.x1 = x1; a.x2 = x2; a.Wp = reinterpret_cast<const uint4 *>(Wp); a.scale = scale; a.shift = shift; a.y = nullptr; a.stats_partial = nullptr;
     a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.L = L; a.gpc = gpc; a.relu = relu & 1; a.KC = KC; a.KC1 = C2 > 0 ? (C1 >> 4) : KC;
     a.tps = CT / best_ns; a.nslab = best_ns; a.nstream = (B + 7) / 8 * 8; a.ngroups = B * gpc;
-    a.sync = ((unsigned)L * 2u) % 128u != 0 ? 2 : 0;
-    a.ids = ids; a.row_max = row_max; a.out_idx = out_idx; a.out_val = out_val; a.M = M;
+    // (no workgroup barriers here: the eight waves of a workgroup walk adjacent column groups of ONE cloud and its four slab workgroups share
+    //  an XCD's L2 -- the shared cache lines of unaligned rows come from L2 either way, and free-running waves let one wave's epilogue sit
+    //  under another's MFMAs: 559 -> 478 us at 64 x 15000 columns, tools/bench_pool_epilogue.py)
+    a.sync = 0;
+    a.ids = ids; a.row_max = row_max; a.out_idx = out_idx; a.out_val = out_val; a.M = M; a.abl = 0;
+#ifdef SONET_VARIANTS
+    if (const char *e = sonet::knob("SONET_BF16_POOL_ABL")) a.abl = atoi(e);
+    if (const char *e = sonet::knob("SONET_BF16_SYNC")) a.sync = atoi(e);
+#endif
     hipStream_t st = sonet::as_stream(stream);
     // (workgroup -> (slab, stream) as in the storing launch: the slabs of a cloud on one XCD; streams >= B leave at once)
     const dim3 gridr((unsigned)(a.nstream * best_ns)), blockr(512);

@@ -136,7 +136,7 @@ def pointmlp_bf16_pool_ok(x1, x2, Cout, M):
         tps = CT // ns
         if tps % 2 and tps % 3:
             continue
-        if tps * KC * 1024 + tps * 32 * 8 + tps * 32 * M * 4 + tps * 32 * 4 + ((L + 15) & ~15) <= 158 * 1024:
+        if tps * KC * 1024 + tps * 32 * 8 + tps * 32 * M * 8 + tps * 32 * 4 + ((L + 15) & ~15) <= 158 * 1024:
             return True
     return False
 

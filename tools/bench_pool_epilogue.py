@@ -43,5 +43,10 @@ for ns in ("3", "4", "6"):
     os.environ["SONET_BF16_POOL_NS"] = ns
     print("  (variants library) %s output slabs: %.1f us" % (ns, t(lambda: ops.pointmlp_bf16_pool(x1, wp, one, bias, False, Cout, ids, M, row_max, x2=x2))))
 os.environ.pop("SONET_BF16_POOL_NS", None)
+for k, v, what in (("SONET_BF16_POOL_ABL", "1", "no epilogue at all"), ("SONET_BF16_POOL_ABL", "2", "epilogue arithmetic, no bin traffic beyond the shadow reads"),
+                   ("SONET_BF16_SYNC", "0", "no workgroup barriers"), ("SONET_BF16_SYNC", "1", "one barrier per column group")):
+    os.environ[k] = v
+    print("  (variants library) %s: %.1f us" % (what, t(lambda: ops.pointmlp_bf16_pool(x1, wp, one, bias, False, Cout, ids, M, row_max, x2=x2))))
+    os.environ.pop(k, None)
 print("layer (store) %.1f us + index_max_gather %.1f us = %.1f us   |   layer with pool epilogue: random node order %.1f us, node-sorted columns %.1f us"
       % (a, b, a + b, c, d))
