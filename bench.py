@@ -167,6 +167,8 @@ def algorithmic(name, B, N, k=3, M=64, C=384):
         cin, cout = dims.split("_")[-1].split("x")              # (pointmlph3_nodeadd_393x1024_L3072: a variant tag in front of the dims)
         if "_flat_" in name or "_gmax" in name:                 # flat node-level stage: ONE cloud whose L columns already span the batch
             B = 1
+        if name.startswith("pointmlpbf16_pool"):                # the layer whose epilogue is the pool: nothing written, the input once -- bound by the matrix pipe
+            return "mfma", 2.0 * int(cin) * int(cout) * B * int(L.split("_")[0])
         if name.startswith("pointmlpbf16"):                     # one bf16 MFMA per product: 175 flop per byte at 320 -> 384, under the machine balance
             return "hbm", 2.0 * (int(cin) + int(cout)) * B * int(L.split("_")[0])    # input + output, once, 2 bytes each
         return "mfma", 2.0 * int(cin) * int(cout) * B * int(L.split("_")[0])     # ("_kmax9": the max over k is in the epilogue)
