@@ -398,6 +398,7 @@ def other_configs(args, dev, world=1, rank=0):
         with ops.precision(precision):
             opt = make_opt(dev, B, N)
             enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+            enc.want_first_pn_out = False                         # (a classifier: nobody reads first_pn_out per point copy)
             synth.fill_state_dict_(enc.state_dict(), 0)
             synth.fill_state_dict_(cls.state_dict(), 1)
             enc.to(dev).train()
@@ -674,6 +675,7 @@ def main():
     B, N = args.batch, args.points
     opt = make_opt(dev, B, N)
     enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    enc.want_first_pn_out = False                                  # (a classifier: nobody reads first_pn_out per point copy)
     enc_sd = synth.fill_state_dict_(enc.state_dict(), 0)          # identical weights on every rank
     cls_sd = synth.fill_state_dict_(cls.state_dict(), 1)
     enc_cpu = {k: v.clone() for k, v in enc_sd.items()}

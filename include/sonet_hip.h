@@ -451,12 +451,40 @@ int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int
                              const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
                              int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream);
 
+/* f32-class twin on NODE-SORTED columns (sonet_som_sort_group_f32: ids_sorted [B][L] i32 non-decreasing per cloud, pos0 [B] = sorted position
+ * of original column 0): the fp16-split layer (sonet_pointmlp_h3_f32) and the per-node arg-max pool of its output in one pass; the output is
+ * never written.  out_idx [B][Cout][M] = winning SORTED column, first maximum above -1000 in column order -- a stable sort keeps the original
+ * order inside a node, so this is the column models/index_max_ext/index_max_cuda.cu:10-26 picks --, pos0[b] where nothing beat -1000 or
+ * row_max[b][m] == 0 (models/networks.py:185: gather index 0 of the original order); out_val [B][Cout][M] = the layer's value there (bit for
+ * bit sonet_pointmlp_h3_f32 + sonet_index_max_gather_f32 on the sorted tensor; -0 reported as +0).  ws: sonet_pointmlp_h3_segpool_ws_size
+ * bytes.  Cout % 32 == 0, C1 % 16 == 0 when x2 is given.
+ *
+ * Normalise-on-load (both entry points below): when xs1 is given the inputs are the RAW outputs of BatchNorm layers whose normalise + ReLU pass
+ * was never run; the operand load applies x = act(raw * xs[c] + xh[c]) (xs1 / xh1 [C1], xs2 / xh2 [C2]; xrelu bit 0 / 1: ReLU on x1's / x2's
+ * channels) exactly as sonet_channel_affine_act_f32 computes it -- the normalised activations of models/layers.py:60-70 never exist in
+ * memory between two layers of the training forward.  Needs Cin <= 1024, Cout % 128 == 0. */
+size_t sonet_pointmlp_h3_segpool_ws_size(int B, int Cout, int M);
+int sonet_pointmlp_h3_segpool_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                  const float *shift, int relu, const int32_t *ids_sorted, const int32_t *pos0,
+                                  const int32_t *row_max, int M, void *ws, int32_t *out_idx, float *out_val,
+                                  int B, int Cout, int L, const float *xs1, const float *xh1, const float *xs2, const float *xh2,
+                                  int xrelu, sonet_stream_t stream);
+/* sonet_pointmlp_h3_stats_f32 with normalise-on-load (xs1 required). */
+int sonet_pointmlp_h3_stats_xaff_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                     const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                     float *mean, float *var, const float *xs1, const float *xh1, const float *xs2, const float *xh2,
+                                     int xrelu, sonet_stream_t stream);
+
 /* Weight gradient of a point-wise layer: dw[o][c] = sum_b sum_l g[b][o][l] * x[b][c][l]  (g [B][Cout][L], x [B][Cin][L], dw
  * [Cout][Cin], f32) -- what autograd computes for the nn.Conv1d / nn.Conv2d(1x1) weights of models/layers.py:282-296.  Both
  * operands are split into three bf16 pieces, six products kept (f32-class, f32 range), f32 accumulation on the matrix cores;
  * partial 128 x 128 blocks over column slices are summed in a fixed order (deterministic).  ws = sonet_wgrad_x3_ws_size bytes. */
 size_t sonet_wgrad_x3_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
+/* ... with normalise-on-load of x (see sonet_pointmlp_h3_stats_xaff_f32): x is the RAW output of a BatchNorm layer, the operand split applies
+ * x = act(raw * xs[c] + xh[c]) first (xs, xh [Cin]; xrelu != 0: ReLU). */
+int sonet_wgrad_x3_xaff_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L,
+                            const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 /* bf16 twin (BASELINE configs[1] "bf16"): g [B][Cout][L], x [B][Cin][L] as bfloat16 bit patterns (16-byte aligned), one bf16 MFMA per
  * product, f32 accumulation, f32 partial blocks over the same column slices, the same fixed-order reduction -> dw [Cout][Cin] f32.
  * Replaces torch.bmm(g, x^T, out_dtype=f32).sum(0) (hipBLASLt) in the bf16 training step.  ws: sonet_wgrad_bf16_ws_size bytes.
@@ -496,6 +524,10 @@ size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L);
  * [C x L] x [L x Ci] GEMM over a gradient that is zero everywhere except at the C*M gathered positions of a cloud. */
 int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
                            float *gw_partial, sonet_stream_t stream);
+/* ... with normalise-on-load of x (see sonet_pointmlp_h3_stats_xaff_f32): x holds the RAW output of a BatchNorm layer, the rows are normalised
+ * on their way into the LDS: x = act(raw * xs[ci] + xh[ci]); xs, xh [Ci], xrelu != 0: ReLU. */
+int sonet_pooled_wgrad_xaff_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
+                                float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                            int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
 /* bf16 training path: x read as bfloat16 bits (sonet_pooled_wgrad_xbf16), gradients written as bfloat16 bits (sonet_pooled_dgrad_obf16) */

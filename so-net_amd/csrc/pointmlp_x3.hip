@@ -246,8 +246,37 @@ __global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const doubl
     }
 }
 
+// SEGPOOL (training forward of the first PointNet's last layer when only the pooled map is consumed, models/layers.py:431 +
+// models/networks.py:180-185): the columns are NODE-SORTED (som_sort_group), the output is never stored; the per-node arg-max of every
+// channel leaves through 64-bit keys (orderable(value) << 32 | 0xFFFFFFFF - column: the order of index_max.hip -- bigger value wins,
+// equal values: the smaller column, NaN never, -0 counts as +0) combined by global atomicMax, keys[B][Cout][M] preset to "-1000 at
+// column 0".  The MFMA operands are swapped (D^T = X^T W^T: the same products in the same order), so a lane holds ONE channel for 16
+// of the wave's 32 points and the maximum over a node's points is a chain over registers; the two half-waves meet in one exchange.
+struct SegPoolArgs {
+    const int32_t *ids;                   // [B][L] node of every (sorted) column
+    const int32_t *pos0;                  // [B] sorted position of original column 0 (what a bin nothing beat gathers)
+    unsigned long long *keys;             // [B][Cout][M]
+    float *v0;                            // [B][Cout] the layer's value at column pos0[b]
+    int M;
+};
+constexpr unsigned long long SP_INIT_KEY = (0x3B85FFFFull << 32) | 0xFFFFFFFFull;   // ord(-1000.0f), column 0 (index_max.hip)
+__device__ __forceinline__ unsigned sp_ord_f32(unsigned bits) {   // total order; -0 == +0; NaN -> 0 (never wins)
+    if (bits == 0x80000000u) bits = 0u;
+    const unsigned o = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+    return (bits & 0x7FFFFFFFu) > 0x7F800000u ? 0u : o;
+}
+
+// XAFF (f32-class training forward): the inputs are the RAW outputs of BatchNorm layers whose normalise + ReLU pass was never run;
+// the operand load applies it -- x = act(raw * scale[c] + shift[c]) per input channel, the arithmetic of sonet_channel_affine_act_f32 bit
+// for bit -- so the normalised activations never exist in memory (models/layers.py:60-70, :282-296 between two layers).
+struct XAffArgs {
+    const float *s1, *h1;                 // [C1] (scale, shift) of x1's channels
+    const float *s2, *h2;                 // [C2] of x2's
+    int relu;                             // bit 0: ReLU on x1's channels, bit 1: on x2's
+};
+
 // ZADD: the per-node addend form with its gathers issued BEFORE the K loop (64 registers; instantiated for MT = 4 only).
-template <int MT, int S, bool F16, bool ZADD = false>
+template <int MT, int S, bool F16, bool ZADD = false, bool SEGPOOL = false, bool XAFF = false>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
@@ -257,8 +286,11 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/,
     double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum and sum of squares of the stored output over this workgroup's columns*/,
     const float *__restrict__ zadd /*optional [B][Cout][ZM]: y = act((W x + zadd[b][o][zidx[b][l]]) * scale + shift)*/,
-    const int32_t *__restrict__ zidx /*[B][L], out of range: + 0*/, int ZM)
+    const int32_t *__restrict__ zidx /*[B][L], out of range: + 0*/, int ZM, const SegPoolArgs sp, const XAffArgs xa)
 {
+    static_assert(!SEGPOOL || (F16 && !ZADD), "the pooled form exists in the fp16-split arithmetic only");
+    static_assert(!XAFF || (F16 && !ZADD), "normalise-on-load exists in the fp16-split arithmetic only");
+    __shared__ __attribute__((aligned(16))) float2 xaff_t[XAFF ? 1024 : 1];     // (XAFF) per input channel (scale, shift), x1's first; past Cin: (0, 0)
     constexpr int NTW = F16 ? 2 : 3;                          // W slices per (chunk, tile): fp16 terms h and m share one
     constexpr int NSL = S * MT * NTW;                         // 1 KiB W slices per stage
     constexpr int NS = (NSL + X3_WAVES - 1) / X3_WAVES;
@@ -300,6 +332,12 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
 
     const int KC1 = C2 > 0 ? (C1 >> 4) : KC;                  // chunks fed by x1 (C1 % 16 == 0 when x2 exists)
     const int nstage = (KC + S - 1) / S;
+    // (SEGPOOL) node of this lane's column (both half-waves hold the wave's 32 columns), position of original column 0 relative to the wave
+    int sp_nid = -1, sp_p0rel = -1;
+    if constexpr (SEGPOOL) {
+        if (pv) sp_nid = sp.ids[b * L + l0 + j];
+        sp_p0rel = wave_valid ? sp.pos0[b] - l0 : -1;
+    }
 
     auto load_b = [&](float (&raw)[S][8], int st) {
 #pragma unroll
@@ -321,6 +359,10 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const int ct_end = min(CT, ct_begin + ct_per_y);
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
         affine[o - ct_begin * 32] = make_float2(F16 ? scale[o] * 0.03125f : scale[o], shift[o]);   // fp16: accumulators hold 32 W.x
+    if constexpr (XAFF) {                                       // (published by the barrier in front of the first stage)
+        for (int c = threadIdx.x; c < KC * 16; c += X3_THREADS)
+            xaff_t[c] = c < C1 ? make_float2(xa.s1[c], xa.h1[c]) : (c - C1 < C2 ? make_float2(xa.s2[c - C1], xa.h2[c - C1]) : make_float2(0.f, 0.f));
+    }
 
     RangeAcc xr = {0, 0u};
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
@@ -362,11 +404,28 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             for (int t = 0; t < NS; ++t)
                 wsm[slot][wave + t * X3_WAVES][lane] = __builtin_bit_cast(uint4, w[t]);
         };
-        auto compute = [&](const float (&raw)[S][8], int slot) {
+        auto compute = [&](const float (&raw_in)[S][8], int slot, int st) {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 unsigned bh[4], bm[4], bl[4];
                 if constexpr (F16) {
+                    float raw[S][8];
+                    if constexpr (XAFF) {
+                        // this lane's 8 channels of the chunk: 16 kc + 8 h + t (x1's channels first: C1 % 16 == 0 with a second input)
+                        const int kc = st * S + i;
+                        const float4 *tp = reinterpret_cast<const float4 *>(&xaff_t[kc * 16 + 8 * h]);
+                        const bool rl = ((kc >= KC1 ? xa.relu >> 1 : xa.relu) & 1) != 0;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const float4 c = tp[p];
+                            float v0 = __fmaf_rn(raw_in[i][2 * p], c.x, c.y), v1 = __fmaf_rn(raw_in[i][2 * p + 1], c.z, c.w);
+                            if (rl) { v0 = (v0 < 0.f) ? 0.f : v0; v1 = (v1 < 0.f) ? 0.f : v1; }
+                            raw[i][2 * p] = v0; raw[i][2 * p + 1] = v1;
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) raw[i][t] = raw_in[i][t];
+                    }
                     if (track) {                                         // wave-uniform: first output-tile group of slab 0 only
 #pragma unroll
                         for (int p = 0; p < 4; ++p) range_track(xr, raw[i][2 * p], raw[i][2 * p + 1]);
@@ -377,6 +436,20 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     const f16x8 Bm = __builtin_bit_cast(f16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));     // 32 * residual
                     const f16x8 Bl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));     // xh
                     f16x8 Ah[MT];
+                    if constexpr (SEGPOOL) {
+                        // D^T = X^T W^T: the fragment registers are the same (A lane l: row l & 31, k = 8 (l >> 5) ..; B lane l: column
+                        // l & 31, same k), every accumulator sees the same three products in the same order
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            Bl, __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 2 + 1][lane]), acc[mt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            Ah[mt] = __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 2 + 0][lane]);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bm, Ah[mt], acc[mt], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Ah[mt], acc[mt], 0, 0, 0);
+                    } else {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                         __builtin_bit_cast(f16x8, wsm[slot][(i * MT + mt) * 2 + 1][lane]), Bl, acc[mt], 0, 0, 0);
@@ -387,9 +460,10 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bh, acc[mt], 0, 0, 0);
+                    }
                 } else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) split3_pair(raw[i][2 * p], raw[i][2 * p + 1], bh[p], bm[p], bl[p]);
+                for (int p = 0; p < 4; ++p) split3_pair(raw_in[i][2 * p], raw_in[i][2 * p + 1], bh[p], bm[p], bl[p]);
                 const bf16x8 Bh = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                 const bf16x8 Bm = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
                 const bf16x8 Bl = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
@@ -423,7 +497,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             stage_write(wreg, (slot) ^ 1);                                   \
             stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
             load_b(bnxt, (st) + 1);                                          \
-            compute(bcur, slot);                                             \
+            compute(bcur, slot, st);                                         \
         }
         int st = 0;
         for (; st + 2 <= nstage; st += 2) {
@@ -433,7 +507,55 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         if (st < nstage) X3_STAGE(st, b0, b1, 0)
 #undef X3_STAGE
 
-        if (stats_partial != nullptr) {
+        if constexpr (SEGPOOL) {
+            // acc[mt][r] = Y[point prow(r) = (r & 3) + 8 (r >> 2) + 4 h of the wave's 32][channel 32 (ct0 + mt) + j]
+            if ((unsigned)sp_p0rel < 32u) {                      // wave-uniform: the group that holds original column 0
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float2 ss = affine[(ct0 + mt - ct_begin) * 32 + j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h == sp_p0rel) {
+                            float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                            if (relu) v = (v < 0.f) ? 0.f : v;
+                            sp.v0[(size_t)b * Cout + (ct0 + mt) * 32 + j] = v;
+                        }
+                }
+            }
+            unsigned remaining = (unsigned)__ballot(pv);         // lanes 0..31 <-> the wave's 32 columns
+            while (remaining != 0u) {                            // one turn per node present (ids are sorted: a node's points are the rows [s0, s0 + nrows))
+                const int s0 = __builtin_ctz(remaining);
+                const int node = __builtin_amdgcn_readlane(sp_nid, s0);
+                const unsigned segmask = (unsigned)__ballot(pv && sp_nid == node);
+                remaining &= ~segmask;
+                if ((unsigned)node >= (unsigned)sp.M) continue;  // an id outside [0, M): nobody's column (index_max.hip ignores it too)
+                const unsigned nrows = (unsigned)__builtin_popcount(segmask);
+                const int trel = 4 * h - s0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float2 ss = affine[(ct0 + mt - ct_begin) * 32 + j];
+                    float m = -__builtin_inff();
+                    int p = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {               // ascending point order, strict '>': the first of equal values stays
+                        const int orow = (r & 3) + 8 * (r >> 2);
+                        float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                        if (relu) v = (v < 0.f) ? 0.f : v;
+                        const bool take = (unsigned)(trel + orow) < nrows && v > m;      // (a NaN fails the compare: it never wins)
+                        m = take ? v : m;
+                        p = take ? orow + 4 * h : p;
+                    }
+                    const float mo = __shfl_xor(m, 32, 64);      // the other half-wave's 16 points
+                    const int po = __shfl_xor(p, 32, 64);
+                    if (mo > m || (mo == m && po < p)) { m = mo; p = po; }
+                    if (h == 0 && m > -__builtin_inff()) {
+                        const unsigned long long key = ((unsigned long long)sp_ord_f32(__float_as_uint(m)) << 32) |
+                                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)(l0 + p));
+                        atomicMax(sp.keys + ((size_t)b * Cout + (ct0 + mt) * 32 + j) * sp.M + node, key);
+                    }
+                }
+            }
+        } else if (stats_partial != nullptr) {
             // Training forward: BatchNorm's batch statistics (models/layers.py:60-70) of the output come out of this epilogue instead of
             // a second pass over the tensor.  A row's 32 columns sit in the 32 lanes of a half wave: four DPP adds + one swizzle per
             // quantity, all lanes active (a padded column stores to an out-of-range offset -- dropped by the descriptor -- and adds 0).
@@ -946,11 +1068,18 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                        const float *scale, const float *shift, int relu, float *y,
                        int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
                        double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr,
-                       const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0, unsigned *kmax = nullptr, int KM = 0)
+                       const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0, unsigned *kmax = nullptr, int KM = 0,
+                       const SegPoolArgs *segpool = nullptr, const XAffArgs *xaff = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
-    SONET_REQUIRE(x1 && Wp3 && scale && shift && (y || kmax), "%s: NULL pointer", what);
+    SONET_REQUIRE(x1 && Wp3 && scale && shift && (y || kmax || segpool), "%s: NULL pointer", what);
+    SONET_REQUIRE(!segpool || (f16 && !gidx && !stats_ws && !zadd && !kmax), "%s: the pooled form takes the plain fp16-split layer only", what);
+    const SegPoolArgs sp = segpool ? *segpool : SegPoolArgs{nullptr, nullptr, nullptr, nullptr, 0};
+    SONET_REQUIRE(!xaff || (f16 && !gidx && !zadd && !kmax && xaff->s1 && xaff->h1 && ((C2 == 0) || (xaff->s2 && xaff->h2))),
+                  "%s: normalise-on-load takes the plain fp16-split layer and a (scale, shift) pair per input panel", what);
+    if (xaff && (C1 + C2 > 1024 || (Cout / 32) % 4 != 0)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: normalise-on-load needs Cin <= 1024 and Cout %% 128 == 0", what);
+    const XAffArgs xa = xaff ? *xaff : XAffArgs{nullptr, nullptr, nullptr, nullptr, 0};
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
     SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
@@ -1014,7 +1143,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         return sonet::launched(what);
     }
 #endif
-    if (f16 && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
+    if (!segpool && !xaff && f16 && CT % H3R_MT == 0 && (kmax || (eg ? atoi(eg) != 0 : (h3r_pick && !zadd)))) {
         // output-channel slabs: the divisor d of the CT / 4 tile groups that needs the fewest rounds of (2 workgroups per CU)
         // x (groups per workgroup); ties go to the larger d (shorter workgroups)
         int dev = 0, cus = 256;
@@ -1060,6 +1189,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         if (want == 1 || want == 2) S = want;
     }
     if (KC == 1) S = 1;
+    if (xaff && MT != 6) MT = 4;
     int ysplit = 1;
     while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
     while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
@@ -1070,7 +1200,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
@@ -1081,9 +1211,30 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         const int cpy = CT / (int)gz.y;
         if (CT % (int)gz.y == 0 && cpy % 4 == 0 && cpy <= 32) {
             hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, true>), gz, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups,
-                               CT, KC, cpy, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM);
+                               CT, KC, cpy, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa);
             return sonet::launched(what);
         }
+    }
+    if (xaff) {                                                  // (MT is 6 or 4 here: Cout % 128 == 0)
+        if (segpool) {
+            if (MT == 6) hipLaunchKernelGGL((pointmlp_x3_kernel<6, 1, true, false, true, true>), X3_ARGS);
+            else         hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, false, true, true>), X3_ARGS);
+            return sonet::launched(what);
+        }
+        if (MT == 6) hipLaunchKernelGGL((pointmlp_x3_kernel<6, 1, true, false, false, true>), X3_ARGS);
+        else         hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, false, false, true>), X3_ARGS);
+        if (stats_ws) sonet::launch_stats_finalize(stats_ws, (int)nwg_x, Cout, 1.0 / ((double)B * L), mean, var, st);
+        return sonet::launched(what);
+    }
+    if (segpool) {
+        // (one K chunk per stage, as the storing launch of the same shape)
+        switch (MT) {
+            case 6: hipLaunchKernelGGL((pointmlp_x3_kernel<6, 1, true, false, true>), X3_ARGS); break;
+            case 4: hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, false, true>), X3_ARGS); break;
+            case 2: hipLaunchKernelGGL((pointmlp_x3_kernel<2, 1, true, false, true>), X3_ARGS); break;
+            default: hipLaunchKernelGGL((pointmlp_x3_kernel<1, 1, true, false, true>), X3_ARGS);
+        }
+        return sonet::launched(what);
     }
     switch (MT) {
         case 6: X3_LAUNCH(6); break;
@@ -1106,6 +1257,66 @@ extern "C" int sonet_pointmlp_h3_nodeadd_f32(const float *x1, int C1, const floa
     SONET_REQUIRE(zadd && zidx && ZM > 0, "sonet_pointmlp_h3_nodeadd_f32: NULL pointer or ZM <= 0");
     return x3_run_impl("sonet_pointmlp_h3_nodeadd_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
                        nullptr, nullptr, nullptr, zadd, zidx, ZM);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void segpool_init_kernel(unsigned long long *__restrict__ keys, long long n)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) keys[t] = SP_INIT_KEY;
+}
+// keys -> (column, value): the epilogue of index_max_kernel (index_max.hip) on the combined keys.  A bin nothing beat (an empty node,
+// or nothing above -1000) and a masked node report original column 0 -- sorted position pos0[b] -- and the layer's value there.
+__global__ __launch_bounds__(256) void segpool_decode_kernel(const unsigned long long *__restrict__ keys, const float *__restrict__ v0,
+                                                              const int32_t *__restrict__ pos0, const int32_t *__restrict__ row_max,
+                                                              int32_t *__restrict__ out_idx, float *__restrict__ out_val, int Cout, int M, long long n)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const long long bc = t / M;
+    const int m = (int)(t - bc * M);
+    const long long b = bc / Cout;
+    const unsigned long long key = keys[t];
+    const bool won = key != SP_INIT_KEY && (row_max == nullptr || row_max[b * M + m] != 0);
+    const unsigned okey = (unsigned)(key >> 32);
+    out_idx[t] = won ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : pos0[b];
+    out_val[t] = won ? __uint_as_float((okey & 0x80000000u) ? (okey ^ 0x80000000u) : ~okey) : v0[bc];
+}
+}  // namespace
+
+extern "C" size_t sonet_pointmlp_h3_segpool_ws_size(int B, int Cout, int M)
+{
+    if (B <= 0 || Cout <= 0 || M <= 0) return 0;
+    return (size_t)B * Cout * M * sizeof(unsigned long long) + (size_t)B * Cout * sizeof(float);
+}
+
+/* The fp16-split layer and the per-node arg-max pool of its output in ONE pass over NODE-SORTED columns; the output itself is never
+ * written (models/layers.py:431 + models/networks.py:180-185 in training, when only the pooled map is consumed).  ids_sorted [B][L] i32
+ * non-decreasing per cloud, pos0 [B] = sorted position of original column 0, row_max [B][M] or NULL.  out_idx [B][Cout][M] = winning
+ * SORTED column (pos0[b] where nothing beat -1000 or the node is masked), out_val = the layer's value there: what sonet_pointmlp_h3_f32
+ * + sonet_index_max_gather_f32 report on the sorted tensor, with position 0 of the original order in place of position 0. */
+extern "C" int sonet_pointmlp_h3_segpool_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                             const float *shift, int relu, const int32_t *ids_sorted, const int32_t *pos0,
+                                             const int32_t *row_max, int M, void *ws, int32_t *out_idx, float *out_val,
+                                             int B, int Cout, int L, const float *xs1, const float *xh1, const float *xs2, const float *xh2,
+                                             int xrelu, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_h3_segpool_f32";
+    SONET_REQUIRE(ids_sorted && pos0 && ws && out_idx && out_val, "%s: NULL pointer", what);
+    SONET_REQUIRE(B > 0 && Cout > 0 && M > 0 && L > 0, "%s: non-positive size", what);
+    const long long n = (long long)B * Cout * M;
+    if (n > 0x7FFFFFFFll * 256) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too many bins", what);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ws);
+    float *v0 = reinterpret_cast<float *>(keys + n);
+    hipStream_t st = sonet::as_stream(stream);
+    hipLaunchKernelGGL(segpool_init_kernel, dim3((unsigned)sonet::ceil_div64(n, 256)), dim3(256), 0, st, keys, n);
+    const SegPoolArgs sp = {ids_sorted, pos0, keys, v0, M};
+    const XAffArgs xa = {xs1, xh1, xs2, xh2, xrelu};
+    const int rc = x3_run_impl(what, true, x1, C1, x2, C2, Wp3, scale, shift, relu, nullptr, B, Cout, L, stream, nullptr, 0,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &sp, xs1 ? &xa : nullptr);
+    if (rc != SONET_OK) return rc;
+    hipLaunchKernelGGL(segpool_decode_kernel, dim3((unsigned)sonet::ceil_div64(n, 256)), dim3(256), 0, st, keys, v0, pos0, row_max, out_idx, out_val, Cout, M, n);
+    return sonet::launched(what);
 }
 
 #ifdef SONET_VARIANTS   // (max over the neighbour planes from the layer epilogue: measured slower than layer + planes_max; variants build only)
@@ -1154,6 +1365,20 @@ extern "C" int sonet_pointmlp_h3_stats_f32(const float *x1, int C1, const float 
     SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_h3_stats_f32: NULL pointer");
     return x3_run_impl("sonet_pointmlp_h3_stats_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
                        reinterpret_cast<double *>(stats_ws), mean, var);
+}
+
+/* sonet_pointmlp_h3_stats_f32 on inputs that are the RAW outputs of BatchNorm layers: x = act(raw * xs[c] + xh[c]) is applied by the operand
+ * load (xs1 / xh1 [C1], xs2 / xh2 [C2] or NULL without x2; xrelu bit 0 / 1: ReLU on x1's / x2's channels), as sonet_channel_affine_act_f32
+ * would have computed it.  Cin <= 1024, Cout % 128 == 0. */
+extern "C" int sonet_pointmlp_h3_stats_xaff_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,
+                                                const float *shift, int relu, float *y, int B, int Cout, int L, void *stats_ws,
+                                                float *mean, float *var, const float *xs1, const float *xh1, const float *xs2, const float *xh2,
+                                                int xrelu, sonet_stream_t stream)
+{
+    SONET_REQUIRE(stats_ws && mean && var && xs1 && xh1, "sonet_pointmlp_h3_stats_xaff_f32: NULL pointer");
+    const XAffArgs xa = {xs1, xh1, xs2, xh2, xrelu};
+    return x3_run_impl("sonet_pointmlp_h3_stats_xaff_f32", true, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                       reinterpret_cast<double *>(stats_ws), mean, var, nullptr, nullptr, 0, nullptr, 0, nullptr, &xa);
 }
 
 extern "C" int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3, const float *scale,

@@ -1153,10 +1153,13 @@ template <typename TX> struct PwR { static constexpr int value = sizeof(TX) == 4
                                                              // 15000 columns (bf16 pairs, single f32 rows) -- two workgroups per CU
 constexpr int PW_M = 64;                                     // entries per output channel kept in registers (M <= PW_M)
 constexpr int PW_T = 768;                                    // threads: two per output channel (C <= 384), each with half of the M entries
+// xs / xh (f32 rows only): x holds the RAW output of a BatchNorm layer; the copy into LDS applies act(raw * xs[ci] + xh[ci]) -- what
+// sonet_channel_affine_act_f32 would have stored -- so the gathers see the normalised activations that were never written.
 template <typename TX>
 __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restrict__ g, const int32_t *__restrict__ pos,
                                                             const TX *__restrict__ x, int C, int M, int Ci, int L,
-                                                            float *__restrict__ out)
+                                                            float *__restrict__ out, const float *__restrict__ xs = nullptr,
+                                                            const float *__restrict__ xh = nullptr, int xrelu = 0)
 {
     // rows in the storage type: bf16 rows stay bf16 in LDS (widened on the read) -- 60 KB per pair of 15000-column rows instead of 120,
     // so two workgroups share a CU and one multiplies while the other loads (round 3 widened on the way in: one workgroup per CU,
@@ -1190,7 +1193,26 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
         const TX *xb = x + ((size_t)b * Ci + ci0) * L;
         __syncthreads();                                                  // the previous pair has been consumed
         const size_t nbytes = (size_t)nr * L * sizeof(TX);
-        if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
+        bool copied = false;
+        if constexpr (sizeof(TX) == 4) {
+            if (xs != nullptr) {                                          // (PW_R == 1: the row is channel ci0)
+                const float sc = xs[ci0], sh = xh[ci0];
+                auto act = [&](float v) { v = __fmaf_rn(v, sc, sh); return (xrelu && v < 0.f) ? 0.f : v; };
+                if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
+                    const float4 *x4 = reinterpret_cast<const float4 *>(xb);
+                    float4 *r4 = reinterpret_cast<float4 *>(rows);
+                    for (int i = threadIdx.x; i < (int)(nbytes >> 4); i += blockDim.x) {
+                        const float4 t = x4[i];
+                        r4[i] = make_float4(act(t.x), act(t.y), act(t.z), act(t.w));
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = act(xb[i]);
+                }
+                copied = true;
+            }
+        }
+        if (copied) {
+        } else if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
             const uint4 *x4 = reinterpret_cast<const uint4 *>(xb);
             uint4 *r4 = reinterpret_cast<uint4 *>(rows);
             for (int i = threadIdx.x; i < (int)(nbytes >> 4); i += blockDim.x) r4[i] = x4[i];
@@ -1222,7 +1244,7 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
 
 template <typename TX>
 static int pooled_wgrad_impl(const char *what, const float *g_pooled, const int32_t *pos, const TX *x, int B, int C, int M, int Ci, int L,
-                             float *gw_partial, sonet_stream_t stream)
+                             float *gw_partial, sonet_stream_t stream, const float *xs = nullptr, const float *xh = nullptr, int xrelu = 0)
 {
     SONET_REQUIRE(g_pooled && pos && x && gw_partial, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && Ci > 0 && L > 0 && B <= 65535, "%s: bad size B=%d C=%d M=%d Ci=%d L=%d", what, B, C, M, Ci, L);
@@ -1233,8 +1255,17 @@ static int pooled_wgrad_impl(const char *what, const float *g_pooled, const int3
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pooled_wgrad_kernel<TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sonet::fail(SONET_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
     hipLaunchKernelGGL(pooled_wgrad_kernel<TX>, dim3((unsigned)sonet::ceil_div(Ci, PW_ROWS), (unsigned)B), dim3(PW_T), lds, sonet::as_stream(stream),
-                       g_pooled, pos, x, C, M, Ci, L, gw_partial);
+                       g_pooled, pos, x, C, M, Ci, L, gw_partial, xs, xh, xrelu);
     return sonet::launched(what);
+}
+
+/* sonet_pooled_wgrad_f32 when x is the RAW output of a BatchNorm layer (normalise-on-load, see sonet_pointmlp_h3_stats_xaff_f32): the rows
+ * are normalised on their way into the LDS: x = act(raw * xs[ci] + xh[ci]); xs, xh [Ci]. */
+extern "C" int sonet_pooled_wgrad_xaff_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,
+                                           float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream)
+{
+    SONET_REQUIRE(xs && xh, "sonet_pooled_wgrad_xaff_f32: NULL pointer");
+    return pooled_wgrad_impl<float>("sonet_pooled_wgrad_xaff_f32", g_pooled, pos, x, B, C, M, Ci, L, gw_partial, stream, xs, xh, xrelu);
 }
 
 extern "C" int sonet_pooled_wgrad_f32(const float *g_pooled, const int32_t *pos, const float *x, int B, int C, int M, int Ci, int L,

@@ -61,10 +61,14 @@ __device__ __forceinline__ void wg_load16(const float *__restrict__ row, bool ro
     }
 }
 
-template <bool FULL /*every tile of every block exists: no guards in the step*/>
+// XAFF: x is the RAW output of a BatchNorm layer whose normalise + ReLU pass was never run -- the split of the x operand applies
+// x = act(raw * xs[c] + xh[c]) first, the arithmetic of sonet_channel_affine_act_f32 bit for bit (a lane's 16 floats are one row: one
+// coefficient pair per lane).  Columns past L need no mask: g is zero there.
+template <bool FULL /*every tile of every block exists: no guards in the step*/, bool XAFF = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
     const float *__restrict__ g, const float *__restrict__ x, float *__restrict__ partial,
-    int Cout, int Cin, int L, int nL /*32-column units per cloud*/, long long units /*B * nL*/, int nsplit, int oblocks, int cblocks)
+    int Cout, int Cin, int L, int nL /*32-column units per cloud*/, long long units /*B * nL*/, int nsplit, int oblocks, int cblocks,
+    const float *__restrict__ xs = nullptr, const float *__restrict__ xh = nullptr, int xrelu = 0)
 {
     __shared__ uint4 apieces[2][4][3][64];                      // [buffer][g tile][piece h, m, l][lane]: 2 x 12 KiB
 
@@ -85,6 +89,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
     // guards): a 64 x 6 gradient would spend 15/16 of its MFMAs on zero rows.
     const int n_ot = FULL ? 4 : min(4, (Cout - ob * WG_BLK + 31) >> 5);
     const bool c_tile = FULL || cb * WG_BLK + wave * 32 < Cin;
+    float xsc = 0.f, xsh = 0.f;                                 // (a row past Cin: act(0 * 0 + 0) = 0)
+    if constexpr (XAFF) { if (c_ok) { xsc = xs[c_row]; xsh = xh[c_row]; } }
 
     f32x16 acc[4];
 #pragma unroll
@@ -97,6 +103,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
         const int l = (int)(u - (long long)b * nL) * WG_UNIT + 16 * h;
         wg_load16(g + ((size_t)b * Cout + (o_ok ? o_row : 0)) * L, o_ok, l, L, vec, ra);
         wg_load16(x + ((size_t)b * Cin + (c_ok ? c_row : 0)) * L, c_ok, l, L, vec, rb);
+    };
+    auto split8x = [&](const float (&raw)[16], int s, uint4 (&pc)[3]) {    // the x operand: (XAFF) normalise + ReLU, then the pieces
+        unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float v0 = raw[8 * s + 2 * p], v1 = raw[8 * s + 2 * p + 1];
+            if constexpr (XAFF) {
+                v0 = __fmaf_rn(v0, xsc, xsh); v1 = __fmaf_rn(v1, xsc, xsh);
+                if (xrelu) { v0 = (v0 < 0.f) ? 0.f : v0; v1 = (v1 < 0.f) ? 0.f : v1; }
+            }
+            wg_split3_pair(v0, v1, ph[p], pm[p], pl[p]);
+        }
+        pc[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        pc[1] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        pc[2] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     };
     auto split8 = [&](const float (&raw)[16], int s, uint4 (&pc)[3]) {     // floats [8 s, 8 s + 8) -> pieces h, m, l
         unsigned ph[4], pm[4], pl[4];
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
         load_unit(u0, ra0, rb0);
         if (u0 + 1 < u1) load_unit(u0 + 1, ra1, rb1);
         split8(ra0, 0, pa);
-        split8(rb0, 0, pb);
+        split8x(rb0, 0, pb);
         int buf = 0;
         // iteration: raw of unit u in (ra_c, rb_c), its step-0 pieces already in (pa, pb), unit u + 1 on its way into (ra_n, rb_n);
         // requests unit u + 2 into (ra_f, rb_f).  (One unit of look-ahead left every 32-column step waiting for memory: 2 us per
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
             step_barrier();                                                              \
             mfmas(buf, pb);                                                              \
             split8(ra_c, 1, pa_n);                                                       \
-            split8(rb_c, 1, pb_n);                                                       \
+            split8x(rb_c, 1, pb_n);                                                      \
             interleave();                                                                \
             buf ^= 1;                                                                    \
             publish(pa_n, buf);                                                          \
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_x3_kernel(
             mfmas(buf, pb_n);                                                            \
             if (more) {                                                                  \
                 split8(ra_n, 0, pa);                                                     \
-                split8(rb_n, 0, pb);                                                     \
+                split8x(rb_n, 0, pb);                                                    \
             }                                                                            \
             interleave();                                                                \
             buf ^= 1;                                                                    \
@@ -480,9 +501,9 @@ extern "C" size_t sonet_wgrad_x3_ws_size(int B, int Cout, int Cin, int L)
     return wg_plan(B, Cout, Cin, L).ws_bytes;
 }
 
-extern "C" int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
+static int wgrad_x3_impl(const char *what, const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L,
+                         const float *xs, const float *xh, int xrelu, sonet_stream_t stream)
 {
-    const char *what = "sonet_wgrad_x3_f32";
     SONET_REQUIRE(g && x && dw && ws, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && Cout > 0 && Cin > 0 && L > 0, "%s: non-positive size", what);
     if ((double)Cout * L * 4.0 >= 8.0e9 || (double)Cin * L * 4.0 >= 8.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
@@ -490,16 +511,30 @@ extern "C" int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, voi
     const long long nwg = (long long)p.oblocks * p.cblocks * p.nsplit;
     if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
     hipStream_t st = sonet::as_stream(stream);
-    if (Cout % WG_BLK == 0 && Cin % WG_BLK == 0)
-        hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
-                           Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
-    else
-        hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws),
-                           Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks);
+    const bool full = Cout % WG_BLK == 0 && Cin % WG_BLK == 0;
+#define WGX_LAUNCH(FF, XX) hipLaunchKernelGGL((wgrad_x3_kernel<FF, XX>), dim3((unsigned)nwg), dim3(WG_THREADS), 0, st, g, x, reinterpret_cast<float *>(ws), \
+                                              Cout, Cin, L, p.nL, p.units, p.nsplit, p.oblocks, p.cblocks, xs, xh, xrelu)
+    if (xs) { if (full) WGX_LAUNCH(true, true); else WGX_LAUNCH(false, true); }
+    else    { if (full) WGX_LAUNCH(true, false); else WGX_LAUNCH(false, false); }
+#undef WGX_LAUNCH
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, reinterpret_cast<const float *>(ws), dw,
                        Cout, Cin, p.nsplit, (size_t)p.oblocks * WG_BLK, p.cblocks * WG_BLK);
     return sonet::launched(what);
+}
+
+extern "C" int sonet_wgrad_x3_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
+{
+    return wgrad_x3_impl("sonet_wgrad_x3_f32", g, x, dw, ws, B, Cout, Cin, L, nullptr, nullptr, 0, stream);
+}
+
+/* The same gradient when x is the RAW output of a BatchNorm layer: the operand split applies x = act(raw * xs[c] + xh[c]) first (xs, xh [Cin];
+ * xrelu: ReLU), exactly what sonet_channel_affine_act_f32 would have stored. */
+extern "C" int sonet_wgrad_x3_xaff_f32(const float *g, const float *x, float *dw, void *ws, int B, int Cout, int Cin, int L,
+                                       const float *xs, const float *xh, int xrelu, sonet_stream_t stream)
+{
+    SONET_REQUIRE(xs && xh, "sonet_wgrad_x3_xaff_f32: NULL pointer");
+    return wgrad_x3_impl("sonet_wgrad_x3_xaff_f32", g, x, dw, ws, B, Cout, Cin, L, xs, xh, xrelu, stream);
 }
 
 extern "C" size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L)

@@ -148,11 +148,14 @@ def _dgrad(g_raw, pack):
     return y if Cp == Ci else y[:, :Ci]
 
 
-def _wgrad(g_raw, x):
-    """sum over clouds of g_raw[b] . x[b]^T  (Cout x Ci, f32).  f32-class modes: ``sonet_wgrad_x3_f32`` (both operands split
+def _wgrad(g_raw, x, xaff=None):
+    """sum over clouds of g_raw[b] . x[b]^T  (Cout x Ci, f32).  xaff = (scale, shift, relu): x holds the RAW output of a BatchNorm layer whose
+    normalise pass was never run (f32-class training, ``ops.H3_NORM_ON_LOAD``): the split-operand kernel normalises on load, whatever the shape.  f32-class modes: ``sonet_wgrad_x3_f32`` (both operands split
     into three bf16 pieces on the matrix cores, partial blocks summed in a fixed order); exact-f32 mode and tiny problems: one
     batched hipBLASLt GEMM (K = L is the long axis); bf16 operands accumulate and come out in f32 (a bf16 per-cloud partial
     would cost three of the eight significand bits)."""
+    if xaff is not None:
+        return _ops.wgrad_x3(g_raw.contiguous().float(), x.contiguous(), xaff=xaff)
     if g_raw.dtype == torch.bfloat16:
         if (_ops.WGRAD_KERNEL and g_raw.is_cuda and x.dtype == torch.bfloat16 and g_raw.shape[0] * g_raw.shape[2] <= 8192
                 and g_raw.shape[1] * x.shape[1] >= 256 * 128 and g_raw.shape[2] % 8 == 0):
@@ -180,6 +183,26 @@ def _wgrad(g_raw, x):
     return torch.bmm(g_raw, x.transpose(1, 2)).sum(0)
 
 
+def _stats_epilogue_ok(x1, wp, Cout):
+    """The training forward takes BatchNorm's batch statistics from the layer kernel's epilogue (big tensors, split-operand / bf16 packs)."""
+    return (_ops.STATS_EPILOGUE and Cout % 32 == 0 and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)
+            and ((wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32)
+                 or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16)))
+
+
+class _Materialise(torch.autograd.Function):
+    """A deferred activation (the RAW output of a BatchNorm layer standing for act(raw * scale + shift), see ``_PointwiseFn`` ``defer``)
+    written out after all: for a consumer without the normalise-on-load form.  The handle's gradient IS the activation's: identity."""
+
+    @staticmethod
+    def forward(ctx, raw, sc, sh, relu):
+        return _ops.channel_affine_act(raw, sc, sh, relu)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, None, None, None
+
+
 class _PointwiseFn(torch.autograd.Function):
     """Differentiable fused layer.  forward: HIP kernels.  backward: two HIP passes turn gy into g_raw (ReLU mask,
     BatchNorm backward: ``sonet_pointwise_bwd_stats/apply``), dgrad = W^T g_raw on the pointmlp kernel, wgrad one
@@ -190,10 +213,15 @@ class _PointwiseFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps, bn_run=None):
+    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps, bn_run=None, xaff=None, defer=False):
+        # xaff = (s1, h1, relu1[, s2, h2, relu2]) ('batch' mode, h3 pack): x1 / x2 are RAW outputs of BatchNorm layers standing for
+        # act(raw * s + h); the operand loads of this layer and of its weight gradient normalise them.  defer: this layer's own
+        # normalise pass is left to ITS consumers -- the first output is raw (standing for the activation: its incoming gradient is the
+        # activation's), followed by (mean, var, sc, sh).
         Cout = weight2d.shape[0]
         dev = x1.device
         ones, zeros = _ops.const_vec(Cout, 1.0, dev), _ops.const_vec(Cout, 0.0, dev)
+        ctx.xaff = xaff
         if mode == 'affine':
             y = _ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
             # mask source: the output itself (y > 0 <=> pre-activation > 0)
@@ -202,9 +230,9 @@ class _PointwiseFn(torch.autograd.Function):
         else:
             # bn_run = (running_mean, running_var, momentum, unbias) or None: the statistics launch below also writes the normalisation
             # coefficients and updates the running statistics (``ops.bn_rider``: one launch instead of three per layer and step)
-            epi = (_ops.STATS_EPILOGUE and Cout % 32 == 0 and x1.shape[0] * x1.shape[2] * Cout * 4 >= (32 << 20)
-                   and ((wp.dtype in (torch.int8, torch.uint8) and x1.dtype == torch.float32)
-                        or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16)))
+            epi = _stats_epilogue_ok(x1, wp, Cout)
+            if xaff is not None and not (epi and wp.dtype == torch.int8):
+                raise RuntimeError("_PointwiseFn: normalise-on-load needs the h3 layer with the statistics epilogue")
             if not epi:
                 raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
             rm, rv, mom, unb = bn_run if bn_run is not None else (None, None, 0.0, 1.0)
@@ -212,24 +240,29 @@ class _PointwiseFn(torch.autograd.Function):
             if epi:
                 # batch statistics out of the layer kernel's epilogue (one pass over raw less; big tensors: the small node-level
                 # ones keep the second-generation kernel, which has no statistics epilogue)
-                raw, mean, var = _ops.pointmlp_stats(x1, wp, ones, bias, False, Cout, x2=x2)
+                raw, mean, var = _ops.pointmlp_stats(x1, wp, ones, bias, False, Cout, x2=x2, xaff=xaff)
             else:
                 mean, var = _ops.channel_stats(raw)
-            y = _ops.channel_affine_act(raw, sc, sh, relu)
+            y = raw if defer else _ops.channel_affine_act(raw, sc, sh, relu)
             ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight2d, sc, sh, raw, mean, invstd, gamma,
                                   zeros)
-            ctx.mark_non_differentiable(mean, var)
+            if defer:
+                ctx.mark_non_differentiable(mean, var, sc, sh)
+            else:
+                ctx.mark_non_differentiable(mean, var)
         # (without this autograd hands backward freshly zero-filled "gradients" of mean and var: two fill launches per layer and step)
         ctx.set_materialize_grads(False)
         ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
         if mode == 'affine':
             return y
+        if defer:
+            return y, mean, var, sc, sh
         return y, mean, var
 
     @staticmethod
     def backward(ctx, gy, *unused):
         if gy is None:                                                    # (the output was not used)
-            return (None,) * 13
+            return (None,) * 15
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
         gy = gy.contiguous()
@@ -256,10 +289,11 @@ class _PointwiseFn(torch.autograd.Function):
         # the weight gradient (HBM-bound) and the input gradient (matrix cores) of a layer are independent: two streams
         ss = _ops.side_stream(g_raw.device) if (ctx.needs_input_grad[2] and (need1 or need2)) else None
         if ctx.needs_input_grad[2]:
+            xa = ctx.xaff
             def _gw():
-                parts = [_wgrad(g_raw, x1)]
+                parts = [_wgrad(g_raw, x1, None if xa is None else xa[:3])]
                 if ctx.has_x2:
-                    parts.append(_wgrad(g_raw, x2))
+                    parts.append(_wgrad(g_raw, x2, None if xa is None else xa[3:6]))
                 return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
             if ss is not None:
                 with ss:
@@ -280,7 +314,7 @@ class _PointwiseFn(torch.autograd.Function):
             g_x1, g_x2 = outs
         if ss is not None:
             ss.join()
-        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None
+        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None, None, None
 
 
 class _PooledLastLayerFn(torch.autograd.Function):
@@ -292,10 +326,39 @@ class _PooledLastLayerFn(torch.autograd.Function):
     scatter-added into it -- exactly what the reference's gather backward does."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M, need_dense=True):
+    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M, need_dense=True, pos0=None, xaff=None):
         Cout = weight2d.shape[0]
         ones = _ops.const_vec(Cout, 1.0, x1.device)
         b = bias.detach().float().contiguous()
+        ctx.pos0 = None
+        ctx.xaff = xaff                       # (sorted form only) x1 / x2 are RAW outputs of BatchNorm layers: see _PointwiseFn
+        if xaff is not None and pos0 is None:
+            raise RuntimeError("_PooledLastLayerFn: normalise-on-load comes with the node-sorted form")
+        if pos0 is not None:
+            # NODE-SORTED columns (the caller ran the hidden layers on som_sort_group's copy; min_idx_i32 = its ids_sorted): the f32-class
+            # layer pools its own output -- neither the B x 384 x kN tensor nor the index_max launch exists.  Positions are sorted
+            # columns (what x1 / x2 are indexed with in the backward); "position 0" of the reference is the sorted position pos0[b]
+            # of original column 0, already in place for bins nothing beat and for empty nodes.
+            if wp.dtype == torch.int8 and _ops.pointmlp_h3_segpool_ok(x1, x2, wp, Cout, M):
+                idx, val = _ops.pointmlp_h3_segpool(x1, wp, ones, b, False, Cout, min_idx_i32, pos0, M, row_max, x2=x2, xaff=xaff)
+            else:
+                # (the weight side of the range guard sent the layer to x3 between the caller's check and here: store + index_max on the
+                #  sorted tensor, "position 0" moved to pos0 by hand)
+                if xaff is not None:
+                    raise RuntimeError("_PooledLastLayerFn: normalise-on-load needs the h3 pack")
+                y = _ops.pointmlp(x1, wp, ones, b, False, Cout, x2=x2)
+                idx0, _ = _ops.index_max_gather(y, min_idx_i32, M, None)
+                Bq = x1.shape[0]
+                at0 = (min_idx_i32[:, :1] == torch.arange(M, device=x1.device, dtype=torch.int32).view(1, M)).unsqueeze(1) & (y[:, :, :1] > -1000.0)
+                never = ((idx0 == 0) & ~at0) | (row_max.unsqueeze(1) == 0)
+                idx = torch.where(never, pos0.view(Bq, 1, 1).expand_as(idx0), idx0).contiguous()
+                val = torch.gather(y, 2, idx.long())
+                del y
+            ctx.save_for_backward(x1, x2, weight2d, idx, row_max)
+            ctx.pos0 = pos0
+            ctx.set_materialize_grads(False)
+            ctx.mark_non_differentiable(idx)
+            return None, val, idx
         if not need_dense and wp.dtype == torch.int16 and _ops.pointmlp_bf16_pool_ok(x1, x2, Cout, M):
             # nobody reads first_pn_out itself (classifier, autoencoder): the layer's epilogue IS the pool -- the B x 384 x kN tensor is
             # neither written nor read back (0.74 GB of HBM traffic each way at B = 64) and the index_max launch is gone; positions and
@@ -317,8 +380,10 @@ class _PooledLastLayerFn(torch.autograd.Function):
         B, C1, L = x1.shape
         C2 = x2.shape[1]
         if g_y is None and g_mm is None:
-            return (None,) * 9
+            return (None,) * 11
         sparse = g_y is None
+        xa = ctx.xaff
+        xa1, xa2 = (None, None) if xa is None else (xa[:3], xa[3:6])
         G = None
         ss = None
         if g_mm is not None:
@@ -342,15 +407,15 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 if ss is not None:
                     with ss:
                         g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()
-                        g_w = ss.keep(torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1), _ops.pooled_wgrad(g_t, gi_t, x2)), dim=1))
+                        g_w = ss.keep(torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1, xa1), _ops.pooled_wgrad(g_t, gi_t, x2, xa2)), dim=1))
                 else:
                     g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()     # B x M x C: coalesced entry loads
-                    g_w = torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1), _ops.pooled_wgrad(g_t, gi_t, x2)), dim=1)
+                    g_w = torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1, xa1), _ops.pooled_wgrad(g_t, gi_t, x2, xa2)), dim=1)
             else:
                 if G is None:
                     G = torch.zeros((B, weight2d.shape[0], L), dtype=x1.dtype, device=x1.device)
                     G.scatter_add_(2, gi.long(), g_mm.to(x1.dtype))
-                g_w = torch.cat((_wgrad(G, x1), _wgrad(G, x2)), dim=1)
+                g_w = torch.cat((_wgrad(G, x1, xa1), _wgrad(G, x2, xa2)), dim=1)
         g_x1 = g_x2 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if sparse:
@@ -371,8 +436,13 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype,
                                                wt_pack=wt_pack)
                 col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
-                g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
-                g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)
+                if ctx.pos0 is None:
+                    g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
+                    g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)
+                else:                                                             # node-sorted columns: original column 0 sits at pos0[b]
+                    p0 = ctx.pos0.long().view(B, 1, 1)
+                    g_x1.scatter_add_(2, p0.expand(B, C1, 1), col0[:, :C1].to(g_x1.dtype).unsqueeze(2))
+                    g_x2.scatter_add_(2, p0.expand(B, C2, 1), col0[:, C1:].to(g_x2.dtype).unsqueeze(2))
             else:
                 packs = _pack_transposed(weight2d, C1, C2)
                 outs = []
@@ -381,7 +451,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 g_x1, g_x2 = outs
         if ss is not None:
             ss.join()
-        return g_x1, g_x2, g_w, g_bias, None, None, None, None, None
+        return g_x1, g_x2, g_w, g_bias, None, None, None, None, None, None, None
 
 
 class _FusedPointwise(_PlainAttrs, nn.Module):
@@ -548,8 +618,12 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             self._affine_gen = getattr(self, '_affine_gen', 0) + 1          # (id() of the tensors can be recycled: count instead)
         return self._affine
 
-    def _run(self, x1, x2, epoch):
-        """x1 (and optional x2): B x C x L contiguous f32 CUDA tensors -> B x Cout x L."""
+    def _run(self, x1, x2, epoch, xaff=None, defer=False):
+        """x1 (and optional x2): B x C x L contiguous f32 CUDA tensors -> B x Cout x L.
+        Training BatchNorm layers of the f32-class first PointNet (``PointResNet.forward_pooled``): ``xaff`` = (s1, h1, relu1[, s2, h2,
+        relu2]) says x1 / x2 are RAW outputs of BatchNorm layers standing for act(raw * s + h) (normalised by this layer's operand loads,
+        or written out first when this layer has no such form); ``defer`` -> ((raw, sc, sh), act_done): this layer's own normalise pass is
+        left to its consumers."""
         relu_fused = self.activation == 'relu'
         norm = self.normalization
         bn = self.norm if norm == 'batch' else None
@@ -565,14 +639,28 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             x1 = x1.to(want)
         if x2 is not None and x2.dtype != want:
             x2 = x2.to(want)
+        if (xaff is not None or defer) and not (train_bn and fuse_act):
+            raise RuntimeError("deferred normalisation is a training-mode BatchNorm + ReLU layer's")
+        if xaff is not None and not (wp.dtype == torch.int8 and _stats_epilogue_ok(x1, wp, self.conv.out_channels)
+                                     and _ops.xaff_ok(x1.shape[1], x2.shape[1] if x2 is not None else 0, self.conv.out_channels)):
+            # (the weight side of the range guard sent this layer to x3 between the caller's check and here, or a shape without the
+            #  normalise-on-load form: its inputs are written out after all)
+            x1 = _Materialise.apply(x1, xaff[0], xaff[1], xaff[2])
+            if x2 is not None:
+                x2 = _Materialise.apply(x2, xaff[3], xaff[4], xaff[5])
+            xaff = None
         if train_bn:
             n = x1.shape[0] * x1.shape[2]
             m = bn.momentum
             # F.batch_norm's running-statistics update rides on the statistics launch of the forward (``ops.bn_rider``) when the buffers allow
             ride = (bn.track_running_stats and m is not None and bn.running_mean is not None and bn.running_mean.is_contiguous()
                     and bn.running_var.is_contiguous() and bn.running_mean.dtype == torch.float32 and bn.running_mean.device == x1.device)
-            y, mean, var = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
-                                              fuse_act, 'batch', bn.eps, (bn.running_mean, bn.running_var, m, n / max(n - 1, 1)) if ride else None)
+            outs = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
+                                      fuse_act, 'batch', bn.eps, (bn.running_mean, bn.running_var, m, n / max(n - 1, 1)) if ride else None,
+                                      xaff, bool(defer))
+            y, mean, var = outs[:3]
+            if defer:
+                y = (y, outs[3], outs[4])
             with torch.no_grad():                                       # F.batch_norm running-stat update
                 if ride:
                     pass
@@ -989,7 +1077,38 @@ class PointResNet(nn.Module):
             self._fused_akey = akey
         return self._fused_w, self._fused_aff
 
-    def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None, need_dense=True):
+    def pooled_sorted_ok(self, x, M):
+        """Training, f32-class arithmetic, nobody reads first_pn_out: the hidden layers may run on NODE-SORTED columns and the last layer
+        pool its own output (``sonet_pointmlp_h3_segpool_f32``).  Decided before any layer runs."""
+        n = len(self.out_channels_list)
+        last = self.layers[n - 1]
+        if not (_ops.POINTMLP_PRECISION == "h3" and _ops.POOLED_TRAIN_EPILOGUE and _ops.H3_SEGPOOL and x.is_cuda and x.dtype == torch.float32):
+            return False
+        if n < 3 or last.normalization is not None or last.activation is not None or not last._fusable():
+            return False
+        c0, ck = self.out_channels_list[0], self.out_channels_list[n - 2]
+        if c0 % 16 != 0 or last.conv.out_channels % 32 != 0 or not 0 < M <= 1024:
+            return False
+        # the pack the layer would pick: h3 (the weight side of the range guard may send it to x3: store + index_max then)
+        return _ops.x3_supported(c0, ck, last.conv.out_channels) and last._h3_ok()
+
+    def norm_on_load_ok(self, x):
+        """f32-class training on node-sorted columns (``pooled_sorted_ok``): the hidden layers may hand their RAW outputs on and leave the
+        normalise + ReLU pass to their consumers' operand loads.  Decided before any layer runs."""
+        n = len(self.out_channels_list)
+        if not (_ops.H3_NORM_ON_LOAD and _ops.WGRAD_KERNEL and _ops.STATS_EPILOGUE and _ops.POINTMLP_PRECISION == "h3" and x.dtype == torch.float32):
+            return False
+        for l in range(n - 1):
+            lay = self.layers[l]
+            if not (lay.normalization == 'batch' and lay.norm.training and lay.activation == 'relu' and lay._fusable()):
+                return False
+            if l >= 1 and not (lay._h3_ok() and _ops.xaff_ok(lay.conv.in_channels, 0, lay.conv.out_channels)
+                               and x.shape[0] * x.shape[2] * lay.conv.out_channels * 4 >= (32 << 20)):
+                return False
+        last = self.layers[n - 1]
+        return _ops.xaff_ok(self.out_channels_list[0], self.out_channels_list[n - 2], last.conv.out_channels)
+
+    def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None, need_dense=True, pos0=None):
         """Training path of the encoder: hidden layers as usual, then the last layer and the per-node arg-max pool as one
         autograd node -> (first_pn_out, first_pn_out_masked_max, gather_index) or None when the layout does not allow it.
         need_dense=False (nobody reads first_pn_out: classifier, autoencoder): where the arithmetic has the kernel for it (bf16) the
@@ -1000,12 +1119,25 @@ class PointResNet(nn.Module):
             return None
         if self.out_channels_list[0] % 16 != 0:                          # decided BEFORE any layer runs (training BN must not run twice)
             return None
-        skip = self.layers[0](x, epoch)
-        t = skip
-        for l in range(1, n - 1):
-            t = self.layers[l](t, epoch)
-        wp = last._packed(skip.shape[1], t.shape[1])
-        return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, bool(need_dense))
+        if pos0 is not None and self.norm_on_load_ok(x):
+            # the normalised activations of the hidden layers are never written: every consumer (next layer, weight gradients, the pooled
+            # last layer and its sparse weight gradient) normalises on load
+            h, _ = self.layers[0]._run(_FusedPointwise._prep(x), None, epoch, defer=True)
+            skip = h
+            for l in range(1, n - 1):
+                h, _ = self.layers[l]._run(h[0], None, epoch, xaff=(h[1], h[2], True), defer=True)
+            wp = last._packed(skip[0].shape[1], h[0].shape[1])
+            if wp.dtype == torch.int8:
+                return _PooledLastLayerFn.apply(skip[0], h[0], last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, False, pos0,
+                                                (skip[1], skip[2], True, h[1], h[2], True))
+            skip, t = _Materialise.apply(skip[0], skip[1], skip[2], True), _Materialise.apply(h[0], h[1], h[2], True)
+        else:
+            skip = self.layers[0](x, epoch)
+            t = skip
+            for l in range(1, n - 1):
+                t = self.layers[l](t, epoch)
+            wp = last._packed(skip.shape[1], t.shape[1])
+        return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, bool(need_dense), pos0)
 
     def forward(self, x, epoch=None):
         self.last_p16 = None

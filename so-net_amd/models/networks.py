@@ -23,6 +23,8 @@ What changes is the data flow of models/networks.py:111-199:
 """
 import math
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -87,6 +89,11 @@ class Transformer(nn.Module):
         if self.opt.dropout > 0.1:
             self.fc2_out = self.dropout2(self.fc2_out)
         return torch.tanh(self.fc3(self.fc2_out, epoch))
+
+
+# Live Segmenter instances of this process: their Model (models/segmenter.py:79-109) reads encoder.first_pn_out per point copy without
+# telling the encoder; a training forward keeps the tensor then (see Encoder._wants_dense; ``encoder.want_first_pn_out = False`` overrides)
+_DENSE_HEADS = weakref.WeakSet()
 
 
 class Encoder(_PlainAttrs, nn.Module):
@@ -227,6 +234,11 @@ class Encoder(_PlainAttrs, nn.Module):
                 _ops.mark_inference(t)
         return out
 
+    def _wants_dense(self):
+        """Does a head read first_pn_out per point copy?  ``want_first_pn_out`` when somebody set it, else: does a Segmenter exist."""
+        v = self.__dict__.get('want_first_pn_out')
+        return bool(v) if v is not None else len(_DENSE_HEADS) > 0
+
     # ---- no-grad node-level stage on the flat column axis (csrc/node_stage.hip) ---------------------------------------------------
     def _node_stage_ok(self, B, M, node_knn_I):
         """KNNModule + final PointNet + global max as five launches on pre-split activations: eval, no autograd, h3 arithmetic, the
@@ -305,9 +317,11 @@ class Encoder(_PlainAttrs, nn.Module):
         fast = sb.assign_sort(xd, snd, opt.k, knn=knn) if fused_pool else None   # no-grad fast path: assignment + node-sorted grouping in two launches (:127-172) ...
         if fast is not None:
             a, g = fast
-        else:
+        elif fused_pool:
             a = sb.assign(xd, opt.k)                                     # :127-128 (ids, counts, sums)
-            g = _ops.som_sort_group(xd, snd, a) if fused_pool else None
+            g = _ops.som_sort_group(xd, snd, a)
+        else:
+            a, g = None, None                                            # (the branch below decides which grouping it wants first)
         if fused_pool:
             # ... -> first PointNet + per-node max-pool in ONE kernel (:175-185)
             sb.node = g["som_node"]
@@ -330,22 +344,44 @@ class Encoder(_PlainAttrs, nn.Module):
             self.__dict__["_stage"] = None
             # (a head that reads the per-point attributes afterwards -- the segmenter -- gets them from this launch: a second som_group
             #  launch for x_decentered / centers was 1 % of the segmenter's step)
-            per_point = bool(getattr(self, 'want_first_pn_out', False))
-            g = _ops.som_group(xd, snd, a, want_centers=per_point, want_decentered=(not use_sn) or per_point, want_augmented=use_sn)   # :140-172
+            train_pooled = torch.is_grad_enabled() and isinstance(self.first_pointnet, PointResNet) and getattr(self, "pooled_backward", True)
+            # who reads first_pn_out densely?  A head that says so (``want_first_pn_out``: segmentation_forward does) -- or, when nobody said
+            # anything and autograd is on, any Segmenter that exists in this process (the reference's own models/segmenter.py Model reads
+            # encoder.first_pn_out after the forward without announcing it: keep its training path whole)
+            per_point = self._wants_dense() if torch.is_grad_enabled() else bool(getattr(self, 'want_first_pn_out', False))
+            # f32-class training, nobody reads first_pn_out: the first PointNet runs on the NODE-SORTED copy of the points (a point-wise
+            # network does not care about the column order; BatchNorm sums the same values) and its last layer pools its own output
+            sorted_pool = (train_pooled and use_sn and not per_point and a is None and self.first_pointnet.pooled_sorted_ok(xd, M)
+                           and int(opt.k) * xd.shape[2] * 384 * 4 < 4e9)
+            if sorted_pool:
+                fast = sb.assign_sort(xd, snd, opt.k)                        # (two launches; the sorted position of a copy = node offset + run start + rank)
+                if fast is not None:
+                    a, g = fast
+                else:
+                    a = sb.assign(xd, opt.k)
+                    g = _ops.som_sort_group(xd, snd, a)
+                self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None, centers=None, x_decentered=None)
+                pn_in = g["x_aug_sorted"]
+            else:
+                if a is None:
+                    a = sb.assign(xd, opt.k)                                 # :127-128 (ids, counts, sums)
+                g = _ops.som_group(xd, snd, a, want_centers=per_point, want_decentered=(not use_sn) or per_point, want_augmented=use_sn)   # :140-172
+                self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None,
+                                  centers=g["centers"], x_decentered=g["x_decentered"])
+                pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
             sb.node = g["som_node"]                                          # :143 cluster mean replaces the nodes
             self.som_node = sb.node
             row_max = g["row_max"]
-            self._lazy = dict(a=a, x=xd, sn=snd, mask=None, min_idx=None,
-                              centers=g["centers"], x_decentered=g["x_decentered"])
-            pn_in = g["x_augmented"] if use_sn else g["x_decentered"]
 
             pooled = None
-            if torch.is_grad_enabled() and isinstance(self.first_pointnet, PointResNet) and getattr(self, "pooled_backward", True):
+            if sorted_pool:
+                pooled = self.first_pointnet.forward_pooled(pn_in, g["ids_sorted"], row_max, M, epoch, need_dense=False, pos0=g["pos0"])
+            elif train_pooled:
                 # training: last layer + arg-max pool as one autograd node (sparse dgrad when only the pooled output is consumed)
                 # (a head that reads first_pn_out densely -- the segmenter -- sets want_first_pn_out; otherwise the tensor is not needed and,
                 #  where the arithmetic has the kernel for it, never written: the pool is the last layer's epilogue)
                 pooled = self.first_pointnet.forward_pooled(pn_in, a.min_idx_i32, row_max, M, epoch,
-                                                            need_dense=bool(getattr(self, 'want_first_pn_out', False)) or not _ops.POOLED_TRAIN_EPILOGUE)
+                                                            need_dense=per_point or not _ops.POOLED_TRAIN_EPILOGUE)
             if pooled is not None:
                 self.first_pn_out, self.first_pn_out_masked_max, _ = pooled
                 if self._first_pn_out is None:
@@ -415,6 +451,7 @@ class Segmenter(_PlainAttrs, nn.Module):
 
     def __init__(self, opt):
         super().__init__()
+        _DENSE_HEADS.add(self)                            # (Encoder._wants_dense)
         self.opt = opt
         self.feature_num = opt.feature_num
         c = 3 + 3 + 3 + 16 + 384 + 384 + self.feature_num * 2

@@ -38,6 +38,11 @@ SIGNATURES = {
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_ws_size": [_i, _i, _i, _i],
     "sonet_pointmlp_bf16_pool": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_pointmlp_h3_segpool_ws_size": [_i, _i, _i],
+    "sonet_pointmlp_h3_segpool_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "sonet_pointmlp_h3_stats_xaff_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sonet_wgrad_x3_xaff_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "sonet_pooled_wgrad_xaff_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "sonet_pack_multi": [_vp, _i, _i, _vp],
     "sonet_pack_multi_kc": [_i, _i],
     "sonet_bn_rider_set": [_vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
@@ -145,6 +150,7 @@ _RESTYPES = {
     "sonet_last_error": ctypes.c_char_p,
     "sonet_pointmlp_pack_size": ctypes.c_size_t,
     "sonet_pointmlp_stats_ws_size": ctypes.c_size_t,
+    "sonet_pointmlp_h3_segpool_ws_size": ctypes.c_size_t,
     "sonet_pointmlp_bf16_stats_ws_size": ctypes.c_size_t,
     "sonet_wgrad_x3_ws_size": ctypes.c_size_t,
     "sonet_wgrad_bf16_ws_size": ctypes.c_size_t,

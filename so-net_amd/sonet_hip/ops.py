@@ -173,6 +173,54 @@ def pointmlp_bf16_pool(x1, wp, scale, shift, relu, Cout, ids, M, row_max=None, x
     return idx, val
 
 
+def pointmlp_h3_segpool_ok(x1, x2, wp, Cout, M):
+    """The shapes ``pointmlp_h3_segpool`` takes: f32 CUDA inputs, an h3 pack, Cout % 32 == 0, C1 % 16 == 0 with a second input."""
+    if not (POOLED_TRAIN_EPILOGUE and H3_SEGPOOL and x1.is_cuda and x1.dtype == torch.float32 and (x2 is None or x2.dtype == torch.float32)
+            and wp.dtype == torch.int8):
+        return False
+    return Cout % 32 == 0 and (x2 is None or x1.shape[1] % 16 == 0) and 0 < M <= 1024
+
+
+def pointmlp_h3_segpool(x1, wp, scale, shift, relu, Cout, ids_sorted, pos0, M, row_max=None, x2=None, xaff=None):
+    """The fp16-split layer and the per-node arg-max pool of its output in one pass over NODE-SORTED columns (``sonet_pointmlp_h3_segpool_f32``);
+    the B x Cout x L output is never written.  ids_sorted B x L i32 (``som_sort_group``), pos0 B i32 = sorted position of original column 0.
+    -> (idx i32, val f32) B x Cout x M: ``index_max_gather(pointmlp(...), ids_sorted, M, row_max)`` with pos0[b] (and the value there) in
+    place of position 0 for bins nothing beat and for masked nodes."""
+    _chk(x1, "x", torch.float32, 3)
+    B, C1, L = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2", torch.float32, 3)
+        if x2.shape[0] != B or x2.shape[2] != L:
+            raise SonetHipError("x2 must be B x C2 x L")
+        C2 = x2.shape[1]
+    if wp.dtype != torch.int8:
+        raise SonetHipError("pointmlp_h3_segpool: an h3 pack")
+    _chk(ids_sorted, "ids_sorted", torch.int32, 2)
+    _chk(pos0, "pos0", torch.int32, 1)
+    if tuple(ids_sorted.shape) != (B, L) or pos0.shape[0] != B:
+        raise SonetHipError("ids_sorted must be B x L and pos0 B")
+    if row_max is not None:
+        _chk(row_max, "row_max", torch.int32, 2)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    dev = _same_device(x1, x2, wp, scale, shift, ids_sorted, pos0, row_max)
+    lib = _lib.load()
+    if wp.numel() != lib.sonet_pointmlp_x3_pack_size(C1 + C2, Cout):
+        raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C1 + C2, Cout))
+    idx = torch.empty((B, Cout, int(M)), dtype=torch.int32, device=dev)
+    val = torch.empty((B, Cout, int(M)), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.sonet_pointmlp_h3_segpool_ws_size(B, Cout, int(M)),), dtype=torch.uint8, device=dev)
+    name = "pointmlph3_segpool_%dx%d_L%d" % (C1 + C2, Cout, L)
+    _range_arm(name)
+    xa = _xaff_args(xaff, C1, C2, dev) if xaff is not None else (None, None, None, None, 0)
+    with _lib.on_device(dev), _timed(name + ("_xaff" if xaff is not None else "")):
+        check(lib.sonet_pointmlp_h3_segpool_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(ids_sorted), ptr(pos0),
+                                                ptr(row_max), int(M), ptr(ws), ptr(idx), ptr(val), B, Cout, L, *xa, stream_ptr()),
+              "sonet_pointmlp_h3_segpool_f32")
+    return idx, val
+
+
 def index_max_gather_p16(planes, index, K, row_max=None):
     """index_max_gather on an activation that exists only as P16 planes (``P16``): values (hi + mid) / 32, the 22-bit values the next
     layer multiplies -> (idx i32, val f32) B x C x K."""
@@ -359,8 +407,9 @@ def node_add_affine_act_(t, z, min_idx_i32, scale, shift, relu):
     return t
 
 
-def wgrad_x3(g, x):
-    """sum_b g[b] . x[b]^T: g B x Cout x L, x B x Cin x L (f32) -> Cout x Cin f32, bf16 x 3 split of both operands on the matrix cores."""
+def wgrad_x3(g, x, xaff=None):
+    """sum_b g[b] . x[b]^T: g B x Cout x L, x B x Cin x L (f32) -> Cout x Cin f32, bf16 x 3 split of both operands on the matrix cores.
+    xaff = (scale, shift, relu): x holds the RAW output of a BatchNorm layer, the operand split applies act(x * scale[c] + shift[c]) first."""
     _chk(g, "g", torch.float32, 3)
     _chk(x, "x", torch.float32, 3)
     dev = _same_device(g, x)
@@ -373,6 +422,17 @@ def wgrad_x3(g, x):
     if g.numel() == 0 or x.numel() == 0:
         return dw.zero_()
     ws = torch.empty((lib.sonet_wgrad_x3_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
+    if xaff is not None:
+        xs, xh, xr = xaff
+        _chk(xs, "xaff scale", torch.float32, 1)
+        _chk(xh, "xaff shift", torch.float32, 1)
+        if xs.numel() != Cin or xh.numel() != Cin:
+            raise SonetHipError("wgrad_x3: xaff needs Cin = %d coefficients" % Cin)
+        _same_device(g, xs, xh)
+        with _lib.on_device(dev), _timed("wgradx3_xaff_%dx%d_L%d" % (Cout, Cin, L)):
+            check(lib.sonet_wgrad_x3_xaff_f32(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, ptr(xs), ptr(xh), int(bool(xr)), stream_ptr()),
+                  "sonet_wgrad_x3_xaff_f32")
+        return dw
     with _lib.on_device(dev), _timed("wgradx3_%dx%d_L%d" % (Cout, Cin, L)):
         check(lib.sonet_wgrad_x3_f32(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_x3_f32")
     return dw
@@ -567,6 +627,11 @@ P16_CHAINS = _os.environ.get("SONET_P16_CHAINS", "1") != "0"
 NODE_STAGE_P16 = _os.environ.get("SONET_NODE_STAGE_P16", "1") != "0"
 # bf16 training: the last layer of the first PointNet + the per-node arg-max pool in one launch, first_pn_out never written (0 = store + index_max)
 POOLED_TRAIN_EPILOGUE = _os.environ.get("SONET_POOLED_TRAIN_EPILOGUE", "1") != "0"
+# f32-class training: the same on node-sorted columns (sonet_pointmlp_h3_segpool_f32; 0 = store + index_max)
+H3_SEGPOOL = _os.environ.get("SONET_H3_SEGPOOL", "1") != "0"
+# ... and the hidden layers of the first PointNet hand their RAW outputs on: normalise + ReLU is applied by the consumers' operand loads
+# (next layer, weight gradient, pooled weight gradient); the normalised activations are never written (0 = a normalise pass per layer)
+H3_NORM_ON_LOAD = _os.environ.get("SONET_H3_NORM_ON_LOAD", "1") != "0"
 WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 
@@ -1122,9 +1187,30 @@ class side_stream:
 STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)
 
 
-def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
+def xaff_ok(C1, C2, Cout):
+    """Shapes the normalise-on-load form of the h3 layer takes (``sonet_pointmlp_h3_stats_xaff_f32`` / the xaff arguments of
+    ``sonet_pointmlp_h3_segpool_f32``)."""
+    return C1 + C2 <= 1024 and Cout % 128 == 0 and (C2 == 0 or C1 % 16 == 0)
+
+
+def _xaff_args(xaff, C1, C2, dev):
+    """xaff = (s1, h1, relu1[, s2, h2, relu2]) -> the C ABI's five arguments."""
+    s1, h1, r1 = xaff[:3]
+    s2, h2, r2 = (xaff[3:6] if len(xaff) >= 6 else (None, None, False))
+    for t, n in ((s1, C1), (h1, C1), (s2, C2), (h2, C2)):
+        if t is None:
+            continue
+        _chk(t, "xaff", torch.float32, 1)
+        if t.numel() != n or t.device != dev:
+            raise SonetHipError("xaff: %d coefficients on %s expected" % (n, dev))
+    if C2 and (s2 is None or h2 is None):
+        raise SonetHipError("xaff: a second input needs its coefficients")
+    return ptr(s1), ptr(h1), ptr(s2), ptr(h2), int(bool(r1)) | (int(bool(r2)) << 1)
+
+
+def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None, xaff=None):
     """pointmlp(...) plus the per-channel (mean, biased var) of its output over (B, L), from the kernel's epilogue.  h3 / x3 packs
-    (f32 storage) only; -> (y, mean, var)."""
+    (f32 storage) only; -> (y, mean, var).  xaff (h3 packs): the inputs are RAW outputs of BatchNorm layers, normalised by the operand load."""
     h3 = wp.dtype == torch.int8
     bf16 = wp.dtype == torch.int16
     if not (h3 or bf16 or wp.dtype == torch.uint8):
@@ -1161,9 +1247,16 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None):
         _range_arm(name)
     fn = lib.sonet_pointmlp_h3_stats_f32 if h3 else lib.sonet_pointmlp_x3_stats_f32
     try:
-        with _lib.on_device(dev), _timed(name):
-            check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
-                     stream_ptr()), "sonet_pointmlp_stats")
+        with _lib.on_device(dev), _timed(name + ("_xaff" if xaff is not None else "")):
+            if xaff is not None:
+                if not h3:
+                    raise SonetHipError("pointmlp_stats: normalise-on-load needs an h3 pack")
+                check(lib.sonet_pointmlp_h3_stats_xaff_f32(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                           ptr(ws), ptr(mean), ptr(var), *_xaff_args(xaff, C1, C2, dev), stream_ptr()),
+                      "sonet_pointmlp_h3_stats_xaff_f32")
+            else:
+                check(fn(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L, ptr(ws), ptr(mean), ptr(var),
+                         stream_ptr()), "sonet_pointmlp_stats")
     finally:
         _rider_done()
     return y, mean, var
@@ -1709,9 +1802,10 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32
     return gx1, gx2
 
 
-def pooled_wgrad(g_pooled_t, pos_i32_t, x):
+def pooled_wgrad(g_pooled_t, pos_i32_t, x, xaff=None):
     """Sparse wgrad of the pooled last layer: g_pooled_t, pos_t B x M x C (TRANSPOSED entries), x B x Ci x L -> g_W C x Ci
-    (= sum over clouds and entries of g * x[:, pos]; per-cloud partials summed in a fixed order)."""
+    (= sum over clouds and entries of g * x[:, pos]; per-cloud partials summed in a fixed order).
+    xaff = (scale, shift, relu) (f32 x): x holds the RAW output of a BatchNorm layer, normalised on its way into the LDS."""
     _chk(g_pooled_t, "g_pooled_t", torch.float32, 3)
     _chk(pos_i32_t, "pos_t", torch.int32, 3)
     _chk(x, "x", dim=3)
@@ -1720,6 +1814,18 @@ def pooled_wgrad(g_pooled_t, pos_i32_t, x):
     Ci, L = x.shape[1], x.shape[2]
     part = torch.empty((B, C, Ci), dtype=torch.float32, device=dev)
     lib = _lib.load()
+    if xaff is not None:
+        xs, xh, xr = xaff
+        _chk(x, "x", torch.float32, 3)
+        _chk(xs, "xaff scale", torch.float32, 1)
+        _chk(xh, "xaff shift", torch.float32, 1)
+        if xs.numel() != Ci or xh.numel() != Ci:
+            raise SonetHipError("pooled_wgrad: xaff needs Ci = %d coefficients" % Ci)
+        _same_device(x, xs, xh)
+        with _lib.on_device(dev), _timed("pooled_wgrad_xaff"):
+            check(lib.sonet_pooled_wgrad_xaff_f32(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), ptr(xs), ptr(xh), int(bool(xr)),
+                                                  stream_ptr()), "sonet_pooled_wgrad_xaff_f32")
+        return part.sum(0)
     fn = lib.sonet_pooled_wgrad_f32 if x.dtype == torch.float32 else lib.sonet_pooled_wgrad_xbf16
     with _lib.on_device(dev), _timed("pooled_wgrad"):
         check(fn(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), stream_ptr()), "sonet_pooled_wgrad")

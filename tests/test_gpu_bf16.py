@@ -561,6 +561,7 @@ def test_training_step_with_pool_epilogue_equals_the_storing_path():
                                                                    som_k=9, som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None,
                                                                    bn_momentum_decay=0.6, classes=40)
                 enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False                      # (said explicitly: a live Segmenter of another test would keep the tensor)
                 synth.fill_state_dict_(enc.state_dict(), 3)
                 synth.fill_state_dict_(cls.state_dict(), 4)
                 enc.to(DEV).train()

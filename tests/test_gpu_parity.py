@@ -554,6 +554,7 @@ def test_pooled_last_layer_node_dense_and_sparse_branches():
             synth.fill_state_dict_(enc.state_dict(), 5)
             enc.to(DEV).train()
             enc.pooled_backward = joint
+            enc.want_first_pn_out = use_dense                         # (a head that reads first_pn_out per point copy says so: the segmenter does)
             feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], True, 0)
             loss = feat.square().mean()
             if use_dense:

@@ -1,0 +1,274 @@
+"""GPU tests of the f32-class training forward's pooled last layer on NODE-SORTED columns (sonet_pointmlp_h3_segpool_f32:
+models/layers.py:431 + models/networks.py:180-185 with models/index_max_ext/index_max_cuda.cu:10-26 as the pool's definition).
+
+Positions: bit-exact.  Values: bit-exact against the storing launch of the same arithmetic (+0 for -0)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import assert_close_rms
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _sorted_case(B, C1, C2, Cout, L, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(B, C1, L, generator=g).to(DEV)
+    x2 = torch.randn(B, C2, L, generator=g).to(DEV) if C2 else None
+    if L >= 8:
+        x1[:, :, 5] = x1[:, :, 3]                                 # exact ties between columns 3 and 5
+        if x2 is not None:
+            x2[:, :, 5] = x2[:, :, 3]
+    W = (torch.randn(Cout, C1 + C2, generator=g) * (C1 + C2) ** -0.5).to(DEV)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    bias[1 % Cout] = -3000.0                                      # a channel that never beats -1000
+    ids = torch.randint(0, M, (B, L), generator=g, dtype=torch.int32)
+    if M > 3:
+        ids[ids == 2] = 3                                          # node 2 is empty
+    if L >= 8:
+        ids[B - 1, 0] = -1                                         # ids nobody owns (sorted: one below, one above the range)
+        ids[B - 1, 1] = M + 5
+    ids = torch.sort(ids, dim=1).values.contiguous()
+    if L >= 8:
+        ids[0, 5] = ids[0, 3]
+        ids[0, 4] = ids[0, 3]                                      # (keeps the row sorted: columns 3..5 in one node -> the tie is inside a node)
+    pos0 = torch.randint(0, L, (B,), generator=g, dtype=torch.int32)
+    row_max = torch.ones(B, M, dtype=torch.int32)
+    row_max[:, 1 % M] = 0                                          # a masked node
+    return x1, x2, W, bias, ids.to(DEV), pos0.to(DEV), row_max.to(DEV)
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L,M", [(64, 64, 256, 384, 15000, 64), (3, 64, 256, 384, 1000, 64), (2, 128, 0, 96, 130, 7),
+                                               (5, 64, 0, 64, 2, 3), (2, 64, 64, 128, 4098, 255), (2, 16, 0, 32, 33, 1)])
+def test_h3_layer_with_sorted_pool_epilogue_equals_layer_then_index_max(B, C1, C2, Cout, L, M):
+    """sonet_pointmlp_h3_segpool_f32 == sonet_pointmlp_h3_f32 followed by sonet_index_max_gather_f32 on the stored tensor: positions and
+    values bit for bit wherever a column beat -1000; bins nothing beat (empty nodes, the -3000 channel), masked nodes: pos0[b] and the
+    layer's value there; ids outside [0, M) ignored; ties: the first column wins."""
+    from sonet_hip import ops
+    x1, x2, W, bias, ids, pos0, row_max = _sorted_case(B, C1, C2, Cout, L, M, B + C1 + Cout + L + M)
+    with ops.precision("h3"):
+        wp = ops.pointmlp_pack(W, "h3")
+        one = ops.const_vec(Cout, 1.0, DEV)
+        assert ops.pointmlp_h3_segpool_ok(x1, x2, wp, Cout, M)
+        y = ops.pointmlp(x1, wp, one, bias, False, Cout, x2=x2)
+        idx_ref, val_ref = ops.index_max_gather(y, ids, M, None)
+        # which bins did something beat -1000 in?
+        valid = (ids >= 0) & (ids < M)
+        tgt = torch.where(valid, ids, torch.full_like(ids, M)).long().unsqueeze(1).expand(B, Cout, L)
+        mx = torch.full((B, Cout, M + 1), float("-inf"), device=DEV).scatter_reduce(2, tgt, y, "amax")[:, :, :M]
+        won0 = mx > -1000.0
+        at0 = torch.gather(y, 2, pos0.long().view(B, 1, 1).expand(B, Cout, M))
+        for rm in (row_max, None):
+            idx, val = ops.pointmlp_h3_segpool(x1, wp, one, bias, False, Cout, ids, pos0, M, rm, x2=x2)
+            won = won0 if rm is None else won0 & (rm.unsqueeze(1) != 0)
+            exp_idx = torch.where(won, idx_ref, pos0.view(B, 1, 1).expand(B, Cout, M))
+            exp_val = torch.where(won, val_ref, at0)
+            assert torch.equal(idx, exp_idx)
+            assert torch.equal(val, exp_val)                      # (== : -0 and +0 compare equal)
+            assert torch.equal(torch.gather(y, 2, idx.long()), val)
+        idx2, val2 = ops.pointmlp_h3_segpool(x1, wp, one, bias, False, Cout, ids, pos0, M, None, x2=x2)
+        assert torch.equal(idx2, idx) and torch.equal(val2, val)  # deterministic (integer max of keys)
+    assert bool((~won0[:, 1 % Cout]).all())                       # the -3000 channel: nothing beat -1000
+
+
+def _opt(B, N):
+    return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024, activation="relu",
+                     normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="avg", bn_momentum=0.1,
+                     bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+
+
+def test_h3_training_step_on_sorted_columns_equals_the_storing_path():
+    """The f32-class training step with the first PointNet on node-sorted columns and the pool in the last layer's epilogue == the step in
+    the original column order that stores first_pn_out and runs index_max on it: the pooled map, the loss, every gradient and the updated
+    BatchNorm statistics agree to f32-class accuracy (the sums run in another order: not bit for bit)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 4, 1500
+    res = {}
+    with ops.precision("h3"):
+        for flag in (True, False):
+            old = ops.H3_SEGPOOL
+            ops.H3_SEGPOOL = flag
+            try:
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False                      # (said explicitly: a live Segmenter of another test would keep the tensor)
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward()
+                names = [n for n, _, _ in rec.records]
+                assert any(n.startswith("pointmlph3_segpool") for n in names) == flag
+                assert any(n.startswith("index_max") for n in names) == (not flag)
+                if flag:
+                    with pytest.raises(AttributeError):
+                        enc.first_pn_out
+                    assert tuple(enc.x_decentered.shape) == (B, 3, 3 * N) and tuple(enc.centers.shape) == (B, 3, 3 * N)   # (lazy attributes)
+                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone(),
+                             enc.som_node.clone())
+            finally:
+                ops.H3_SEGPOOL = old
+    assert_close_rms(res[True][4].cpu().numpy(), res[False][4].cpu().numpy(), 1e-6, "som_node")   # (f64 sums in another order)
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-5 * abs(float(res[False][0]))
+    assert_close_rms(res[True][3].cpu().numpy(), res[False][3].cpu().numpy(), 1e-5, "first_pn_out_masked_max")
+    assert res[True][1].keys() == res[False][1].keys()
+    for k in res[True][1]:
+        # (conv biases in front of a training-mode BatchNorm: true gradient zero, both sides hold rounding noise)
+        if k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3"):
+            continue
+        assert_close_rms(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), 5e-5, k)
+    for k in res[True][2]:
+        assert_close_rms(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), 1e-5, k)
+
+
+def test_sorted_pool_handles_an_empty_node_like_the_reference():
+    """A cloud with an EMPTY node: the reference gathers position 0 of first_pn_out for it (models/networks.py:185) and its gradient flows to
+    original column 0.  On sorted columns that column sits at pos0[b]: same pooled map, same gradients as the storing path."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 2, 700
+    grads = {}
+    with ops.precision("h3"):
+        for flag in (True, False):
+            old = ops.H3_SEGPOOL
+            ops.H3_SEGPOOL = flag
+            try:
+                opt = _opt(B, N)
+                enc = NW.Encoder(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 5)
+                enc.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=21, device=torch.device(DEV))
+                node = inp["node"].clone()
+                node[:, :, 7] = 50.0                               # a node far away from every point: empty
+                feat = enc(inp["pc"], inp["sn"], node, inp["node_knn_I"], True, 0)
+                assert int(enc._lazy["a"].count[:, 7].sum()) == 0     # (nobody chose node 7)
+                mm = enc.first_pn_out_masked_max
+                (feat.square().mean() + mm[:, :, 7].square().mean()).backward()
+                grads[flag] = ({k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}, mm.detach().clone())
+            finally:
+                ops.H3_SEGPOOL = old
+    assert_close_rms(grads[True][1].cpu().numpy(), grads[False][1].cpu().numpy(), 1e-5, "masked max")
+    for k in grads[True][0]:
+        if k.startswith("first_pointnet") and not (k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3")):
+            assert_close_rms(grads[True][0][k].cpu().numpy(), grads[False][0][k].cpu().numpy(), 5e-5, k)
+
+
+# ------------------------------------------------------------------------------------------ normalise-on-load
+def _raw_case(B, C, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = (torch.randn(B, C, L, generator=g) * 1.7 + 0.3).to(DEV)
+    sc = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(C, generator=g) * 0.4).to(DEV)
+    return raw, sc, sh
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,L", [(64, 64, 0, 128, 15000), (16, 128, 0, 256, 4100), (16, 64, 256, 384, 4100), (16, 48, 0, 128, 4099)])
+def test_layer_with_normalise_on_load_equals_layer_on_the_normalised_tensor(B, C1, C2, Cout, L):
+    """sonet_pointmlp_h3_stats_xaff_f32 on RAW inputs == sonet_pointmlp_h3_stats_f32 on sonet_channel_affine_act_f32's output: the
+    operand load does the same fma + ReLU, so the outputs agree bit for bit (and the batch statistics to summation order)."""
+    from sonet_hip import ops
+    r1, s1, h1 = _raw_case(B, C1, L, 1 + C1 + L)
+    r2, s2, h2 = _raw_case(B, C2, L, 2 + C2 + L) if C2 else (None, None, None)
+    gen = torch.Generator().manual_seed(Cout)
+    W = (torch.randn(Cout, C1 + C2, generator=gen) * (C1 + C2) ** -0.5).to(DEV)
+    bias = (torch.randn(Cout, generator=gen) * 0.1).to(DEV)
+    with ops.precision("h3"):
+        wp = ops.pointmlp_pack(W, "h3")
+        one = ops.const_vec(Cout, 1.0, DEV)
+        assert ops.xaff_ok(C1, C2, Cout)
+        y1 = ops.channel_affine_act(r1, s1, h1, True)
+        y2 = ops.channel_affine_act(r2, s2, h2, False) if C2 else None
+        ref = ops.pointmlp_stats(y1, wp, one, bias, False, Cout, x2=y2)
+        xa = (s1, h1, True) + ((s2, h2, False) if C2 else ())
+        got = ops.pointmlp_stats(r1, wp, one, bias, False, Cout, x2=r2, xaff=xa)
+    assert torch.equal(got[0], ref[0])
+    for a, b, n in zip(got[1:], ref[1:], ("mean", "var")):        # (the reference launch may be the second-generation kernel: other partial sums)
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), n
+
+
+@pytest.mark.parametrize("B,Cout,Cin,L", [(64, 128, 64, 15000), (8, 256, 128, 4100), (3, 70, 45, 1001)])
+def test_wgrad_with_normalise_on_load_equals_wgrad_on_the_normalised_tensor(B, Cout, Cin, L):
+    from sonet_hip import ops
+    raw, sc, sh = _raw_case(B, Cin, L, Cout + L)
+    g = (torch.randn(B, Cout, L, generator=torch.Generator().manual_seed(L)) * 1e-3).to(DEV)
+    for relu in (True, False):
+        y = ops.channel_affine_act(raw, sc, sh, relu)
+        assert torch.equal(ops.wgrad_x3(g, raw, xaff=(sc, sh, relu)), ops.wgrad_x3(g, y)), relu
+
+
+@pytest.mark.parametrize("B,C,M,Ci,L", [(64, 384, 64, 64, 15000), (3, 384, 64, 256, 3000), (2, 96, 8, 48, 131)])
+def test_pooled_wgrad_with_normalise_on_load_equals_pooled_wgrad_on_the_normalised_tensor(B, C, M, Ci, L):
+    from sonet_hip import ops
+    raw, sc, sh = _raw_case(B, Ci, L, C + L)
+    gen = torch.Generator().manual_seed(B + L)
+    g_t = torch.randn(B, M, C, generator=gen).to(DEV)
+    pos_t = torch.randint(0, L, (B, M, C), generator=gen, dtype=torch.int32).to(DEV)
+    y = ops.channel_affine_act(raw, sc, sh, True)
+    assert torch.equal(ops.pooled_wgrad(g_t, pos_t, raw, (sc, sh, True)), ops.pooled_wgrad(g_t, pos_t, y))
+
+
+def test_sorted_pool_with_normalise_on_load_equals_sorted_pool_on_the_normalised_tensors():
+    from sonet_hip import ops
+    B, C1, C2, Cout, L, M = 8, 64, 256, 384, 5001, 64
+    _, _, W, bias, ids, pos0, row_max = _sorted_case(B, C1, C2, Cout, L, M, 77)
+    r1, s1, h1 = _raw_case(B, C1, L, 5)
+    r2, s2, h2 = _raw_case(B, C2, L, 6)
+    with ops.precision("h3"):
+        wp = ops.pointmlp_pack(W, "h3")
+        one = ops.const_vec(Cout, 1.0, DEV)
+        y1, y2 = ops.channel_affine_act(r1, s1, h1, True), ops.channel_affine_act(r2, s2, h2, True)
+        ref = ops.pointmlp_h3_segpool(y1, wp, one, bias, False, Cout, ids, pos0, M, row_max, x2=y2)
+        got = ops.pointmlp_h3_segpool(r1, wp, one, bias, False, Cout, ids, pos0, M, row_max, x2=r2, xaff=(s1, h1, True, s2, h2, True))
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+def test_h3_training_step_with_normalise_on_load_equals_the_step_with_normalise_passes():
+    """Same sorted columns, same kernels' arithmetic: only the 128 x 64 weight gradient changes kernels (hipBLASLt -> the split-operand kernel
+    with normalise-on-load), so everything agrees to f32-class accuracy -- and no normalise pass runs on the point-level tensors."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 8, 3000                                                 # (big enough for the statistics epilogue: B x kN x 128 x 4 >= 32 MB)
+    res = {}
+    with ops.precision("h3"):
+        for flag in (True, False):
+            old = ops.H3_NORM_ON_LOAD
+            ops.H3_NORM_ON_LOAD = flag
+            try:
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward()
+                names = [n for n, _, _ in rec.records]
+                assert any(n.endswith("_xaff") for n in names) == flag
+                assert any(n.startswith("pointmlph3_segpool") for n in names)
+                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone())
+            finally:
+                ops.H3_NORM_ON_LOAD = old
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-5 * abs(float(res[False][0]))
+    assert_close_rms(res[True][3].cpu().numpy(), res[False][3].cpu().numpy(), 1e-5, "first_pn_out_masked_max")
+    assert res[True][1].keys() == res[False][1].keys()
+    for k in res[True][1]:
+        if k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3"):
+            continue
+        assert_close_rms(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), 5e-5, k)
+    for k in res[True][2]:
+        assert_close_rms(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), 1e-5, k)
