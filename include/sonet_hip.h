@@ -453,8 +453,10 @@ int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int
 
 /* f32-class twin on NODE-SORTED columns (sonet_som_sort_group_f32: ids_sorted [B][L] i32 non-decreasing per cloud, pos0 [B] = sorted position
  * of original column 0): the fp16-split layer (sonet_pointmlp_h3_f32) and the per-node arg-max pool of its output in one pass; the output is
- * never written.  out_idx [B][Cout][M] = winning SORTED column, first maximum above -1000 in column order -- a stable sort keeps the original
- * order inside a node, so this is the column models/index_max_ext/index_max_cuda.cu:10-26 picks --, pos0[b] where nothing beat -1000 or
+ * never written.  out_idx [B][Cout][M] = winning SORTED column = first maximum above -1000 in sorted column order (what
+ * models/index_max_ext/index_max_cuda.cu:10-26 reports on the sorted tensor; the sort kernels leave the order INSIDE a node to the arrival of
+ * their atomics, so among columns of a node with exactly EQUAL values the winner need not be the one with the lowest original index -- the
+ * pooled value is the same), pos0[b] where nothing beat -1000 or
  * row_max[b][m] == 0 (models/networks.py:185: gather index 0 of the original order); out_val [B][Cout][M] = the layer's value there (bit for
  * bit sonet_pointmlp_h3_f32 + sonet_index_max_gather_f32 on the sorted tensor; -0 reported as +0).  ws: sonet_pointmlp_h3_segpool_ws_size
  * bytes.  Cout % 32 == 0, C1 % 16 == 0 when x2 is given.

@@ -403,7 +403,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
             if sparse and g_mm.shape[1] <= 384 and g_mm.shape[2] <= 64 and L * 8 <= 152 * 1024:
                 # 24,576 entries per cloud instead of a dense GEMM over kN columns (the kernel's limits: C, M, two rows in LDS);
                 # on the side stream: the sparse dgrad below does not depend on it (0.66 + 0.83 ms in sequence otherwise)
-                ss = _ops.side_stream(x1.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+                ss = _ops.side_stream(x1.device) if ((ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and _ops.POOLED_SIDE_STREAM) else None
                 if ss is not None:
                     with ss:
                         g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()

@@ -632,6 +632,8 @@ H3_SEGPOOL = _os.environ.get("SONET_H3_SEGPOOL", "1") != "0"
 # ... and the hidden layers of the first PointNet hand their RAW outputs on: normalise + ReLU is applied by the consumers' operand loads
 # (next layer, weight gradient, pooled weight gradient); the normalised activations are never written (0 = a normalise pass per layer)
 H3_NORM_ON_LOAD = _os.environ.get("SONET_H3_NORM_ON_LOAD", "1") != "0"
+# the sorted training path takes its assignment + node-sorted grouping from the two-launch SOM stage of the no-grad path (0 = som_assign + som_sort_group)
+TRAIN_ASSIGN_SORT = _os.environ.get("SONET_TRAIN_ASSIGN_SORT", "1") != "0"
 WGRAD_KERNEL = _os.environ.get("SONET_WGRAD_KERNEL", "1") != "0"       # 0: torch.bmm (hipBLASLt f32) for the dense weight gradients
 
 
@@ -1143,6 +1145,8 @@ def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
 
 # backward: the weight gradient of a layer does not depend on its input gradient -- the two run on two HIP streams
 BWD_SIDE_STREAM = _os.environ.get("SONET_BWD_SIDE_STREAM", "1") != "0"
+# ... of the pooled last layer in particular: its sparse weight gradient beside its sparse input gradient (0 = one after the other)
+POOLED_SIDE_STREAM = _os.environ.get("SONET_POOLED_SIDE_STREAM", "1") != "0"
 _side_streams = {}
 
 

@@ -74,6 +74,31 @@ def test_h3_layer_with_sorted_pool_epilogue_equals_layer_then_index_max(B, C1, C
     assert bool((~won0[:, 1 % Cout]).all())                       # the -3000 channel: nothing beat -1000
 
 
+def _rel_rms(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).square().mean().sqrt() / b.square().mean().sqrt().clamp_min(1e-30))
+
+
+def _compare_steps(got, ref):
+    """(loss, grads, running statistics, pooled map) of two training steps of the same arithmetic class whose BatchNorm sums ran in
+    different orders.  Forward: f32-class.  Gradients: the network has three arg-max pools (per node, over the K neighbours, over the
+    nodes) and every bin routes its gradient to ONE winner; a 1e-7 change of the forward flips a few of the 10^5 winners, and one flip
+    moves a weight gradient by ~sqrt(2 / bins) rel-rms (tools/grad_dev_h3.py, profiles/r05c_grad_dev_h3.log: the reference's own float32
+    run sits 1e-3 .. 5e-3 from its float64 run for the same reason) -- bounded at that level here; the kernels are pinned bit for bit
+    one by one above."""
+    assert abs(float(got[0]) - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+    assert_close_rms(got[3].cpu().numpy(), ref[3].cpu().numpy(), 1e-5, "first_pn_out_masked_max")
+    assert got[1].keys() == ref[1].keys()
+    for k in got[1]:
+        # (conv biases sit in front of a training-mode BatchNorm -- directly, or through the pools for the first PointNet's last layer --:
+        #  true gradient zero, both sides hold rounding noise)
+        if k.endswith("conv.bias"):
+            continue
+        assert _rel_rms(got[1][k], ref[1][k]) <= 1e-2, (k, _rel_rms(got[1][k], ref[1][k]))
+    for k in got[2]:
+        assert_close_rms(got[2][k].cpu().numpy(), ref[2][k].cpu().numpy(), 1e-5, k)
+
+
 def _opt(B, N):
     return Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024, activation="relu",
                      normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="avg", bn_momentum=0.1,
@@ -118,16 +143,7 @@ def test_h3_training_step_on_sorted_columns_equals_the_storing_path():
             finally:
                 ops.H3_SEGPOOL = old
     assert_close_rms(res[True][4].cpu().numpy(), res[False][4].cpu().numpy(), 1e-6, "som_node")   # (f64 sums in another order)
-    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-5 * abs(float(res[False][0]))
-    assert_close_rms(res[True][3].cpu().numpy(), res[False][3].cpu().numpy(), 1e-5, "first_pn_out_masked_max")
-    assert res[True][1].keys() == res[False][1].keys()
-    for k in res[True][1]:
-        # (conv biases in front of a training-mode BatchNorm: true gradient zero, both sides hold rounding noise)
-        if k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3"):
-            continue
-        assert_close_rms(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), 5e-5, k)
-    for k in res[True][2]:
-        assert_close_rms(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), 1e-5, k)
+    _compare_steps(res[True], res[False])
 
 
 def test_sorted_pool_handles_an_empty_node_like_the_reference():
@@ -159,8 +175,8 @@ def test_sorted_pool_handles_an_empty_node_like_the_reference():
                 ops.H3_SEGPOOL = old
     assert_close_rms(grads[True][1].cpu().numpy(), grads[False][1].cpu().numpy(), 1e-5, "masked max")
     for k in grads[True][0]:
-        if k.startswith("first_pointnet") and not (k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3")):
-            assert_close_rms(grads[True][0][k].cpu().numpy(), grads[False][0][k].cpu().numpy(), 5e-5, k)
+        if k.startswith("first_pointnet") and not k.endswith("conv.bias"):
+            assert _rel_rms(grads[True][0][k], grads[False][0][k]) <= 1e-2, k          # (winner flips: see _compare_steps)
 
 
 # ------------------------------------------------------------------------------------------ normalise-on-load
@@ -263,12 +279,4 @@ def test_h3_training_step_with_normalise_on_load_equals_the_step_with_normalise_
                              {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone())
             finally:
                 ops.H3_NORM_ON_LOAD = old
-    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-5 * abs(float(res[False][0]))
-    assert_close_rms(res[True][3].cpu().numpy(), res[False][3].cpu().numpy(), 1e-5, "first_pn_out_masked_max")
-    assert res[True][1].keys() == res[False][1].keys()
-    for k in res[True][1]:
-        if k.endswith("conv.bias") and not k.startswith("first_pointnet.layers.3"):
-            continue
-        assert_close_rms(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), 5e-5, k)
-    for k in res[True][2]:
-        assert_close_rms(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), 1e-5, k)
+    _compare_steps(res[True], res[False])

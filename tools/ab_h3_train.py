@@ -3,6 +3,8 @@ what bench.py --mode train --precision h3 times) in the variants of round 5, in 
     A  store + index_max        the last layer of the first PointNet writes first_pn_out, index_max pools it (round 4)
     B  sorted pool              the first PointNet on node-sorted columns, the last layer pools its own output (sonet_pointmlp_h3_segpool_f32)
     C  B + normalise-on-load    the hidden layers hand their RAW outputs on; no normalise + ReLU pass, no normalised activations in memory
+    D  C, the sparse weight gradient of the pooled layer AFTER its sparse input gradient (not beside it on the side stream)
+    E  C, no side stream anywhere in the backward
 then one instrumented step of each (per-kernel times by events on the launching stream).
 
   python tools/ab_h3_train.py [--rounds 6] [--steps 24] [--precision h3]"""
@@ -26,13 +28,18 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--precision", default="h3")
+    ap.add_argument("--only", default="", help="letters of the variants to run, e.g. ACD")
+    ap.add_argument("--no-kernels", action="store_true")
     args = ap.parse_args()
     import bench
     from models import networks as NW
     from sonet_hip import dp, host, ops, synth
     dev = torch.device("cuda:0")
     B, N = args.batch, args.points
-    variants = [("A_store_index_max", False, False), ("B_sorted_pool", True, False), ("C_sorted_pool_norm_on_load", True, True)]
+    variants = [("A_store_index_max", False, False, True, True), ("B_sorted_pool", True, False, True, True), ("C_sorted_pool_norm_on_load", True, True, True, True),
+                ("D_C_pooled_pair_in_sequence", True, True, False, True), ("E_C_no_side_stream_at_all", True, True, False, False)]
+    if args.only:
+        variants = [v for v in variants if v[0][0] in args.only]
     with ops.precision(args.precision):
         opt = bench.make_opt(dev, B, N)
         enc, cls = NW.Encoder(opt), NW.Classifier(opt)
@@ -60,7 +67,7 @@ def main():
             return loss
 
         def select(v):
-            ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD = v[1], v[2]
+            ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD, ops.POOLED_SIDE_STREAM, ops.BWD_SIDE_STREAM = v[1], v[2], v[3], v[4]
 
         def window(v):
             select(v)
@@ -87,7 +94,7 @@ def main():
                   % (v[0], statistics.median(w), min(w), base / statistics.median(w), " ".join("%.3f" % x for x in w)))
         # one instrumented step of each variant (events around every C-ABI launch: the step runs serialised by them, the times are
         # the kernels' own)
-        for v in variants:
+        for v in ([] if args.no_kernels else variants):
             select(v)
             step()
             torch.cuda.synchronize()
