@@ -880,7 +880,8 @@ __device__ __forceinline__ void pd_store(uint16_t *p, size_t i, float v) {     /
 }
 template <typename TO>
 __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
-                                                           const float *__restrict__ ent_val, const float *__restrict__ W,
+                                                           const float *__restrict__ ent_val, const float *__restrict__ g_pooled /*[B][E]: the entries' values by id*/,
+                                                           const float *__restrict__ W,
                                                            int E, int M, int Cin, int C1, int L, int nbucket,
                                                            TO *__restrict__ gx1, TO *__restrict__ gx2, int abl /*experiments (variants build): 1 no stores, 2 no accumulation, 4 no sort*/)
 {
@@ -901,32 +902,124 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
     const int nq = sb < nbucket ? tile_off[(size_t)b * (nbucket + 1) + sb + 1] - beg : 0;
     const uint32_t *kb = ent_key + (size_t)b * E + beg;
     const float *vb = ent_val + (size_t)b * E + beg;
+    const float *gb = g_pooled + (size_t)b * E;
     if (i == 0) nq_all[q] = nq;
     __syncthreads();
     int nmax = 0;
 #pragma unroll
     for (int t = 0; t < PD_CQ; ++t) nmax = max(nmax, nq_all[t]);
-    // Every group sorts ITS bucket by (column, entry id) -- rank sort: an entry counts the smaller keys (they are distinct) -- so the order
-    // of the fma chain of an accumulator is fixed whatever order the bucket atomics took; then thread (i, q) applies the group's entries
-    // to channel ch0 + i (no two threads touch the same accumulator).  Buckets beyond PD_SQ entries (never at the benchmark shape) go in
-    // rounds of PD_SQ consecutive RANKS, the keys compared straight from global memory: still one fixed order.
-    const bool small = nq <= PD_SQ;
-    if (small) for (int e = i; e < nq; e += PD_CH) staged[e] = kb[e];
-    for (int base = 0; base < nmax; base += PD_SQ) {
-        __syncthreads();                                                    // staged keys visible / the previous round consumed
-        const int n = min(PD_SQ, max(0, nq - base));
-        for (int e = i; e < nq; e += PD_CH) {
-            const uint32_t key = small ? staged[e] : kb[e];
-            int rank = 0;
-            if (abl & 4) rank = e;
-            else if (small) { for (int t = 0; t < nq; ++t) rank += staged[t] < key; }
-            else       { for (int t = 0; t < nq; ++t) rank += kb[t] < key; }
-            if (rank >= base && rank < base + n) {
-                // per entry, once: the W row offset and the accumulator row (the division by M per (entry, thread) was half of the
-                // kernel's instructions in round 2)
-                keys[rank - base] = (key >> 20) + (uint32_t)(q * PD_SB);    // column inside the tile
-                vals[rank - base] = vb[e];
-                wrow[rank - base] = ((int)(key & 0xFFFFFu) / M) * Cin + ch0;
+    // Every group sorts ITS bucket by (column, entry id), so that the order of the fma chain of an accumulator is fixed whatever order the
+    // bucket atomics took; then thread (i, q) applies the group's entries to channel ch0 + i (no two threads touch the same accumulator).
+    //
+    // Column mode (every column of the bucket holds <= PD_SQ entries: always, except when more than PD_SQ channels of a node pick the
+    // same point): a histogram over the 32 columns, then rounds of WHOLE columns (as many as fit PD_SQ entries); a round's entries are
+    // scattered into their column's segment of an LDS list (any order) and every entry ranks itself among the entries of ITS column
+    // (the keys are distinct): position = segment start + rank.  nq + nq * (entries of a column) / 40 LDS operations per thread instead
+    // of the nq * nq / 40 of a rank over the whole bucket -- on node-sorted columns (the f32-class training forward) a small node
+    // drops its 384 entries into one or two buckets, and the whole-bucket rank sort was 0.77 of the kernel's 1.73 ms there (0.34 of 1.23 ms
+    // in the original column order: tools/bench_pooled_sorted.py).
+    // Rank mode (a column beyond PD_SQ entries): rounds of PD_SQ consecutive ranks over the whole bucket, the keys compared straight
+    // from global memory.  Either way: one fixed order, the same bits.
+    __shared__ int colcnt_s[PD_CQ][PD_SB], segstart_s[PD_CQ][PD_SB], cursor_s[PD_CQ][PD_SB], rounds_s[PD_CQ];
+    int *colcnt = colcnt_s[q], *segstart = segstart_s[q], *cursor = cursor_s[q];
+    for (int c = i; c < PD_SB; c += PD_CH) colcnt[c] = 0;
+    __syncthreads();
+    // (a bucket that fits one round -- the usual case -- is read ONCE: a thread keeps its keys for the scatter)
+    constexpr int PD_KR = (PD_SQ + PD_CH - 1) / PD_CH;
+    uint32_t myk[PD_KR];
+    const bool one_round = nq <= PD_SQ;
+    if (one_round) {
+#pragma unroll
+        for (int t = 0; t < PD_KR; ++t) {
+            const int e = i + t * PD_CH;
+            myk[t] = e < nq ? kb[e] : 0xFFFFFFFFu;
+            if (e < nq) atomicAdd(&colcnt[myk[t] >> 20], 1);
+        }
+    } else {
+        for (int e = i; e < nq; e += PD_CH) atomicAdd(&colcnt[kb[e] >> 20], 1);
+    }
+    __syncthreads();
+    bool colmode = true;
+    int nr = 0;
+    {
+        int run = 0;
+        for (int c = 0; c < PD_SB; ++c) {
+            const int cc = colcnt[c];
+            if (cc > PD_SQ) colmode = false;
+            if (run + cc > PD_SQ) { ++nr; run = 0; }
+            run += cc;
+        }
+        if (run > 0) ++nr;
+    }
+    if (!colmode) nr = (nq + PD_SQ - 1) / PD_SQ;
+    if (i == 0) rounds_s[q] = nr;
+    __syncthreads();
+    int rmax = 0;
+#pragma unroll
+    for (int t = 0; t < PD_CQ; ++t) rmax = max(rmax, rounds_s[t]);
+    (void)nmax;
+    int cnext = 0;                                                          // (column mode) first column of the next round
+    for (int r = 0; r < rmax; ++r) {
+        // (the four groups of a workgroup may be in different modes and out of rounds at different times: every barrier sits outside the
+        //  mode branches)
+        int n = 0, c_lo = cnext, c_hi = cnext;
+        const int base = r * PD_SQ;
+        if (colmode) {
+            while (c_hi < PD_SB && n + colcnt[c_hi] <= PD_SQ) { n += colcnt[c_hi]; ++c_hi; }
+            cnext = c_hi;
+        } else {
+            n = min(PD_SQ, max(0, nq - base));
+        }
+        __syncthreads();                                                    // the previous round's lists are consumed
+        if (colmode) {
+            for (int c = i; c < PD_SB; c += PD_CH) {
+                if (c >= c_lo && c < c_hi) {
+                    int s0 = 0;
+                    for (int cc = c_lo; cc < c; ++cc) s0 += colcnt[cc];
+                    segstart[c] = s0;
+                    cursor[c] = s0;
+                }
+            }
+        }
+        __syncthreads();
+        if (colmode && n > 0) {
+            if (one_round) {                                                // (then every column is in this round)
+#pragma unroll
+                for (int t = 0; t < PD_KR; ++t)
+                    if (i + t * PD_CH < nq) staged[atomicAdd(&cursor[myk[t] >> 20], 1)] = myk[t];
+            } else {
+                for (int e = i; e < nq; e += PD_CH) {
+                    const uint32_t key = kb[e];
+                    const int col = (int)(key >> 20);
+                    if (col >= c_lo && col < c_hi) staged[atomicAdd(&cursor[col], 1)] = key;
+                }
+            }
+        }
+        __syncthreads();
+        if (colmode) {
+            for (int t = i; t < n; t += PD_CH) {
+                const uint32_t key = staged[t];
+                const int col = (int)(key >> 20);
+                const int s0 = segstart[col], s1 = s0 + colcnt[col];
+                int rank = 0;
+                if (abl & 4) rank = t - s0;
+                else for (int u = s0; u < s1; ++u) rank += staged[u] < key;
+                const int id = (int)(key & 0xFFFFFu);
+                keys[s0 + rank] = (uint32_t)(col + q * PD_SB);              // column inside the tile
+                vals[s0 + rank] = gb[id];
+                wrow[s0 + rank] = (id / M) * Cin + ch0;                     // (per entry, once: the division per (entry, thread) was half of the kernel in round 2)
+            }
+        } else if (n > 0) {
+            for (int e = i; e < nq; e += PD_CH) {
+                const uint32_t key = kb[e];
+                int rank = 0;
+                if (abl & 4) rank = e;
+                else for (int t = 0; t < nq; ++t) rank += kb[t] < key;
+                if (rank >= base && rank < base + n) {
+                    keys[rank - base] = (key >> 20) + (uint32_t)(q * PD_SB);
+                    vals[rank - base] = vb[e];
+                    wrow[rank - base] = ((int)(key & 0xFFFFFu) / M) * Cin + ch0;
+                }
             }
         }
         __syncthreads();
@@ -935,10 +1028,10 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
             // before their first fma
             // The entries are sorted by column: the fma chain of a column runs in a REGISTER and is written when the column changes (an
             // LDS read-add-write per entry serialises on the LDS latency -- hipcc cannot tell that two accumulators differ; this was most
-            // of the kernel's time).  Same chain, same order, same bits.  A column that continues from the previous round of a very
-            // large bucket resumes from the stored value.
+            // of the kernel's time).  Same chain, same order, same bits.  (Rank mode: a column that continues from the previous round
+            // resumes from the stored value; the accumulators start at zero, so resuming is always right.)
             int cur = (int)keys[0];
-            float sum = base > 0 ? acc[cur * ld + i] : 0.f;
+            float sum = acc[cur * ld + i];
             for (int e0 = 0; e0 < n; e0 += PD_WB) {
                 float wv[PD_WB];
 #pragma unroll
@@ -953,13 +1046,13 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
                         if (col != cur) {
                             acc[cur * ld + i] = sum;
                             cur = col;
-                            sum = base > 0 ? acc[cur * ld + i] : 0.f;
+                            sum = acc[cur * ld + i];
                         }
                         sum = __fmaf_rn(vals[e0 + t], wv[t], sum);
                     }
                 }
             }
-            if (n > 0) acc[cur * ld + i] = sum;
+            acc[cur * ld + i] = sum;
         }
     }
     __syncthreads();
@@ -1299,7 +1392,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     int abl = 0;
     if (const char *e = sonet::knob("SONET_PD_ABL")) abl = atoi(e);
     hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B, PB_Q), dim3(1024), (size_t)(2 * sonet::ceil_div(nbucket, PB_Q) + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
-    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, ent_key, ent_val, W, E, M, Cin, C1,
+    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, ent_key, ent_val, g_pooled, W, E, M, Cin, C1,
                        L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);
 }
