@@ -641,8 +641,9 @@ def train_bench(args, enc, cls, inp, world, rank, dev):
         "vs_baseline": None, "dtype": ("bf16 (bf16 storage of activations and gradients, one bf16 MFMA per product, f32 accumulate, f32 master weights; "
                                        "weight gradients: sonet_wgrad_bf16, bf16 operands -> f32, fixed-order reduction; the two KNN-level ones and 64 x 6 on hipBLASLt)"
                                        if ops.POINTMLP_PRECISION == "bf16"
-                                       else "f32 (%s forward, x3 dgrad; weight gradients: sonet_wgrad_x3, 3 x bf16 split of both operands, fixed-order "
-                                            "reduction; narrow ones on hipBLASLt f32)" % ops.POINTMLP_PRECISION), "data": "synthetic",
+                                       else "f32 (%s forward -- the first PointNet on node-sorted columns, its last layer pools its own output, hidden activations "
+                                            "normalised by their consumers' operand loads --, x3 dgrad; weight gradients: sonet_wgrad_x3, 3 x bf16 split of both "
+                                            "operands, fixed-order reduction; 64 x 6 on hipBLASLt f32)" % ops.POINTMLP_PRECISION), "data": "synthetic",
         "config": {"workload": "ModelNet40 classifier training step, %d pts, 8x8 SOM, k=3, som_k=9" % N, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": "dp%d: batch shards + %d-byte gradient all-reduce per step in %d bucket(s) started from gradient hooks during backward"
                                   % (world, nbytes, max(1, len(reducer.buckets)))},

@@ -20,6 +20,7 @@ B, N = 64, 5000
 with ops.precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"):
     opt = bench.make_opt(dev, B, N)
     enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+    enc.want_first_pn_out = False
     synth.fill_state_dict_(enc.state_dict(), 0)
     synth.fill_state_dict_(cls.state_dict(), 1)
     enc.to(dev).train()
