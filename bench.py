@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other BASELINE.json configs (training step bf16 / f32-class, segmenter, autoencoder + Chamfer) under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps per window of each `other_configs` entry")
+    ap.add_argument("--only-other", default="", help="comma-separated substrings: run only the `other_configs` entries whose name contains one (experiments)")
     ap.add_argument("--windows", type=int, default=3, help="timed windows of K steps of the headline (the first one is `value`)")
     ap.add_argument("--range-check-every", type=int, default=None,
                     help="period (replays) of the non-blocking operand-range check of the replayed graphs (default: sonet_hip.graph.CHECK_EVERY; 0 = off)")
@@ -385,13 +386,19 @@ def other_configs(args, dev, world=1, rank=0):
     K = max(1, args.other_steps)
     out = {}
 
+    only = [w for w in getattr(args, "only_other", "").split(",") if w]
+
     def guarded(name, fn):
+        if only and not any(w in name for w in only):
+            return
         t0 = time.perf_counter()
         try:
             out[name] = fn()
         except Exception as e:                                   # noqa: BLE001 -- the headline must still be printed
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        # (every entry starts from an empty allocator cache: the blocks a previous entry's model left cached are of no use to the next)
+        torch.cuda.empty_cache()
 
     def train(precision):
         B, N = args.batch, args.points

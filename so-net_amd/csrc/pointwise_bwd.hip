@@ -872,6 +872,59 @@ __global__ __launch_bounds__(1024) void pooled_bucket_kernel(const int32_t *__re
     }
 }
 
+// One wave per 32-column bucket: its entries sorted by (column, entry id) -- the keys are distinct -- into skey.  A histogram over the 32
+// columns, the entries scattered into their column's segment of an LDS list (any order), every entry ranked among the entries of ITS
+// column: position = segment start + rank.  nq * (entries of a column) compares instead of the nq * nq of a rank over the whole bucket
+// -- on node-sorted columns (the f32-class training forward) a small node drops its 384 entries into one or two buckets, and ranking
+// every entry against the whole bucket in every (bucket, channel slab) workgroup was 0.77 of the dgrad kernel's 1.73 ms there (0.34 of
+// 1.23 ms in the original column order: tools/bench_pooled_sorted.py).  Buckets beyond PS_CAP entries: ranks over the whole bucket from
+// global memory.  Either way one fixed order.
+constexpr int PS_CAP = 2048;
+__global__ __launch_bounds__(64) void pooled_sort_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ ent_key,
+                                                         uint32_t *__restrict__ skey, int E, int nbucket)
+{
+    __shared__ int colcnt[PD_SB], segstart[PD_SB], cursor[PD_SB];
+    __shared__ uint32_t tmp[PS_CAP];
+    const int sb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int beg = tile_off[(size_t)b * (nbucket + 1) + sb];
+    const int nq = tile_off[(size_t)b * (nbucket + 1) + sb + 1] - beg;
+    const uint32_t *kb = ent_key + (size_t)b * E + beg;
+    uint32_t *out = skey + (size_t)b * E + beg;
+    if (nq > PS_CAP) {
+        for (int e = lane; e < nq; e += 64) {
+            const uint32_t key = kb[e];
+            int rank = 0;
+            for (int t = 0; t < nq; ++t) rank += kb[t] < key;
+            out[rank] = key;
+        }
+        return;
+    }
+    if (lane < PD_SB) colcnt[lane] = 0;
+    __syncthreads();
+    for (int e = lane; e < nq; e += 64) atomicAdd(&colcnt[kb[e] >> 20], 1);
+    __syncthreads();
+    if (lane < PD_SB) {
+        int s0 = 0;
+        for (int c = 0; c < lane; ++c) s0 += colcnt[c];
+        segstart[lane] = s0;
+        cursor[lane] = s0;
+    }
+    __syncthreads();
+    for (int e = lane; e < nq; e += 64) {
+        const uint32_t key = kb[e];
+        tmp[atomicAdd(&cursor[key >> 20], 1)] = key;
+    }
+    __syncthreads();
+    for (int t = lane; t < nq; t += 64) {
+        const uint32_t key = tmp[t];
+        const int col = (int)(key >> 20);
+        const int s0 = segstart[col], s1 = s0 + colcnt[col];
+        int rank = 0;
+        for (int u = s0; u < s1; ++u) rank += tmp[u] < key;
+        out[s0 + rank] = key;
+    }
+}
+
 __device__ __forceinline__ void pd_store(float *p, size_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void pd_store(uint16_t *p, size_t i, float v) {     // bfloat16, round to nearest even
     unsigned r;
@@ -885,15 +938,14 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
                                                            int E, int M, int Cin, int C1, int L, int nbucket,
                                                            TO *__restrict__ gx1, TO *__restrict__ gx2, int abl /*experiments (variants build): 1 no stores, 2 no accumulation, 4 no sort*/)
 {
-    extern __shared__ float sm_f[];              // acc[PD_TL][PD_CH + 1] | per group: keys, vals, wrow, staged keys [PD_SQ] each
+    extern __shared__ float sm_f[];              // acc[PD_TL][PD_CH + 1] | per group: keys, vals, wrow [PD_SQ] each
     constexpr int ld = PD_CH + 1;
     float *acc = sm_f;
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
     const int i = tid % PD_CH, q = tid / PD_CH;                             // channel ch0 + i, column quarter q
-    uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld) + q * 4 * PD_SQ;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(sm_f + PD_TL * ld) + q * 3 * PD_SQ;
     float *vals = reinterpret_cast<float *>(keys + PD_SQ);
     int *wrow = reinterpret_cast<int *>(keys + 2 * PD_SQ);
-    uint32_t *staged = keys + 3 * PD_SQ;
     __shared__ int nq_all[PD_CQ];
     const int ch0 = blockIdx.z * PD_CH, nch = min(PD_CH, Cin - ch0);        // this workgroup's input channels
     for (int t = tid; t < PD_TL * ld; t += nth) acc[t] = 0.f;
@@ -908,119 +960,20 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
     int nmax = 0;
 #pragma unroll
     for (int t = 0; t < PD_CQ; ++t) nmax = max(nmax, nq_all[t]);
-    // Every group sorts ITS bucket by (column, entry id), so that the order of the fma chain of an accumulator is fixed whatever order the
-    // bucket atomics took; then thread (i, q) applies the group's entries to channel ch0 + i (no two threads touch the same accumulator).
-    //
-    // Column mode (every column of the bucket holds <= PD_SQ entries: always, except when more than PD_SQ channels of a node pick the
-    // same point): a histogram over the 32 columns, then rounds of WHOLE columns (as many as fit PD_SQ entries); a round's entries are
-    // scattered into their column's segment of an LDS list (any order) and every entry ranks itself among the entries of ITS column
-    // (the keys are distinct): position = segment start + rank.  nq + nq * (entries of a column) / 40 LDS operations per thread instead
-    // of the nq * nq / 40 of a rank over the whole bucket -- on node-sorted columns (the f32-class training forward) a small node
-    // drops its 384 entries into one or two buckets, and the whole-bucket rank sort was 0.77 of the kernel's 1.73 ms there (0.34 of 1.23 ms
-    // in the original column order: tools/bench_pooled_sorted.py).
-    // Rank mode (a column beyond PD_SQ entries): rounds of PD_SQ consecutive ranks over the whole bucket, the keys compared straight
-    // from global memory.  Either way: one fixed order, the same bits.
-    __shared__ int colcnt_s[PD_CQ][PD_SB], segstart_s[PD_CQ][PD_SB], cursor_s[PD_CQ][PD_SB], rounds_s[PD_CQ];
-    int *colcnt = colcnt_s[q], *segstart = segstart_s[q], *cursor = cursor_s[q];
-    for (int c = i; c < PD_SB; c += PD_CH) colcnt[c] = 0;
-    __syncthreads();
-    // (a bucket that fits one round -- the usual case -- is read ONCE: a thread keeps its keys for the scatter)
-    constexpr int PD_KR = (PD_SQ + PD_CH - 1) / PD_CH;
-    uint32_t myk[PD_KR];
-    const bool one_round = nq <= PD_SQ;
-    if (one_round) {
-#pragma unroll
-        for (int t = 0; t < PD_KR; ++t) {
-            const int e = i + t * PD_CH;
-            myk[t] = e < nq ? kb[e] : 0xFFFFFFFFu;
-            if (e < nq) atomicAdd(&colcnt[myk[t] >> 20], 1);
-        }
-    } else {
-        for (int e = i; e < nq; e += PD_CH) atomicAdd(&colcnt[kb[e] >> 20], 1);
-    }
-    __syncthreads();
-    bool colmode = true;
-    int nr = 0;
-    {
-        int run = 0;
-        for (int c = 0; c < PD_SB; ++c) {
-            const int cc = colcnt[c];
-            if (cc > PD_SQ) colmode = false;
-            if (run + cc > PD_SQ) { ++nr; run = 0; }
-            run += cc;
-        }
-        if (run > 0) ++nr;
-    }
-    if (!colmode) nr = (nq + PD_SQ - 1) / PD_SQ;
-    if (i == 0) rounds_s[q] = nr;
-    __syncthreads();
-    int rmax = 0;
-#pragma unroll
-    for (int t = 0; t < PD_CQ; ++t) rmax = max(rmax, rounds_s[t]);
-    (void)nmax;
-    int cnext = 0;                                                          // (column mode) first column of the next round
-    for (int r = 0; r < rmax; ++r) {
-        // (the four groups of a workgroup may be in different modes and out of rounds at different times: every barrier sits outside the
-        //  mode branches)
-        int n = 0, c_lo = cnext, c_hi = cnext;
-        const int base = r * PD_SQ;
-        if (colmode) {
-            while (c_hi < PD_SB && n + colcnt[c_hi] <= PD_SQ) { n += colcnt[c_hi]; ++c_hi; }
-            cnext = c_hi;
-        } else {
-            n = min(PD_SQ, max(0, nq - base));
-        }
+    // The group's bucket arrives SORTED by (column, entry id) (pooled_sort_kernel below: once per bucket instead of once per (bucket,
+    // channel slab)), so the order of the fma chain of an accumulator is fixed whatever order the bucket atomics took; thread (i, q)
+    // applies the group's entries to channel ch0 + i (no two threads touch the same accumulator).  Rounds of PD_SQ consecutive entries: a
+    // column that continues in the next round resumes from the stored value.
+    (void)vb;
+    for (int base = 0; base < nmax; base += PD_SQ) {
+        const int n = min(PD_SQ, max(0, nq - base));
         __syncthreads();                                                    // the previous round's lists are consumed
-        if (colmode) {
-            for (int c = i; c < PD_SB; c += PD_CH) {
-                if (c >= c_lo && c < c_hi) {
-                    int s0 = 0;
-                    for (int cc = c_lo; cc < c; ++cc) s0 += colcnt[cc];
-                    segstart[c] = s0;
-                    cursor[c] = s0;
-                }
-            }
-        }
-        __syncthreads();
-        if (colmode && n > 0) {
-            if (one_round) {                                                // (then every column is in this round)
-#pragma unroll
-                for (int t = 0; t < PD_KR; ++t)
-                    if (i + t * PD_CH < nq) staged[atomicAdd(&cursor[myk[t] >> 20], 1)] = myk[t];
-            } else {
-                for (int e = i; e < nq; e += PD_CH) {
-                    const uint32_t key = kb[e];
-                    const int col = (int)(key >> 20);
-                    if (col >= c_lo && col < c_hi) staged[atomicAdd(&cursor[col], 1)] = key;
-                }
-            }
-        }
-        __syncthreads();
-        if (colmode) {
-            for (int t = i; t < n; t += PD_CH) {
-                const uint32_t key = staged[t];
-                const int col = (int)(key >> 20);
-                const int s0 = segstart[col], s1 = s0 + colcnt[col];
-                int rank = 0;
-                if (abl & 4) rank = t - s0;
-                else for (int u = s0; u < s1; ++u) rank += staged[u] < key;
-                const int id = (int)(key & 0xFFFFFu);
-                keys[s0 + rank] = (uint32_t)(col + q * PD_SB);              // column inside the tile
-                vals[s0 + rank] = gb[id];
-                wrow[s0 + rank] = (id / M) * Cin + ch0;                     // (per entry, once: the division per (entry, thread) was half of the kernel in round 2)
-            }
-        } else if (n > 0) {
-            for (int e = i; e < nq; e += PD_CH) {
-                const uint32_t key = kb[e];
-                int rank = 0;
-                if (abl & 4) rank = e;
-                else for (int t = 0; t < nq; ++t) rank += kb[t] < key;
-                if (rank >= base && rank < base + n) {
-                    keys[rank - base] = (key >> 20) + (uint32_t)(q * PD_SB);
-                    vals[rank - base] = vb[e];
-                    wrow[rank - base] = ((int)(key & 0xFFFFFu) / M) * Cin + ch0;
-                }
-            }
+        for (int t = i; t < n; t += PD_CH) {
+            const uint32_t key = kb[base + t];
+            const int id = (int)(key & 0xFFFFFu);
+            keys[t] = (key >> 20) + (uint32_t)(q * PD_SB);                  // column inside the tile
+            vals[t] = gb[id];
+            wrow[t] = (id / M) * Cin + ch0;                                 // (per entry, once: the division per (entry, thread) was half of the kernel in round 2)
         }
         __syncthreads();
         if (i < nch && n > 0 && !(abl & 2)) {
@@ -1231,7 +1184,7 @@ extern "C" size_t sonet_pooled_dgrad_ws_size(int B, int C, int M, int L)
 {
     if (B <= 0 || C <= 0 || M <= 0 || L <= 0) return 0;
     const size_t E = (size_t)C * M, nbucket = (size_t)sonet::ceil_div(L, PD_SB);
-    return (size_t)B * (E * 8 + (nbucket + 1) * 4);
+    return (size_t)B * (E * 12 + (nbucket + 1) * 4);            // bucket lists (key, value), the sorted keys, bucket offsets
 }
 
 // Sparse wgrad of the pooled last layer: the gradient of first_pn_out exists only at the C*M gathered positions of a
@@ -1383,16 +1336,18 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     SONET_REQUIRE((C2 == 0) == (gx2 == nullptr), "%s: gx2 and C2 disagree", what);
     const int Cin = C1 + C2, E = C * M, ntile = sonet::ceil_div(L, PD_TL), nbucket = sonet::ceil_div(L, PD_SB);
     if ((long long)C * M >= (1 << 20) || B > 65535) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C*M=%d entries per cloud (max 2^20)", what, E);
-    const size_t lds2 = ((size_t)PD_TL * (PD_CH + 1) + (size_t)PD_CQ * 4 * PD_SQ) * 4;
+    const size_t lds2 = ((size_t)PD_TL * (PD_CH + 1) + (size_t)PD_CQ * 3 * PD_SQ) * 4;
     if ((size_t)(2 * nbucket + 1) * 4 > 64 * 1024) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: L=%d too large for the bucket counters", what, L);
     uint32_t *ent_key = reinterpret_cast<uint32_t *>(ws);
     float *ent_val = reinterpret_cast<float *>(ent_key + (size_t)B * E);
-    int32_t *tile_off = reinterpret_cast<int32_t *>(ent_val + (size_t)B * E);
+    uint32_t *skey = reinterpret_cast<uint32_t *>(ent_val + (size_t)B * E);
+    int32_t *tile_off = reinterpret_cast<int32_t *>(skey + (size_t)B * E);
     hipStream_t st = sonet::as_stream(stream);
     int abl = 0;
     if (const char *e = sonet::knob("SONET_PD_ABL")) abl = atoi(e);
     hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B, PB_Q), dim3(1024), (size_t)(2 * sonet::ceil_div(nbucket, PB_Q) + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
-    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, ent_key, ent_val, g_pooled, W, E, M, Cin, C1,
+    if (!(abl & 4)) hipLaunchKernelGGL(pooled_sort_kernel, dim3(nbucket, B), dim3(64), 0, st, tile_off, ent_key, skey, E, nbucket);
+    hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, (abl & 4) ? ent_key : skey, ent_val, g_pooled, W, E, M, Cin, C1,
                        L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);
 }
