@@ -1190,9 +1190,20 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     }
     if (KC == 1) S = 1;
     if (xaff && MT != 6) MT = 4;
+    // output-channel slabs per column group: the smallest divisor of the CT / MT tile groups that fills the chip (>= 1024 workgroups) --
+    // any divisor, not only powers of two: 768 -> 640 at 4096 columns (the dgrad of the final PointNet's first layer: 5 groups of 4 tiles)
+    // ran on 32 workgroups, 0.20 ms for 0.03 ms of matrix work -- and slabs of <= 32 tiles (the affine table)
     int ysplit = 1;
-    while (nwg_x * ysplit < 1024 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
-    while (CT / ysplit > 32 && (CT / MT) % (ysplit * 2) == 0) ysplit *= 2;
+    {
+        const int groups = CT / MT;
+        int best = 0;
+        for (int d = 1; d <= groups; ++d) {
+            if (groups % d != 0 || CT / d > 32) continue;
+            best = d;
+            if (nwg_x * d >= 1024) break;
+        }
+        if (best > 0) ysplit = best;
+    }
     if (const char *e = sonet::knob("SONET_POINTMLP_YSPLIT")) {  // tuning knob (bench experiments only): output-channel slabs per column group.
         const int want = atoi(e);                           // 1152 workgroups on 768 resident slots run 1.5 rounds; 2 slabs of half the work
         if (want >= 1 && (CT / MT) % want == 0 && CT / want <= 32) ysplit = want;   // each would run 3 rounds of half the length (X re-read twice)

@@ -190,6 +190,23 @@ def _stats_epilogue_ok(x1, wp, Cout):
                  or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16)))
 
 
+def _leaf_of(weight2d):
+    """The parameter behind a layer's weight2d view (a weak reference: autograd contexts must not keep modules alive)."""
+    import weakref
+    base = weight2d._base if weight2d._base is not None else weight2d
+    try:
+        return weakref.ref(base)
+    except TypeError:
+        return None
+
+
+def _grad_slot_empty(wleaf):
+    """True when the weight gradient this backward returns will be STORED as the parameter's .grad (no kernel reads it during the backward
+    pass) rather than added to an existing one: only then may its side-stream launches stay un-joined until the end of the pass."""
+    p = wleaf() if wleaf is not None else None
+    return p is not None and p.grad is None
+
+
 class _Materialise(torch.autograd.Function):
     """A deferred activation (the RAW output of a BatchNorm layer standing for act(raw * scale + shift), see ``_PointwiseFn`` ``defer``)
     written out after all: for a consumer without the normalise-on-load form.  The handle's gradient IS the activation's: identity."""
@@ -253,6 +270,7 @@ class _PointwiseFn(torch.autograd.Function):
         # (without this autograd hands backward freshly zero-filled "gradients" of mean and var: two fill launches per layer and step)
         ctx.set_materialize_grads(False)
         ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
+        ctx.wleaf = _leaf_of(weight2d)
         if mode == 'affine':
             return y
         if defer:
@@ -263,6 +281,7 @@ class _PointwiseFn(torch.autograd.Function):
     def backward(ctx, gy, *unused):
         if gy is None:                                                    # (the output was not used)
             return (None,) * 15
+        ctx.defer_ok = _grad_slot_empty(ctx.wleaf)
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
         gy = gy.contiguous()
@@ -298,6 +317,7 @@ class _PointwiseFn(torch.autograd.Function):
             if ss is not None:
                 with ss:
                     g_w = ss.keep(_gw())
+                ss.reads(g_raw, x1, x2 if ctx.has_x2 else None, *([t for t in xa if torch.is_tensor(t)] if xa is not None else []))
             else:
                 g_w = _gw()
         g_x1 = g_x2 = None
@@ -313,7 +333,8 @@ class _PointwiseFn(torch.autograd.Function):
                 outs.append(_dgrad(g_raw, pk))
             g_x1, g_x2 = outs
         if ss is not None:
-            ss.join()
+            # (the weight gradient is not needed before the backward pass is over -- unless it is about to be ADDED to an existing .grad)
+            ss.join(defer=ctx.defer_ok)
         return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None, None, None
 
 
@@ -331,6 +352,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
         ones = _ops.const_vec(Cout, 1.0, x1.device)
         b = bias.detach().float().contiguous()
         ctx.pos0 = None
+        ctx.wleaf = _leaf_of(weight2d)
         ctx.xaff = xaff                       # (sorted form only) x1 / x2 are RAW outputs of BatchNorm layers: see _PointwiseFn
         if xaff is not None and pos0 is None:
             raise RuntimeError("_PooledLastLayerFn: normalise-on-load comes with the node-sorted form")
@@ -408,6 +430,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                     with ss:
                         g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()
                         g_w = ss.keep(torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1, xa1), _ops.pooled_wgrad(g_t, gi_t, x2, xa2)), dim=1))
+                    ss.reads(g_mm, gi, x1, x2, *([t for t in xa if torch.is_tensor(t)] if xa is not None else []))
                 else:
                     g_t, gi_t = g_mm.transpose(1, 2).contiguous(), gi.transpose(1, 2).contiguous()     # B x M x C: coalesced entry loads
                     g_w = torch.cat((_ops.pooled_wgrad(g_t, gi_t, x1, xa1), _ops.pooled_wgrad(g_t, gi_t, x2, xa2)), dim=1)
@@ -450,7 +473,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                     outs.append(_dgrad(G, pk))
                 g_x1, g_x2 = outs
         if ss is not None:
-            ss.join()
+            ss.join(defer=_grad_slot_empty(ctx.wleaf))
         return g_x1, g_x2, g_w, g_bias, None, None, None, None, None, None, None
 
 

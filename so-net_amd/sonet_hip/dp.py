@@ -179,6 +179,7 @@ class GradientAllReducer:
             # finishes bucket 2 before bucket 1 still issues the collectives in the order every other rank does
             while self._next_launch < len(self.buckets) and self._pending[self._next_launch] == 0:
                 bo, bn, members = self.buckets[self._next_launch]
+                _join_side_streams()                              # (weight gradients still in flight on a side stream: sonet_hip.ops.side_stream.join(defer=True))
                 _copy_all(self._views[self._next_launch], [self.params[j].grad for j in members])
                 self._work[self._next_launch] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
                 self._next_launch += 1
@@ -254,6 +255,11 @@ class GradientAllReducer:
         if self._armed:
             self._arm()                                               # next backward
         return self._flat.numel() * self._flat.element_size()
+
+
+def _join_side_streams():
+    from . import ops
+    ops.join_side_streams()
 
 
 def _copy_all(dst, src):

@@ -1183,9 +1183,51 @@ class side_stream:
             t.record_stream(self.main)
         return t
 
-    def join(self):
+    def reads(self, *ts):
+        """Tensors the launches of the block READ that were allocated on the main stream and may be released before the side stream is
+        joined (``join(defer=True)``): the caching allocator must not hand their memory out again before the side stream has passed this point."""
         if self.on:
-            self.main.wait_stream(self.side)
+            for t in ts:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.side)
+
+    def join(self, defer=False):
+        """The current stream waits for the side stream.  ``defer=True`` (from an autograd backward only, ``ops.DEFER_WGRAD_JOIN``): the wait is
+        left to the END of the backward pass (an engine callback) -- or to whoever reads a gradient earlier and calls
+        ``ops.join_side_streams()`` first (the gradient all-reducer's bucket hooks do) --, so that the launches behind this point on the
+        current stream (the next layer's backward) run beside the side stream's instead of waiting for them.  Everything the side-stream
+        launches read must have gone through ``reads()``."""
+        if not self.on:
+            return
+        idx = self.side.device.index
+        if defer and DEFER_WGRAD_JOIN and torch._C._current_graph_task_id() != -1:
+            _pending_join[idx] = (self.main, self.side)
+            if not _join_queued[0]:
+                _join_queued[0] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
+            return
+        self.main.wait_stream(self.side)
+        _pending_join.pop(idx, None)
+
+
+# weight gradients are not needed before the backward pass is over: their side-stream launches are joined there (0 = at the end of every
+# layer's backward, the behaviour up to round 5's first session)
+DEFER_WGRAD_JOIN = _os.environ.get("SONET_DEFER_WGRAD_JOIN", "1") != "0"
+_pending_join = {}               # device index -> (main stream, side stream) with launches nobody has waited for yet
+_join_queued = [False]
+
+
+def join_side_streams():
+    """Every stream that handed work to a side stream with a deferred join waits for it now (a no-op when nothing is pending).  Call it
+    before reading a weight gradient INSIDE a backward pass (gradient hooks); after ``backward()`` has returned it has already happened."""
+    for idx in list(_pending_join):
+        main, side = _pending_join.pop(idx)
+        main.wait_stream(side)
+
+
+def _end_of_backward_join():
+    _join_queued[0] = False
+    join_side_streams()
 
 
 STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)

@@ -280,3 +280,52 @@ def test_h3_training_step_with_normalise_on_load_equals_the_step_with_normalise_
             finally:
                 ops.H3_NORM_ON_LOAD = old
     _compare_steps(res[True], res[False])
+
+
+# ------------------------------------------------------------------------------------------ deferred side-stream joins
+@pytest.mark.parametrize("precision", ["bf16", "h3"])
+def test_weight_gradients_joined_at_the_end_of_backward_equal_joined_per_layer(precision):
+    """``ops.DEFER_WGRAD_JOIN``: the side stream that computes the weight gradients is joined at the end of the backward pass (an engine
+    callback; the gradient all-reducer's hooks join earlier) instead of at the end of every layer's backward.  Same kernels, same inputs:
+    on the bit-reproducible paths (bf16; f32-class in the original column order) every gradient of three consecutive steps -- with an Adam
+    update in between, memory released and re-used -- must be bit-identical to the per-layer joins.  (A gradient read before its side-stream
+    launch has finished, or an operand whose memory was handed out again, would show here.)"""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    from sonet_hip.optim import FusedAdam
+    B, N = 6, 2200
+    out = {}
+    old = (ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL)
+    try:
+        ops.H3_SEGPOOL = False                                     # (the sorted path's BatchNorm sums are not run-to-run reproducible)
+        with ops.precision(precision):
+            for flag in (True, False):
+                ops.DEFER_WGRAD_JOIN = flag
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                oe, oc = FusedAdam(enc.parameters(), lr=1e-3), FusedAdam(cls.parameters(), lr=1e-3)
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                snaps = []
+                for it in range(3):
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    enc.zero_grad(set_to_none=True)
+                    cls.zero_grad(set_to_none=True)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward()
+                    junk = [torch.empty(1 << 22, device=DEV).fill_(float(it)) for _ in range(8)]      # memory churn right behind the backward
+                    del junk
+                    snaps.append({k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(cls.named_parameters()) if p.grad is not None})
+                    oe.step()
+                    oc.step()
+                out[flag] = snaps
+    finally:
+        ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL = old
+    for it in range(3):
+        assert out[True][it].keys() == out[False][it].keys()
+        for k in out[True][it]:
+            assert torch.equal(out[True][it][k], out[False][it][k]), (it, k)

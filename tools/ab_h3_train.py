@@ -5,6 +5,7 @@ what bench.py --mode train --precision h3 times) in the variants of round 5, in 
     C  B + normalise-on-load    the hidden layers hand their RAW outputs on; no normalise + ReLU pass, no normalised activations in memory
     D  C, the sparse weight gradient of the pooled layer AFTER its sparse input gradient (not beside it on the side stream)
     E  C, no side stream anywhere in the backward
+    F  C, the side stream joined at the END of the backward pass (weight gradients are not needed before) instead of at the end of every layer
 then one instrumented step of each (per-kernel times by events on the launching stream).
 
   python tools/ab_h3_train.py [--rounds 6] [--steps 24] [--precision h3]"""
@@ -30,14 +31,17 @@ def main():
     ap.add_argument("--precision", default="h3")
     ap.add_argument("--only", default="", help="letters of the variants to run, e.g. ACD")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--all-kernels", action="store_true")
     args = ap.parse_args()
     import bench
     from models import networks as NW
     from sonet_hip import dp, host, ops, synth
     dev = torch.device("cuda:0")
     B, N = args.batch, args.points
-    variants = [("A_store_index_max", False, False, True, True), ("B_sorted_pool", True, False, True, True), ("C_sorted_pool_norm_on_load", True, True, True, True),
-                ("D_C_pooled_pair_in_sequence", True, True, False, True), ("E_C_no_side_stream_at_all", True, True, False, False)]
+    variants = [("A_store_index_max", False, False, True, True, False), ("B_sorted_pool", True, False, True, True, False),
+                ("C_sorted_pool_norm_on_load", True, True, True, True, False),
+                ("D_C_pooled_pair_in_sequence", True, True, False, True, False), ("E_C_no_side_stream_at_all", True, True, False, False, False),
+                ("F_C_joins_at_the_end_of_backward", True, True, True, True, True)]
     if args.only:
         variants = [v for v in variants if v[0][0] in args.only]
     with ops.precision(args.precision):
@@ -67,7 +71,7 @@ def main():
             return loss
 
         def select(v):
-            ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD, ops.POOLED_SIDE_STREAM, ops.BWD_SIDE_STREAM = v[1], v[2], v[3], v[4]
+            ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD, ops.POOLED_SIDE_STREAM, ops.BWD_SIDE_STREAM, ops.DEFER_WGRAD_JOIN = v[1], v[2], v[3], v[4], v[5]
 
         def window(v):
             select(v)
@@ -104,7 +108,7 @@ def main():
             summ = rec.summary()
             tot = sum(d["total_ms"] for d in summ.values())
             print("\n%s: %.3f ms in %d launches of the C ABI (aten / RCCL launches are not in this list)" % (v[0], tot, sum(d["count"] for d in summ.values())))
-            for name, d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:22]:
+            for name, d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[: (60 if args.all_kernels else 22)]:
                 print("   %8.3f ms  x%-3d %s" % (d["total_ms"], d["count"], name))
         select(variants[-1])
 
