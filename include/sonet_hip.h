@@ -196,6 +196,16 @@ int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const f
                        const float *scale, const float *shift, int relu, float *y,
                        int B, int Cout, int L, sonet_stream_t stream);
 
+/* The input gradient of a layer behind a training-mode BatchNorm (+ ReLU) (models/layers.py:60-70, :282-296 in the backward) with the
+ * BatchNorm / ReLU backward applied by the operand load:  y = (W . g_raw) * scale + shift,
+ *     g_raw[k] = a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k]
+ * (gy, raw [B][C][L]; a, b, c0 from sonet_bn_bwd_coeffs_f32, sc, sh the forward's normalisation) -- what sonet_pointwise_bwd_apply_f32 followed
+ * by sonet_pointmlp_x3_f32 compute, bit for bit, in one pass over (gy, raw).  g_raw_out (or NULL) receives g_raw: the weight gradient's operand.
+ * Wp3: the bf16-split pack of the C x Cout matrix (W^T of the layer); C <= 512, Cout % 32 == 0. */
+int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
+                              const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                              float *g_raw_out, float *y, int B, int Cout, int L, sonet_stream_t stream);
+
 /* The same layer on bf16 MFMA with a 3-way bf16 split of both operands (6 MFMAs per product term set):
  * f32-class accuracy (classifier forward within 3e-6 * max(|ref|, rms) of the reference; tolerance 1e-5) at
  * 6/16 of the f32-MFMA cost.  Requires Cout % 32 == 0 and, with a second input, C1 % 16 == 0.

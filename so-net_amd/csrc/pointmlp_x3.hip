@@ -275,8 +275,20 @@ struct XAffArgs {
     int relu;                             // bit 0: ReLU on x1's channels, bit 1: on x2's
 };
 
+// BNB (f32-class training backward, bf16-split arithmetic): the input gradient of a layer whose OUTPUT went through a training-mode BatchNorm
+// + ReLU.  x1 is gy (the gradient of the activation), bnb.raw the layer's raw output; the operand load applies the BatchNorm / ReLU backward
+//      g_raw = a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k]
+// -- sonet_pointwise_bwd_apply_f32's arithmetic, bit for bit -- and multiplies by W^T; the workgroups of the first output slab also write g_raw
+// (the weight gradient's operand).  The separate pass over (gy, raw) and one read of g_raw are gone (models/layers.py:60-70 backward).
+struct BnbArgs {
+    const float *raw;                     // [B][C1][L]
+    const float *a, *b, *c0, *sc, *sh;    // [C1]
+    float *g_out;                         // [B][C1][L] (may be NULL)
+    int relu;
+};
+
 // ZADD: the per-node addend form with its gathers issued BEFORE the K loop (64 registers; instantiated for MT = 4 only).
-template <int MT, int S, bool F16, bool ZADD = false, bool SEGPOOL = false, bool XAFF = false>
+template <int MT, int S, bool F16, bool ZADD = false, bool SEGPOOL = false, bool XAFF = false, bool BNB = false>
 __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2, const uint4 *__restrict__ Wp3,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y,
@@ -286,8 +298,12 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     int KCP /*chunks per cout tile in the pack (fp16 flavour: KC rounded up to H3_KPAD; bf16: KC)*/,
     double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum and sum of squares of the stored output over this workgroup's columns*/,
     const float *__restrict__ zadd /*optional [B][Cout][ZM]: y = act((W x + zadd[b][o][zidx[b][l]]) * scale + shift)*/,
-    const int32_t *__restrict__ zidx /*[B][L], out of range: + 0*/, int ZM, const SegPoolArgs sp, const XAffArgs xa)
+    const int32_t *__restrict__ zidx /*[B][L], out of range: + 0*/, int ZM, const SegPoolArgs sp, const XAffArgs xa, const BnbArgs bnb)
 {
+    static_assert(!BNB || (!F16 && !ZADD && !SEGPOOL && !XAFF && S == 1), "the BatchNorm-backward operand exists in the bf16-split layer only");
+    constexpr int BW = BNB ? 16 : 8;                          // registers per chunk and lane: 8 rows of the input (+ 8 of raw)
+    __shared__ __attribute__((aligned(16))) float4 bnb_t[BNB ? 512 : 1];        // (BNB) per input channel (a, b, c0, sc)
+    __shared__ float bnb_h[BNB ? 512 : 1];                                       //       ... and sh
     static_assert(!SEGPOOL || (F16 && !ZADD), "the pooled form exists in the fp16-split arithmetic only");
     static_assert(!XAFF || (F16 && !ZADD), "normalise-on-load exists in the fp16-split arithmetic only");
     __shared__ __attribute__((aligned(16))) float2 xaff_t[XAFF ? 1024 : 1];     // (XAFF) per input channel (scale, shift), x1's first; past Cin: (0, 0)
@@ -339,7 +355,11 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         sp_p0rel = wave_valid ? sp.pos0[b] - l0 : -1;
     }
 
-    auto load_b = [&](float (&raw)[S][8], int st) {
+    const __amdgpu_buffer_rsrc_t rbn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(BNB ? bnb.raw + b * (long long)C1 * L : x1), 0, (int)((unsigned)(BNB ? C1 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc(
+        (BNB && bnb.g_out) ? bnb.g_out + b * (long long)C1 * L : y, 0, (int)((unsigned)((BNB && bnb.g_out) ? C1 : 0) * rowB), 0x00020000);
+    auto load_b = [&](float (&raw)[S][BW], int st) {
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int kc = st * S + i;
@@ -351,6 +371,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 const unsigned so = row0 + (unsigned)t * rb;
                 raw[i][t] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r2, vox, so, 0)
                                                               : __builtin_amdgcn_raw_buffer_load_b32(r1, vox1, so, 0));
+                if constexpr (BNB) raw[i][8 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, vox, so, 0));
             }
         }
     };
@@ -359,6 +380,13 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
     const int ct_end = min(CT, ct_begin + ct_per_y);
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += X3_THREADS)
         affine[o - ct_begin * 32] = make_float2(F16 ? scale[o] * 0.03125f : scale[o], shift[o]);   // fp16: accumulators hold 32 W.x
+    if constexpr (BNB) {                                        // (published by the barrier in front of the first stage; past C1: zeros)
+        for (int c = threadIdx.x; c < KC * 16; c += X3_THREADS) {
+            const bool ok = c < C1;
+            bnb_t[c] = ok ? make_float4(bnb.a[c], bnb.b[c], bnb.c0[c], bnb.sc[c]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bnb_h[c] = ok ? bnb.sh[c] : 0.f;
+        }
+    }
     if constexpr (XAFF) {                                       // (published by the barrier in front of the first stage)
         for (int c = threadIdx.x; c < KC * 16; c += X3_THREADS)
             xaff_t[c] = c < C1 ? make_float2(xa.s1[c], xa.h1[c]) : (c - C1 < C2 ? make_float2(xa.s2[c - C1], xa.h2[c - C1]) : make_float2(0.f, 0.f));
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
             for (int t = 0; t < NS; ++t)
                 wsm[slot][wave + t * X3_WAVES][lane] = __builtin_bit_cast(uint4, w[t]);
         };
-        auto compute = [&](const float (&raw_in)[S][8], int slot, int st) {
+        auto compute = [&](const float (&raw_in)[S][BW], int slot, int st) {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 unsigned bh[4], bm[4], bl[4];
@@ -462,8 +490,30 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bh, acc[mt], 0, 0, 0);
                     }
                 } else {
+                float gv[8];
+                if constexpr (BNB) {
+                    // this lane's 8 channels of the chunk: 16 kc + 8 h + t
+                    const int kc = st * S + i;
+                    const int k0 = kc * 16 + 8 * h;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) split3_pair(raw_in[i][2 * p], raw_in[i][2 * p + 1], bh[p], bm[p], bl[p]);
+                    for (int t = 0; t < 8; ++t) {
+                        const float4 c = bnb_t[k0 + t];
+                        const float rv = raw_in[i][8 + t];
+                        float gg = raw_in[i][t];
+                        if (bnb.relu && !(__fmaf_rn(rv, c.w, bnb_h[k0 + t]) > 0.f)) gg = 0.f;
+                        gv[t] = __fmaf_rn(c.x, gg, __fmaf_rn(c.y, rv, c.z));
+                    }
+                    if (bnb.g_out != nullptr && ct0 == 0 && pv) {          // (the first output slab's first tile group: every (channel, column) once)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gv[t]), rgo, vox, (unsigned)(kc * 16 + t) * rowB, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) gv[t] = raw_in[i][t];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) split3_pair(gv[2 * p], gv[2 * p + 1], bh[p], bm[p], bl[p]);
                 const bf16x8 Bh = __builtin_bit_cast(bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                 const bf16x8 Bm = __builtin_bit_cast(bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
                 const bf16x8 Bl = __builtin_bit_cast(bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
@@ -485,7 +535,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
         };
 
         i32x4_t wreg[NS];
-        float b0[S][8], b1[S][8];
+        float b0[S][BW], b1[S][BW];
         __syncthreads();
         stage_load(wreg, 0);
         load_b(b0, 0);
@@ -1069,7 +1119,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                        int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
                        double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr,
                        const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0, unsigned *kmax = nullptr, int KM = 0,
-                       const SegPoolArgs *segpool = nullptr, const XAffArgs *xaff = nullptr)
+                       const SegPoolArgs *segpool = nullptr, const XAffArgs *xaff = nullptr, const BnbArgs *bnbp = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -1080,6 +1130,10 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                   "%s: normalise-on-load takes the plain fp16-split layer and a (scale, shift) pair per input panel", what);
     if (xaff && (C1 + C2 > 1024 || (Cout / 32) % 4 != 0)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: normalise-on-load needs Cin <= 1024 and Cout %% 128 == 0", what);
     const XAffArgs xa = xaff ? *xaff : XAffArgs{nullptr, nullptr, nullptr, nullptr, 0};
+    SONET_REQUIRE(!bnbp || (!f16 && !gidx && !zadd && !kmax && !segpool && !xaff && !stats_ws && C2 == 0 && bnbp->raw && bnbp->a && bnbp->b && bnbp->c0
+                            && bnbp->sc && bnbp->sh), "%s: the BatchNorm-backward operand takes the plain bf16-split layer with one input panel", what);
+    if (bnbp && C1 > 512) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the BatchNorm-backward operand needs <= 512 input channels", what);
+    const BnbArgs bnb = bnbp ? *bnbp : BnbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
     SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
@@ -1211,7 +1265,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     const int ct_per_y = CT / ysplit;
     if (ct_per_y > 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: Cout=%d too large", what, Cout);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(X3_THREADS);
-#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa
+#define X3_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa, bnb
 #define X3_LAUNCH(MM) do { if (f16) { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, true>), X3_ARGS); \
                                       else        hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 1, true>), X3_ARGS); } \
                            else     { if (S == 2) hipLaunchKernelGGL((pointmlp_x3_kernel<MM, 2, false>), X3_ARGS); \
@@ -1222,9 +1276,18 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
         const int cpy = CT / (int)gz.y;
         if (CT % (int)gz.y == 0 && cpy % 4 == 0 && cpy <= 32) {
             hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, true, true>), gz, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups,
-                               CT, KC, cpy, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa);
+                               CT, KC, cpy, gidx, L1, rlog, KCP, stats_ws, zadd, zidx, ZM, sp, xa, bnb);
             return sonet::launched(what);
         }
+    }
+    if (bnbp) {
+        switch (MT) {
+            case 6: hipLaunchKernelGGL((pointmlp_x3_kernel<6, 1, false, false, false, false, true>), X3_ARGS); break;
+            case 4: hipLaunchKernelGGL((pointmlp_x3_kernel<4, 1, false, false, false, false, true>), X3_ARGS); break;
+            case 2: hipLaunchKernelGGL((pointmlp_x3_kernel<2, 1, false, false, false, false, true>), X3_ARGS); break;
+            default: hipLaunchKernelGGL((pointmlp_x3_kernel<1, 1, false, false, false, false, true>), X3_ARGS);
+        }
+        return sonet::launched(what);
     }
     if (xaff) {                                                  // (MT is 6 or 4 here: Cout % 128 == 0)
         if (segpool) {
@@ -1399,6 +1462,22 @@ extern "C" int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float 
     SONET_REQUIRE(stats_ws && mean && var, "sonet_pointmlp_x3_stats_f32: NULL pointer");
     return x3_run_impl("sonet_pointmlp_x3_stats_f32", false, x1, C1, x2, C2, Wp3, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
                        reinterpret_cast<double *>(stats_ws), mean, var);
+}
+
+/* The input gradient of a layer behind a training-mode BatchNorm (+ ReLU) with the BatchNorm / ReLU backward applied by the operand load:
+ * y = (W . g_raw) * scale + shift with g_raw[k] = a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k]  (gy, raw [B][C][L],
+ * the coefficients [C]: sonet_bn_bwd_coeffs_f32's a, b, c0 and the forward's normalisation sc, sh) -- what sonet_pointwise_bwd_apply_f32 +
+ * sonet_pointmlp_x3_f32 compute, bit for bit, in one pass over (gy, raw); g_raw_out (or NULL) receives g_raw for the weight gradient.
+ * Wp3: the bf16-split pack (sonet_pointmlp_x3_pack*) of the C x Cout matrix; C <= 512, Cout % 32 == 0. */
+extern "C" int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
+                                         const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                                         float *g_raw_out, float *y, int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_x3_bnb_f32";
+    SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y, "%s: NULL pointer", what);
+    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu};
+    return x3_run_impl(what, false, gy, C, nullptr, 0, Wp3, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn);
 }
 
 extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,

@@ -286,6 +286,7 @@ class _PointwiseFn(torch.autograd.Function):
         x1, x2, weight2d = saved[:3]
         gy = gy.contiguous()
         g_gamma = g_beta = g_bias = None
+        fused_gx1 = None
         if ctx.mode == 'affine':
             sc, y, ones, zeros = saved[3:7]
             src = y if ctx.relu else gy                                   # relu=False: the mask input is unused
@@ -301,8 +302,20 @@ class _PointwiseFn(torch.autograd.Function):
             n = float(raw.shape[0] * raw.shape[2])
             sums = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu, want_sums=True)
             a, b, c0, g_gamma, g_beta = _ops.bn_bwd_coeffs(sums, mean, invstd, gamma, n)
-            g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a, b, c0)
             g_bias = zeros.clone()                                        # a bias in front of BatchNorm has no gradient
+            # f32-class, one input panel, an input gradient to compute: the BatchNorm / ReLU backward rides on the operand load of the
+            # dgrad launch (which also writes g_raw for the weight gradient) instead of being a pass of its own over (gy, raw)
+            if (_ops.BNB_ON_LOAD and ctx.needs_input_grad[0] and not ctx.has_x2 and gy.dtype == torch.float32 and gy.is_cuda
+                    and raw.shape[1] <= 512 and _ops.POINTMLP_PRECISION in ("h3", "x3")):
+                pk = _pack_transposed(weight2d, x1.shape[1], 0)[0]
+                if pk is not None and pk[0].dtype == torch.uint8:
+                    wpt, Ci, Cp = pk
+                    dev = gy.device
+                    yb, g_raw = _ops.pointmlp_x3_bnb(gy, raw, wpt, _ops.const_vec(Cp, 1.0, dev), _ops.const_vec(Cp, 0.0, dev), a, b, c0, sc, sh, ctx.relu,
+                                                     Cp, want_g_raw=ctx.needs_input_grad[2])
+                    fused_gx1 = yb if Cp == Ci else yb[:, :Ci]
+            if fused_gx1 is None:
+                g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a, b, c0)
         g_w = None
         need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
         # the weight gradient (HBM-bound) and the input gradient (matrix cores) of a layer are independent: two streams
@@ -321,7 +334,9 @@ class _PointwiseFn(torch.autograd.Function):
             else:
                 g_w = _gw()
         g_x1 = g_x2 = None
-        if need1 or need2:
+        if fused_gx1 is not None:
+            g_x1 = fused_gx1
+        elif need1 or need2:
             Cout = weight2d.shape[0]
             ones_i = None
             packs = _pack_transposed(weight2d, x1.shape[1], x2.shape[1] if ctx.has_x2 else 0)

@@ -1115,6 +1115,41 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     return y
 
 
+# f32-class training backward: the BatchNorm / ReLU backward of a layer is applied by the operand load of its input-gradient launch, which also
+# writes g_raw for the weight gradient (sonet_pointmlp_x3_bnb_f32; 0 = a pass of its own, sonet_pointwise_bwd_apply_f32)
+BNB_ON_LOAD = _os.environ.get("SONET_BNB_ON_LOAD", "1") != "0"
+
+
+def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True):
+    """(W . g_raw) * scale + shift with g_raw = a * (gy masked by raw * sc + sh > 0 when relu) + b * raw + c0 per input channel, in one pass
+    over (gy, raw) -- ``pointwise_bwd_apply`` + ``pointmlp`` on an x3 pack, bit for bit.  -> (y B x Cout x L, g_raw or None)."""
+    _chk(gy, "gy", torch.float32, 3)
+    _chk(raw, "raw", torch.float32, 3)
+    if raw.shape != gy.shape:
+        raise SonetHipError("pointmlp_x3_bnb: gy and raw must have the same shape")
+    B, C, L = gy.shape
+    if wpt.dtype != torch.uint8:
+        raise SonetHipError("pointmlp_x3_bnb: an x3 pack")
+    for t in (scale, shift):
+        _chk(t, "scale / shift", torch.float32, 1)
+    for t in (a, b, c0, sc, sh):
+        _chk(t, "coefficient", torch.float32, 1)
+        if t.numel() != C:
+            raise SonetHipError("pointmlp_x3_bnb: %d coefficients expected" % C)
+    dev = _same_device(gy, raw, wpt, scale, shift, a, b, c0, sc, sh)
+    lib = _lib.load()
+    if wpt.numel() != lib.sonet_pointmlp_x3_pack_size(C, Cout):
+        raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C, Cout))
+    y = torch.empty((B, Cout, L), dtype=torch.float32, device=dev)
+    g_raw = torch.empty_like(gy) if want_g_raw else None
+    if y.numel() == 0:
+        return y, g_raw
+    with _lib.on_device(dev), _timed("pointmlpx3_bnb_%dx%d_L%d" % (C, Cout, L)):
+        check(lib.sonet_pointmlp_x3_bnb_f32(ptr(gy), ptr(raw), C, ptr(wpt), ptr(scale), ptr(shift), ptr(a), ptr(b), ptr(c0), ptr(sc), ptr(sh),
+                                            int(bool(relu)), ptr(g_raw), ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_x3_bnb_f32")
+    return y, g_raw
+
+
 def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
     """act((W . cat(x1, x2) + z[:, :, zidx]) * scale + shift) in one launch: z B x Cout x M f32 (the per-node block of the layer's
     pre-activation), zidx B x L i32 (out of range: + 0).  h3 packs only."""

@@ -329,3 +329,58 @@ def test_weight_gradients_joined_at_the_end_of_backward_equal_joined_per_layer(p
         assert out[True][it].keys() == out[False][it].keys()
         for k in out[True][it]:
             assert torch.equal(out[True][it][k], out[False][it][k]), (it, k)
+
+
+# ------------------------------------------------------------------------------------------ BatchNorm backward on load
+@pytest.mark.parametrize("B,C,Cout,L,relu", [(64, 256, 128, 15000, True), (8, 128, 64, 4100, True), (3, 512, 512, 577, False), (2, 48, 96, 131, True)])
+def test_dgrad_with_batchnorm_backward_on_load_equals_apply_then_dgrad(B, C, Cout, L, relu):
+    """sonet_pointmlp_x3_bnb_f32 == sonet_pointwise_bwd_apply_f32 followed by sonet_pointmlp_x3_f32 on its output: the input gradient and
+    the g_raw side output, bit for bit (incl. channel counts that are not multiples of 16 and ragged column tails)."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C + L)
+    gy = (torch.randn(B, C, L, generator=g) * 1e-3).to(DEV)
+    raw = (torch.randn(B, C, L, generator=g) * 1.5).to(DEV)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    a, b, c0 = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV), (torch.randn(C, generator=g) * 1e-5).to(DEV)
+    Wt = (torch.randn(Cout, C, generator=g) * C ** -0.5).to(DEV)           # the dgrad's matrix: Cout (= the layer's Cin) x C
+    wpt = ops.pointmlp_pack(Wt, "x3")
+    one, zero = ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV)
+    g_raw_ref = ops.pointwise_bwd_apply(gy, raw, sc, sh, relu, a, b, c0)
+    y_ref = ops.pointmlp(g_raw_ref, wpt, one, zero, False, Cout)
+    y, g_raw = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cout)
+    assert torch.equal(g_raw, g_raw_ref)
+    assert torch.equal(y, y_ref)
+    y2, none = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cout, want_g_raw=False)
+    assert none is None and torch.equal(y2, y_ref)
+
+
+def test_training_step_with_batchnorm_backward_on_load_is_bit_identical():
+    """ops.BNB_ON_LOAD on / off on the bit-reproducible f32-class path (original column order): every gradient identical."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 6, 2200
+    out = {}
+    old = (ops.BNB_ON_LOAD, ops.H3_SEGPOOL)
+    try:
+        ops.H3_SEGPOOL = False
+        with ops.precision("h3"):
+            for flag in (True, False):
+                ops.BNB_ON_LOAD = flag
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"]).backward()
+                assert any(n.startswith("pointmlpx3_bnb") for n, _, _ in rec.records) == flag
+                out[flag] = {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+    finally:
+        ops.BNB_ON_LOAD, ops.H3_SEGPOOL = old
+    assert out[True].keys() == out[False].keys()
+    for k in out[True]:
+        assert torch.equal(out[True][k], out[False][k]), k

@@ -6,6 +6,7 @@ what bench.py --mode train --precision h3 times) in the variants of round 5, in 
     D  C, the sparse weight gradient of the pooled layer AFTER its sparse input gradient (not beside it on the side stream)
     E  C, no side stream anywhere in the backward
     F  C, the side stream joined at the END of the backward pass (weight gradients are not needed before) instead of at the end of every layer
+    G  F, the BatchNorm / ReLU backward applied by the operand load of the input-gradient launch (which writes g_raw for the weight gradient)
 then one instrumented step of each (per-kernel times by events on the launching stream).
 
   python tools/ab_h3_train.py [--rounds 6] [--steps 24] [--precision h3]"""
@@ -41,7 +42,8 @@ def main():
     variants = [("A_store_index_max", False, False, True, True, False), ("B_sorted_pool", True, False, True, True, False),
                 ("C_sorted_pool_norm_on_load", True, True, True, True, False),
                 ("D_C_pooled_pair_in_sequence", True, True, False, True, False), ("E_C_no_side_stream_at_all", True, True, False, False, False),
-                ("F_C_joins_at_the_end_of_backward", True, True, True, True, True)]
+                ("F_C_joins_at_the_end_of_backward", True, True, True, True, True),
+                ("G_F_batchnorm_backward_on_load", True, True, True, True, True, True)]
     if args.only:
         variants = [v for v in variants if v[0][0] in args.only]
     with ops.precision(args.precision):
@@ -72,6 +74,7 @@ def main():
 
         def select(v):
             ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD, ops.POOLED_SIDE_STREAM, ops.BWD_SIDE_STREAM, ops.DEFER_WGRAD_JOIN = v[1], v[2], v[3], v[4], v[5]
+            ops.BNB_ON_LOAD = len(v) > 6 and v[6]
 
         def window(v):
             select(v)
