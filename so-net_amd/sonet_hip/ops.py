@@ -1235,10 +1235,11 @@ class side_stream:
         if not self.on:
             return
         idx = self.side.device.index
-        if defer and DEFER_WGRAD_JOIN and torch._C._current_graph_task_id() != -1:
+        task = torch._C._current_graph_task_id()
+        if defer and DEFER_WGRAD_JOIN and task != -1:
             _pending_join[idx] = (self.main, self.side)
-            if not _join_queued[0]:
-                _join_queued[0] = True
+            if _join_queued[0] != task:                      # (once per backward pass; a pass that died with an exception never ran its callback)
+                _join_queued[0] = task
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
             return
         self.main.wait_stream(self.side)
@@ -1249,7 +1250,7 @@ class side_stream:
 # layer's backward, the behaviour up to round 5's first session)
 DEFER_WGRAD_JOIN = _os.environ.get("SONET_DEFER_WGRAD_JOIN", "1") != "0"
 _pending_join = {}               # device index -> (main stream, side stream) with launches nobody has waited for yet
-_join_queued = [False]
+_join_queued = [-1]             # id of the autograd graph task whose end-of-pass callback is queued
 
 
 def join_side_streams():
@@ -1261,7 +1262,7 @@ def join_side_streams():
 
 
 def _end_of_backward_join():
-    _join_queued[0] = False
+    _join_queued[0] = -1
     join_side_streams()
 
 
