@@ -201,10 +201,16 @@ int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const f
  *     g_raw[k] = a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k]
  * (gy, raw [B][C][L]; a, b, c0 from sonet_bn_bwd_coeffs_f32, sc, sh the forward's normalisation) -- what sonet_pointwise_bwd_apply_f32 followed
  * by sonet_pointmlp_x3_f32 compute, bit for bit, in one pass over (gy, raw).  g_raw_out (or NULL) receives g_raw: the weight gradient's operand.
- * Wp3: the bf16-split pack of the C x Cout matrix (W^T of the layer); C <= 512, Cout % 32 == 0. */
+ * Wp3: the bf16-split pack of the C x Cout matrix (W^T of the layer); C <= 512, Cout % 32 == 0.
+ * praw / psc / psh / prelu / pstats_ws / psums (all or none): y is gy of the layer BELOW; with that layer's raw output praw [B][Cout][L] and
+ * normalisation psc, psh [Cout] the epilogue also returns its BatchNorm-backward sums psums[0 .. Cout) = sum of gy * mask, psums[Cout .. 2 Cout) =
+ * sum of gy * mask * praw (double; what sonet_pointwise_bwd_stats_f32 computes from one more pass over (gy, praw)); pstats_ws:
+ * sonet_pointmlp_stats_ws_size(B, Cout, L) bytes. */
 int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
                               const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
-                              float *g_raw_out, float *y, int B, int Cout, int L, sonet_stream_t stream);
+                              float *g_raw_out, float *y, int B, int Cout, int L,
+                              const float *praw, const float *psc, const float *psh, int prelu, void *pstats_ws, double *psums,
+                              sonet_stream_t stream);
 
 /* The same layer on bf16 MFMA with a 3-way bf16 split of both operands (6 MFMAs per product term set):
  * f32-class accuracy (classifier forward within 3e-6 * max(|ref|, rms) of the reference; tolerance 1e-5) at

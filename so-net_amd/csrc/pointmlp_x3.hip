@@ -246,6 +246,29 @@ __global__ __launch_bounds__(256) void stats_partial_finalize_kernel(const doubl
     }
 }
 
+// partial (sum, sum) pairs of the workgroups -> sums[0 .. C) and sums[C .. 2 C) in double precision, fixed order: the layout
+// sonet_bn_bwd_coeffs_f32 reads (BnbArgs::pstats)
+__global__ __launch_bounds__(256) void bwd_sums_finalize_kernel(const double *__restrict__ partial, int nwg, int C, double *__restrict__ sums)
+{
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = t; k < nwg; k += 256) {
+        const double *p = partial + ((size_t)k * C + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+    r1[t] = s1;
+    r2[t] = s2;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { r1[t] += r1[t + off]; r2[t] += r2[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) { sums[c] = r1[0]; sums[C + c] = r2[0]; }
+}
+
 // SEGPOOL (training forward of the first PointNet's last layer when only the pooled map is consumed, models/layers.py:431 +
 // models/networks.py:180-185): the columns are NODE-SORTED (som_sort_group), the output is never stored; the per-node arg-max of every
 // channel leaves through 64-bit keys (orderable(value) << 32 | 0xFFFFFFFF - column: the order of index_max.hip -- bigger value wins,
@@ -285,6 +308,13 @@ struct BnbArgs {
     const float *a, *b, *c0, *sc, *sh;    // [C1]
     float *g_out;                         // [B][C1][L] (may be NULL)
     int relu;
+    // (optional) the OUTPUT of this launch is gy of the layer below; when that layer's raw output and normalisation are at hand (the training
+    // forward normalises on load: they are this layer's saved input) the epilogue also computes ITS BatchNorm-backward sums -- per channel
+    // sum of gy * mask and of gy * mask * praw, what sonet_pointwise_bwd_stats_f32 would read (gy, praw) once more for
+    const float *praw;                    // [B][Cout][L] or NULL
+    const float *psc, *psh;               // [Cout]
+    int prelu;
+    double *pstats;                       // [gridDim.x][Cout][2] partial sums
 };
 
 // ZADD: the per-node addend form with its gathers issued BEFORE the K loop (64 registers; instantiated for MT = 4 only).
@@ -605,6 +635,41 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     }
                 }
             }
+        } else if (BNB && bnb.pstats != nullptr) {
+            // the output is gy of the layer below: its BatchNorm-backward sums from here (same reduction as the forward statistics below)
+            const unsigned voy_s = pv ? voy : 0x7FFFFF00u;
+            const __amdgpu_buffer_rsrc_t rpr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(bnb.praw + b * (long long)Cout * L), 0, (int)((unsigned)Cout * rowB), 0x00020000);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
+                const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = (r & 3) + 8 * (r >> 2);
+                    const float2 ss = aff[orow];
+                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                    if (relu) v = (v < 0.f) ? 0.f : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy_s, so_tile + (unsigned)orow * rowB, 0);
+                    const int ch = (ct0 + mt) * 32 + orow + 4 * h;
+                    // (requested here: 16 MT exposed round trips per lane.  Requested before the K loop -- 64 more registers, one workgroup
+                    //  less per CU for every launch of this instantiation -- the launch was no faster: docs/findings.md R5.9)
+                    const float pr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rpr, voy_s, so_tile + (unsigned)orow * rowB, 0));
+                    float gm = pv ? v : 0.f;
+                    if (bnb.prelu && !(__fmaf_rn(pr, bnb.psc[ch], bnb.psh[ch]) > 0.f)) gm = 0.f;
+                    const float s1 = row32_sum(gm), s2 = row32_sum(gm * pr);
+                    if (j == 0) red[wave][mt * 32 + orow + 4 * h] = make_float2(s1, s2);
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < MT * 32; t += X3_THREADS) {
+                const double a_ = ((double)red[0][t].x + (double)red[1][t].x) + ((double)red[2][t].x + (double)red[3][t].x);
+                const double q_ = ((double)red[0][t].y + (double)red[1][t].y) + ((double)red[2][t].y + (double)red[3][t].y);
+                double *dst = bnb.pstats + ((size_t)blockIdx.x * Cout + (size_t)ct0 * 32 + t) * 2;
+                dst[0] = a_;
+                dst[1] = q_;
+            }
+            __syncthreads();                                    // (red is reused by the next tile group)
         } else if (stats_partial != nullptr) {
             // Training forward: BatchNorm's batch statistics (models/layers.py:60-70) of the output come out of this epilogue instead of
             // a second pass over the tensor.  A row's 32 columns sit in the 32 lanes of a half wave: four DPP adds + one swizzle per
@@ -1119,7 +1184,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
                        int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
                        double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr,
                        const float *zadd = nullptr, const int32_t *zidx = nullptr, int ZM = 0, unsigned *kmax = nullptr, int KM = 0,
-                       const SegPoolArgs *segpool = nullptr, const XAffArgs *xaff = nullptr, const BnbArgs *bnbp = nullptr)
+                       const SegPoolArgs *segpool = nullptr, const XAffArgs *xaff = nullptr, const BnbArgs *bnbp = nullptr, double *bnb_psums = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -1133,7 +1198,9 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     SONET_REQUIRE(!bnbp || (!f16 && !gidx && !zadd && !kmax && !segpool && !xaff && !stats_ws && C2 == 0 && bnbp->raw && bnbp->a && bnbp->b && bnbp->c0
                             && bnbp->sc && bnbp->sh), "%s: the BatchNorm-backward operand takes the plain bf16-split layer with one input panel", what);
     if (bnbp && C1 > 512) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the BatchNorm-backward operand needs <= 512 input channels", what);
-    const BnbArgs bnb = bnbp ? *bnbp : BnbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    SONET_REQUIRE(!bnbp || ((bnbp->praw == nullptr) == (bnbp->pstats == nullptr) && (bnbp->pstats == nullptr) == (bnb_psums == nullptr) &&
+                            (!bnbp->praw || (bnbp->psc && bnbp->psh))), "%s: the sums of the layer below need praw, psc, psh, a workspace and the output", what);
+    const BnbArgs bnb = bnbp ? *bnbp : BnbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr};
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
     SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
@@ -1287,6 +1354,7 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
             case 2: hipLaunchKernelGGL((pointmlp_x3_kernel<2, 1, false, false, false, false, true>), X3_ARGS); break;
             default: hipLaunchKernelGGL((pointmlp_x3_kernel<1, 1, false, false, false, false, true>), X3_ARGS);
         }
+        if (bnb.pstats) hipLaunchKernelGGL(bwd_sums_finalize_kernel, dim3((unsigned)Cout), dim3(256), 0, st, bnb.pstats, (int)nwg_x, Cout, bnb_psums);
         return sonet::launched(what);
     }
     if (xaff) {                                                  // (MT is 6 or 4 here: Cout % 128 == 0)
@@ -1471,13 +1539,15 @@ extern "C" int sonet_pointmlp_x3_stats_f32(const float *x1, int C1, const float 
  * Wp3: the bf16-split pack (sonet_pointmlp_x3_pack*) of the C x Cout matrix; C <= 512, Cout % 32 == 0. */
 extern "C" int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
                                          const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
-                                         float *g_raw_out, float *y, int B, int Cout, int L, sonet_stream_t stream)
+                                         float *g_raw_out, float *y, int B, int Cout, int L,
+                                         const float *praw, const float *psc, const float *psh, int prelu, void *pstats_ws, double *psums,
+                                         sonet_stream_t stream)
 {
     const char *what = "sonet_pointmlp_x3_bnb_f32";
     SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y, "%s: NULL pointer", what);
-    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu};
+    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu, praw, psc, psh, prelu, reinterpret_cast<double *>(pstats_ws)};
     return x3_run_impl(what, false, gy, C, nullptr, 0, Wp3, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn);
+                       nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn, psums);
 }
 
 extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,

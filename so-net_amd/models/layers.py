@@ -190,6 +190,19 @@ def _stats_epilogue_ok(x1, wp, Cout):
                  or (wp.dtype == torch.int16 and x1.dtype == torch.bfloat16)))
 
 
+def _bwd_sums_hint(gy, raw, relu):
+    """The BatchNorm-backward sums of the layer whose output gradient is ``gy`` when the launch that produced gy computed them in its
+    epilogue (``ops.pointmlp_x3_bnb(..., below=...)``) -- valid only if gy is still exactly that tensor: same object, never added to (autograd
+    accumulates a second consumer's gradient IN PLACE: the version counter moves), and computed against this very raw tensor."""
+    h = getattr(gy, "_sonet_bwd_sums", None)
+    if h is None:
+        return None
+    sums, raw_ptr, version, hrelu = h
+    if raw_ptr != raw.data_ptr() or version != gy._version or hrelu != bool(relu) or sums.numel() != 2 * raw.shape[1] or not gy.is_contiguous():
+        return None
+    return sums
+
+
 def _leaf_of(weight2d):
     """The parameter behind a layer's weight2d view (a weak reference: autograd contexts must not keep modules alive)."""
     import weakref
@@ -284,6 +297,7 @@ class _PointwiseFn(torch.autograd.Function):
         ctx.defer_ok = _grad_slot_empty(ctx.wleaf)
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
+        gy_in = gy
         gy = gy.contiguous()
         g_gamma = g_beta = g_bias = None
         fused_gx1 = None
@@ -300,7 +314,10 @@ class _PointwiseFn(torch.autograd.Function):
         else:
             sc, sh, raw, mean, invstd, gamma, zeros = saved[3:10]
             n = float(raw.shape[0] * raw.shape[2])
-            sums = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu, want_sums=True)
+            # (the launch that produced gy may have left this layer's sums on it: _bwd_sums_hint)
+            sums = _bwd_sums_hint(gy_in, raw, ctx.relu)
+            if sums is None:
+                sums = _ops.pointwise_bwd_stats(gy, raw, sc, sh, ctx.relu, want_sums=True)
             a, b, c0, g_gamma, g_beta = _ops.bn_bwd_coeffs(sums, mean, invstd, gamma, n)
             g_bias = zeros.clone()                                        # a bias in front of BatchNorm has no gradient
             # f32-class, one input panel, an input gradient to compute: the BatchNorm / ReLU backward rides on the operand load of the
@@ -311,9 +328,16 @@ class _PointwiseFn(torch.autograd.Function):
                 if pk is not None and pk[0].dtype == torch.uint8:
                     wpt, Ci, Cp = pk
                     dev = gy.device
-                    yb, g_raw = _ops.pointmlp_x3_bnb(gy, raw, wpt, _ops.const_vec(Cp, 1.0, dev), _ops.const_vec(Cp, 0.0, dev), a, b, c0, sc, sh, ctx.relu,
-                                                     Cp, want_g_raw=ctx.needs_input_grad[2])
+                    xa_ = ctx.xaff
+                    # x1 is the RAW output of the layer below (normalise-on-load) and nothing is padded: this launch's output is that
+                    # layer's gy, and its BatchNorm-backward sums come out of the epilogue (handed over on the tensor: _bwd_sums_hint)
+                    below = (x1, xa_[0], xa_[1], xa_[2]) if (_ops.BWD_STATS_EPILOGUE and xa_ is not None and Cp == Ci and x1.dtype == torch.float32) else None
+                    res = _ops.pointmlp_x3_bnb(gy, raw, wpt, _ops.const_vec(Cp, 1.0, dev), _ops.const_vec(Cp, 0.0, dev), a, b, c0, sc, sh, ctx.relu,
+                                               Cp, want_g_raw=ctx.needs_input_grad[2], below=below)
+                    yb, g_raw = res[0], res[1]
                     fused_gx1 = yb if Cp == Ci else yb[:, :Ci]
+                    if below is not None:
+                        fused_gx1._sonet_bwd_sums = (res[2], x1.data_ptr(), fused_gx1._version, bool(xa_[2]))
             if fused_gx1 is None:
                 g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a, b, c0)
         g_w = None

@@ -1120,9 +1120,17 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
 BNB_ON_LOAD = _os.environ.get("SONET_BNB_ON_LOAD", "1") != "0"
 
 
-def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True):
+# ... and, when the layer BELOW handed its raw output on (normalise-on-load), the same launch's epilogue can compute that layer's BatchNorm-backward
+# sums from its output (no statistics pass over (gy, raw) of the layer below).  OFF: measured slower -- the reduction costs the dgrad launch 0.33-0.44 ms
+# for the 0.2-0.3 ms pass it replaces (docs/findings.md R5.9); kept as a tested record.
+BWD_STATS_EPILOGUE = _os.environ.get("SONET_BWD_STATS_EPILOGUE", "0") != "0"
+
+
+def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True, below=None):
     """(W . g_raw) * scale + shift with g_raw = a * (gy masked by raw * sc + sh > 0 when relu) + b * raw + c0 per input channel, in one pass
-    over (gy, raw) -- ``pointwise_bwd_apply`` + ``pointmlp`` on an x3 pack, bit for bit.  -> (y B x Cout x L, g_raw or None)."""
+    over (gy, raw) -- ``pointwise_bwd_apply`` + ``pointmlp`` on an x3 pack, bit for bit.  -> (y B x Cout x L, g_raw or None[, sums]).
+    below = (praw B x Cout x L, psc, psh, prelu): y is gy of the layer below; -> also its BatchNorm-backward sums (float64 [2 Cout], the
+    layout of ``pointwise_bwd_stats(..., want_sums=True)``) from the epilogue."""
     _chk(gy, "gy", torch.float32, 3)
     _chk(raw, "raw", torch.float32, 3)
     if raw.shape != gy.shape:
@@ -1144,9 +1152,24 @@ def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, wa
     g_raw = torch.empty_like(gy) if want_g_raw else None
     if y.numel() == 0:
         return y, g_raw
-    with _lib.on_device(dev), _timed("pointmlpx3_bnb_%dx%d_L%d" % (C, Cout, L)):
+    praw = psc = psh = pws = sums = None
+    prelu = False
+    if below is not None:
+        praw, psc, psh, prelu = below
+        _chk(praw, "praw", torch.float32, 3)
+        if tuple(praw.shape) != (B, Cout, L) or psc.numel() != Cout or psh.numel() != Cout:
+            raise SonetHipError("pointmlp_x3_bnb: the layer below must be B x Cout x L with Cout coefficients")
+        _chk(psc, "psc", torch.float32, 1)
+        _chk(psh, "psh", torch.float32, 1)
+        _same_device(gy, praw, psc, psh)
+        pws = torch.empty((lib.sonet_pointmlp_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
+        sums = torch.empty((2 * Cout,), dtype=torch.float64, device=dev)
+    with _lib.on_device(dev), _timed("pointmlpx3_bnb%s_%dx%d_L%d" % ("s" if below is not None else "", C, Cout, L)):
         check(lib.sonet_pointmlp_x3_bnb_f32(ptr(gy), ptr(raw), C, ptr(wpt), ptr(scale), ptr(shift), ptr(a), ptr(b), ptr(c0), ptr(sc), ptr(sh),
-                                            int(bool(relu)), ptr(g_raw), ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_x3_bnb_f32")
+                                            int(bool(relu)), ptr(g_raw), ptr(y), B, Cout, L, ptr(praw), ptr(psc), ptr(psh), int(bool(prelu)),
+                                            ptr(pws), ptr(sums), stream_ptr()), "sonet_pointmlp_x3_bnb_f32")
+    if below is not None:
+        return y, g_raw, sums
     return y, g_raw
 
 

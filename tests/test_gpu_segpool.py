@@ -384,3 +384,63 @@ def test_training_step_with_batchnorm_backward_on_load_is_bit_identical():
     assert out[True].keys() == out[False].keys()
     for k in out[True]:
         assert torch.equal(out[True][k], out[False][k]), k
+
+
+@pytest.mark.parametrize("B,C,Cout,L", [(64, 256, 128, 15000), (8, 128, 64, 4100), (3, 64, 96, 577)])
+def test_dgrad_epilogue_returns_the_batchnorm_backward_sums_of_the_layer_below(B, C, Cout, L):
+    """ops.pointmlp_x3_bnb(..., below=(praw, psc, psh, relu)): the launch's output is gy of the layer below; its epilogue returns that layer's
+    sums (sum gy * mask, sum gy * mask * praw) as sonet_pointwise_bwd_stats_f32 computes them from one more pass (double accumulation of
+    32-column float partials: equal to summation order); output and g_raw are untouched."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C + L)
+    gy = (torch.randn(B, C, L, generator=g) * 1e-3).to(DEV)
+    raw = (torch.randn(B, C, L, generator=g) * 1.5).to(DEV)
+    praw = (torch.randn(B, Cout, L, generator=g) * 1.5 + 0.2).to(DEV)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    psc, psh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    a, b, c0 = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV), (torch.randn(C, generator=g) * 1e-5).to(DEV)
+    wpt = ops.pointmlp_pack((torch.randn(Cout, C, generator=g) * C ** -0.5).to(DEV), "x3")
+    one, zero = ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV)
+    y_ref, g_ref = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout)
+    for prelu in (True, False):
+        y, g_raw, sums = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout, below=(praw, psc, psh, prelu))
+        assert torch.equal(y, y_ref) and torch.equal(g_raw, g_ref)
+        ref = ops.pointwise_bwd_stats(y_ref, praw, psc, psh, prelu, want_sums=True)
+        scale = (y_ref.double().abs() * (praw.double().abs() + 1)).sum(dim=(0, 2)).repeat(2)     # the size of the summed terms per channel
+        assert float(((sums - ref).abs() / scale).max()) <= 1e-6, prelu
+        assert torch.equal(sums, ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout, below=(praw, psc, psh, prelu))[2])   # fixed order
+
+
+def test_training_step_with_backward_sums_from_the_dgrad_epilogue():
+    """ops.BWD_STATS_EPILOGUE on / off: the statistics launches of the hidden layers whose gradient comes from one dgrad launch disappear;
+    forward identical, gradients within the arg-max-flip bound (the sums differ by summation order)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 8, 3000
+    res = {}
+    old = ops.BWD_STATS_EPILOGUE
+    try:
+        with ops.precision("h3"):
+            for flag in (True, False):
+                ops.BWD_STATS_EPILOGUE = flag
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward()
+                names = [n for n, _, _ in rec.records]
+                assert any(n.startswith("pointmlpx3_bnbs_") for n in names) == flag
+                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone(),
+                             sum(1 for n in names if n == "pointwise_bwd_stats"))
+    finally:
+        ops.BWD_STATS_EPILOGUE = old
+    assert res[True][4] < res[False][4]
+    _compare_steps(res[True], res[False])
