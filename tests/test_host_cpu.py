@@ -258,3 +258,58 @@ def test_freeze_gc_freezes_and_unfreezes():
     assert n >= before and n > 1000 and gc.get_freeze_count() == n   # (a Python process tracks far more than a thousand objects)
     host.unfreeze_gc()
     assert gc.get_freeze_count() == 0
+
+
+def test_encoder_keeps_first_pn_out_for_a_live_segmenter_unless_told_otherwise():
+    """Training forwards do not write first_pn_out when only its per-node maximum is consumed -- unless a head reads it per point copy.
+    A head that says so sets ``want_first_pn_out``; the reference's own segmenter Model does not, so a live Segmenter in the process
+    keeps the tensor (models/segmenter.py:79-109 reads encoder.first_pn_out after the forward)."""
+    import gc
+    from models import networks as NW
+    opt = Namespace(gpu_id=0, device=torch.device("cpu"), batch_size=2, input_pc_num=256, surface_normal=True,
+                    feature_num=1024, activation="relu", normalization="batch", dropout=0.7, node_num=64, k=3, som_k=9,
+                    som_k_type="avg", bn_momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=50)
+    gc.collect()
+    base = len(NW._DENSE_HEADS)
+    enc = NW.Encoder(opt)
+    if base == 0:
+        assert enc._wants_dense() is False
+    seg = NW.Segmenter(opt)
+    assert len(NW._DENSE_HEADS) == base + 1 and enc._wants_dense() is True
+    enc.want_first_pn_out = False                                  # said explicitly: wins over the registry
+    assert enc._wants_dense() is False
+    enc.want_first_pn_out = True
+    assert enc._wants_dense() is True
+    del enc.__dict__["want_first_pn_out"]
+    del seg
+    gc.collect()
+    assert len(NW._DENSE_HEADS) == base
+    if base == 0:
+        assert enc._wants_dense() is False
+
+
+def test_backward_sums_hint_is_dropped_when_the_gradient_was_accumulated_into():
+    """The BatchNorm-backward sums a dgrad launch leaves on its output (models.layers._bwd_sums_hint) are valid only for exactly that
+    tensor: autograd adds a second consumer's gradient IN PLACE, which moves the version counter."""
+    from models import layers as L
+    raw = torch.zeros(2, 4, 8)
+    gy = torch.ones(2, 4, 8)
+    sums = torch.zeros(8, dtype=torch.float64)
+    assert L._bwd_sums_hint(gy, raw, True) is None
+    gy._sonet_bwd_sums = (sums, raw.data_ptr(), gy._version, True)
+    assert L._bwd_sums_hint(gy, raw, True) is sums
+    assert L._bwd_sums_hint(gy, raw, False) is None                # another mask
+    assert L._bwd_sums_hint(gy, torch.zeros(2, 4, 8), True) is None   # another raw tensor
+    gy.add_(1.0)                                                   # what autograd's accumulation does
+    assert L._bwd_sums_hint(gy, raw, True) is None
+
+
+def test_deferred_side_stream_join_is_inert_without_a_gpu():
+    from sonet_hip import ops
+    ops.join_side_streams()                                        # nothing pending: a no-op
+    ss = ops.side_stream(torch.device("cpu"))
+    with ss:
+        pass
+    ss.reads(torch.zeros(3))
+    ss.join(defer=True)
+    assert not ops._pending_join

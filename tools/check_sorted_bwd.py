@@ -1,4 +1,4 @@
-"""debug: the sparse pooled dgrad / wgrad kernels on the positions the sorted pool hands them, against float64 torch (scatter + matmul)."""
+"""tools/check_sorted_bwd.py -- the sparse pooled dgrad / wgrad kernels on the positions the sorted pool hands them, against float64 torch (scatter + matmul)."""
 import os, sys
 from argparse import Namespace
 import numpy as np
