@@ -387,6 +387,13 @@ int sonet_som_assign_sort_f32(const float *x, const float *sn, const float *node
                               int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
                               float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
                               int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream);
+/* ... with a deterministic order inside a node (wave, slot, lane order of a 512-point workgroup instead of the arrival order of LDS atomics):
+ * the same sorted copy in every run.  The f32-class TRAINING forward uses it (its BatchNorm batch sums run over the sorted columns); the
+ * no-grad forward, which only takes maxima over a node's points, keeps the atomics. */
+int sonet_som_assign_sort_det_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                              int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                              float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                              int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream);
 /* ... whose second launch also does sonet_knn_stage_prepare_f32 (below) on the cluster means it computes: center [B][3][M], center_p16 and rec
  * are bit-identical to the separate launch on som_node, and the no-grad forward needs no launch for KNNModule's index / coordinate side
  * (models/layers.py:319-350). */

@@ -673,7 +673,8 @@ template <int KSEL, int IB>
 __global__ __launch_bounds__(SP_THREADS) void som_assign_rank_kernel(
     const float *__restrict__ x, const float *__restrict__ node, int N, int M, int nW,
     int32_t *__restrict__ min32, int64_t *__restrict__ min64, uint16_t *__restrict__ rank16,
-    int32_t *__restrict__ cnt_part /*[B][nW][M]*/, double *__restrict__ sum_part /*[B][nW][3][M]*/)
+    int32_t *__restrict__ cnt_part /*[B][nW][M]*/, double *__restrict__ sum_part /*[B][nW][3][M]*/,
+    int det /*ranks independent of the arrival order of the LDS atomics (+ 4 M ints of LDS)*/)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *nodes = reinterpret_cast<float4 *>(smem);
@@ -698,9 +699,65 @@ __global__ __launch_bounds__(SP_THREADS) void som_assign_rank_kernel(
         if (n < N) {
             pc[p][0] = xb[n]; pc[p][1] = xb[N + n]; pc[p][2] = xb[2 * (size_t)N + n];
             som_select_keys<KSEL, IB>(pc[p][0], pc[p][1], pc[p][2], nodes, M, bi[p]);
+            if (!det) {
+#pragma unroll
+                for (int s = 0; s < KSEL; ++s) rk[p][s] = atomicAdd(&cnt[bi[p][s]], 1);   // the copy's rank among this workgroup's copies of the node
+            }
+        }
+    }
+    if (det) {
+        // Ranks that do not depend on the arrival order of LDS atomics (the f32-class TRAINING forward runs its first PointNet on the sorted
+        // copy: BatchNorm's batch sums must see the same column order in every run).  Order inside the workgroup: wave, then slot (p, s),
+        // then lane.  Per slot a wave walks the distinct node ids among its lanes: the lanes of an id take the wave's running count of
+        // that node plus the number of lower lanes with the same id, one lane adds the group's size.  The waves' counts are prefixed
+        // after a barrier.  (~40 turns per slot on 64 nodes: the training path only; the no-grad forward keeps the atomics.)
+        int *whist = reinterpret_cast<int *>(stage + 3 * CAP);              // [waves][M], zeroed below before use
+        constexpr int NWAVE = SP_THREADS / 64;
+        for (int t = tid; t < NWAVE * M; t += SP_THREADS) whist[t] = 0;
+        __syncthreads();
+        const int wave = tid >> 6, lane = tid & 63;
+        const unsigned long long lower = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int p = 0; p < SP_PPT; ++p) {
+            const bool valid = w * SP_T + p * SP_THREADS + tid < N;
 #pragma unroll
             for (int s = 0; s < KSEL; ++s) {
-                rk[p][s] = atomicAdd(&cnt[bi[p][s]], 1);                    // the copy's rank among this workgroup's copies of the node
+                const int id = valid ? bi[p][s] : -1;
+                unsigned long long rem = __ballot(id >= 0);
+                int r = 0;
+                while (rem != 0ull) {
+                    const int l0 = __builtin_ctzll(rem);
+                    const int id0 = __builtin_amdgcn_readlane(id, l0);
+                    const unsigned long long grp = __ballot(id == id0);
+                    rem &= ~grp;
+                    const int basev = whist[wave * M + id0];
+                    if (id == id0) r = basev + __builtin_popcountll(grp & lower);
+                    if (lane == l0) whist[wave * M + id0] = basev + __builtin_popcountll(grp);
+                }
+                rk[p][s] = r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < SP_PPT; ++p) {
+            if (w * SP_T + p * SP_THREADS + tid < N) {
+#pragma unroll
+                for (int s = 0; s < KSEL; ++s)
+                    for (int w2 = 0; w2 < wave; ++w2) rk[p][s] += whist[w2 * M + bi[p][s]];
+            }
+        }
+        for (int m = tid; m < M; m += SP_THREADS) {
+            int c = 0;
+            for (int w2 = 0; w2 < NWAVE; ++w2) c += whist[w2 * M + m];
+            cnt[m] = c;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < SP_PPT; ++p) {
+        const int n = w * SP_T + p * SP_THREADS + tid;
+        if (n < N) {
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) {
                 const size_t o = (size_t)b * kN + (size_t)s * N + n;
                 min32[o] = bi[p][s];
                 if (min64 != nullptr) min64[o] = bi[p][s];
@@ -923,7 +980,7 @@ extern "C" size_t sonet_som_assign_sort_ws_size(int B, int N, int M, int k)
 static int som_assign_sort_impl(const char *what, const float *x, const float *sn, const float *node, int B, int N, int M, int k,
                                 int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
                                 float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
-                                int32_t *pos0, int32_t *node_off, void *ws, const KnnPrep &kp, sonet_stream_t stream)
+                                int32_t *pos0, int32_t *node_off, void *ws, const KnnPrep &kp, sonet_stream_t stream, int det = 0)
 {
     SONET_REQUIRE(x && sn && node && min_idx_i32 && count && x_aug_sorted && ids_sorted && pos0 && node_off && ws, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && N > 0 && M > 0, "%s: non-positive size B=%d N=%d M=%d", what, B, N, M);
@@ -936,13 +993,13 @@ static int som_assign_sort_impl(const char *what, const float *x, const float *s
     int32_t *cnt_part = reinterpret_cast<int32_t *>(sum_part + (size_t)B * nW * 3 * M);
     uint16_t *rank16 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cnt_part) + (((size_t)B * nW * M * 4 + 7) & ~(size_t)7));
     dim3 grid((unsigned)nW, (unsigned)B), block(SP_THREADS);
-    const size_t lds1 = (size_t)M * (sizeof(float4) + 2 * sizeof(int)) + (size_t)3 * k * SP_T * sizeof(float);
+    const size_t lds1 = (size_t)M * (sizeof(float4) + 2 * sizeof(int)) + (size_t)3 * k * SP_T * sizeof(float) + (det ? (size_t)(SP_THREADS / 64) * M * sizeof(int) : 0);
     const size_t lds2 = (size_t)M * (3 * sizeof(double) + 3 * sizeof(float) + 5 * sizeof(int)) + (size_t)8 * k * SP_T * sizeof(float);
 #define SP_LAUNCH(KK) do { \
         if (M <= 64) { if (lds1 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_assign_rank_kernel<KK, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what); \
-                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 6>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part); } \
+                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 6>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part, det); } \
         else         { if (lds1 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_assign_rank_kernel<KK, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return sonet::fail(SONET_ERR_LAUNCH, "%s: LDS", what); \
-                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 10>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part); } } while (0)
+                       hipLaunchKernelGGL((som_assign_rank_kernel<KK, 10>), grid, block, lds1, st, x, node, N, M, nW, min_idx_i32, min_idx_i64, rank16, cnt_part, sum_part, det); } } while (0)
     switch (k) { case 1: SP_LAUNCH(1); break; case 2: SP_LAUNCH(2); break; case 3: SP_LAUNCH(3); break; default: SP_LAUNCH(4); }
 #undef SP_LAUNCH
     if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(som_sort_fill2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
@@ -961,6 +1018,20 @@ extern "C" int sonet_som_assign_sort_f32(const float *x, const float *sn, const 
     kp.I = nullptr; kp.KI = kp.K = kp.avg = kp.G = 0; kp.BM = kp.Lm = 0; kp.center = nullptr; kp.center_p16 = nullptr; kp.rec = nullptr;
     return som_assign_sort_impl("sonet_som_assign_sort_f32", x, sn, node, B, N, M, k, min_idx_i32, min_idx_i64, count, sum_ws, som_node, row_max,
                                 x_aug_sorted, ids_sorted, pos0, node_off, ws, kp, stream);
+}
+
+/* sonet_som_assign_sort_f32 with a sort whose order INSIDE a node does not depend on the arrival order of atomics (wave, slot, lane order
+ * inside a 512-point workgroup, workgroups in order): the same sorted copy in every run -- what the f32-class training forward wants, whose
+ * BatchNorm batch sums run over the sorted columns.  Same ids, counts, means, node offsets. */
+extern "C" int sonet_som_assign_sort_det_f32(const float *x, const float *sn, const float *node, int B, int N, int M, int k,
+                                             int32_t *min_idx_i32, int64_t *min_idx_i64, int32_t *count, double *sum_ws,
+                                             float *som_node, int32_t *row_max, float *x_aug_sorted, int32_t *ids_sorted,
+                                             int32_t *pos0, int32_t *node_off, void *ws, sonet_stream_t stream)
+{
+    KnnPrep kp;
+    kp.I = nullptr; kp.KI = kp.K = kp.avg = kp.G = 0; kp.BM = kp.Lm = 0; kp.center = nullptr; kp.center_p16 = nullptr; kp.rec = nullptr;
+    return som_assign_sort_impl("sonet_som_assign_sort_det_f32", x, sn, node, B, N, M, k, min_idx_i32, min_idx_i64, count, sum_ws, som_node, row_max,
+                                x_aug_sorted, ids_sorted, pos0, node_off, ws, kp, stream, 1);
 }
 
 /* sonet_som_assign_sort_f32 whose second launch also does sonet_knn_stage_prepare_f32 on the cluster means it computes (KNNModule's index /

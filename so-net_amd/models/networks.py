@@ -354,7 +354,9 @@ class Encoder(_PlainAttrs, nn.Module):
             sorted_pool = (train_pooled and use_sn and not per_point and a is None and self.first_pointnet.pooled_sorted_ok(xd, M)
                            and int(opt.k) * xd.shape[2] * 384 * 4 < 4e9)
             if sorted_pool:
-                fast = sb.assign_sort(xd, snd, opt.k) if _ops.TRAIN_ASSIGN_SORT else None   # (two launches; the sorted position of a copy = node offset + run start + rank)
+                # (two launches; the sorted position of a copy = node offset + run start + rank, the rank in a fixed order: BatchNorm's batch
+                #  sums over the sorted columns are the same in every run)
+                fast = sb.assign_sort(xd, snd, opt.k, deterministic=True) if _ops.TRAIN_ASSIGN_SORT else None
                 if fast is not None:
                     a, g = fast
                 else:

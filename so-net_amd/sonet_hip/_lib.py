@@ -48,6 +48,7 @@ SIGNATURES = {
     "sonet_pack_multi_kc": [_i, _i],
     "sonet_bn_rider_set": [_vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sonet_som_assign_sort_det_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_knn_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_som_group_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

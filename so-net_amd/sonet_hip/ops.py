@@ -312,11 +312,13 @@ def som_sort_group(x, sn, a):
     return out
 
 
-def som_assign_sort(x, sn, node, k, want_i64=False, knn=None):
+def som_assign_sort(x, sn, node, k, want_i64=False, knn=None, deterministic=False):
     """som_assign + som_sort_group of the no-grad pooled path in two launches (``sonet_som_assign_sort_f32``): -> (SomAssignment,
     dict(som_node, row_max, x_aug_sorted, ids_sorted, pos0, node_off, count)).  Node ids / counts bit-identical to the separate calls.
     knn = (knn_I B x M x KI int64, K, center_avg): the second launch also does ``knn_stage_prepare`` on the cluster means
-    (``sonet_som_assign_sort_knn_f32``); its result is the dict's "knn_prep"."""
+    (``sonet_som_assign_sort_knn_f32``); its result is the dict's "knn_prep".
+    deterministic (without knn): the order INSIDE a node does not depend on the arrival order of atomics (``sonet_som_assign_sort_det_f32``):
+    the same sorted copy in every run."""
     _chk(x, "x", torch.float32, 3)
     _chk(sn, "sn", torch.float32, 3)
     _chk(node, "node", torch.float32, 3)
@@ -360,8 +362,9 @@ def som_assign_sort(x, sn, node, k, want_i64=False, knn=None):
                                                     stream_ptr()), "sonet_som_assign_sort_knn_f32")
         out["knn_prep"] = prep
         return r, out
-    with _lib.on_device(dev), _timed("som_assign_sort"):
-        check(lib.sonet_som_assign_sort_f32(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
+    fn = lib.sonet_som_assign_sort_det_f32 if deterministic else lib.sonet_som_assign_sort_f32
+    with _lib.on_device(dev), _timed("som_assign_sort_det" if deterministic else "som_assign_sort"):
+        check(fn(ptr(x), ptr(sn), ptr(node), B, N, M, k, ptr(r.min_idx_i32), ptr(r.min_idx_i64), ptr(r.count),
                                             ptr(r.sum_ws), ptr(out["som_node"]), ptr(out["row_max"]), ptr(out["x_aug_sorted"]),
                                             ptr(out["ids_sorted"]), ptr(out["pos0"]), ptr(out["node_off"]), ptr(ws), stream_ptr()),
               "sonet_som_assign_sort_f32")

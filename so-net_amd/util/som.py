@@ -97,7 +97,7 @@ class BatchSOM():
         self.last_assignment = a
         return a
 
-    def assign_sort(self, x, sn, k, knn=None):
+    def assign_sort(self, x, sn, k, knn=None, deterministic=False):
         """Assignment + node-sorted grouping in two launches (the no-grad pooled path of the level-2 Encoder): -> (assignment,
         grouping dict), or None when the batch is outside what the fused launches take (B > 65535, M > 1024, k > 4) -- the caller
         then uses assign() + som_sort_group."""
@@ -108,7 +108,8 @@ class BatchSOM():
         if x.shape[0] > 65535 or M > 1024 or not (1 <= int(k) <= min(4, M)):
             return None
         # (knn = (node_knn_I, K, center_avg): KNNModule's index / coordinate side rides on the second launch -- grouping dict "knn_prep")
-        a, g = _ops.som_assign_sort(x.contiguous(), sn, node, int(k), knn=knn)
+        # (deterministic: the order inside a node independent of atomics' arrival -- the training forward's sorted copy)
+        a, g = _ops.som_assign_sort(x.contiguous(), sn, node, int(k), knn=knn, deterministic=bool(deterministic) and knn is None)
         self.last_assignment = a
         return a, g
 

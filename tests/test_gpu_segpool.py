@@ -444,3 +444,71 @@ def test_training_step_with_backward_sums_from_the_dgrad_epilogue():
         ops.BWD_STATS_EPILOGUE = old
     assert res[True][4] < res[False][4]
     _compare_steps(res[True], res[False])
+
+
+# ------------------------------------------------------------------------------------------ deterministic sort of the training forward
+@pytest.mark.parametrize("B,N,M,k", [(64, 5000, 64, 3), (3, 700, 64, 3), (2, 513, 128, 2), (2, 100, 7, 1)])
+def test_deterministic_sort_is_stable_and_equal_to_the_default_up_to_the_order_inside_a_node(B, N, M, k):
+    """sonet_som_assign_sort_det_f32: same ids / counts / means / node offsets as sonet_som_assign_sort_f32, every node's run holds the same
+    columns, in an order that is the same in every run -- and that IS the stable order inside a 512-point workgroup for k = 1."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + N + M)
+    x = (torch.rand(B, 3, N, generator=g) * 2 - 1).to(DEV)
+    sn = torch.nn.functional.normalize(torch.randn(B, 3, N, generator=g), dim=1).to(DEV)
+    node = (torch.rand(B, 3, M, generator=g) * 2 - 1).to(DEV)
+    a0, g0 = ops.som_assign_sort(x, sn, node, k)
+    a1, g1 = ops.som_assign_sort(x, sn, node, k, deterministic=True)
+    a2, g2 = ops.som_assign_sort(x, sn, node, k, deterministic=True)
+    assert torch.equal(a0.min_idx_i32, a1.min_idx_i32) and torch.equal(a0.count, a1.count)
+    for key in ("ids_sorted", "node_off", "row_max"):
+        assert torch.equal(g0[key], g1[key]), key
+    assert_close_rms(g1["som_node"].cpu().numpy(), g0["som_node"].cpu().numpy(), 1e-6, "som_node")
+    for key in ("x_aug_sorted", "ids_sorted", "pos0", "som_node"):
+        assert torch.equal(g1[key], g2[key]), key                 # the same sorted copy in every run
+    # the same multiset of columns per node (sorting every node's run by its channel values makes the two copies equal)
+    kN = k * N
+    for gg in (g0, g1):
+        gg["_key"] = gg["ids_sorted"].double() * 1e6 + gg["x_aug_sorted"][:, 3].double() * 1e3 + gg["x_aug_sorted"][:, 4].double()
+    o0, o1 = torch.argsort(g0["_key"], dim=1), torch.argsort(g1["_key"], dim=1)
+    s0 = torch.gather(g0["x_aug_sorted"], 2, o0.unsqueeze(1).expand(B, 6, kN))
+    s1 = torch.gather(g1["x_aug_sorted"], 2, o1.unsqueeze(1).expand(B, 6, kN))
+    assert torch.equal(s0, s1)
+    if k == 1 and N <= 512:
+        # one workgroup, one copy per point: wave / slot / lane order = slot p (points tid, then 256 + tid) ... every node's run lists its
+        # points of the first 256 in ascending order, then those of the second 256
+        ids = a1.min_idx_i32.long()
+        order = torch.argsort(ids * 2 + (torch.arange(N, device=DEV) >= 256).long().unsqueeze(0), dim=1, stable=True)
+        ref = torch.gather(sn, 2, order.unsqueeze(1).expand(B, 3, N))
+        assert torch.equal(g1["x_aug_sorted"][:, 3:], ref)
+
+
+def test_sorted_training_forward_is_bit_reproducible():
+    """With the deterministic sort the f32-class training step on node-sorted columns gives the same loss, pooled map, gradients and running
+    statistics in every run, bit for bit."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 6, 2200
+    outs = []
+    with ops.precision("h3"):
+        for _ in range(2):
+            opt = _opt(B, N)
+            enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+            enc.want_first_pn_out = False
+            synth.fill_state_dict_(enc.state_dict(), 3)
+            synth.fill_state_dict_(cls.state_dict(), 4)
+            enc.to(DEV).train()
+            cls.to(DEV).train()
+            inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+            with ops.kernel_timing() as rec:
+                feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                loss.backward()
+            assert any(n == "som_assign_sort_det" for n, _, _ in rec.records) and any(n.startswith("pointmlph3_segpool") for n, _, _ in rec.records)
+            outs.append((loss.detach().clone(), enc.first_pn_out_masked_max.detach().clone(),
+                         {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    for k in outs[0][3]:
+        assert torch.equal(outs[0][3][k], outs[1][3][k]), k
