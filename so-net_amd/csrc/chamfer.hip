@@ -10,31 +10,50 @@ namespace {
 constexpr int CH_THREADS = 256;
 constexpr int CH_TILE = 1024;
 
+// Two database points per step in packed f32 (v_pk_add_f32 / v_pk_mul_f32: each lane of a pair is an IEEE single operation, so the
+// distances are the bits of the scalar form): the tile holds PAIRS -- (x0, x1, y0, y1) and (z0, z1) -- and the 8 arithmetic operations of a
+// pair cost 8 instructions instead of 16; the two compare / select steps stay scalar and in order (ascending j, strict '<').
+typedef float ch_f2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_kernel(const float *__restrict__ q, const float *__restrict__ db,
                                                                  int32_t *__restrict__ nn, int Nq, int Nd)
 {
-    __shared__ float4 tile[CH_TILE];
+    __shared__ float4 txy[CH_TILE / 2];                          // (x0, x1, y0, y1) of database points 2 t, 2 t + 1
+    __shared__ float2 tz[CH_TILE / 2];                           // (z0, z1)
     const int b = blockIdx.y;
     const int i = blockIdx.x * CH_THREADS + threadIdx.x;
     const float *qb = q + (size_t)b * 3 * Nq, *dbb = db + (size_t)b * 3 * Nd;
     const bool valid = i < Nq;
     const float px = valid ? qb[i] : 0.f, py = valid ? qb[Nq + i] : 0.f, pz = valid ? qb[2 * (size_t)Nq + i] : 0.f;
+    const ch_f2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz};
     float best = __builtin_inff();
     int bi = 0;
     for (int t0 = 0; t0 < Nd; t0 += CH_TILE) {
         const int cnt = min(CH_TILE, Nd - t0);
+        const int npair = (cnt + 1) >> 1;
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += CH_THREADS)
-            tile[t] = make_float4(dbb[t0 + t], dbb[Nd + t0 + t], dbb[2 * (size_t)Nd + t0 + t], 0.f);
+        for (int t = threadIdx.x; t < npair; t += CH_THREADS) {
+            const int j0 = t0 + 2 * t, j1 = j0 + 1;
+            const bool has1 = 2 * t + 1 < cnt;
+            // (an odd tail: the second point of the last pair is a copy of the first -- its distance is equal, never strictly smaller)
+            const int jb = has1 ? j1 : j0;
+            txy[t] = make_float4(dbb[j0], dbb[jb], dbb[Nd + j0], dbb[Nd + jb]);
+            tz[t] = make_float2(dbb[2 * (size_t)Nd + j0], dbb[2 * (size_t)Nd + jb]);
+        }
         __syncthreads();
 #pragma unroll 4
-        for (int t = 0; t < cnt; ++t) {
-            const float4 p = tile[t];
-            const float dx = __fsub_rn(px, p.x), dy = __fsub_rn(py, p.y), dz = __fsub_rn(pz, p.z);
-            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            const bool lt = d < best;
-            best = lt ? d : best;
-            bi = lt ? t0 + t : bi;
+        for (int t = 0; t < npair; ++t) {
+            const float4 a = txy[t];
+            const float2 c = tz[t];
+            const ch_f2 X = {a.x, a.y}, Y = {a.z, a.w}, Z = {c.x, c.y};
+            const ch_f2 dx = PX - X, dy = PY - Y, dz = PZ - Z;
+            const ch_f2 d = (dx * dx + dy * dy) + dz * dz;         // (-ffp-contract=off: no fused multiply-add)
+            const bool lt0 = d[0] < best;
+            best = lt0 ? d[0] : best;
+            bi = lt0 ? t0 + 2 * t : bi;
+            const bool lt1 = d[1] < best;
+            best = lt1 ? d[1] : best;
+            bi = lt1 ? t0 + 2 * t + 1 : bi;
         }
     }
     if (valid) nn[(size_t)b * Nq + i] = bi;
