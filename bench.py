@@ -829,7 +829,12 @@ def main():
             raise SystemExit("bench.py: h3 operand range violated on the synthetic batch: %s" % (range_bad[:3],))
         # the other two arithmetics of the same path on the same batch (graph replay, same K): extra keys, not `value`
         other = {}
-        if world == 1 and not args.no_other_precisions and use_graph:
+
+        def measure_other_arithmetics():
+            # (called AFTER the BASELINE configs of `other_configs`: extra keys, and ten seconds of matrix-heavy forwards in front of the training
+            #  entries would only warm the chip up for them)
+            if not (world == 1 and not args.no_other_precisions and use_graph):
+                return
             from sonet_hip.graph import GraphedForward
             for mode in ("bf16", "x3", "f32"):
                 if mode == ops.POINTMLP_PRECISION:
@@ -980,6 +985,7 @@ def main():
         line["other_configs"] = other_configs(args, dev, 1, 0)
     elif train_entries:
         line["other_configs"] = train_entries
+    measure_other_arithmetics()                                # (fills line["other_arithmetics"]: the same dict object)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
     return line
