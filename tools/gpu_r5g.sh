@@ -1,13 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out/r5g
-python -m pytest tests/test_gpu_node_stage.py -x -q 2>&1 | tail -3
-export SONET_HIP_LIB=$GRAFT_REPO_ROOT/so-net_amd/lib/libsonet_hip_variants.so
-cd /tmp && export TMPDIR=/tmp
-for gy in 1 2 4 8; do
-SONET_KSI_GY=$gy rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gy$gy -o ab -- python $GRAFT_REPO_ROOT/tools/ab_node_stage.py --rounds 2 --steps 30 --in-flight 1 > /dev/null 2>&1
-python -c "
-import csv
-for r in csv.DictReader(open('/tmp/prof_gy$gy/ab_kernel_stats.csv')):
-    if 'knn_stage_input' in r['Name'] or 'H3pArgs' in r['Name'] or 'fill2' in r['Name']: print('gy $gy', r['Name'][:60], r['Calls'], r['AverageNs'])
-"
-done
+# the two bench lines of the final tree (bench.py's order of entries changed after the r05f set): default command and the driver's command
+TAG=${1:-r05g}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+P=$R/gpurun_out/$TAG/profiles; mkdir -p $P
+timeout 600 python bench.py --steps 50 --warmup 10 2> /dev/null | tail -1 > $P/${TAG}_bench_forward.json
+timeout 600 python bench.py --steps 20 --warmup 5 2> /dev/null | tail -1 > $P/${TAG}_bench_forward_driver_command.json
+for p in bf16 h3; do timeout 300 python bench.py --mode train --precision $p --steps 40 --warmup 8 2> /dev/null | tail -1 > $P/${TAG}_bench_train_$p.json; done
+ls $P
