@@ -741,8 +741,9 @@ def main():
             dp.barrier()
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        assert torch.isfinite(out).all()
         # further windows of the same K steps (`value` is the FIRST window, as the contract says; the spread is on the line)
+        # (nothing but the barrier between two windows: the first call of any other operator -- the isfinite check below -- loads its code
+        #  object, the GPU idles for a millisecond, and the window behind it starts on sagging clocks: 10-12 % low, docs/findings.md R5.11)
         window_s = [elapsed]
         for _ in range(max(0, args.windows - 1)):
             dp.barrier()
@@ -753,6 +754,7 @@ def main():
                 dp.barrier()
                 torch.cuda.synchronize()
             window_s.append(time.perf_counter() - tw)
+        assert torch.isfinite(out).all()
         single = None
         overlap_ok = None
         if use_graph and P > 1:
