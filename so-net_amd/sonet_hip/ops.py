@@ -1261,7 +1261,7 @@ class side_stream:
         if not self.on:
             return
         idx = self.side.device.index
-        task = torch._C._current_graph_task_id()
+        task = _graph_task_id() if _graph_task_id is not None else -1     # (-1: not inside an autograd pass, or a torch without the query)
         if defer and DEFER_WGRAD_JOIN and task != -1:
             _pending_join[idx] = (self.main, self.side)
             if _join_queued[0] != task:                      # (once per backward pass; a pass that died with an exception never ran its callback)
@@ -1275,6 +1275,7 @@ class side_stream:
 # weight gradients are not needed before the backward pass is over: their side-stream launches are joined there (0 = at the end of every
 # layer's backward, the behaviour up to round 5's first session)
 DEFER_WGRAD_JOIN = _os.environ.get("SONET_DEFER_WGRAD_JOIN", "1") != "0"
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 _pending_join = {}               # device index -> (main stream, side stream) with launches nobody has waited for yet
 _join_queued = [-1]             # id of the autograd graph task whose end-of-pass callback is queued
 
