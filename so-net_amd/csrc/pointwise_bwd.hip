@@ -1034,6 +1034,112 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
     }
 }
 
+// Four channels per thread (Cin a multiple of 4).  The accumulate loop of the kernel above is bound by instruction issue, not by latency: per
+// (entry, channel) three LDS reads, an address, a global load, a compare and one fma.  Here thread (i4, q, s) owns channels 4 i4 .. 4 i4 + 3 of the
+// columns [8 s, 8 s + 8) of quarter q: the same per-entry overhead (one 16-byte LDS read, one 16-byte load of W) feeds four fmas, and the
+// sixteen sub-ranges of a tile (their entry counts differ less than the four quarters') share the wave's loop trips.  Same entries in the same
+// (column, entry id) order per accumulator: the same bits as the kernel above.
+constexpr int PD4_LD = PD_CH + 4;              // accumulator row pitch: 16-byte aligned groups of four channels
+constexpr int PD4_WB = 8;                      // entries (a W float4 each) requested before the first fma
+template <typename TO>
+__global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad4_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ skey,
+                                                            const float *__restrict__ g_pooled, const float *__restrict__ W,
+                                                            int E, int M, int Cin, int C1, int L, int nbucket,
+                                                            TO *__restrict__ gx1, TO *__restrict__ gx2)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm_f4[];       // acc[PD_TL][PD4_LD] | per quarter: uint4 ent[PD_SQ] (column, value bits, W row offset, -)
+    constexpr int ld = PD4_LD;
+    float *acc = sm_f4;
+    uint4 *ent_all = reinterpret_cast<uint4 *>(sm_f4 + PD_TL * ld);
+    __shared__ int nq_all[PD_CQ], subcnt[PD_CQ][4];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const int q = tid / PD_CH, tq = tid - q * PD_CH;                        // column quarter, thread inside it
+    const int sub = tq / 10, i4 = tq - sub * 10;                            // 8-column sub-range, channel quad
+    uint4 *ent = ent_all + q * PD_SQ;
+    const int ch0 = blockIdx.z * PD_CH, nch = min(PD_CH, Cin - ch0);
+    for (int t = tid; t < PD_TL * ld; t += nth) acc[t] = 0.f;
+    const int sb = tile * PD_CQ + q;
+    const int beg = sb < nbucket ? tile_off[(size_t)b * (nbucket + 1) + sb] : 0;
+    const int nq = sb < nbucket ? tile_off[(size_t)b * (nbucket + 1) + sb + 1] - beg : 0;
+    const uint32_t *kb = skey + (size_t)b * E + beg;
+    const float *gb = g_pooled + (size_t)b * E;
+    if (tq == 0) nq_all[q] = nq;
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int t = 0; t < PD_CQ; ++t) nmax = max(nmax, nq_all[t]);
+    for (int base = 0; base < nmax; base += PD_SQ) {
+        const int n = min(PD_SQ, max(0, nq - base));
+        __syncthreads();                                                    // the previous round's list is consumed
+        if (tq < 4) subcnt[q][tq] = 0;
+        __syncthreads();
+        for (int t = tq; t < n; t += PD_CH) {
+            const uint32_t key = kb[base + t];
+            const int id = (int)(key & 0xFFFFFu), colq = (int)(key >> 20);
+            ent[t] = make_uint4((unsigned)(colq + q * PD_SB), __float_as_uint(gb[id]), (unsigned)((id / M) * Cin + ch0), 0u);
+            atomicAdd(&subcnt[q][colq >> 3], 1);
+        }
+        __syncthreads();
+        int lo = 0;
+        for (int t = 0; t < sub; ++t) lo += subcnt[q][t];
+        const int cnt = subcnt[q][sub];
+        if (4 * i4 < nch && cnt > 0) {
+            // (sorted by column: the chains of a column run in registers and are written when the column changes; a column that continues
+            //  from the previous round resumes from the stored value -- the accumulators start at zero)
+            int cur = (int)ent[lo].x;
+            float4 sum = *reinterpret_cast<const float4 *>(acc + cur * ld + 4 * i4);
+            for (int e0 = 0; e0 < cnt; e0 += PD4_WB) {
+                uint4 en[PD4_WB];
+                float4 wv[PD4_WB];
+#pragma unroll
+                for (int t = 0; t < PD4_WB; ++t) {
+                    en[t] = ent[lo + (e0 + t < cnt ? e0 + t : cnt - 1)];
+                    wv[t] = *reinterpret_cast<const float4 *>(W + (size_t)en[t].z + 4 * i4);
+                }
+#pragma unroll
+                for (int t = 0; t < PD4_WB; ++t) {
+                    if (e0 + t < cnt) {
+                        const int col = (int)en[t].x;
+                        if (col != cur) {
+                            *reinterpret_cast<float4 *>(acc + cur * ld + 4 * i4) = sum;
+                            cur = col;
+                            sum = *reinterpret_cast<const float4 *>(acc + cur * ld + 4 * i4);
+                        }
+                        const float v = __uint_as_float(en[t].y);
+                        sum.x = __fmaf_rn(v, wv[t].x, sum.x);
+                        sum.y = __fmaf_rn(v, wv[t].y, sum.y);
+                        sum.z = __fmaf_rn(v, wv[t].z, sum.z);
+                        sum.w = __fmaf_rn(v, wv[t].w, sum.w);
+                    }
+                }
+            }
+            *reinterpret_cast<float4 *>(acc + cur * ld + 4 * i4) = sum;
+        }
+    }
+    __syncthreads();
+    const int l0 = tile * PD_TL;
+    if (sizeof(TO) == 2 && (L & 1) == 0) {
+        for (int idx = tid; idx < nch * (PD_TL / 2); idx += nth) {
+            const int r = idx / (PD_TL / 2), col = (idx - r * (PD_TL / 2)) * 2;
+            if (l0 + col >= L) continue;
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(acc[col * ld + r]), "v"(acc[(col + 1) * ld + r]));
+            const int ch = ch0 + r;
+            TO *dst = ch < C1 ? gx1 + ((size_t)b * C1 + ch) * L + l0 + col : gx2 + ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col;
+            *reinterpret_cast<unsigned *>(dst) = pk;
+        }
+        return;
+    }
+    for (int idx = tid; idx < nch * PD_TL; idx += nth) {
+        const int r = idx / PD_TL, col = idx - r * PD_TL;
+        if (l0 + col >= L) continue;
+        const float v = acc[col * ld + r];
+        const int ch = ch0 + r;
+        if (ch < C1) pd_store(gx1, ((size_t)b * C1 + ch) * L + l0 + col, v);
+        else pd_store(gx2, ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col, v);
+    }
+}
+
 // ---- the same dgrad on the matrix cores (bf16 training path) -------------------------------------------------------------
 // g_x[:, tile] = W^T (320 x 384) . G (384 x 64 columns), G the tile of the never-built dense gradient: the workgroup zeroes a 48 KB
 // bf16 image of G^T in LDS, drops the tile's entries into it (in this model a (channel, column) pair occurs at most once -- node m's
@@ -1347,6 +1453,14 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     if (const char *e = sonet::knob("SONET_PD_ABL")) abl = atoi(e);
     hipLaunchKernelGGL(pooled_bucket_kernel, dim3(B, PB_Q), dim3(1024), (size_t)(2 * sonet::ceil_div(nbucket, PB_Q) + 1) * 4, st, pos, g_pooled, E, L, nbucket, tile_off, ent_key, ent_val);
     if (!(abl & 4)) hipLaunchKernelGGL(pooled_sort_kernel, dim3(nbucket, B), dim3(64), 0, st, tile_off, ent_key, skey, E, nbucket);
+    int one = 0;
+    if (const char *e = sonet::knob("SONET_PD_ONE")) one = atoi(e);     // (variants build: 1 = the one-channel-per-thread kernel)
+    if (Cin % 4 == 0 && abl == 0 && !one) {
+        const size_t lds4 = (size_t)PD_TL * PD4_LD * 4 + (size_t)PD_CQ * PD_SQ * 16;
+        hipLaunchKernelGGL(pooled_dgrad4_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds4, st, tile_off, skey, g_pooled, W, E, M, Cin, C1,
+                           L, nbucket, gx1, gx2 ? gx2 : gx1);
+        return sonet::launched(what);
+    }
     hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, (abl & 4) ? ent_key : skey, ent_val, g_pooled, W, E, M, Cin, C1,
                        L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);

@@ -575,7 +575,7 @@ def test_pooled_dgrad_vs_dense():
     """Sparse W^T.g of the pooled last layer vs scatter_add + dense matmul (float64), incl. duplicate and empty-node positions."""
     from sonet_hip import ops
     gen = torch.Generator().manual_seed(11)
-    for B, C, M, C1, C2, L in [(2, 384, 64, 64, 256, 3072), (1, 32, 5, 16, 0, 100), (3, 96, 8, 16, 48, 130)]:
+    for B, C, M, C1, C2, L in [(2, 384, 64, 64, 256, 3072), (1, 32, 5, 16, 0, 100), (3, 96, 8, 16, 48, 130), (2, 40, 6, 10, 17, 70), (2, 48, 7, 44, 0, 257)]:
         g = torch.randn(B, C, M, generator=gen)
         pos = torch.randint(0, L, (B, C, M), generator=gen, dtype=torch.int32)
         pos[:, : C // 4, 0] = 0
