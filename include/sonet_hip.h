@@ -212,6 +212,13 @@ int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int C, const vo
                               const float *praw, const float *psc, const float *psh, int prelu, void *pstats_ws, double *psums,
                               sonet_stream_t stream);
 
+/* The same launch with an accumulating store: y = (W . g_raw) * scale + shift + yadd, yadd [B][Cout][L] another gradient of the same tensor
+ * that was computed earlier (the first layer's output of the first PointNet feeds the second layer AND the last one, models/layers.py:417-431:
+ * autograd would add the two gradients in a pass of its own).  The f32 sum is the one that pass would store; yadd == y is allowed. */
+int sonet_pointmlp_x3_bnb_acc_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
+                                  const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                                  float *g_raw_out, const float *yadd, float *y, int B, int Cout, int L, sonet_stream_t stream);
+
 /* The same layer on bf16 MFMA with a 3-way bf16 split of both operands (6 MFMAs per product term set):
  * f32-class accuracy (classifier forward within 3e-6 * max(|ref|, rms) of the reference; tolerance 1e-5) at
  * 6/16 of the f32-MFMA cost.  Requires Cout % 32 == 0 and, with a second input, C1 % 16 == 0.

@@ -315,6 +315,9 @@ struct BnbArgs {
     const float *psc, *psh;               // [Cout]
     int prelu;
     double *pstats;                       // [gridDim.x][Cout][2] partial sums
+    // (optional) another gradient of the same tensor, already computed (the layer's input has a second consumer whose backward ran
+    // earlier): y = this launch's product + yadd -- autograd's accumulation (one more pass over both, a third tensor) done by the store
+    const float *yadd;                    // [B][Cout][L] or NULL
 };
 
 // ZADD: the per-node addend form with its gathers issued BEFORE the K loop (64 registers; instantiated for MT = 4 only).
@@ -725,17 +728,36 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 }
             }
         } else if (pv) {
+            bool addy = false;
+            __amdgpu_buffer_rsrc_t rya = ry;
+            if constexpr (BNB) {
+                addy = bnb.yadd != nullptr;
+                if (addy) rya = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bnb.yadd + b * (long long)Cout * L), 0, (int)((unsigned)Cout * rowB), 0x00020000);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned so_tile = (unsigned)((ct0 + mt) * 32) * rowB;
                 const float2 *aff = affine + (ct0 + mt - ct_begin) * 32 + 4 * h;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int orow = (r & 3) + 8 * (r >> 2);
-                    const float2 ss = aff[orow];
-                    float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
-                    if (relu) v = (v < 0.f) ? 0.f : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                for (int r0 = 0; r0 < 16; r0 += 8) {                    // (the addend eight rows at a time: registers)
+                    float ya[8];
+                    if constexpr (BNB) {
+                        if (addy) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                ya[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    rya, voy, so_tile + (unsigned)(((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * rowB, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) {
+                        const int orow = (r & 3) + 8 * (r >> 2);
+                        const float2 ss = aff[orow];
+                        float v = __fmaf_rn(acc[mt][r], ss.x, ss.y);
+                        if (relu) v = (v < 0.f) ? 0.f : v;
+                        if constexpr (BNB) { if (addy) v = v + ya[r - r0]; }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, voy, so_tile + (unsigned)orow * rowB, 0);
+                    }
                 }
             }
         }
@@ -1200,7 +1222,8 @@ static int x3_run_impl(const char *what, bool f16, const float *x1, int C1, cons
     if (bnbp && C1 > 512) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the BatchNorm-backward operand needs <= 512 input channels", what);
     SONET_REQUIRE(!bnbp || ((bnbp->praw == nullptr) == (bnbp->pstats == nullptr) && (bnbp->pstats == nullptr) == (bnb_psums == nullptr) &&
                             (!bnbp->praw || (bnbp->psc && bnbp->psh))), "%s: the sums of the layer below need praw, psc, psh, a workspace and the output", what);
-    const BnbArgs bnb = bnbp ? *bnbp : BnbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr};
+    SONET_REQUIRE(!bnbp || !bnbp->yadd || !bnbp->pstats, "%s: an accumulated output and the sums of the layer below do not combine", what);
+    const BnbArgs bnb = bnbp ? *bnbp : BnbArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
     SONET_REQUIRE(C2 == 0 || C1 % 16 == 0, "%s: with a second input C1=%d must be a multiple of 16", what, C1);
@@ -1545,9 +1568,23 @@ extern "C" int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int 
 {
     const char *what = "sonet_pointmlp_x3_bnb_f32";
     SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y, "%s: NULL pointer", what);
-    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu, praw, psc, psh, prelu, reinterpret_cast<double *>(pstats_ws)};
+    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu, praw, psc, psh, prelu, reinterpret_cast<double *>(pstats_ws), nullptr};
     return x3_run_impl(what, false, gy, C, nullptr, 0, Wp3, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
                        nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn, psums);
+}
+
+/* sonet_pointmlp_x3_bnb_f32 with the store accumulating: y = (W . g_raw) * scale + shift + yadd  (yadd [B][Cout][L]: another gradient of the
+ * same tensor, computed earlier; yadd == y is allowed -- every element is read and written by one lane).  The f32 sum is the one autograd's
+ * accumulation of the two gradients would store. */
+extern "C" int sonet_pointmlp_x3_bnb_acc_f32(const float *gy, const float *raw, int C, const void *Wp3, const float *scale, const float *shift,
+                                             const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                                             float *g_raw_out, const float *yadd, float *y, int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_x3_bnb_acc_f32";
+    SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y && yadd, "%s: NULL pointer", what);
+    const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu, nullptr, nullptr, nullptr, 0, nullptr, yadd};
+    return x3_run_impl(what, false, gy, C, nullptr, 0, Wp3, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn, nullptr);
 }
 
 extern "C" int sonet_pointmlp_x3_f32(const float *x1, int C1, const float *x2, int C2, const void *Wp3,

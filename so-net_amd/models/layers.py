@@ -233,6 +233,27 @@ class _Materialise(torch.autograd.Function):
         return gy, None, None, None
 
 
+class _GradCarry:
+    """A gradient handed from one autograd node to another outside autograd's own accumulation.  The first layer's output of the first
+    PointNet has two consumers (the second layer and the last one, models/layers.py:417-431); the last layer's backward runs first and its
+    input gradient would wait in the engine's buffer until the second layer's arrives, to be added by a pass of its own (three tensors
+    through memory).  Instead the early node ``put``s its gradient here and returns None, the late node ``take``s it and has the store of its
+    input-gradient launch add it (``ops.pointmlp_x3_bnb(acc=...)``), or adds it itself where that launch does not run.  A deposit is valid
+    inside the backward pass that made it only."""
+    __slots__ = ("g", "task")
+
+    def __init__(self):
+        self.g, self.task = None, -1
+
+    def put(self, g):
+        self.g, self.task = g, _ops._graph_task_id()
+
+    def take(self):
+        g, task = self.g, self.task
+        self.g, self.task = None, -1
+        return g if (g is not None and task == _ops._graph_task_id()) else None
+
+
 class _PointwiseFn(torch.autograd.Function):
     """Differentiable fused layer.  forward: HIP kernels.  backward: two HIP passes turn gy into g_raw (ReLU mask,
     BatchNorm backward: ``sonet_pointwise_bwd_stats/apply``), dgrad = W^T g_raw on the pointmlp kernel, wgrad one
@@ -243,7 +264,7 @@ class _PointwiseFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps, bn_run=None, xaff=None, defer=False):
+    def forward(ctx, x1, x2, weight2d, bias, gamma, beta, wp, scale, shift, relu, mode, eps, bn_run=None, xaff=None, defer=False, carry=None):
         # xaff = (s1, h1, relu1[, s2, h2, relu2]) ('batch' mode, h3 pack): x1 / x2 are RAW outputs of BatchNorm layers standing for
         # act(raw * s + h); the operand loads of this layer and of its weight gradient normalise them.  defer: this layer's own
         # normalise pass is left to ITS consumers -- the first output is raw (standing for the activation: its incoming gradient is the
@@ -252,6 +273,7 @@ class _PointwiseFn(torch.autograd.Function):
         dev = x1.device
         ones, zeros = _ops.const_vec(Cout, 1.0, dev), _ops.const_vec(Cout, 0.0, dev)
         ctx.xaff = xaff
+        ctx.carry = carry                     # (_GradCarry) another consumer of x1 leaves its gradient there: this node returns the sum
         if mode == 'affine':
             y = _ops.pointmlp(x1, wp, scale, shift, relu, Cout, x2=x2)
             # mask source: the output itself (y > 0 <=> pre-activation > 0)
@@ -292,8 +314,9 @@ class _PointwiseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
+        carried = ctx.carry.take() if ctx.carry is not None else None
         if gy is None:                                                    # (the output was not used)
-            return (None,) * 15
+            return (carried,) + (None,) * 15
         ctx.defer_ok = _grad_slot_empty(ctx.wleaf)
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
@@ -332,8 +355,12 @@ class _PointwiseFn(torch.autograd.Function):
                     # x1 is the RAW output of the layer below (normalise-on-load) and nothing is padded: this launch's output is that
                     # layer's gy, and its BatchNorm-backward sums come out of the epilogue (handed over on the tensor: _bwd_sums_hint)
                     below = (x1, xa_[0], xa_[1], xa_[2]) if (_ops.BWD_STATS_EPILOGUE and xa_ is not None and Cp == Ci and x1.dtype == torch.float32) else None
+                    acc = None
+                    if (carried is not None and below is None and Cp == Ci and carried.dtype == torch.float32 and carried.is_contiguous()
+                            and tuple(carried.shape) == (gy.shape[0], Cp, gy.shape[2])):
+                        acc, carried = carried, None
                     res = _ops.pointmlp_x3_bnb(gy, raw, wpt, _ops.const_vec(Cp, 1.0, dev), _ops.const_vec(Cp, 0.0, dev), a, b, c0, sc, sh, ctx.relu,
-                                               Cp, want_g_raw=ctx.needs_input_grad[2], below=below)
+                                               Cp, want_g_raw=ctx.needs_input_grad[2], below=below, acc=acc)
                     yb, g_raw = res[0], res[1]
                     fused_gx1 = yb if Cp == Ci else yb[:, :Ci]
                     if below is not None:
@@ -371,10 +398,12 @@ class _PointwiseFn(torch.autograd.Function):
                     continue
                 outs.append(_dgrad(g_raw, pk))
             g_x1, g_x2 = outs
+        if carried is not None:                                           # (not taken by the launch above)
+            g_x1 = carried if g_x1 is None else g_x1 + carried.to(g_x1.dtype)
         if ss is not None:
             # (the weight gradient is not needed before the backward pass is over -- unless it is about to be ADDED to an existing .grad)
             ss.join(defer=ctx.defer_ok)
-        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None, None, None
+        return g_x1, g_x2, g_w, g_bias, g_gamma, g_beta, None, None, None, None, None, None, None, None, None, None
 
 
 class _PooledLastLayerFn(torch.autograd.Function):
@@ -386,8 +415,9 @@ class _PooledLastLayerFn(torch.autograd.Function):
     scatter-added into it -- exactly what the reference's gather backward does."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M, need_dense=True, pos0=None, xaff=None):
+    def forward(ctx, x1, x2, weight2d, bias, wp, min_idx_i32, row_max, M, need_dense=True, pos0=None, xaff=None, carry=None):
         Cout = weight2d.shape[0]
+        ctx.carry = carry                     # (_GradCarry) x1's other consumer adds this node's x1 gradient to its own
         ones = _ops.const_vec(Cout, 1.0, x1.device)
         b = bias.detach().float().contiguous()
         ctx.pos0 = None
@@ -441,7 +471,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
         B, C1, L = x1.shape
         C2 = x2.shape[1]
         if g_y is None and g_mm is None:
-            return (None,) * 11
+            return (None,) * 12
         sparse = g_y is None
         xa = ctx.xaff
         xa1, xa2 = (None, None) if xa is None else (xa[:3], xa[3:6])
@@ -513,7 +543,10 @@ class _PooledLastLayerFn(torch.autograd.Function):
                 g_x1, g_x2 = outs
         if ss is not None:
             ss.join(defer=_grad_slot_empty(ctx.wleaf))
-        return g_x1, g_x2, g_w, g_bias, None, None, None, None, None, None, None
+        if ctx.carry is not None and g_x1 is not None:
+            ctx.carry.put(g_x1)
+            g_x1 = None
+        return g_x1, g_x2, g_w, g_bias, None, None, None, None, None, None, None, None
 
 
 class _FusedPointwise(_PlainAttrs, nn.Module):
@@ -680,7 +713,7 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             self._affine_gen = getattr(self, '_affine_gen', 0) + 1          # (id() of the tensors can be recycled: count instead)
         return self._affine
 
-    def _run(self, x1, x2, epoch, xaff=None, defer=False):
+    def _run(self, x1, x2, epoch, xaff=None, defer=False, carry=None):
         """x1 (and optional x2): B x C x L contiguous f32 CUDA tensors -> B x Cout x L.
         Training BatchNorm layers of the f32-class first PointNet (``PointResNet.forward_pooled``): ``xaff`` = (s1, h1, relu1[, s2, h2,
         relu2]) says x1 / x2 are RAW outputs of BatchNorm layers standing for act(raw * s + h) (normalised by this layer's operand loads,
@@ -701,7 +734,7 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             x1 = x1.to(want)
         if x2 is not None and x2.dtype != want:
             x2 = x2.to(want)
-        if (xaff is not None or defer) and not (train_bn and fuse_act):
+        if (xaff is not None or defer or carry is not None) and not (train_bn and fuse_act):
             raise RuntimeError("deferred normalisation is a training-mode BatchNorm + ReLU layer's")
         if xaff is not None and not (wp.dtype == torch.int8 and _stats_epilogue_ok(x1, wp, self.conv.out_channels)
                                      and _ops.xaff_ok(x1.shape[1], x2.shape[1] if x2 is not None else 0, self.conv.out_channels)):
@@ -719,7 +752,7 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
                     and bn.running_var.is_contiguous() and bn.running_mean.dtype == torch.float32 and bn.running_mean.device == x1.device)
             outs = _PointwiseFn.apply(x1, x2, self._weight2d(), self._bias(), bn.weight, bn.bias, wp, None, None,
                                       fuse_act, 'batch', bn.eps, (bn.running_mean, bn.running_var, m, n / max(n - 1, 1)) if ride else None,
-                                      xaff, bool(defer))
+                                      xaff, bool(defer), carry)
             y, mean, var = outs[:3]
             if defer:
                 y = (y, outs[3], outs[4])
@@ -1186,13 +1219,18 @@ class PointResNet(nn.Module):
             # last layer and its sparse weight gradient) normalises on load
             h, _ = self.layers[0]._run(_FusedPointwise._prep(x), None, epoch, defer=True)
             skip = h
+            # the first layer's output feeds the second layer and the last one: the last layer's input gradient (computed first) is added
+            # by the store of the second layer's input-gradient launch, not by a pass of autograd's (``_GradCarry``)
+            carry = _GradCarry() if (_ops.GRAD_CARRY and _ops._graph_task_id is not None and torch.is_grad_enabled() and skip[0].requires_grad) else None
             for l in range(1, n - 1):
-                h, _ = self.layers[l]._run(h[0], None, epoch, xaff=(h[1], h[2], True), defer=True)
+                h, _ = self.layers[l]._run(h[0], None, epoch, xaff=(h[1], h[2], True), defer=True, carry=carry if l == 1 else None)
             wp = last._packed(skip[0].shape[1], h[0].shape[1])
             if wp.dtype == torch.int8:
                 return _PooledLastLayerFn.apply(skip[0], h[0], last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, False, pos0,
-                                                (skip[1], skip[2], True, h[1], h[2], True))
+                                                (skip[1], skip[2], True, h[1], h[2], True), carry)
             skip, t = _Materialise.apply(skip[0], skip[1], skip[2], True), _Materialise.apply(h[0], h[1], h[2], True)
+            return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M,
+                                            bool(need_dense), pos0, None, carry)
         else:
             skip = self.layers[0](x, epoch)
             t = skip

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sonet_pointmlp_h3_segpool_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sonet_pointmlp_h3_stats_xaff_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sonet_pointmlp_x3_bnb_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "sonet_pointmlp_x3_bnb_acc_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_wgrad_x3_xaff_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "sonet_pooled_wgrad_xaff_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "sonet_pack_multi": [_vp, _i, _i, _vp],

@@ -1129,11 +1129,18 @@ BNB_ON_LOAD = _os.environ.get("SONET_BNB_ON_LOAD", "1") != "0"
 BWD_STATS_EPILOGUE = _os.environ.get("SONET_BWD_STATS_EPILOGUE", "0") != "0"
 
 
-def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True, below=None):
+# a tensor with two consumers in the first PointNet (the first layer's output): the gradient of the consumer whose backward runs first is added by
+# the store of the other's input-gradient launch (models/layers.py ``_GradCarry``; 0 = autograd's accumulation, a pass over three tensors)
+GRAD_CARRY = _os.environ.get("SONET_GRAD_CARRY", "1") != "0"
+
+
+def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True, below=None, acc=None):
     """(W . g_raw) * scale + shift with g_raw = a * (gy masked by raw * sc + sh > 0 when relu) + b * raw + c0 per input channel, in one pass
     over (gy, raw) -- ``pointwise_bwd_apply`` + ``pointmlp`` on an x3 pack, bit for bit.  -> (y B x Cout x L, g_raw or None[, sums]).
     below = (praw B x Cout x L, psc, psh, prelu): y is gy of the layer below; -> also its BatchNorm-backward sums (float64 [2 Cout], the
-    layout of ``pointwise_bwd_stats(..., want_sums=True)``) from the epilogue."""
+    layout of ``pointwise_bwd_stats(..., want_sums=True)``) from the epilogue.
+    acc (B x Cout x L, f32): another gradient of the same tensor, computed earlier -- y = the product + acc from the store of this launch (what
+    autograd's accumulation of the two would hold, bit for bit); not together with ``below``."""
     _chk(gy, "gy", torch.float32, 3)
     _chk(raw, "raw", torch.float32, 3)
     if raw.shape != gy.shape:
@@ -1157,6 +1164,16 @@ def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, wa
         return y, g_raw
     praw = psc = psh = pws = sums = None
     prelu = False
+    if acc is not None:
+        _chk(acc, "acc", torch.float32, 3)
+        if below is not None or tuple(acc.shape) != (B, Cout, L):
+            raise SonetHipError("pointmlp_x3_bnb: acc must be B x Cout x L and does not combine with the sums of the layer below")
+        _same_device(gy, acc)
+        with _lib.on_device(dev), _timed("pointmlpx3_bnba_%dx%d_L%d" % (C, Cout, L)):
+            check(lib.sonet_pointmlp_x3_bnb_acc_f32(ptr(gy), ptr(raw), C, ptr(wpt), ptr(scale), ptr(shift), ptr(a), ptr(b), ptr(c0), ptr(sc), ptr(sh),
+                                                    int(bool(relu)), ptr(g_raw), ptr(acc), ptr(y), B, Cout, L, stream_ptr()),
+                  "sonet_pointmlp_x3_bnb_acc_f32")
+        return y, g_raw
     if below is not None:
         praw, psc, psh, prelu = below
         _chk(praw, "praw", torch.float32, 3)

@@ -354,6 +354,72 @@ def test_dgrad_with_batchnorm_backward_on_load_equals_apply_then_dgrad(B, C, Cou
     assert none is None and torch.equal(y2, y_ref)
 
 
+@pytest.mark.parametrize("B,C,Cout,L,relu", [(64, 128, 64, 15000, True), (3, 256, 128, 577, True), (2, 48, 96, 131, False)])
+def test_dgrad_with_accumulating_store_equals_dgrad_plus_the_other_gradient(B, C, Cout, L, relu):
+    """sonet_pointmlp_x3_bnb_acc_f32 == sonet_pointmlp_x3_bnb_f32 followed by the f32 addition autograd's accumulation would run, bit for
+    bit; the g_raw side output is untouched by the addend."""
+    from sonet_hip import ops
+    g = torch.Generator().manual_seed(B + C + L + 1)
+    gy = (torch.randn(B, C, L, generator=g) * 1e-3).to(DEV)
+    raw = (torch.randn(B, C, L, generator=g) * 1.5).to(DEV)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    a, b, c0 = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV), (torch.randn(C, generator=g) * 1e-5).to(DEV)
+    Wt = (torch.randn(Cout, C, generator=g) * C ** -0.5).to(DEV)
+    other = (torch.randn(B, Cout, L, generator=g) * 1e-3).to(DEV)
+    other[:, :, ::7] = 0.0                                                 # (the sparse gradient of the pooled layer: mostly zeros)
+    wpt = ops.pointmlp_pack(Wt, "x3")
+    one, zero = ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV)
+    y_ref, g_raw_ref = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cout)
+    keep = other.clone()
+    y, g_raw = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cout, acc=other)
+    assert torch.equal(other, keep)
+    assert torch.equal(g_raw, g_raw_ref)
+    assert torch.equal(y, y_ref + other) and torch.equal(y, other + y_ref)
+    with pytest.raises(ops.SonetHipError):
+        ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cout, acc=other[:, :, :-1].contiguous())
+
+
+def test_training_step_with_the_carried_gradient_is_bit_identical():
+    """ops.GRAD_CARRY on / off on the node-sorted f32-class path (bit-reproducible: deterministic sort): the gradient the last layer of the
+    first PointNet sends to the first layer's output is added by the second layer's input-gradient launch instead of by autograd --
+    every gradient identical; also with a second backward pass through a retained graph (a deposit is consumed once per pass)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 8, 3000
+    out = {}
+    old = ops.GRAD_CARRY
+    try:
+        with ops.precision("h3"):
+            for flag in (True, False):
+                ops.GRAD_CARRY = flag
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                with ops.kernel_timing() as rec:
+                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                    loss.backward(retain_graph=True)
+                names = [n for n, _, _ in rec.records]
+                assert any(n.startswith("pointmlpx3_bnba_") for n in names) == flag, names
+                out[flag] = {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+                enc.zero_grad(set_to_none=True)
+                cls.zero_grad(set_to_none=True)
+                loss.backward()
+                again = {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+                for k in again:
+                    assert torch.equal(again[k], out[flag][k]), ("second pass", flag, k)
+    finally:
+        ops.GRAD_CARRY = old
+    assert out[True].keys() == out[False].keys()
+    for k in out[True]:
+        assert torch.equal(out[True][k], out[False][k]), k
+
+
 def test_training_step_with_batchnorm_backward_on_load_is_bit_identical():
     """ops.BNB_ON_LOAD on / off on the bit-reproducible f32-class path (original column order): every gradient identical."""
     from models import networks as NW
