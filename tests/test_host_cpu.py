@@ -313,3 +313,49 @@ def test_deferred_side_stream_join_is_inert_without_a_gpu():
     ss.reads(torch.zeros(3))
     ss.join(defer=True)
     assert not ops._pending_join
+
+
+def test_carried_gradient_is_consumed_once_and_only_in_the_pass_that_deposited_it():
+    """models.layers._GradCarry (the gradient the pooled last layer hands to the second layer of the first PointNet outside autograd's
+    accumulation) on a CPU miniature of that graph: y feeds a 'layer' and, with the layer's output, a 'pool'.  The full pass returns the
+    sum of both gradients of y; a pass that runs the pool alone leaves a deposit nobody may use in a later pass."""
+    from models import layers as L
+    from sonet_hip import ops
+    if ops._graph_task_id is None:
+        pytest.skip("this torch has no graph-task query: the carry is never created")
+    c = L._GradCarry()
+
+    class Pool(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y, h):
+            return y.sum() + 2.0 * h.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            c.put(g * torch.ones(3))
+            return None, 2.0 * g * torch.ones(3)
+
+    class Layer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            return 3.0 * y
+
+        @staticmethod
+        def backward(ctx, g):
+            t = c.take()
+            return 3.0 * g if t is None else 3.0 * g + t
+
+    x = torch.zeros(3, requires_grad=True)
+    y = x * 1.0
+    h = Layer.apply(y)
+    out = Pool.apply(y, h)
+    (gx,) = torch.autograd.grad(out, x, retain_graph=True)
+    assert torch.equal(gx, torch.full((3,), 7.0))                 # 1 (pool) + 3 * 2 (through the layer)
+    assert c.g is None                                             # consumed
+    (gx,) = torch.autograd.grad(out, x, retain_graph=True)
+    assert torch.equal(gx, torch.full((3,), 7.0))                 # once per pass
+    torch.autograd.grad(out, h, retain_graph=True)                 # the pool alone: a deposit is left behind
+    assert c.g is not None
+    (gx,) = torch.autograd.grad(h.sum(), x, retain_graph=True)     # the layer alone, another pass: the stale deposit is dropped
+    assert torch.equal(gx, torch.full((3,), 3.0)) and c.g is None
+    assert c.take() is None

@@ -1,17 +1,10 @@
 #!/bin/bash
-mkdir -p gpurun_out/r5i
-python -m pytest tests/test_gpu_bf16.py tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_fc_head.py -x -q 2>&1 | tail -25 > gpurun_out/r5i/pytest.log
-cat gpurun_out/r5i/pytest.log
-python tools/bench_wgrad_bf16.py > gpurun_out/r5i/wgrad_bf16.log 2>&1; cat gpurun_out/r5i/wgrad_bf16.log
-python bench.py --mode train --precision bf16 --steps 40 --warmup 5 > gpurun_out/r5i/train_bf16.json 2> gpurun_out/r5i/train_bf16.err
-SONET_PACK_REGISTRY=0 python bench.py --mode train --precision bf16 --steps 40 --warmup 5 > gpurun_out/r5i/train_bf16_noreg.json 2> gpurun_out/r5i/train_bf16_noreg.err
-python bench.py --mode train --precision h3 --steps 30 --warmup 5 > gpurun_out/r5i/train_h3.json 2> gpurun_out/r5i/train_h3.err
-python - <<'PY'
-import json
-for n in ("train_bf16", "train_bf16_noreg", "train_h3"):
-    try:
-        d = json.loads(open("gpurun_out/r5i/%s.json" % n).read().strip().splitlines()[-1])
-        print(n, d["value"], d["ms_per_step"])
-    except Exception as e:
-        print(n, "failed", e, open("gpurun_out/r5i/%s.err" % n).read()[-1500:])
-PY
+# the carried gradient (ops.GRAD_CARRY): its tests, G | H in one process, the h3 training line
+TAG=${1:-r05i}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+P=$R/gpurun_out/$TAG/profiles; mkdir -p $P
+timeout 200 python -m pytest tests/test_gpu_segpool.py -q -m gpu -x 2>&1 | tail -8 > $P/${TAG}_pytest_segpool.log
+timeout 120 python tools/ab_h3_train.py --only GH --rounds 5 --steps 24 --no-kernels > $P/${TAG}_ab_h3_train.log 2>&1
+timeout 120 python bench.py --mode train --precision h3 --steps 40 --warmup 8 2> /dev/null | tail -1 > $P/${TAG}_bench_train_h3.json
+cat $P/${TAG}_pytest_segpool.log; grep -v amdgpu.ids $P/${TAG}_ab_h3_train.log | cut -c1-150; python -c "
+import json;d=json.load(open('$P/${TAG}_bench_train_h3.json'));print(d['value'],d['ms_per_step'])"
