@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad_kernel(const int32
 // (column, entry id) order per accumulator: the same bits as the kernel above.
 constexpr int PD4_LD = PD_CH + 4;              // accumulator row pitch: 16-byte aligned groups of four channels
 constexpr int PD4_WB = 8;                      // entries (a W float4 each) requested before the first fma
+#ifdef SONET_VARIANTS   // (the column-owned form: replaced by the entry-balanced kernel below, kept as the bit-exact twin of the one-channel kernel)
 template <typename TO>
 __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad4_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ skey,
                                                             const float *__restrict__ g_pooled, const float *__restrict__ W,
@@ -1114,6 +1115,128 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad4_kernel(const int3
                 }
             }
             *reinterpret_cast<float4 *>(acc + cur * ld + 4 * i4) = sum;
+        }
+    }
+    __syncthreads();
+    const int l0 = tile * PD_TL;
+    if (sizeof(TO) == 2 && (L & 1) == 0) {
+        for (int idx = tid; idx < nch * (PD_TL / 2); idx += nth) {
+            const int r = idx / (PD_TL / 2), col = (idx - r * (PD_TL / 2)) * 2;
+            if (l0 + col >= L) continue;
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(acc[col * ld + r]), "v"(acc[(col + 1) * ld + r]));
+            const int ch = ch0 + r;
+            TO *dst = ch < C1 ? gx1 + ((size_t)b * C1 + ch) * L + l0 + col : gx2 + ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col;
+            *reinterpret_cast<unsigned *>(dst) = pk;
+        }
+        return;
+    }
+    for (int idx = tid; idx < nch * PD_TL; idx += nth) {
+        const int r = idx / PD_TL, col = idx - r * PD_TL;
+        if (l0 + col >= L) continue;
+        const float v = acc[col * ld + r];
+        const int ch = ch0 + r;
+        if (ch < C1) pd_store(gx1, ((size_t)b * C1 + ch) * L + l0 + col, v);
+        else pd_store(gx2, ((size_t)b * (Cin - C1) + (ch - C1)) * L + l0 + col, v);
+    }
+}
+#endif  // SONET_VARIANTS
+
+// Entry-balanced form (the product's kernel).  In the column-owned form a wave's loop runs as long as its fullest 8-column sub-range (mean 13 entries, a long tail: a small
+// node drops its 384 entries on a handful of columns).  Here the tile's sorted list -- its four buckets are consecutive in `skey` -- is staged
+// as ONE list, PD5_R entries per round, and cut into sixteen chunks of equal LENGTH, one per group of ten threads (four channels each): every
+// lane of the workgroup runs the same number of entries (+- 1).  A column that straddles a chunk boundary: the later chunk starts from zero
+// for it and leaves its partial sum in `head`; after the round the first such chunk of a run on one column adds the run's partial sums to
+// the accumulator in chunk order -- a fixed order, so the result is reproducible run to run (it differs from the column-owned kernels in the
+// last bit where a column was cut: another association of the same sum).
+constexpr int PD_SPARSE_KERNEL = 5;           // input widths that are multiples of 4 (the variants build can ask for 4: SONET_PD_KERNEL)
+constexpr int PD5_R = 384;                     // entries per round (LDS: five workgroups per CU)
+constexpr int PD5_G = 16;                      // chunks = groups of ten threads
+template <typename TO>
+__global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad5_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ skey,
+                                                            const float *__restrict__ g_pooled, const float *__restrict__ W,
+                                                            int E, int M, int Cin, int C1, int L, int nbucket,
+                                                            TO *__restrict__ gx1, TO *__restrict__ gx2)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm_f5[];       // acc[PD_TL][PD4_LD] | head[PD5_G][PD_CH] | uint4 ent[PD5_R]
+    constexpr int ld = PD4_LD;
+    static_assert(PD_CH * PD_CQ == PD5_G * 10 && PD_CH == 40, "sixteen groups of ten threads, four channels each");
+    float *acc = sm_f5;
+    float *head = sm_f5 + PD_TL * ld;
+    uint4 *ent = reinterpret_cast<uint4 *>(head + PD5_G * PD_CH);
+    __shared__ int headcol[PD5_G];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const int grp = tid / 10, i4 = tid - grp * 10;
+    const int ch0 = blockIdx.z * PD_CH, nch = min(PD_CH, Cin - ch0);
+    for (int t = tid; t < PD_TL * ld; t += nth) acc[t] = 0.f;
+    const int32_t *to = tile_off + (size_t)b * (nbucket + 1);
+    int bo[PD_CQ + 1];
+#pragma unroll
+    for (int t = 0; t <= PD_CQ; ++t) bo[t] = to[min(tile * PD_CQ + t, nbucket)];
+    const int beg = bo[0], N = bo[PD_CQ] - beg;
+    const uint32_t *kb = skey + (size_t)b * E + beg;
+    const float *gb = g_pooled + (size_t)b * E;
+    for (int base = 0; base < N; base += PD5_R) {
+        const int n = min(PD5_R, N - base);
+        __syncthreads();                                                    // the accumulators are zeroed / the previous round is merged
+        for (int t = tid; t < n; t += nth) {
+            const int e = beg + base + t;
+            const uint32_t key = kb[base + t];
+            const int id = (int)(key & 0xFFFFFu);
+            const int q = (e >= bo[1]) + (e >= bo[2]) + (e >= bo[3]);      // the bucket of the tile this entry sits in
+            ent[t] = make_uint4((unsigned)((int)(key >> 20) + q * PD_SB), __float_as_uint(gb[id]), (unsigned)((id / M) * Cin + ch0), 0u);
+        }
+        __syncthreads();
+        // chunk grp: the first n % 16 chunks take one entry more (the non-empty chunks are the first ones)
+        const int per = n / PD5_G, rem = n - per * PD5_G;
+        const int lo = grp * per + min(grp, rem), cnt = per + (grp < rem ? 1 : 0);
+        const bool cont = cnt > 0 && lo > 0 && ent[lo - 1].x == ent[lo].x;  // my first column began in the chunk before
+        if (i4 == 0) headcol[grp] = cont ? (int)ent[lo].x : -1;
+        if (4 * i4 < nch && cnt > 0) {
+            int cur = (int)ent[lo].x;
+            bool in_head = cont;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!in_head) sum = *reinterpret_cast<const float4 *>(acc + cur * ld + 4 * i4);
+            for (int e0 = 0; e0 < cnt; e0 += PD4_WB) {
+                uint4 en[PD4_WB];
+                float4 wv[PD4_WB];
+#pragma unroll
+                for (int t = 0; t < PD4_WB; ++t) {
+                    en[t] = ent[lo + (e0 + t < cnt ? e0 + t : cnt - 1)];
+                    wv[t] = *reinterpret_cast<const float4 *>(W + (size_t)en[t].z + 4 * i4);
+                }
+#pragma unroll
+                for (int t = 0; t < PD4_WB; ++t) {
+                    if (e0 + t < cnt) {
+                        const int col = (int)en[t].x;
+                        if (col != cur) {
+                            *reinterpret_cast<float4 *>(in_head ? head + grp * PD_CH + 4 * i4 : acc + cur * ld + 4 * i4) = sum;
+                            in_head = false;
+                            cur = col;
+                            sum = *reinterpret_cast<const float4 *>(acc + cur * ld + 4 * i4);
+                        }
+                        const float v = __uint_as_float(en[t].y);
+                        sum.x = __fmaf_rn(v, wv[t].x, sum.x);
+                        sum.y = __fmaf_rn(v, wv[t].y, sum.y);
+                        sum.z = __fmaf_rn(v, wv[t].z, sum.z);
+                        sum.w = __fmaf_rn(v, wv[t].w, sum.w);
+                    }
+                }
+            }
+            *reinterpret_cast<float4 *>(in_head ? head + grp * PD_CH + 4 * i4 : acc + cur * ld + 4 * i4) = sum;
+        }
+        __syncthreads();
+        // the cut columns: the first chunk of a run of partial sums on one column adds the run, in chunk order
+        if (4 * i4 < nch && grp > 0) {
+            const int hc = headcol[grp];
+            if (hc >= 0 && headcol[grp - 1] != hc) {
+                float4 s = *reinterpret_cast<const float4 *>(acc + hc * ld + 4 * i4);
+                for (int g = grp; g < PD5_G && headcol[g] == hc; ++g) {
+                    const float4 hv = *reinterpret_cast<const float4 *>(head + g * PD_CH + 4 * i4);
+                    s.x += hv.x; s.y += hv.y; s.z += hv.z; s.w += hv.w;
+                }
+                *reinterpret_cast<float4 *>(acc + hc * ld + 4 * i4) = s;
+            }
         }
     }
     __syncthreads();
@@ -1455,12 +1578,22 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     if (!(abl & 4)) hipLaunchKernelGGL(pooled_sort_kernel, dim3(nbucket, B), dim3(64), 0, st, tile_off, ent_key, skey, E, nbucket);
     int one = 0;
     if (const char *e = sonet::knob("SONET_PD_ONE")) one = atoi(e);     // (variants build: 1 = the one-channel-per-thread kernel)
-    if (Cin % 4 == 0 && abl == 0 && !one) {
+    int which = PD_SPARSE_KERNEL;
+    if (const char *e = sonet::knob("SONET_PD_KERNEL")) which = atoi(e);   // (variants build: 4 = column-owned sub-ranges, 5 = equal-length chunks)
+    if (Cin % 4 == 0 && abl == 0 && !one && which == 5) {
+        const size_t lds5 = (size_t)PD_TL * PD4_LD * 4 + (size_t)PD5_G * PD_CH * 4 + (size_t)PD5_R * 16;
+        hipLaunchKernelGGL(pooled_dgrad5_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds5, st, tile_off, skey, g_pooled, W, E, M, Cin, C1,
+                           L, nbucket, gx1, gx2 ? gx2 : gx1);
+        return sonet::launched(what);
+    }
+#ifdef SONET_VARIANTS
+    if (Cin % 4 == 0 && abl == 0 && !one && which == 4) {
         const size_t lds4 = (size_t)PD_TL * PD4_LD * 4 + (size_t)PD_CQ * PD_SQ * 16;
         hipLaunchKernelGGL(pooled_dgrad4_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds4, st, tile_off, skey, g_pooled, W, E, M, Cin, C1,
                            L, nbucket, gx1, gx2 ? gx2 : gx1);
         return sonet::launched(what);
     }
+#endif
     hipLaunchKernelGGL(pooled_dgrad_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds2, st, tile_off, (abl & 4) ? ent_key : skey, ent_val, g_pooled, W, E, M, Cin, C1,
                        L, nbucket, gx1, gx2 ? gx2 : gx1, abl);
     return sonet::launched(what);

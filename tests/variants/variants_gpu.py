@@ -140,3 +140,33 @@ def test_pointmlp_kmax_epilogue(B, C, Cout, M, K):
         ref = ops.planes_max(ops.pointmlp(x, wp, scale, shift, relu, Cout), K)
         got = variants.pointmlp_kmax(x, wp, scale, shift, relu, Cout, M)
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("B,C,M,C1,C2,L", [(3, 384, 64, 64, 256, 3000), (2, 96, 8, 16, 48, 130), (2, 48, 7, 44, 0, 257), (8, 384, 64, 64, 256, 15000)])
+def test_sparse_input_gradient_kernels_agree(B, C, M, C1, C2, L, monkeypatch):
+    """pooled_dgrad: the one-channel kernel (SONET_PD_ONE=1), its four-channel column-owned twin (SONET_PD_KERNEL=4: the same bits) and the
+    product's entry-balanced kernel (5: the same sums, a cut column associates differently -- f32 rounding of a handful of terms), incl. positions
+    piled on few columns (chunks that are one column from end to end) and a partial channel slab."""
+    from sonet_hip import ops
+    gen = torch.Generator().manual_seed(B + L)
+    g = torch.randn(B, C, M, generator=gen)
+    pos = torch.randint(0, L, (B, C, M), generator=gen, dtype=torch.int32)
+    pos[:, : C // 2, : max(M // 2, 1)] = 5                                 # hundreds of entries on one column
+    pos[:, C // 2:, 0] = L - 1
+    W = torch.randn(C, C1 + C2, generator=gen) * 0.1
+    outs = {}
+    for name, env in (("one", {"SONET_PD_ONE": "1"}), ("k4", {"SONET_PD_KERNEL": "4"}), ("k5", {"SONET_PD_KERNEL": "5"}), ("default", {})):
+        for k in ("SONET_PD_ONE", "SONET_PD_KERNEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = ops.pooled_dgrad(g.to(DEV), pos.to(DEV), W.to(DEV), C1, C2, L)
+        b = ops.pooled_dgrad(g.to(DEV), pos.to(DEV), W.to(DEV), C1, C2, L)
+        outs[name] = torch.cat([t for t in a if t is not None and t.numel()], dim=1)
+        assert torch.equal(outs[name], torch.cat([t for t in b if t is not None and t.numel()], dim=1))       # run to run
+    assert torch.equal(outs["one"], outs["k4"])
+    assert torch.equal(outs["default"], outs["k5"])
+    G = torch.zeros(B, C, L, dtype=torch.float64).scatter_add_(2, pos.long(), g.double())
+    ref = torch.matmul(W.double().t().unsqueeze(0), G)
+    for name in ("k4", "k5"):
+        assert float((outs[name].cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), name

@@ -1,15 +1,11 @@
 #!/bin/bash
-mkdir -p gpurun_out/r5l
-timeout 600 python -m pytest tests/test_gpu_bf16.py -x -q 2>&1 | tail -25 > gpurun_out/r5l/pytest.log; cat gpurun_out/r5l/pytest.log
-timeout 300 python bench.py --mode train --precision bf16 --steps 40 --warmup 5 2> gpurun_out/r5l/train_bf16.err | tail -1 > gpurun_out/r5l/train_bf16.json
-SONET_POOLED_TRAIN_EPILOGUE=0 timeout 300 python bench.py --mode train --precision bf16 --steps 40 --warmup 5 2> /dev/null | tail -1 > gpurun_out/r5l/train_bf16_store.json
-python - <<'PY'
-import json
-for n in ("train_bf16", "train_bf16_store"):
-    try:
-        d = json.loads(open("gpurun_out/r5l/%s.json" % n).read())
-        print(n, d["value"], d["ms_per_step"])
-    except Exception as e:
-        print(n, "failed", e)
-PY
-tail -5 gpurun_out/r5l/train_bf16.err
+# the entry-balanced sparse input gradient as the product's kernel: every test that reaches it (+ the variants suite: one-channel == column-owned,
+# entry-balanced vs float64), the f32-class training line, the microbench out of the product library
+TAG=${1:-r05l}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+P=$R/gpurun_out/$TAG/profiles; mkdir -p $P
+timeout 200 python -m pytest tests -q -m gpu -x -k "pooled or train or segpool or variants or golden" 2>&1 | tail -4 > $P/${TAG}_pytest_train_paths.log
+timeout 60 python bench.py --mode train --precision h3 --steps 40 --warmup 8 2> /dev/null | tail -1 > $P/${TAG}_bench_train_h3.json
+timeout 60 python tools/bench_pooled_sorted.py 2>&1 | grep -v "amdgpu\|Warning\|detach" > $P/${TAG}_bench_pooled_sorted.log
+cat $P/${TAG}_pytest_train_paths.log $P/${TAG}_bench_pooled_sorted.log | cut -c1-200; python -c "
+import json;d=json.load(open('$P/${TAG}_bench_train_h3.json'));print(d['value'],d['ms_per_step'])"
