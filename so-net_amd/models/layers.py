@@ -226,6 +226,7 @@ class _Materialise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, sc, sh, relu):
+        ctx.set_materialize_grads(False)      # (a consumer that hands its gradient on through a ``_GradCarry`` returns None: no zero tensor for it)
         return _ops.channel_affine_act(raw, sc, sh, relu)
 
     @staticmethod

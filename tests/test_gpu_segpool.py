@@ -282,6 +282,52 @@ def test_h3_training_step_with_normalise_on_load_equals_the_step_with_normalise_
     _compare_steps(res[True], res[False])
 
 
+@pytest.mark.parametrize("which", [1, 2])
+def test_h3_training_step_with_a_hidden_layer_that_materialises_its_input(which, monkeypatch):
+    """A hidden layer of the first PointNet that finds no normalise-on-load form for itself AFTER the forward decided on deferred
+    activations (the weight side of the range guard can do that between the decision and the launch) writes its input out through the
+    identity node ``_Materialise`` and carries on; layer 1 doing so is also the consumer of the carried gradient (its input-gradient launch
+    then has another input tensor than the pooled layer).  Same step as the plain one to f32-class accuracy."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 8, 3000
+    res = {}
+    real = ops.xaff_ok
+    with ops.precision("h3"):
+        for patched in (True, False):
+            opt = _opt(B, N)
+            enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+            enc.want_first_pn_out = False
+            synth.fill_state_dict_(enc.state_dict(), 3)
+            synth.fill_state_dict_(cls.state_dict(), 4)
+            enc.to(DEV).train()
+            cls.to(DEV).train()
+            inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+            if patched:
+                lay = enc.first_pointnet.layers[which]
+                run = lay._run
+
+                def run_without_the_form(*a, _run=run, **k):
+                    monkeypatch.setattr(ops, "xaff_ok", lambda *aa, **kk: False)
+                    try:
+                        return _run(*a, **k)
+                    finally:
+                        monkeypatch.setattr(ops, "xaff_ok", real)
+                object.__setattr__(lay, "_run", run_without_the_form)
+            with ops.kernel_timing() as rec:
+                feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                loss.backward()
+            names = [n for n, _, _ in rec.records]
+            assert any(n.startswith("pointmlph3_segpool") for n in names)
+            # (the materialised input is one normalise pass more on a point-level tensor)
+            res[patched] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                            {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone(),
+                            sum(n.startswith("channel_affine_act") for n in names))
+    assert res[True][4] == res[False][4] + 1
+    _compare_steps(res[True][:4], res[False][:4])
+
+
 # ------------------------------------------------------------------------------------------ deferred side-stream joins
 @pytest.mark.parametrize("precision", ["bf16", "h3"])
 def test_weight_gradients_joined_at_the_end_of_backward_equal_joined_per_layer(precision):
