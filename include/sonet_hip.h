@@ -562,6 +562,18 @@ int sonet_pooled_wgrad_xaff_f32(const float *g_pooled, const int32_t *pos, const
                                 float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                            int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
+/* ... with what used to follow the launch riding on its store (C1 + C2 a multiple of 4; node-sorted f32-class training path):
+ *  col0 [B][C1 + C2], pos0 [B] (both or neither): gx[b][:, pos0[b]] += col0[b] -- every channel of an EMPTY node gathers position 0
+ *    (models/networks.py:185): their entries are one dense mat-vec per cloud (the caller's) landing on one column;
+ *  sraw [B][C2][L], ssc, ssh [C2], srelu, tail_ws (sonet_pooled_dgrad_tail_ws_size bytes), sums [2 C2] (all or none; C2 > 0): gx2 is gy of the
+ *    BatchNorm (+ ReLU) layer (models/layers.py:60-70, :282-296) whose RAW output is sraw; sums[0 .. C2) = sum over (b, l) of gy * mask,
+ *    sums[C2 .. 2 C2) = sum of gy * mask * raw with mask = !srelu || raw * ssc + ssh > 0: what sonet_pointwise_bwd_stats_f32 computes from one
+ *    more pass over (gy, raw); double precision, fixed order. */
+size_t sonet_pooled_dgrad_tail_ws_size(int B, int C2, int L);
+int sonet_pooled_dgrad_tail_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                int L, void *ws, float *gx1, float *gx2, const float *col0, const int32_t *pos0,
+                                const float *sraw, const float *ssc, const float *ssh, int srelu, void *tail_ws, double *sums,
+                                sonet_stream_t stream);
 /* bf16 training path: x read as bfloat16 bits (sonet_pooled_wgrad_xbf16), gradients written as bfloat16 bits (sonet_pooled_dgrad_obf16) */
 int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
                              float *gw_partial, sonet_stream_t stream);

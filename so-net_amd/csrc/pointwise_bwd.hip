@@ -1152,12 +1152,52 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad4_kernel(const int3
 constexpr int PD_SPARSE_KERNEL = 5;           // input widths that are multiples of 4 (the variants build can ask for 4: SONET_PD_KERNEL)
 constexpr int PD5_R = 384;                     // entries per round (LDS: five workgroups per CU)
 constexpr int PD5_G = 16;                      // chunks = groups of ten threads
-template <typename TO>
+// TAIL (f32 outputs): what used to follow the launch rides on its store.
+//  * col0 / pos0: every channel of an EMPTY node gathers position 0 (models/networks.py:185) -- those entries are one dense mat-vec per cloud
+//    (the caller's), whose result lands on ONE column, pos0[b]: added by the thread that stores that column (two scatter_add launches less,
+//    and the tensors are final when the launch is over, which the next item needs).
+//  * sraw / ssc / ssh / spart: gx2 is gy of the layer that produced x2; when that layer handed its RAW output on (normalise-on-load: the
+//    raw tensor IS x2) its BatchNorm-backward sums -- per channel sum of gy * mask and of gy * mask * raw, what
+//    sonet_pointwise_bwd_stats_f32 reads (gy, raw) once more for -- are taken from the tile while it is stored: the launch reads raw
+//    (1 GB at 64 x 256 x 15000) instead of a pass reading gy AND raw.  A 32-column block of a channel is a half wave: five shuffles per
+//    quantity, block sums through the LDS in a fixed order, one (double, double) per (cloud, tile, channel), summed by pd_sums_finalize_kernel.
+struct PdTail {
+    const float *col0;                    // [B][Cin] or NULL
+    const int32_t *pos0;                  // [B]
+    const float *sraw;                    // [B][Cin - C1][L] or NULL
+    const float *ssc, *ssh;               // [Cin - C1]
+    int srelu;
+    double *spart;                        // [B * gridDim.x][Cin - C1][2]
+};
+
+__global__ __launch_bounds__(256) void pd_sums_finalize_kernel(const double *__restrict__ partial, int n, int C, double *__restrict__ sums)
+{
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = t; k < n; k += 256) {
+        const double *p = partial + ((size_t)k * C + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+    r1[t] = s1;
+    r2[t] = s2;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { r1[t] += r1[t + off]; r2[t] += r2[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) { sums[c] = r1[0]; sums[C + c] = r2[0]; }
+}
+
+template <typename TO, bool TAIL = false>
 __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad5_kernel(const int32_t *__restrict__ tile_off, const uint32_t *__restrict__ skey,
                                                             const float *__restrict__ g_pooled, const float *__restrict__ W,
                                                             int E, int M, int Cin, int C1, int L, int nbucket,
-                                                            TO *__restrict__ gx1, TO *__restrict__ gx2)
+                                                            TO *__restrict__ gx1, TO *__restrict__ gx2, const PdTail tail)
 {
+    static_assert(!TAIL || sizeof(TO) == 4, "the tail exists for f32 outputs");
     extern __shared__ __attribute__((aligned(16))) float sm_f5[];       // acc[PD_TL][PD4_LD] | head[PD5_G][PD_CH] | uint4 ent[PD5_R]
     constexpr int ld = PD4_LD;
     static_assert(PD_CH * PD_CQ == PD5_G * 10 && PD_CH == 40, "sixteen groups of ten threads, four channels each");
@@ -1241,6 +1281,67 @@ __global__ __launch_bounds__(PD_CH * PD_CQ) void pooled_dgrad5_kernel(const int3
     }
     __syncthreads();
     const int l0 = tile * PD_TL;
+    if constexpr (TAIL) {
+        // units of (channel r, 32-column block): one per half wave and step; `head` is free now: block sums [160][2]
+        float *ust = head;
+        const int hw = tid >> 5, ln = tid & 31;
+        const int p0 = tail.col0 ? tail.pos0[b] : -1;
+        const int C2 = Cin - C1;
+        float *g1 = reinterpret_cast<float *>(gx1), *g2 = reinterpret_cast<float *>(gx2);
+        // (eight units at a time: the loads of a batch -- accumulator rows from the LDS, raw and its coefficients from memory -- are all
+        //  requested before the first store; one unit per trip left every trip waiting for its own load: 1.74 ms against 1.0 ms apart)
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            float v[8], rw[8], sc[8], sh[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int u = hw + 5 * (k0 + t), r = u >> 2, blk = u & 3;
+                const int col = blk * 32 + ln, l = l0 + col, ch = ch0 + r;
+                const bool ok = r < nch && l < L;
+                v[t] = ok ? acc[col * ld + r] : 0.f;
+                if (ok && l == p0) v[t] = v[t] + tail.col0[(size_t)b * Cin + ch];
+                const bool st = ok && ch >= C1 && tail.sraw != nullptr;
+                rw[t] = st ? tail.sraw[((size_t)b * C2 + (ch - C1)) * L + l] : 0.f;
+                sc[t] = st ? tail.ssc[ch - C1] : 0.f;
+                sh[t] = st ? tail.ssh[ch - C1] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int u = hw + 5 * (k0 + t), r = u >> 2, blk = u & 3;
+                const int col = blk * 32 + ln, l = l0 + col, ch = ch0 + r;
+                const bool ok = r < nch && l < L;
+                float s1 = 0.f, s2 = 0.f;
+                if (ok) {
+                    if (ch < C1) g1[((size_t)b * C1 + ch) * L + l] = v[t];
+                    else {
+                        g2[((size_t)b * C2 + (ch - C1)) * L + l] = v[t];
+                        if (tail.sraw) {
+                            float gm = v[t];
+                            if (tail.srelu && !(__fmaf_rn(rw[t], sc[t], sh[t]) > 0.f)) gm = 0.f;
+                            s1 = gm;
+                            s2 = gm * rw[t];
+                        }
+                    }
+                }
+                if (tail.sraw) {
+                    s1 = row32_sum(s1);
+                    s2 = row32_sum(s2);
+                    if (ln == 0) { ust[2 * u] = s1; ust[2 * u + 1] = s2; }
+                }
+            }
+        }
+        if (tail.sraw) {
+            __syncthreads();
+            if (tid < nch && ch0 + tid >= C1) {
+                double a = 0.0, q = 0.0;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) { a += (double)ust[2 * (tid * 4 + blk)]; q += (double)ust[2 * (tid * 4 + blk) + 1]; }
+                double *dst = tail.spart + (((size_t)b * gridDim.x + tile) * C2 + (ch0 + tid - C1)) * 2;
+                dst[0] = a;
+                dst[1] = q;
+            }
+        }
+        return;
+    }
     if (sizeof(TO) == 2 && (L & 1) == 0) {
         for (int idx = tid; idx < nch * (PD_TL / 2); idx += nth) {
             const int r = idx / (PD_TL / 2), col = (idx - r * (PD_TL / 2)) * 2;
@@ -1558,7 +1659,7 @@ extern "C" int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *po
 
 template <typename TO>
 static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
-                             int L, void *ws, TO *gx1, TO *gx2, sonet_stream_t stream)
+                             int L, void *ws, TO *gx1, TO *gx2, sonet_stream_t stream, const PdTail *tail = nullptr, double *tail_sums = nullptr)
 {
     SONET_REQUIRE(g_pooled && pos && W && ws && gx1, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C > 0 && M > 0 && C1 > 0 && C2 >= 0 && L > 0, "%s: non-positive size", what);
@@ -1580,10 +1681,20 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
     if (const char *e = sonet::knob("SONET_PD_ONE")) one = atoi(e);     // (variants build: 1 = the one-channel-per-thread kernel)
     int which = PD_SPARSE_KERNEL;
     if (const char *e = sonet::knob("SONET_PD_KERNEL")) which = atoi(e);   // (variants build: 4 = column-owned sub-ranges, 5 = equal-length chunks)
+    if (tail && !(Cin % 4 == 0 && abl == 0 && !one && which == 5 && sizeof(TO) == 4))
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the tail needs f32 outputs and C1 + C2 a multiple of 4", what);
     if (Cin % 4 == 0 && abl == 0 && !one && which == 5) {
         const size_t lds5 = (size_t)PD_TL * PD4_LD * 4 + (size_t)PD5_G * PD_CH * 4 + (size_t)PD5_R * 16;
+        if (tail) {
+            if constexpr (sizeof(TO) == 4) {
+                hipLaunchKernelGGL((pooled_dgrad5_kernel<TO, true>), dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds5, st, tile_off, skey, g_pooled, W, E, M,
+                                   Cin, C1, L, nbucket, gx1, gx2 ? gx2 : gx1, *tail);
+                if (tail->sraw) hipLaunchKernelGGL(pd_sums_finalize_kernel, dim3((unsigned)C2), dim3(256), 0, st, tail->spart, B * ntile, C2, tail_sums);
+                return sonet::launched(what);
+            }
+        }
         hipLaunchKernelGGL(pooled_dgrad5_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds5, st, tile_off, skey, g_pooled, W, E, M, Cin, C1,
-                           L, nbucket, gx1, gx2 ? gx2 : gx1);
+                           L, nbucket, gx1, gx2 ? gx2 : gx1, PdTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr});
         return sonet::launched(what);
     }
 #ifdef SONET_VARIANTS
@@ -1603,6 +1714,31 @@ extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos,
                                       int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream)
 {
     return pooled_dgrad_impl<float>("sonet_pooled_dgrad_f32", g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream);
+}
+
+extern "C" size_t sonet_pooled_dgrad_tail_ws_size(int B, int C2, int L)
+{
+    if (B <= 0 || C2 <= 0 || L <= 0) return 0;
+    return (size_t)B * sonet::ceil_div(L, PD_TL) * C2 * 2 * sizeof(double);
+}
+
+/* sonet_pooled_dgrad_f32 with what used to follow it riding on the store (C1 + C2 a multiple of 4):
+ *  col0 [B][C1 + C2], pos0 [B] (both or neither): gx[b][:, pos0[b]] += col0[b] -- the dense part of the gradient (the entries of empty nodes all
+ *    gather one column, models/networks.py:185; the caller computes their mat-vec);
+ *  sraw [B][C2][L], ssc, ssh [C2], srelu, tail_ws (sonet_pooled_dgrad_tail_ws_size bytes), sums [2 C2] (all or none, C2 > 0): gx2 is gy of the
+ *    BatchNorm (+ ReLU) layer whose RAW output is sraw; sums[0 .. C2) = sum over (b, l) of gy * mask, sums[C2 .. 2 C2) = sum of gy * mask * raw,
+ *    mask = !srelu || raw * ssc + ssh > 0 -- the sums sonet_pointwise_bwd_stats_f32 computes from one more pass over (gy, raw); fixed order. */
+extern "C" int sonet_pooled_dgrad_tail_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                           int L, void *ws, float *gx1, float *gx2, const float *col0, const int32_t *pos0,
+                                           const float *sraw, const float *ssc, const float *ssh, int srelu, void *tail_ws, double *sums,
+                                           sonet_stream_t stream)
+{
+    const char *what = "sonet_pooled_dgrad_tail_f32";
+    SONET_REQUIRE((col0 == nullptr) == (pos0 == nullptr), "%s: col0 and pos0 come together", what);
+    SONET_REQUIRE((sraw == nullptr) == (tail_ws == nullptr) && (sraw == nullptr) == (sums == nullptr) && (!sraw || (ssc && ssh && C2 > 0 && gx2)),
+                  "%s: the sums need sraw, ssc, ssh, a workspace, the output and a second panel", what);
+    const PdTail t = {col0, pos0, sraw, ssc, ssh, srelu, reinterpret_cast<double *>(tail_ws)};
+    return pooled_dgrad_impl<float>(what, g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream, &t, sums);
 }
 
 /* gradients written as bfloat16 bit patterns (f32 accumulation in LDS as above, one rounding on the store) */

@@ -526,9 +526,25 @@ class _PooledLastLayerFn(torch.autograd.Function):
                         if wt.shape[0] % 32:
                             wt = torch.cat((wt, wt.new_zeros(32 - wt.shape[0] % 32, wt.shape[1])), dim=0)
                         wt_pack = _ops.pointmlp_pack(wt, "bf16")
+                col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
+                if ctx.pos0 is not None and wt_pack is None and _ops.pooled_dgrad_tail_ok(C1, C2, x1.dtype):
+                    # node-sorted f32-class path: the column-0 part is added by the store of the launch, and when x2 IS the raw output of the
+                    # layer below (normalise-on-load) that layer's BatchNorm-backward sums come out of the same store, handed over on the
+                    # gradient tensor (_bwd_sums_hint): no statistics pass over (gy, raw) of the widest hidden layer
+                    below = (x2, xa[3], xa[4], xa[5]) if (xa is not None and C2 > 0 and x2.dtype == torch.float32 and x2.is_contiguous()) else None
+                    res = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, col0=col0.contiguous(),
+                                            pos0=ctx.pos0.to(torch.int32).contiguous(), below=below)
+                    g_x1, g_x2 = res[0], res[1]
+                    if below is not None:
+                        g_x2._sonet_bwd_sums = (res[2], x2.data_ptr(), g_x2._version, bool(xa[5]))
+                    if ss is not None:
+                        ss.join(defer=_grad_slot_empty(ctx.wleaf))
+                    if ctx.carry is not None and g_x1 is not None:
+                        ctx.carry.put(g_x1)
+                        g_x1 = None
+                    return g_x1, g_x2, g_w, g_bias, None, None, None, None, None, None, None, None
                 g_x1, g_x2 = _ops.pooled_dgrad(g_mm.float(), torch.where(occ, gi, torch.full_like(gi, -1)), w, C1, C2, L, out_dtype=x1.dtype,
                                                wt_pack=wt_pack)
-                col0 = torch.matmul((g_mm.float() * (~occ)).sum(dim=2), w)        # B x (C1 + C2)
                 if ctx.pos0 is None:
                     g_x1[:, :, 0] += col0[:, :C1].to(g_x1.dtype)
                     g_x2[:, :, 0] += col0[:, C1:].to(g_x2.dtype)

@@ -126,6 +126,8 @@ SIGNATURES = {
     "sonet_pooled_wgrad_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "sonet_pooled_dgrad_obf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_pooled_dgrad_tail_ws_size": [_i, _i, _i],
+    "sonet_pooled_dgrad_tail_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "sonet_pooled_dgrad_mfma_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -170,6 +172,7 @@ _RESTYPES = {
     "sonet_pointresnet_bf16_pool_ws_size": ctypes.c_size_t,
     "sonet_pointresnet_pool_ws_size": ctypes.c_size_t,
     "sonet_pooled_dgrad_ws_size": ctypes.c_size_t,
+    "sonet_pooled_dgrad_tail_ws_size": ctypes.c_size_t,
     "sonet_som_assign_sort_ws_size": ctypes.c_size_t,
     "sonet_chamfer_nn2_ws_size": ctypes.c_size_t,
 }

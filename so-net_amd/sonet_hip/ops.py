@@ -1902,9 +1902,23 @@ def pooled_dgrad_mfma_ok(C, C1, C2, L):
     return POOLED_DGRAD_MFMA and L % 2 == 0 and C % 16 == 0 and C <= 384 and ct % 2 == 0 and ct <= 12
 
 
-def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32, wt_pack=None):
+# the sparse input gradient of the pooled layer on node-sorted columns (f32-class training): the column-0 part of the gradient (empty nodes) and
+# the BatchNorm-backward sums of the layer that produced x2 can ride on the store of the launch (sonet_pooled_dgrad_tail_f32) instead of being two
+# scatter_add launches and a statistics pass over (gy, raw) of that layer.  OFF: measured slower -- 1.24 ms against 1.00 ms for the three
+# launches apart (the store phase reads raw in 128-byte pieces from five workgroups per CU; docs/findings.md R5.14); kept as a tested record.
+POOLED_DGRAD_TAIL = _os.environ.get("SONET_POOLED_DGRAD_TAIL", "0") != "0"
+
+
+def pooled_dgrad_tail_ok(C1, C2, out_dtype):
+    return POOLED_DGRAD_TAIL and out_dtype == torch.float32 and (C1 + C2) % 4 == 0
+
+
+def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32, wt_pack=None, col0=None, pos0=None, below=None):
     """Sparse W^T . g for a gradient that exists only at the pooled positions: g_pooled, pos B x C x M -> (gx1 B x C1 x L, gx2 B x C2 x L).
-    wt_pack (bf16 outputs only): pointmlp_pack(W^T, "bf16") -> the matrix-core kernel (g and W rounded to bf16)."""
+    wt_pack (bf16 outputs only): pointmlp_pack(W^T, "bf16") -> the matrix-core kernel (g and W rounded to bf16).
+    col0 (B x (C1 + C2), f32) with pos0 (B, i32): gx[b][:, pos0[b]] += col0[b], by the store of the launch (``pooled_dgrad_tail_ok``).
+    below = (raw B x C2 x L, sc, sh, relu): gx2 is gy of the BatchNorm layer whose raw output is ``raw`` -> a third result, its
+    BatchNorm-backward sums (float64 [2 C2], the layout of ``pointwise_bwd_stats(..., want_sums=True)``), taken from the tiles as they are stored."""
     _chk(g_pooled, "g_pooled", torch.float32, 3)
     _chk(pos_i32, "pos", torch.int32, 3)
     _chk(weight2d, "weight", torch.float32, 2)
@@ -1914,6 +1928,34 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32
     ws = torch.empty((lib.sonet_pooled_dgrad_ws_size(B, C, M, int(L)),), dtype=torch.uint8, device=dev)
     gx1 = torch.empty((B, C1, int(L)), dtype=out_dtype, device=dev)
     gx2 = torch.empty((B, C2, int(L)), dtype=out_dtype, device=dev) if C2 else None
+    if col0 is not None or pos0 is not None or below is not None:
+        if out_dtype != torch.float32 or (C1 + C2) % 4 or wt_pack is not None:
+            raise SonetHipError("pooled_dgrad: col0 / below need f32 outputs and C1 + C2 a multiple of 4")
+        if (col0 is None) != (pos0 is None):
+            raise SonetHipError("pooled_dgrad: col0 and pos0 come together")
+        if col0 is not None:
+            _chk(col0, "col0", torch.float32, 2)
+            _chk(pos0, "pos0", torch.int32, 1)
+            if tuple(col0.shape) != (B, C1 + C2) or pos0.numel() != B:
+                raise SonetHipError("pooled_dgrad: col0 must be B x (C1 + C2), pos0 B")
+            _same_device(g_pooled, col0, pos0)
+        raw = sc = sh = tws = sums = None
+        relu = False
+        if below is not None:
+            raw, sc, sh, relu = below
+            _chk(raw, "below raw", torch.float32, 3)
+            _chk(sc, "below sc", torch.float32, 1)
+            _chk(sh, "below sh", torch.float32, 1)
+            if C2 == 0 or tuple(raw.shape) != (B, C2, int(L)) or sc.numel() != C2 or sh.numel() != C2:
+                raise SonetHipError("pooled_dgrad: below = (raw B x C2 x L, sc, sh, relu) with C2 coefficients")
+            _same_device(g_pooled, raw, sc, sh)
+            tws = torch.empty((lib.sonet_pooled_dgrad_tail_ws_size(B, C2, int(L)),), dtype=torch.uint8, device=dev)
+            sums = torch.empty((2 * C2,), dtype=torch.float64, device=dev)
+        with _lib.on_device(dev), _timed("pooled_dgrad_tail%s" % ("_sums" if below is not None else "")):
+            check(lib.sonet_pooled_dgrad_tail_f32(ptr(g_pooled), ptr(pos_i32), ptr(weight2d), B, C, M, C1, C2, int(L), ptr(ws), ptr(gx1), ptr(gx2),
+                                                  ptr(col0), ptr(pos0), ptr(raw), ptr(sc), ptr(sh), int(bool(relu)), ptr(tws), ptr(sums), stream_ptr()),
+                  "sonet_pooled_dgrad_tail_f32")
+        return (gx1, gx2, sums) if below is not None else (gx1, gx2)
     if wt_pack is not None and out_dtype == torch.bfloat16 and pooled_dgrad_mfma_ok(C, C1, C2, int(L)):
         if wt_pack.dtype != torch.int16 or wt_pack.numel() != lib.sonet_pointmlp_bf16_pack_size(C, (C1 + C2 + 31) // 32 * 32) // 2:
             raise SonetHipError("pooled_dgrad: wt_pack is not the bf16 pack of W^T")

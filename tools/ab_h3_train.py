@@ -8,6 +8,8 @@ what bench.py --mode train --precision h3 times) in the variants of round 5, in 
     F  C, the side stream joined at the END of the backward pass (weight gradients are not needed before) instead of at the end of every layer
     G  F, the BatchNorm / ReLU backward applied by the operand load of the input-gradient launch (which writes g_raw for the weight gradient)
     H  G, the two gradients of the first layer's output added by the store of the second layer's input-gradient launch (ops.GRAD_CARRY)
+    I  H, the column-0 part and the BatchNorm-backward sums of the widest hidden layer on the store of the sparse input gradient (ops.POOLED_DGRAD_TAIL:
+       off in the product, measured slower stand-alone -- docs/findings.md R5.14; not timed in a step)
 then one instrumented step of each (per-kernel times by events on the launching stream).
 
   python tools/ab_h3_train.py [--rounds 6] [--steps 24] [--precision h3]"""
@@ -45,7 +47,8 @@ def main():
                 ("D_C_pooled_pair_in_sequence", True, True, False, True, False), ("E_C_no_side_stream_at_all", True, True, False, False, False),
                 ("F_C_joins_at_the_end_of_backward", True, True, True, True, True),
                 ("G_F_batchnorm_backward_on_load", True, True, True, True, True, True),
-                ("H_G_carried_gradient", True, True, True, True, True, True, True)]
+                ("H_G_carried_gradient", True, True, True, True, True, True, True),
+                ("I_H_tail_of_the_sparse_input_gradient", True, True, True, True, True, True, True, True)]
     if args.only:
         variants = [v for v in variants if v[0][0] in args.only]
     with ops.precision(args.precision):
@@ -78,6 +81,7 @@ def main():
             ops.H3_SEGPOOL, ops.H3_NORM_ON_LOAD, ops.POOLED_SIDE_STREAM, ops.BWD_SIDE_STREAM, ops.DEFER_WGRAD_JOIN = v[1], v[2], v[3], v[4], v[5]
             ops.BNB_ON_LOAD = len(v) > 6 and v[6]
             ops.GRAD_CARRY = len(v) > 7 and v[7]
+            ops.POOLED_DGRAD_TAIL = len(v) > 8 and v[8]
 
         def window(v):
             select(v)

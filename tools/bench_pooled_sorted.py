@@ -21,9 +21,9 @@ cap = {}
 orig_d, orig_w = ops.pooled_dgrad, ops.pooled_wgrad
 
 
-def grab_d(g_pooled, pos, w, C1, C2, L, out_dtype=torch.float32, wt_pack=None):
+def grab_d(g_pooled, pos, w, C1, C2, L, out_dtype=torch.float32, wt_pack=None, **tail):
     cap["d"] = (g_pooled.clone(), pos.clone(), w.clone(), C1, C2, L)
-    return orig_d(g_pooled, pos, w, C1, C2, L, out_dtype=out_dtype, wt_pack=wt_pack)
+    return orig_d(g_pooled, pos, w, C1, C2, L, out_dtype=out_dtype, wt_pack=wt_pack, **tail)
 
 
 def grab_w(g_t, pos_t, x, xaff=None):
@@ -85,6 +85,25 @@ for tag, seg in (("original column order", False), ("node-sorted columns", True)
         ops.pooled_dgrad(g_pooled, pos, w, C1, C2, L)
         torch.cuda.current_stream().wait_stream(side)
     print("   side by side on two streams: %.4f ms" % timeit(both))
+    if seg and C2 and (C1 + C2) % 4 == 0:
+        # what follows the launch in the training step, as launches of their own against riding on its store (ops.POOLED_DGRAD_TAIL)
+        gen = torch.Generator().manual_seed(5)
+        raw2 = torch.randn(B, C2, L, generator=gen).to(dev)
+        sc2, sh2 = (torch.rand(C2, generator=gen) + 0.5).to(dev), (torch.randn(C2, generator=gen) * 0.3).to(dev)
+        col0 = (torch.randn(B, C1 + C2, generator=gen) * 1e-4).to(dev)
+        p0 = torch.randint(0, L, (B,), generator=gen, dtype=torch.int32).to(dev)
+        p0l = p0.long().view(B, 1, 1)
+
+        def apart():
+            a, b2 = ops.pooled_dgrad(g_pooled, pos, w, C1, C2, L)
+            a.scatter_add_(2, p0l.expand(B, C1, 1), col0[:, :C1].unsqueeze(2))
+            b2.scatter_add_(2, p0l.expand(B, C2, 1), col0[:, C1:].unsqueeze(2))
+            return ops.pointwise_bwd_stats(b2, raw2, sc2, sh2, True, want_sums=True)
+        t_a = timeit(apart)
+        t_b = timeit(lambda: ops.pooled_dgrad(g_pooled, pos, w, C1, C2, L, col0=col0, pos0=p0, below=(raw2, sc2, sh2, True)))
+        t_c = timeit(lambda: ops.pooled_dgrad(g_pooled, pos, w, C1, C2, L, col0=col0, pos0=p0))
+        print("   pooled_dgrad + 2 scatter_add + statistics pass of the %d-channel layer: %.4f ms   on the store of the launch: %.4f ms (column 0 only: %.4f ms)"
+              % (C2, t_a, t_b, t_c))
     if variants_lib:
         for abl, what in ((4, "no sort"), (2, "no accumulation"), (1, "no stores"), (6, "no sort, no accumulation")):
             os.environ["SONET_PD_ABL"] = str(abl)
