@@ -359,3 +359,19 @@ def test_carried_gradient_is_consumed_once_and_only_in_the_pass_that_deposited_i
     (gx,) = torch.autograd.grad(h.sum(), x, retain_graph=True)     # the layer alone, another pass: the stale deposit is dropped
     assert torch.equal(gx, torch.full((3,), 3.0)) and c.g is None
     assert c.take() is None
+
+
+def test_data_flow_knobs_default_to_what_was_measured_faster():
+    """The round-5 data-flow switches of sonet_hip.ops: the measured-faster forms are on, the two measured-slower records (BatchNorm-backward
+    sums in a producer's epilogue / on the sparse input gradient's store: docs/findings.md R5.9, R5.14) are off -- unless the environment
+    says otherwise, which is how the A/B tools flip them."""
+    from sonet_hip import ops
+    on = ["H3_SEGPOOL", "H3_NORM_ON_LOAD", "TRAIN_ASSIGN_SORT", "POOLED_SIDE_STREAM", "DEFER_WGRAD_JOIN", "BNB_ON_LOAD", "GRAD_CARRY"]
+    off = ["BWD_STATS_EPILOGUE", "POOLED_DGRAD_TAIL"]
+    for name in on + off:
+        env = "SONET_" + name
+        if env in os.environ:
+            continue
+        assert getattr(ops, name) is (name in on), name
+    assert not ops.pooled_dgrad_tail_ok(64, 256, torch.float32) or ops.POOLED_DGRAD_TAIL
+    assert not ops.pooled_dgrad_tail_ok(64, 256, torch.bfloat16)
