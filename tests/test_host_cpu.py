@@ -375,3 +375,61 @@ def test_data_flow_knobs_default_to_what_was_measured_faster():
         assert getattr(ops, name) is (name in on), name
     assert not ops.pooled_dgrad_tail_ok(64, 256, torch.float32) or ops.POOLED_DGRAD_TAIL
     assert not ops.pooled_dgrad_tail_ok(64, 256, torch.bfloat16)
+
+
+def test_host_model_of_the_entry_balanced_sparse_input_gradient():
+    """The chunk logic of pooled_dgrad5_kernel (csrc/pointwise_bwd.hip) restated on the host for one channel: a round's sorted entries cut into
+    sixteen chunks of equal length (the first n % 16 one longer, so the non-empty chunks are the first ones); a chunk whose first column began
+    in the chunk before starts it from zero and parks the partial sum; after the round the first parked chunk of a run on one column adds the
+    run to the accumulator in chunk order; a column that continues from the previous ROUND resumes from the accumulator.  Integer-valued
+    entries: every order of additions gives the same float, so the model must reproduce the plain per-column sums exactly -- incl. rounds
+    shorter than sixteen entries, chunks that are one column from end to end, and columns cut three times."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    R, G = 24, 16                                                  # (the kernel: 384 entries per round; small here to force many rounds)
+
+    def run(cols, vals, order):
+        acc = {}
+        for base in range(0, len(cols), R):
+            n = min(R, len(cols) - base)
+            ent = list(zip(cols[base:base + n], vals[base:base + n]))
+            per, rem = divmod(n, G)
+            span = [(g * per + min(g, rem), per + (1 if g < rem else 0)) for g in range(G)]
+            headcol = [ent[lo][0] if (cnt > 0 and lo > 0 and ent[lo - 1][0] == ent[lo][0]) else -1 for lo, cnt in span]
+            head = [0.0] * G
+            for g in order(G):                                     # (the chunks run concurrently on the GPU: any order must do)
+                lo, cnt = span[g]
+                if cnt == 0:
+                    continue
+                in_head, cur = headcol[g] >= 0, ent[lo][0]
+                s = 0.0 if in_head else acc.get(cur, 0.0)
+                for c, v in ent[lo:lo + cnt]:
+                    if c != cur:
+                        if in_head:
+                            head[g] = s
+                        else:
+                            acc[cur] = s
+                        in_head, cur, s = False, c, acc.get(c, 0.0)
+                    s += v
+                if in_head:
+                    head[g] = s
+                else:
+                    acc[cur] = s
+            for g in range(1, G):
+                hc = headcol[g]
+                if hc >= 0 and headcol[g - 1] != hc:
+                    s, k = acc.get(hc, 0.0), g
+                    while k < G and headcol[k] == hc:
+                        s += head[k]
+                        k += 1
+                    acc[hc] = s
+        return acc
+
+    for trial in range(600):
+        n = int(rng.integers(1, 130))
+        cols = np.sort(rng.integers(0, int(rng.integers(1, 12)), n)).tolist()
+        vals = rng.integers(1, 100, n).astype(float).tolist()
+        ref = {}
+        for c, v in zip(cols, vals):
+            ref[c] = ref.get(c, 0.0) + v
+        assert run(cols, vals, range) == ref and run(cols, vals, lambda G: reversed(range(G))) == ref, (trial, cols)
