@@ -212,8 +212,21 @@ def golden_train_step(ref, tag, B, N, seed):
     Gradients are stored twice: from the reference as it is (float32 on CPU) and from the SAME reference code run
     in float64 (``grad64/``).  The float32 CPU backward of train-mode BatchNorm under the very sparse gradients of
     the arg-max pools loses ~3 digits to cancellation (its deviation from the float64 run is stored as
-    ``ref32_dev/``), so the float64 run is the ground truth the HIP path is held to."""
+    ``ref32_dev/``), so the float64 run is the ground truth the HIP path is held to.
+
+    ``route64/pool{1,2,3}`` (``route32/`` for the float32 run): the arg-max positions the run took at its three pools -- pool1 = what
+    ``index_max.forward_cuda`` returned times ``mask_row_max`` (the gather index of models/networks.py:185), pool2 / pool3 = the indices
+    of the two ``torch.max(..., dim=...)`` calls (models/layers.py:365, models/networks.py:197) -- recorded while the unmodified reference
+    runs.  A float64 restatement with these positions FORCED must reproduce ``grad64/`` (tests/f64_classifier.py)."""
     def run(dtype):
+        log = {}
+        orig_max = torch.max
+
+        def recording_max(*a, **k):
+            r = orig_max(*a, **k)
+            if isinstance(r, tuple) and a and torch.is_tensor(a[0]) and a[0].is_floating_point() and a[0].dim() in (3, 4):
+                log["pool2" if a[0].dim() == 4 else "pool3"] = r[1].clone()
+            return r
         opt = ref_harness.make_opt(batch_size=B, input_pc_num=N, dropout=0.0, classes=40)
         model = ref.classifier.Model(opt)
         synth.fill_state_dict_(model.encoder.state_dict(), seed=seed)
@@ -225,26 +238,43 @@ def golden_train_step(ref, tag, B, N, seed):
             model.encoder.som_builder.node = model.encoder.som_builder.node.double()
             model.optimizer_encoder = torch.optim.Adam(model.encoder.parameters(), lr=0.001)
             model.optimizer_classifier = torch.optim.Adam(model.classifier.parameters(), lr=0.001)
-            # the reference's index_max extension reads float32 only (index_max.cpp:92): cast at the shim, indices only
-            ext = ref.index_max
-            fwd = ext.forward_cpu
-            ref.networks.index_max = type(ext)("index_max")
-            ref.networks.index_max.forward_cuda = lambda d, i, K: fwd(d.float().contiguous(), i, K)
+        # the reference's index_max extension reads float32 only (index_max.cpp:92): cast at the shim (a no-op in the float32 run),
+        # indices only; the shim also records what the extension returned
+        ext = ref.index_max
+        fwd = ext.forward_cpu
+        ref.networks.index_max = type(ext)("index_max")
+
+        def forward_cuda(d, i, K):
+            out = fwd(d.float().contiguous(), i, K)
+            log["pool1_raw"] = out.clone()
+            return out
+        ref.networks.index_max.forward_cuda = forward_cuda
         model.set_input(inp["pc"].to(dtype), inp["sn"].to(dtype), inp["label"], inp["node"].to(dtype), inp["node_knn_I"])
+        torch.max = recording_max
         try:
             with ref_harness.sorted_topk():
                 model.optimize(epoch=0)
         finally:
+            torch.max = orig_max
             ref.networks.index_max = ref.index_max
-        return model, inp
+        row_max = orig_max(model.encoder.mask, dim=1)[0]                            # util/som.py:267
+        log["pool1"] = log.pop("pool1_raw").long() * row_max.unsqueeze(1).long()    # models/networks.py:185
+        return model, inp, log
 
-    model, inp = run(torch.float32)
-    model64, _ = run(torch.float64)
+    model, inp, route32 = run(torch.float32)
+    model64, _, route64 = run(torch.float64)
     enc = dict(model.encoder.named_parameters())
     enc64 = dict(model64.encoder.named_parameters())
     arrays = dict(B=B, N=N, seed=seed, pc=inp["pc"], sn=inp["sn"], node=inp["node"], node_knn_I=inp["node_knn_I"],
                   label=inp["label"], loss=model.loss.detach(), loss64=model64.loss.detach(), feature=model.feature.detach(),
                   score=model.score.detach())
+
+    for name, route in (("route32", route32), ("route64", route64)):
+        assert int(route["pool1"].max()) < 32768 and int(route["pool2"].max()) < 128 and int(route["pool3"].max()) < 128
+        arrays[name + "/pool1"] = route["pool1"].to(torch.int16)
+        arrays[name + "/pool2"] = route["pool2"].to(torch.int8)
+        arrays[name + "/pool3"] = route["pool3"].to(torch.int8)
+        print("   %s: pool1 %s pool2 %s pool3 %s" % (name, tuple(route["pool1"].shape), tuple(route["pool2"].shape), tuple(route["pool3"].shape)))
 
     def sub(t):                                   # strided subsample keeps the fixture small (<= ~16k values per tensor)
         f = t.detach().flatten()
@@ -342,6 +372,11 @@ def main():
         ref = ref_harness.import_reference(with_faiss_shim=True)
         golden_autoencoder(ref, "b2_n1024", B=2, N=1024, seed=401)
         golden_autoencoder(ref, "b2_n5000", B=2, N=5000, seed=402)            # BASELINE configs[3] size: 5000 gt vs 1280 predicted points
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "train512":        # the small training fixture alone (as main() below makes it)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        golden_train_step(ref_harness.import_reference(), "b16_n512", B=16, N=512, seed=201)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "train5000":       # own mode: the configs[1] / configs[4] point count, ~1.5 min of CPU
         torch.manual_seed(0)

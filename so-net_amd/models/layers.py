@@ -213,11 +213,57 @@ def _leaf_of(weight2d):
         return None
 
 
-def _grad_slot_empty(wleaf):
-    """True when the weight gradient this backward returns will be STORED as the parameter's .grad (no kernel reads it during the backward
-    pass) rather than added to an existing one: only then may its side-stream launches stay un-joined until the end of the pass."""
+class _UseToken:
+    """One forward use of a weight by a node whose backward launches its weight gradient on the side stream.  It lives as long as the
+    node's context (i.e. the autograd graph) does; ``done`` once that node's backward has run."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
+def _register_use(wleaf):
+    """Called by the forward of such a node (grad mode): remembers on the PARAMETER that one more node of a live graph will produce a
+    gradient for it.  Returns the token the node keeps in its context."""
+    import weakref
     p = wleaf() if wleaf is not None else None
-    return p is not None and p.grad is None
+    if p is None:
+        return None
+    live = getattr(p, "_sonet_uses", None)
+    if live is None:
+        live = weakref.WeakSet()
+        try:
+            p._sonet_uses = live
+        except (AttributeError, RuntimeError):
+            return None
+    tok = _UseToken()
+    live.add(tok)
+    return tok
+
+
+def _grad_slot_empty(wleaf, token=None):
+    """True when NOTHING reads the weight gradient this backward returns before the backward pass is over -- only then may its side-stream
+    launches stay un-joined until the end of the pass:
+      * it will be STORED as the parameter's .grad, not added to an existing one (``p.grad is None``);
+      * this node is the parameter's ONLY producer in the graphs alive now (a weight used twice -- a Siamese encoder, the encoder called
+        twice before one backward -- has its two gradients summed by the engine on the MAIN stream as soon as both exist);
+      * the parameter carries no tensor hook and no post-accumulate-grad hook (they run on the main stream inside the pass).
+    Hooks registered on the AccumulateGrad NODE from C++ (torch DistributedDataParallel's reducer) are not visible from here: under DDP
+    set SONET_DEFER_WGRAD_JOIN=0 (training section); ``sonet_hip.dp.GradientAllReducer`` joins the side streams itself."""
+    p = wleaf() if wleaf is not None else None
+    if p is None or p.grad is not None:
+        return False
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        return False
+    if token is None:
+        return False
+    if token.done:                            # (a second backward through a retained graph: be conservative)
+        return False
+    token.done = True
+    live = getattr(p, "_sonet_uses", None)
+    if live is None:
+        return False
+    return not any((t is not token) and (not t.done) for t in live)
 
 
 class _Materialise(torch.autograd.Function):
@@ -307,6 +353,7 @@ class _PointwiseFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.relu, ctx.mode, ctx.has_x2 = relu, mode, x2 is not None
         ctx.wleaf = _leaf_of(weight2d)
+        ctx.use_token = _register_use(ctx.wleaf) if ctx.needs_input_grad[2] else None
         if mode == 'affine':
             return y
         if defer:
@@ -318,7 +365,7 @@ class _PointwiseFn(torch.autograd.Function):
         carried = ctx.carry.take() if ctx.carry is not None else None
         if gy is None:                                                    # (the output was not used)
             return (carried,) + (None,) * 15
-        ctx.defer_ok = _grad_slot_empty(ctx.wleaf)
+        ctx.defer_ok = _grad_slot_empty(ctx.wleaf, ctx.use_token)
         saved = ctx.saved_tensors
         x1, x2, weight2d = saved[:3]
         gy_in = gy
@@ -423,6 +470,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
         b = bias.detach().float().contiguous()
         ctx.pos0 = None
         ctx.wleaf = _leaf_of(weight2d)
+        ctx.use_token = _register_use(ctx.wleaf) if ctx.needs_input_grad[2] else None
         ctx.xaff = xaff                       # (sorted form only) x1 / x2 are RAW outputs of BatchNorm layers: see _PointwiseFn
         if xaff is not None and pos0 is None:
             raise RuntimeError("_PooledLastLayerFn: normalise-on-load comes with the node-sorted form")
@@ -538,7 +586,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                     if below is not None:
                         g_x2._sonet_bwd_sums = (res[2], x2.data_ptr(), g_x2._version, bool(xa[5]))
                     if ss is not None:
-                        ss.join(defer=_grad_slot_empty(ctx.wleaf))
+                        ss.join(defer=_grad_slot_empty(ctx.wleaf, ctx.use_token))
                     if ctx.carry is not None and g_x1 is not None:
                         ctx.carry.put(g_x1)
                         g_x1 = None
@@ -559,7 +607,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
                     outs.append(_dgrad(G, pk))
                 g_x1, g_x2 = outs
         if ss is not None:
-            ss.join(defer=_grad_slot_empty(ctx.wleaf))
+            ss.join(defer=_grad_slot_empty(ctx.wleaf, ctx.use_token))
         if ctx.carry is not None and g_x1 is not None:
             ctx.carry.put(g_x1)
             g_x1 = None

@@ -153,8 +153,10 @@ class Encoder(_PlainAttrs, nn.Module):
         if self._first_pn_out is None and self._lazy is not None and self._lazy.get("first_p16") is not None:
             self._first_pn_out = self._lazy["first_p16"].float()
         if self._first_pn_out is None and self._lazy is not None and self._lazy.get("not_materialised"):
-            raise AttributeError("Encoder.first_pn_out was not materialised by this training forward (only its per-node maximum is consumed: the "
-                                 "pool ran in the last layer's epilogue); set encoder.want_first_pn_out = True before the forward to keep it")
+            # (RuntimeError, not AttributeError: nn.Module.__getattr__ is the fall-back of a property that raises AttributeError and would
+            #  replace this message by "'Encoder' object has no attribute 'first_pn_out'" -- and make hasattr() / getattr(.., None) lie)
+            raise RuntimeError("Encoder.first_pn_out was not materialised by this training forward (only its per-node maximum is consumed: the "
+                               "pool ran in the last layer's epilogue); set encoder.want_first_pn_out = True before the forward to keep it")
         if self._first_pn_out is None and self._lazy is not None:
             st = self._lazy
             g = _ops.som_group(st["x"], st["sn"], st["a"], want_augmented=st["sn"] is not None, want_decentered=st["sn"] is None)

@@ -6,6 +6,26 @@ import torch
 
 from . import _lib
 from ._lib import SonetHipError, check, ptr, stream_ptr
+import functools as _functools
+import threading as _threading
+
+# per-THREAD host state: the C side's BatchNorm rider is thread_local, so is the record of having armed it.  (The deferred side-stream
+# joins are NOT: autograd runs backward nodes on its per-device worker thread and the end-of-pass callback on whichever thread finished
+# the pass -- they share one locked table, and joining a stream somebody else registered is only a wait.)
+_tls = _threading.local()
+_join_lock = _threading.Lock()
+
+
+def _consumes_rider(fn):
+    """A statistics-producing call: whatever happens inside it -- a failed argument check included -- the BatchNorm rider armed for it
+    (``bn_rider``) is disarmed when it returns, so that it can never ride on an unrelated later launch."""
+    @_functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        finally:
+            _rider_done()
+    return wrapped
 
 
 # ---- optional per-launch timing with HIP events on the launch stream (used by bench.py) ----------
@@ -1280,33 +1300,39 @@ class side_stream:
         idx = self.side.device.index
         task = _graph_task_id() if _graph_task_id is not None else -1     # (-1: not inside an autograd pass, or a torch without the query)
         if defer and DEFER_WGRAD_JOIN and task != -1:
-            _pending_join[idx] = (self.main, self.side)
-            if _join_queued[0] != task:                      # (once per backward pass; a pass that died with an exception never ran its callback)
+            with _join_lock:
+                _pending_join[idx] = (self.main, self.side)
+                queue = _join_queued[0] != task              # (once per backward pass; a pass that died with an exception never ran its callback)
                 _join_queued[0] = task
+            if queue:
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
             return
         self.main.wait_stream(self.side)
-        _pending_join.pop(idx, None)
+        with _join_lock:
+            _pending_join.pop(idx, None)
 
 
 # weight gradients are not needed before the backward pass is over: their side-stream launches are joined there (0 = at the end of every
 # layer's backward, the behaviour up to round 5's first session)
 DEFER_WGRAD_JOIN = _os.environ.get("SONET_DEFER_WGRAD_JOIN", "1") != "0"
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
-_pending_join = {}               # device index -> (main stream, side stream) with launches nobody has waited for yet
+_pending_join = {}               # device index -> (main stream, side stream) with launches nobody has waited for yet (under _join_lock)
 _join_queued = [-1]             # id of the autograd graph task whose end-of-pass callback is queued
 
 
 def join_side_streams():
     """Every stream that handed work to a side stream with a deferred join waits for it now (a no-op when nothing is pending).  Call it
     before reading a weight gradient INSIDE a backward pass (gradient hooks); after ``backward()`` has returned it has already happened."""
-    for idx in list(_pending_join):
-        main, side = _pending_join.pop(idx)
+    with _join_lock:
+        pairs = list(_pending_join.values())
+        _pending_join.clear()
+    for main, side in pairs:
         main.wait_stream(side)
 
 
 def _end_of_backward_join():
-    _join_queued[0] = -1
+    with _join_lock:
+        _join_queued[0] = -1
     join_side_streams()
 
 
@@ -1334,6 +1360,7 @@ def _xaff_args(xaff, C1, C2, dev):
     return ptr(s1), ptr(h1), ptr(s2), ptr(h2), int(bool(r1)) | (int(bool(r2)) << 1)
 
 
+@_consumes_rider
 def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None, xaff=None):
     """pointmlp(...) plus the per-channel (mean, biased var) of its output over (B, L), from the kernel's epilogue.  h3 / x3 packs
     (f32 storage) only; -> (y, mean, var).  xaff (h3 packs): the inputs are RAW outputs of BatchNorm layers, normalised by the operand load."""
@@ -1456,6 +1483,7 @@ def pointmlp_h3p_pack(weight2d):
     return wp
 
 
+@_consumes_rider
 def pointmlp_h3p(x1, wp, scale, shift, relu, Cout, x2=None, out="f32", gidx=None, z=None, zidx=None, stats=False, tag=None):
     """y = act((W . cat(x1, x2) [+ z[:, :, zidx]]) * scale + shift) on P16 inputs (x1, x2: ``P16``).
     out: "f32" -> B x Cout x L f32 tensor, "p16" -> ``P16``, "both" -> (f32, P16).  gidx (B x L i32): column l of x1 is x1[:, :, gidx[b, l]].
@@ -1734,6 +1762,7 @@ def pointresnet_bf16_pool(sg, wstream, affine, M):
     return out
 
 
+@_consumes_rider
 def channel_stats(y):
     """per-channel (mean, biased var) over (B, L) of y B x C x L (f32 or bf16 storage; f64 sums either way)."""
     _chk(y, "y", dim=3)
@@ -1804,16 +1833,12 @@ def const_vec(C, value, device):
     return t
 
 
-_rider_armed = None
-
-
 def _rider_done():
     """After a statistics-producing call: the rider was consumed by its finalize launch -- or, if the call failed before launching,
     must not linger for an unrelated later launch."""
-    global _rider_armed
-    if _rider_armed is not None:
+    if getattr(_tls, "rider_armed", None) is not None:
         _lib.load().sonet_bn_rider_set(None, None, 0.0, 0.0, 0.0, None, None, None, None, None)
-        _rider_armed = None
+        _tls.rider_armed = None
 
 
 def bn_rider(gamma, beta, eps, running_mean=None, running_var=None, momentum=0.0, unbias=1.0):
@@ -1827,11 +1852,10 @@ def bn_rider(gamma, beta, eps, running_mean=None, running_var=None, momentum=0.0
     if running_mean is not None:
         for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
             _chk(t, n, torch.float32, 1)
-    global _rider_armed
     g_, b_ = gamma.detach().contiguous(), beta.detach().contiguous()
     check(_lib.load().sonet_bn_rider_set(ptr(g_), ptr(b_), float(eps), float(momentum), float(unbias),
                                          ptr(running_mean), ptr(running_var), ptr(out[0]), ptr(out[1]), ptr(out[2])), "sonet_bn_rider_set")
-    _rider_armed = (g_, b_, out)                      # (keeps the operands alive until the statistics call has consumed the rider)
+    _tls.rider_armed = (g_, b_, out)                   # (keeps the operands alive until the statistics call has consumed the rider)
     if running_mean is not None:
         # written through raw pointers by the coming launch: move the version counters as an in-place aten op would
         torch.autograd.graph.increment_version(running_mean)

@@ -575,7 +575,7 @@ def test_training_step_with_pool_epilogue_equals_the_storing_path():
                 assert any(n.startswith("pointmlpbf16_pool") for n in names) == flag
                 assert any(n.startswith("index_max") for n in names) == (not flag)
                 if flag:
-                    with pytest.raises(AttributeError):
+                    with pytest.raises(RuntimeError, match="want_first_pn_out"):
                         enc.first_pn_out
                 res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
                              {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone())

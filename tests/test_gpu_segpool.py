@@ -134,7 +134,7 @@ def test_h3_training_step_on_sorted_columns_equals_the_storing_path():
                 assert any(n.startswith("pointmlph3_segpool") for n in names) == flag
                 assert any(n.startswith("index_max") for n in names) == (not flag)
                 if flag:
-                    with pytest.raises(AttributeError):
+                    with pytest.raises(RuntimeError, match="want_first_pn_out"):
                         enc.first_pn_out
                     assert tuple(enc.x_decentered.shape) == (B, 3, 3 * N) and tuple(enc.centers.shape) == (B, 3, 3 * N)   # (lazy attributes)
                 res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
