@@ -202,7 +202,8 @@ int sonet_pointmlp_f32(const float *x1, int C1, const float *x2, int C2, const f
  * (gy, raw [B][C][L]; a, b, c0 from sonet_bn_bwd_coeffs_f32, sc, sh the forward's normalisation) -- what sonet_pointwise_bwd_apply_f32 followed
  * by sonet_pointmlp_x3_f32 compute, bit for bit, in one pass over (gy, raw).  g_raw_out (or NULL) receives g_raw: the weight gradient's operand.
  * Wp3: the bf16-split pack of the C x Cout matrix (W^T of the layer); C <= 512, Cout % 32 == 0.
- * praw / psc / psh / prelu / pstats_ws / psums (all or none): y is gy of the layer BELOW; with that layer's raw output praw [B][Cout][L] and
+ * praw / psc / psh / prelu / pstats_ws / psums: VARIANTS build only (the product library returns SONET_ERR_UNSUPPORTED unless they are NULL / 0:
+ * the epilogue measured slower than the pass it replaces, docs/findings.md R5.9).  All or none: y is gy of the layer BELOW; with that layer's raw output praw [B][Cout][L] and
  * normalisation psc, psh [Cout] the epilogue also returns its BatchNorm-backward sums psums[0 .. Cout) = sum of gy * mask, psums[Cout .. 2 Cout) =
  * sum of gy * mask * praw (double; what sonet_pointwise_bwd_stats_f32 computes from one more pass over (gy, praw)); pstats_ws:
  * sonet_pointmlp_stats_ws_size(B, Cout, L) bytes. */
@@ -562,18 +563,6 @@ int sonet_pooled_wgrad_xaff_f32(const float *g_pooled, const int32_t *pos, const
                                 float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                            int L, void *ws, float *gx1, float *gx2, sonet_stream_t stream);
-/* ... with what used to follow the launch riding on its store (C1 + C2 a multiple of 4; node-sorted f32-class training path):
- *  col0 [B][C1 + C2], pos0 [B] (both or neither): gx[b][:, pos0[b]] += col0[b] -- every channel of an EMPTY node gathers position 0
- *    (models/networks.py:185): their entries are one dense mat-vec per cloud (the caller's) landing on one column;
- *  sraw [B][C2][L], ssc, ssh [C2], srelu, tail_ws (sonet_pooled_dgrad_tail_ws_size bytes), sums [2 C2] (all or none; C2 > 0): gx2 is gy of the
- *    BatchNorm (+ ReLU) layer (models/layers.py:60-70, :282-296) whose RAW output is sraw; sums[0 .. C2) = sum over (b, l) of gy * mask,
- *    sums[C2 .. 2 C2) = sum of gy * mask * raw with mask = !srelu || raw * ssc + ssh > 0: what sonet_pointwise_bwd_stats_f32 computes from one
- *    more pass over (gy, raw); double precision, fixed order. */
-size_t sonet_pooled_dgrad_tail_ws_size(int B, int C2, int L);
-int sonet_pooled_dgrad_tail_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
-                                int L, void *ws, float *gx1, float *gx2, const float *col0, const int32_t *pos0,
-                                const float *sraw, const float *ssc, const float *ssh, int srelu, void *tail_ws, double *sums,
-                                sonet_stream_t stream);
 /* bf16 training path: x read as bfloat16 bits (sonet_pooled_wgrad_xbf16), gradients written as bfloat16 bits (sonet_pooled_dgrad_obf16) */
 int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
                              float *gw_partial, sonet_stream_t stream);
@@ -648,6 +637,20 @@ int sonet_pointmlp_h3_kmax_f32(const float *x1, int C1, const float *x2, int C2,
 size_t sonet_chamfer_nn2_ws_size(int B, int Na, int Nb);
 int sonet_chamfer_nn2_f32(const float *a, const float *b, int32_t *nn_ab, int32_t *nn_ba, void *ws, int B, int Na, int Nb,
                           sonet_stream_t stream);
+
+/* sonet_pooled_dgrad_f32 with what used to follow the launch riding on its store -- measured slower than the launches it replaces
+ * (docs/findings.md R5.14) -- (C1 + C2 a multiple of 4; node-sorted f32-class training path):
+ *  col0 [B][C1 + C2], pos0 [B] (both or neither): gx[b][:, pos0[b]] += col0[b] -- every channel of an EMPTY node gathers position 0
+ *    (models/networks.py:185): their entries are one dense mat-vec per cloud (the caller's) landing on one column;
+ *  sraw [B][C2][L], ssc, ssh [C2], srelu, tail_ws (sonet_pooled_dgrad_tail_ws_size bytes), sums [2 C2] (all or none; C2 > 0): gx2 is gy of the
+ *    BatchNorm (+ ReLU) layer (models/layers.py:60-70, :282-296) whose RAW output is sraw; sums[0 .. C2) = sum over (b, l) of gy * mask,
+ *    sums[C2 .. 2 C2) = sum of gy * mask * raw with mask = !srelu || raw * ssc + ssh > 0: what sonet_pointwise_bwd_stats_f32 computes from one
+ *    more pass over (gy, raw); double precision, fixed order. */
+size_t sonet_pooled_dgrad_tail_ws_size(int B, int C2, int L);
+int sonet_pooled_dgrad_tail_f32(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
+                                int L, void *ws, float *gx1, float *gx2, const float *col0, const int32_t *pos0,
+                                const float *sraw, const float *ssc, const float *ssh, int srelu, void *tail_ws, double *sums,
+                                sonet_stream_t stream);
 #endif /* SONET_VARIANTS */
 
 /* Packs of a matrix given by element strides: element (o, c) = W[o * row_stride + c * col_stride] for o < rows, c < Cin; rows in

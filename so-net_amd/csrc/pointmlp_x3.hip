@@ -638,6 +638,8 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                     }
                 }
             }
+#ifdef SONET_VARIANTS
+        // (variants build only: measured slower than the separate statistics pass, docs/findings.md R5.9 -- kept as a tested record)
         } else if (BNB && bnb.pstats != nullptr) {
             // the output is gy of the layer below: its BatchNorm-backward sums from here (same reduction as the forward statistics below)
             const unsigned voy_s = pv ? voy : 0x7FFFFF00u;
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(X3_THREADS) void pointmlp_x3_kernel(
                 dst[1] = q_;
             }
             __syncthreads();                                    // (red is reused by the next tile group)
+#endif
         } else if (stats_partial != nullptr) {
             // Training forward: BatchNorm's batch statistics (models/layers.py:60-70) of the output come out of this epilogue instead of
             // a second pass over the tensor.  A row's 32 columns sit in the 32 lanes of a half wave: four DPP adds + one swizzle per
@@ -1568,6 +1571,12 @@ extern "C" int sonet_pointmlp_x3_bnb_f32(const float *gy, const float *raw, int 
 {
     const char *what = "sonet_pointmlp_x3_bnb_f32";
     SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y, "%s: NULL pointer", what);
+#ifndef SONET_VARIANTS
+    // (the epilogue that also computes the BatchNorm-backward sums of the layer below measured slower than the pass it replaces -- docs/findings.md
+    //  R5.9 -- and is compiled into the variants build only)
+    if (praw || pstats_ws || psums)
+        return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the sums of the layer below (praw / psums) are a variants-build record, pass NULL", what);
+#endif
     const BnbArgs bn = {raw, a, b, c0, sc, sh, g_raw_out, relu, praw, psc, psh, prelu, reinterpret_cast<double *>(pstats_ws), nullptr};
     return x3_run_impl(what, false, gy, C, nullptr, 0, Wp3, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
                        nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &bn, psums);

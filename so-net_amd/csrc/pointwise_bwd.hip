@@ -1685,6 +1685,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
         return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the tail needs f32 outputs and C1 + C2 a multiple of 4", what);
     if (Cin % 4 == 0 && abl == 0 && !one && which == 5) {
         const size_t lds5 = (size_t)PD_TL * PD4_LD * 4 + (size_t)PD5_G * PD_CH * 4 + (size_t)PD5_R * 16;
+#ifdef SONET_VARIANTS
         if (tail) {
             if constexpr (sizeof(TO) == 4) {
                 hipLaunchKernelGGL((pooled_dgrad5_kernel<TO, true>), dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds5, st, tile_off, skey, g_pooled, W, E, M,
@@ -1693,6 +1694,7 @@ static int pooled_dgrad_impl(const char *what, const float *g_pooled, const int3
                 return sonet::launched(what);
             }
         }
+#endif
         hipLaunchKernelGGL(pooled_dgrad5_kernel<TO>, dim3(ntile, B, sonet::ceil_div(Cin, PD_CH)), dim3(PD_CH * PD_CQ), lds5, st, tile_off, skey, g_pooled, W, E, M, Cin, C1,
                            L, nbucket, gx1, gx2 ? gx2 : gx1, PdTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr});
         return sonet::launched(what);
@@ -1716,6 +1718,8 @@ extern "C" int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos,
     return pooled_dgrad_impl<float>("sonet_pooled_dgrad_f32", g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream);
 }
 
+#ifdef SONET_VARIANTS
+// (variants build only: riding on the store of the sparse input gradient measured slower than the launches it replaces, docs/findings.md R5.14)
 extern "C" size_t sonet_pooled_dgrad_tail_ws_size(int B, int C2, int L)
 {
     if (B <= 0 || C2 <= 0 || L <= 0) return 0;
@@ -1740,6 +1744,7 @@ extern "C" int sonet_pooled_dgrad_tail_f32(const float *g_pooled, const int32_t 
     const PdTail t = {col0, pos0, sraw, ssc, ssh, srelu, reinterpret_cast<double *>(tail_ws)};
     return pooled_dgrad_impl<float>(what, g_pooled, pos, W, B, C, M, C1, C2, L, ws, gx1, gx2, stream, &t, sums);
 }
+#endif /* SONET_VARIANTS */
 
 /* gradients written as bfloat16 bit patterns (f32 accumulation in LDS as above, one rounding on the store) */
 extern "C" int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,

@@ -402,7 +402,7 @@ class _PointwiseFn(torch.autograd.Function):
                     xa_ = ctx.xaff
                     # x1 is the RAW output of the layer below (normalise-on-load) and nothing is padded: this launch's output is that
                     # layer's gy, and its BatchNorm-backward sums come out of the epilogue (handed over on the tensor: _bwd_sums_hint)
-                    below = (x1, xa_[0], xa_[1], xa_[2]) if (_ops.BWD_STATS_EPILOGUE and xa_ is not None and Cp == Ci and x1.dtype == torch.float32) else None
+                    below = (x1, xa_[0], xa_[1], xa_[2]) if (_ops.BWD_STATS_EPILOGUE and _ops.variants_only() and xa_ is not None and Cp == Ci and x1.dtype == torch.float32) else None
                     acc = None
                     if (carried is not None and below is None and Cp == Ci and carried.dtype == torch.float32 and carried.is_contiguous()
                             and tuple(carried.shape) == (gy.shape[0], Cp, gy.shape[2])):

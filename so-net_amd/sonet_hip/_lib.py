@@ -126,8 +126,6 @@ SIGNATURES = {
     "sonet_pooled_wgrad_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "sonet_pooled_dgrad_obf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "sonet_pooled_dgrad_tail_ws_size": [_i, _i, _i],
-    "sonet_pooled_dgrad_tail_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "sonet_pooled_dgrad_mfma_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_fwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp],
     "sonet_bn_bwd_coeffs_f32": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -182,6 +180,8 @@ VARIANT_SIGNATURES = {
     "sonet_chamfer_nn2_ws_size": [_i, _i, _i],
     "sonet_chamfer_nn2_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_h3_kmax_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_pooled_dgrad_tail_ws_size": [_i, _i, _i],
+    "sonet_pooled_dgrad_tail_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -1146,7 +1146,13 @@ BNB_ON_LOAD = _os.environ.get("SONET_BNB_ON_LOAD", "1") != "0"
 # ... and, when the layer BELOW handed its raw output on (normalise-on-load), the same launch's epilogue can compute that layer's BatchNorm-backward
 # sums from its output (no statistics pass over (gy, raw) of the layer below).  OFF: measured slower -- the reduction costs the dgrad launch 0.33-0.44 ms
 # for the 0.2-0.3 ms pass it replaces (docs/findings.md R5.9); kept as a tested record.
+# VARIANTS build only (the product library compiles neither this epilogue nor the tail below: ``variants_only()``).
 BWD_STATS_EPILOGUE = _os.environ.get("SONET_BWD_STATS_EPILOGUE", "0") != "0"
+
+
+def variants_only():
+    """True when the loaded library is the variants build (tools/, tests/variants): the measured-slower records are callable."""
+    return hasattr(_lib.load(), "sonet_pooled_dgrad_tail_f32")
 
 
 # a tensor with two consumers in the first PointNet (the first layer's output): the gradient of the consumer whose backward runs first is added by
@@ -1934,7 +1940,7 @@ POOLED_DGRAD_TAIL = _os.environ.get("SONET_POOLED_DGRAD_TAIL", "0") != "0"
 
 
 def pooled_dgrad_tail_ok(C1, C2, out_dtype):
-    return POOLED_DGRAD_TAIL and out_dtype == torch.float32 and (C1 + C2) % 4 == 0
+    return POOLED_DGRAD_TAIL and out_dtype == torch.float32 and (C1 + C2) % 4 == 0 and variants_only()
 
 
 def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32, wt_pack=None, col0=None, pos0=None, below=None):
@@ -1953,6 +1959,9 @@ def pooled_dgrad(g_pooled, pos_i32, weight2d, C1, C2, L, out_dtype=torch.float32
     gx1 = torch.empty((B, C1, int(L)), dtype=out_dtype, device=dev)
     gx2 = torch.empty((B, C2, int(L)), dtype=out_dtype, device=dev) if C2 else None
     if col0 is not None or pos0 is not None or below is not None:
+        if not variants_only():
+            raise SonetHipError("pooled_dgrad: col0 / below ride on sonet_pooled_dgrad_tail_f32, a measured-slower record of the variants build "
+                                "(SONET_HIP_LIB=%s)" % _lib.VARIANTS_PATH)
         if out_dtype != torch.float32 or (C1 + C2) % 4 or wt_pack is not None:
             raise SonetHipError("pooled_dgrad: col0 / below need f32 outputs and C1 + C2 a multiple of 4")
         if (col0 is None) != (pos0 is None):

@@ -24,20 +24,34 @@ def _bn_train(y, sd, prefix):
     return F.batch_norm(y, None, None, sd[prefix + ".norm.weight"], sd[prefix + ".norm.bias"], True, 0.1, 1e-5)
 
 
-def _conv(x, sd, prefix, bn, relu):
+_TAKEN = {}          # the ReLU patterns the last free run took: {layer prefix: bool tensor}
+
+
+def _act(y, relu, mask, key=None):
+    """ReLU, free (``mask`` None) or FORCED: a given 0 / 1 pattern instead of the sign test -- the other discrete decision of the step."""
+    if not relu:
+        return y
+    if mask is None:
+        if key is not None:
+            _TAKEN[key] = (y > 0).detach()
+        return F.relu(y)
+    return y * mask.reshape(y.shape).to(y.dtype)
+
+
+def _conv(x, sd, prefix, bn, relu, masks=None):
     w = sd[prefix + ".conv.weight"]
     y = (F.conv2d if x.dim() == 4 else F.conv1d)(x, w if w.dim() == x.dim() else w.reshape(w.shape[0], w.shape[1], *([1] * (x.dim() - 2))),
                                                     sd[prefix + ".conv.bias"])
     if bn:
         y = _bn_train(y, sd, prefix)
-    return F.relu(y) if relu else y
+    return _act(y, relu, None if masks is None else masks[prefix], prefix)
 
 
-def _linear(x, sd, prefix, bn, relu):
+def _linear(x, sd, prefix, bn, relu, masks=None):
     y = F.linear(x, sd[prefix + ".linear.weight"], sd[prefix + ".linear.bias"])
     if bn:
         y = _bn_train(y, sd, prefix)
-    return F.relu(y) if relu else y
+    return _act(y, relu, None if masks is None else masks["cls." + prefix], "cls." + prefix)
 
 
 def leaf_params(sd, device, dtype=torch.float64):
@@ -90,14 +104,17 @@ def index_max_positions(first, min_idx, M, zero_pos=None):
     return out
 
 
-def train_step(enc, cls, label, node_knn_I, som_k=9, pc=None, sn=None, node=None, k=3, stage=None, route=None):
+def train_step(enc, cls, label, node_knn_I, som_k=9, pc=None, sn=None, node=None, k=3, stage=None, route=None, masks=None):
     """One forward + backward.  ``enc`` / ``cls``: ``leaf_params`` dictionaries.
     Inputs either (pc, sn, node) -- the SOM stage runs here, in their dtype -- or ``stage`` = dict(x_aug B x 6 x kN, min_idx B x kN,
     row_max B x M, som_node B x 3 x M[, pos0 B]) taken from the implementation under test (any column order: a point-wise network and
     BatchNorm's batch sums do not care; pos0 = where original column 0 sits in that order, the reference's gather position of an empty
     node, models/networks.py:185).  ``route`` = None (free) or dict(pool1 B x 384 x M positions ALREADY multiplied by row_max, pool2 B x 512 x M,
-    pool3 B x F).  -> dict(loss, feature, score, grads {key: tensor}, route {pool1, pool2, pool3})."""
+    pool3 B x F).  ``masks`` = None (ReLU as usual) or {layer prefix ("first_pointnet.layers.0" .. "cls.fc2"): 0 / 1 tensor with the
+    element count of that layer's output, in the column order of the stage}: the ReLU pattern of the run under test, forced.
+    -> dict(loss, feature, score, grads {key: tensor}, route {pool1, pool2, pool3}, masks {layer prefix: the ReLU pattern a free run took})."""
     dt = next(iter(enc.values())).dtype
+    _TAKEN.clear()
     if stage is None:
         min_idx, row_max, som_node, x_aug = som_stage(pc.to(dt), sn.to(dt), node.to(dt), k)
     else:
@@ -106,8 +123,8 @@ def train_step(enc, cls, label, node_knn_I, som_k=9, pc=None, sn=None, node=None
     x_aug, som_node = x_aug.detach(), som_node.detach()
     M = som_node.shape[2]
     p = "first_pointnet.layers."
-    l0 = _conv(x_aug, enc, p + "0", True, True)
-    t = _conv(_conv(l0, enc, p + "1", True, True), enc, p + "2", True, True)
+    l0 = _conv(x_aug, enc, p + "0", True, True, masks)
+    t = _conv(_conv(l0, enc, p + "1", True, True, masks), enc, p + "2", True, True, masks)
     first = _conv(torch.cat((l0, t), dim=1), enc, p + "3", False, False)          # B x 384 x kN
     if route is None:
         zero_pos = None if stage is None or stage.get("pos0") is None else stage["pos0"]
@@ -126,17 +143,17 @@ def train_step(enc, cls, label, node_knn_I, som_k=9, pc=None, sn=None, node=None
     nb = knn_gather(som_node)
     center = nb.mean(dim=3, keepdim=True)
     h = torch.cat(((nb - center).detach(), knn_gather(masked_max)), dim=1)
-    h = _conv(_conv(h, enc, "knnlayer.layers.0", True, True), enc, "knnlayer.layers.1", True, True)   # B x 512 x M x K'
+    h = _conv(_conv(h, enc, "knnlayer.layers.0", True, True, masks), enc, "knnlayer.layers.1", True, True, masks)   # B x 512 x M x K'
     pool2 = h.max(dim=3)[1] if route is None else route["pool2"].long()
     knn_feature = h.gather(3, pool2.unsqueeze(3)).squeeze(3)
     f = torch.cat((center.squeeze(3).detach(), knn_feature), dim=1)
-    final = _conv(_conv(f, enc, "final_pointnet.layers.0", True, True), enc, "final_pointnet.layers.1", False, False)
+    final = _conv(_conv(f, enc, "final_pointnet.layers.0", True, True, masks), enc, "final_pointnet.layers.1", False, False)
     pool3 = final.max(dim=2)[1] if route is None else route["pool3"].long()
     feature = final.gather(2, pool3.unsqueeze(2)).squeeze(2)
-    s = _linear(_linear(feature, cls, "fc1", True, True), cls, "fc2", True, True)
+    s = _linear(_linear(feature, cls, "fc1", True, True, masks), cls, "fc2", True, True, masks)
     score = _linear(s, cls, "fc3", False, False)
     loss = F.cross_entropy(score, label.long())
     leaves = {k_: v for k_, v in list(enc.items()) + [("cls." + k_, v) for k_, v in cls.items()] if v.requires_grad}
     gr = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
     return dict(loss=loss.detach(), feature=feature.detach(), score=score.detach(), grads={k_: g for k_, g in zip(leaves, gr) if g is not None},
-                route=dict(pool1=pool1, pool2=pool2, pool3=pool3))
+                route=dict(pool1=pool1, pool2=pool2, pool3=pool3), masks=dict(_TAKEN))

@@ -328,85 +328,6 @@ def test_h3_training_step_with_a_hidden_layer_that_materialises_its_input(which,
     _compare_steps(res[True][:4], res[False][:4])
 
 
-@pytest.mark.parametrize("B,C,M,C1,C2,L", [(64, 384, 64, 64, 256, 15000), (3, 384, 64, 64, 256, 3000), (2, 96, 8, 16, 48, 130), (2, 48, 7, 44, 0, 257)])
-def test_pooled_dgrad_with_its_tail_equals_dgrad_then_scatter_and_statistics(B, C, M, C1, C2, L):
-    """sonet_pooled_dgrad_tail_f32: the gradients == sonet_pooled_dgrad_f32 followed by the addition of the column-0 part at pos0 (bit for
-    bit: the same f32 add), the BatchNorm-backward sums of the layer below == float64 sums over the same gradient and mask (and the
-    statistics pass on it); run to run identical; incl. a ragged last tile, a channel slab that mixes the two panels and no second panel."""
-    from sonet_hip import ops
-    gen = torch.Generator().manual_seed(B + L + C2)
-    g = (torch.randn(B, C, M, generator=gen) * 1e-2).to(DEV)
-    pos = torch.randint(0, L, (B, C, M), generator=gen, dtype=torch.int32)
-    pos[:, : C // 4, 0] = L - 1                                          # a pile on the last column of the ragged tile
-    pos[:, 0, 1] = -1
-    pos = pos.to(DEV)
-    W = (torch.randn(C, C1 + C2, generator=gen) * 0.1).to(DEV)
-    col0 = (torch.randn(B, C1 + C2, generator=gen) * 1e-2).to(DEV)
-    p0 = torch.randint(0, L, (B,), generator=gen, dtype=torch.int32)
-    p0[0] = L - 1
-    p0 = p0.to(DEV)
-    r1, r2 = ops.pooled_dgrad(g, pos, W, C1, C2, L)
-    p0l = p0.long().view(B, 1, 1)
-    r1.scatter_add_(2, p0l.expand(B, C1, 1), col0[:, :C1].unsqueeze(2))
-    if C2:
-        r2.scatter_add_(2, p0l.expand(B, C2, 1), col0[:, C1:].unsqueeze(2))
-    a1, a2 = ops.pooled_dgrad(g, pos, W, C1, C2, L, col0=col0, pos0=p0)
-    assert torch.equal(a1, r1) and (C2 == 0 or torch.equal(a2, r2))
-    if C2 == 0:
-        return
-    raw = (torch.randn(B, C2, L, generator=gen) * 1.5).to(DEV)
-    sc, sh = (torch.rand(C2, generator=gen) + 0.5).to(DEV), (torch.randn(C2, generator=gen) * 0.3).to(DEV)
-    for relu in (True, False):
-        b1, b2, sums = ops.pooled_dgrad(g, pos, W, C1, C2, L, col0=col0, pos0=p0, below=(raw, sc, sh, relu))
-        assert torch.equal(b1, r1) and torch.equal(b2, r2)
-        keep = (raw.double() * sc.double().view(1, C2, 1) + sh.double().view(1, C2, 1)) > 0 if relu else torch.ones_like(raw, dtype=torch.bool)
-        gm = torch.where(keep, r2.double(), torch.zeros((), dtype=torch.float64, device=DEV))
-        ref = torch.cat((gm.sum(dim=(0, 2)), (gm * raw.double()).sum(dim=(0, 2))))
-        scale = torch.cat((gm.abs().sum(dim=(0, 2)), (gm * raw.double()).abs().sum(dim=(0, 2)))) + 1e-30
-        assert float(((sums - ref).abs() / scale).max()) <= 2e-6
-        other = ops.pointwise_bwd_stats(r2, raw, sc, sh, relu, want_sums=True)
-        assert float(((sums - other).abs() / scale).max()) <= 2e-6
-        again = ops.pooled_dgrad(g, pos, W, C1, C2, L, col0=col0, pos0=p0, below=(raw, sc, sh, relu))[2]
-        assert torch.equal(again, sums)
-    with pytest.raises(ops.SonetHipError):
-        ops.pooled_dgrad(g, pos, W, C1, C2, L, col0=col0)
-
-
-def test_training_step_with_the_tail_of_the_sparse_input_gradient():
-    """ops.POOLED_DGRAD_TAIL on / off on the node-sorted f32-class path: the statistics pass over (gy, raw) of the widest hidden layer and
-    the two scatter_add launches are gone, the step is the same to f32-class accuracy (the sums run in another order)."""
-    from models import networks as NW
-    from sonet_hip import ops, synth
-    B, N = 8, 3000
-    res = {}
-    old = ops.POOLED_DGRAD_TAIL
-    try:
-        with ops.precision("h3"):
-            for flag in (True, False):
-                ops.POOLED_DGRAD_TAIL = flag
-                opt = _opt(B, N)
-                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
-                enc.want_first_pn_out = False
-                synth.fill_state_dict_(enc.state_dict(), 3)
-                synth.fill_state_dict_(cls.state_dict(), 4)
-                enc.to(DEV).train()
-                cls.to(DEV).train()
-                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
-                with ops.kernel_timing() as rec:
-                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
-                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
-                    loss.backward()
-                names = [n for n, _, _ in rec.records]
-                assert ("pooled_dgrad_tail_sums" in names) == flag and ("pooled_dgrad" in names) != flag
-                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
-                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone(),
-                             sum(n == "pointwise_bwd_stats" for n in names))
-    finally:
-        ops.POOLED_DGRAD_TAIL = old
-    assert res[True][4] == res[False][4] - 1
-    _compare_steps(res[True][:4], res[False][:4])
-
-
 # ------------------------------------------------------------------------------------------ deferred side-stream joins
 @pytest.mark.parametrize("precision", ["bf16", "h3"])
 def test_weight_gradients_joined_at_the_end_of_backward_equal_joined_per_layer(precision):
@@ -575,66 +496,6 @@ def test_training_step_with_batchnorm_backward_on_load_is_bit_identical():
     assert out[True].keys() == out[False].keys()
     for k in out[True]:
         assert torch.equal(out[True][k], out[False][k]), k
-
-
-@pytest.mark.parametrize("B,C,Cout,L", [(64, 256, 128, 15000), (8, 128, 64, 4100), (3, 64, 96, 577)])
-def test_dgrad_epilogue_returns_the_batchnorm_backward_sums_of_the_layer_below(B, C, Cout, L):
-    """ops.pointmlp_x3_bnb(..., below=(praw, psc, psh, relu)): the launch's output is gy of the layer below; its epilogue returns that layer's
-    sums (sum gy * mask, sum gy * mask * praw) as sonet_pointwise_bwd_stats_f32 computes them from one more pass (double accumulation of
-    32-column float partials: equal to summation order); output and g_raw are untouched."""
-    from sonet_hip import ops
-    g = torch.Generator().manual_seed(B + C + L)
-    gy = (torch.randn(B, C, L, generator=g) * 1e-3).to(DEV)
-    raw = (torch.randn(B, C, L, generator=g) * 1.5).to(DEV)
-    praw = (torch.randn(B, Cout, L, generator=g) * 1.5 + 0.2).to(DEV)
-    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
-    psc, psh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.3).to(DEV)
-    a, b, c0 = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV), (torch.randn(C, generator=g) * 1e-5).to(DEV)
-    wpt = ops.pointmlp_pack((torch.randn(Cout, C, generator=g) * C ** -0.5).to(DEV), "x3")
-    one, zero = ops.const_vec(Cout, 1.0, DEV), ops.const_vec(Cout, 0.0, DEV)
-    y_ref, g_ref = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout)
-    for prelu in (True, False):
-        y, g_raw, sums = ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout, below=(praw, psc, psh, prelu))
-        assert torch.equal(y, y_ref) and torch.equal(g_raw, g_ref)
-        ref = ops.pointwise_bwd_stats(y_ref, praw, psc, psh, prelu, want_sums=True)
-        scale = (y_ref.double().abs() * (praw.double().abs() + 1)).sum(dim=(0, 2)).repeat(2)     # the size of the summed terms per channel
-        assert float(((sums - ref).abs() / scale).max()) <= 1e-6, prelu
-        assert torch.equal(sums, ops.pointmlp_x3_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, True, Cout, below=(praw, psc, psh, prelu))[2])   # fixed order
-
-
-def test_training_step_with_backward_sums_from_the_dgrad_epilogue():
-    """ops.BWD_STATS_EPILOGUE on / off: the statistics launches of the hidden layers whose gradient comes from one dgrad launch disappear;
-    forward identical, gradients within the arg-max-flip bound (the sums differ by summation order)."""
-    from models import networks as NW
-    from sonet_hip import ops, synth
-    B, N = 8, 3000
-    res = {}
-    old = ops.BWD_STATS_EPILOGUE
-    try:
-        with ops.precision("h3"):
-            for flag in (True, False):
-                ops.BWD_STATS_EPILOGUE = flag
-                opt = _opt(B, N)
-                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
-                enc.want_first_pn_out = False
-                synth.fill_state_dict_(enc.state_dict(), 3)
-                synth.fill_state_dict_(cls.state_dict(), 4)
-                enc.to(DEV).train()
-                cls.to(DEV).train()
-                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
-                with ops.kernel_timing() as rec:
-                    feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
-                    loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
-                    loss.backward()
-                names = [n for n, _, _ in rec.records]
-                assert any(n.startswith("pointmlpx3_bnbs_") for n in names) == flag
-                res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
-                             {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, enc.first_pn_out_masked_max.detach().clone(),
-                             sum(1 for n in names if n == "pointwise_bwd_stats"))
-    finally:
-        ops.BWD_STATS_EPILOGUE = old
-    assert res[True][4] < res[False][4]
-    _compare_steps(res[True], res[False])
 
 
 # ------------------------------------------------------------------------------------------ deterministic sort of the training forward

@@ -22,6 +22,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "so-net_amd"))
 sys.path.insert(0, ROOT)
+if "--only" not in sys.argv or "I" in sys.argv[sys.argv.index("--only") + 1].upper():
+    import _variants  # noqa: E402,F401  (variant I rides on sonet_pooled_dgrad_tail_f32: a variants-build record since round 6)
 
 import torch  # noqa: E402
 

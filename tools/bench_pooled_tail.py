@@ -5,6 +5,7 @@ BatchNorm-backward statistics pass of the 256-channel layer -- as launches of th
 import os
 import sys
 
+import _variants  # noqa: F401  (sonet_pooled_dgrad_tail_f32 is a variants-build record since round 6)
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "so-net_amd"))
