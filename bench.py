@@ -472,19 +472,21 @@ def other_configs(args, dev, world=1, rank=0):
                     enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=False)
                 ref32 = _encoder_parity(enc, inp, 2, tol=1e-5)
                 ratio = (after["feature_err_over_bound"] * tol) / max(ref32["feature_err_over_bound"] * 1e-5, 1e-12)
-                # REPORTED, NOT GATED: the figure is the bf16 feature error on weights ~100 Adam steps on random labels left behind -- a
+                # The RATIO below is reported, not gated: the figure is the bf16 feature error on weights ~100 Adam steps on random labels left behind -- a
                 # worse-conditioned network (the first layer's folded BatchNorm scale 2 -> 5.7, running variances 0.5 -> 0.06:
                 # tools/bf16_drift.py), on which the f32-class arithmetic is further from the oracle too.  A ratio to that error is an
                 # explanation, not a bound (a 14 % feature error would pass a 2^14 ratio), so no pass/fail is derived from it: the gate
                 # of this entry is the node ids (bit-exact) plus the `before` check above on the fixtures' weights at the stated tolerance.
+                # What IS gated (`ok` must not be blind to a regression of the bf16 numerics after training): a loose absolute
+                # ceiling of 4 x the fixtures' bound -- the f32-class entries' ceiling -- on the feature error itself (measured 1.4 x).
                 gate.update(f32_class_same_weights_err_over_1e5_bound=ref32["feature_err_over_bound"], bf16_over_f32_class_error=round(ratio, 1),
-                            gated=False, ok=bool(after["min_idx_bit_exact"]))
+                            gated=True, ceiling_over_bound=4.0, ok=bool(after["min_idx_bit_exact"] and after["feature_err_over_bound"] <= 4.0))
             else:
                 gate.update(gated=True, ok=bool(after["min_idx_bit_exact"] and after["feature_err_over_bound"] <= 4.0))
             gate["what"] = ("the same check with the weights and BatchNorm running statistics the timed Adam steps left behind (random labels, %d steps: "
                             "a worse-conditioned network, see tools/bf16_drift.py).  f32-class: gated at node ids bit-exact and features within 4 x the "
-                            "fixtures' bound.  bf16: node ids bit-exact is the gate; the feature error is REPORTED UNGATED (with the f32-class error on the "
-                            "same weights beside it) -- no bound on it is claimed" % (5 + 3 * K + 3))
+                            "fixtures' bound.  bf16: node ids bit-exact and features within 4 x the fixtures' bf16 bound (a loose ceiling: the ratio to the "
+                            "f32-class error on the same weights is reported beside it, as an explanation, not a bound)" % (5 + 3 * K + 3))
             par["after_the_timed_steps"] = gate
             par["ok"] = bool(par["ok"] and gate["ok"])
             med = sorted(ts)[len(ts) // 2]

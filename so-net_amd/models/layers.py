@@ -263,7 +263,9 @@ def _grad_slot_empty(wleaf, token=None):
     live = getattr(p, "_sonet_uses", None)
     if live is None:
         return False
-    return not any((t is not token) and (not t.done) for t in live)
+    # (ANY other live use counts, also one whose backward has already run in this pass: the engine adds the two gradients on the main stream
+    #  as soon as the second exists, so neither producer of a shared weight may leave its launch un-joined)
+    return not any(t is not token for t in live)
 
 
 class _Materialise(torch.autograd.Function):

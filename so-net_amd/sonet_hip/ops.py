@@ -1034,7 +1034,15 @@ class _PackRegistry:
         e["src"] = None                                                 # (no strong reference to the weight: only its address and its weakref)
         self.entries[key] = e
         self.tables.pop(dev.index, None)
+        # the entry (and its GPU buffer) goes when the weight goes -- not when some other weight next turns stale (a sweep that builds
+        # model after model would otherwise pile up packs of dead weights)
+        weakref.finalize(base, self._drop, key, e)
         return e
+
+    def _drop(self, key, e):
+        if self.entries.get(key) is e:
+            del self.entries[key]
+            self.tables.pop(key[1], None)
 
     def refresh(self, device):
         """One ``sonet_pack_multi`` launch over every stale entry of ``device``."""

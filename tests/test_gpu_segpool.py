@@ -377,6 +377,51 @@ def test_weight_gradients_joined_at_the_end_of_backward_equal_joined_per_layer(p
             assert torch.equal(out[True][it][k], out[False][it][k]), (it, k)
 
 
+def test_shared_weights_and_hooked_weights_join_their_side_streams_in_time():
+    """a weight with TWO producers in one backward pass (the encoder called twice before one backward: a Siamese use) has
+    its two gradients summed by the autograd engine on the main stream as soon as both exist, and a tensor hook on a weight reads its
+    gradient inside the pass -- neither may see a side-stream launch that is still running.  The deferred join is therefore taken only
+    for single-producer, hook-free weights (models/layers.py ``_grad_slot_empty``); here: the gradients of a two-call step and what a
+    hook saw are bit-identical to per-layer joins (ops.DEFER_WGRAD_JOIN = False)."""
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 6, 2200
+    out, seen = {}, {}
+    old = (ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL)
+    try:
+        ops.H3_SEGPOOL = False                                     # (bit-reproducible path)
+        with ops.precision("h3"):
+            for flag in (True, False):
+                ops.DEFER_WGRAD_JOIN = flag
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                a, b = synth.make_inputs(B, N, seed=9, device=torch.device(DEV)), synth.make_inputs(B, N, seed=10, device=torch.device(DEV))
+                hooked = enc.first_pointnet.layers[1].conv.weight
+                seen[flag] = []
+                h = hooked.register_hook(lambda g_, log=seen[flag]: log.append(g_.clone()))
+                fa = enc(a["pc"], a["sn"], a["node"], a["node_knn_I"], is_train=True, epoch=0)
+                fb = enc(b["pc"], b["sn"], b["node"], b["node_knn_I"], is_train=True, epoch=0)
+                loss = torch.nn.functional.cross_entropy(cls(fa, 0), a["label"]) + torch.nn.functional.cross_entropy(cls(fb, 0), b["label"])
+                loss.backward()
+                junk = [torch.empty(1 << 22, device=DEV).fill_(1.0) for _ in range(8)]
+                del junk
+                h.remove()
+                out[flag] = {k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(cls.named_parameters()) if p.grad is not None}
+    finally:
+        ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL = old
+    assert out[True].keys() == out[False].keys() and len(out[True]) > 30
+    for k in out[True]:
+        assert torch.equal(out[True][k], out[False][k]), k
+    assert len(seen[True]) == len(seen[False]) >= 1
+    for x, y in zip(seen[True], seen[False]):
+        assert torch.equal(x, y)
+
+
 # ------------------------------------------------------------------------------------------ BatchNorm backward on load
 @pytest.mark.parametrize("B,C,Cout,L,relu", [(64, 256, 128, 15000, True), (8, 128, 64, 4100, True), (3, 512, 512, 577, False), (2, 48, 96, 131, True)])
 def test_dgrad_with_batchnorm_backward_on_load_equals_apply_then_dgrad(B, C, Cout, L, relu):

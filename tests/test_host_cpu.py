@@ -433,3 +433,41 @@ def test_host_model_of_the_entry_balanced_sparse_input_gradient():
         for c, v in zip(cols, vals):
             ref[c] = ref.get(c, 0.0) + v
         assert run(cols, vals, range) == ref and run(cols, vals, lambda G: reversed(range(G))) == ref, (trial, cols)
+
+
+def test_deferred_join_only_for_single_producer_hook_free_weights():
+    """models/layers.py ``_grad_slot_empty``: the side-stream join of a layer's weight gradient may wait for the end of the
+    backward pass only when nothing reads that gradient earlier -- the parameter has no .grad yet, no tensor / post-accumulate hook, and
+    this node is its only producer among the graphs alive (tokens registered by the forwards, dead with their graph)."""
+    import gc
+    import weakref
+    from models import layers as L
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    ref = weakref.ref(p)
+    t1 = L._register_use(ref)
+    assert L._grad_slot_empty(ref, t1)                       # one producer, nothing attached
+    assert not L._grad_slot_empty(ref, t1)                   # the same node again (a second backward through a retained graph)
+    del t1
+    t2, t3 = L._register_use(ref), L._register_use(ref)      # two producers in one pass: the engine sums their gradients on the main stream
+    assert not L._grad_slot_empty(ref, t2)                   # as soon as the second exists -- NEITHER may stay un-joined
+    assert not L._grad_slot_empty(ref, t3)
+    del t2, t3
+    t4, t5 = L._register_use(ref), L._register_use(ref)
+    del t4                                                   # a graph that was dropped without a backward
+    gc.collect()
+    assert L._grad_slot_empty(ref, t5)
+    del t5
+    t6 = L._register_use(ref)
+    h = p.register_hook(lambda g: g)
+    assert not L._grad_slot_empty(ref, t6)                   # a tensor hook reads the gradient inside the pass
+    h.remove()
+    del t6
+    t7 = L._register_use(ref)
+    h2 = p.register_post_accumulate_grad_hook(lambda q: None)
+    assert not L._grad_slot_empty(ref, t7)
+    h2.remove()
+    del t7
+    t8 = L._register_use(ref)
+    p.grad = torch.zeros_like(p)
+    assert not L._grad_slot_empty(ref, t8)                   # accumulation into an existing .grad happens on the main stream
+    assert not L._grad_slot_empty(ref, None) and not L._grad_slot_empty(None, t8)
