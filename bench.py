@@ -934,7 +934,7 @@ def main():
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
-                    "unit": dom["unit"], "frac": dom["frac"], "traffic": dom.get("traffic"),
+                    "unit": dom["unit"], "frac": dom["frac"], "mean_ms": dom["mean_ms"], "traffic": dom.get("traffic"),
                     "traffic_source": dom.get("traffic_source")}
         if dom["bound"] == "mfma" and rank == 0 and ops.POINTMLP_PRECISION == "h3":
             # `peak` is the nominal dense rate (2.4 GHz).  With all 256 CUs on the matrix pipe the chip is power-limited:
@@ -992,7 +992,52 @@ def main():
     measure_other_arithmetics()                                # (fills line["other_arithmetics"]: the same dict object)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, enc_cpu, cls_cpu)
+    line["summary"] = _summary(line, B, N, world)             # LAST key: a record that keeps only the tail of the line keeps this
     return line
+
+
+def _summary(line, B, N, world):
+    """The figures a reader of the line wants first, in under 2000 characters and at the very END of the JSON line (the driver's
+    record keeps the last 2000 characters).  Everything here is a copy of, or simple arithmetic on, entries further up the line."""
+    ms = line["ms_per_step"]
+    roof = line.get("roofline") or {}
+    out = {"value": line["value"], "value_median": line["value_median"], "ms_per_step": ms,
+           "windows_clouds_per_s": line["windows"]["clouds_per_s"],
+           "single_stream": (line.get("single_stream") or {}).get("clouds_per_s")}
+    if roof.get("bound") == "mfma":
+        # the whole forward as ONE roofline figure: SURVEY 8(a) totals 5.6 GFLOP per cloud (first PointNet 4.927 + KNNModule 0.53 + final
+        # PointNet 0.15); `value` in clouds/s x that = useful TFLOP/s of the step, against the same ceilings as the dominant kernel
+        step_tf = line["value"] / world * 5.6e9 / 1e12
+        sus = (roof.get("sustained") or {}).get("peak")
+        out["step"] = {"useful_tflops": round(step_tf, 1), "frac_of_nominal": round(step_tf / roof["peak"], 4),
+                       "frac_of_sustained": round(step_tf / sus, 4) if sus else None,
+                       "what": "5.6 GFLOP per cloud x clouds/s: the time outside the fused kernel is matrix work of the node-level stage at "
+                               "about the same rate, not idle time (DESIGN.md section 9)"}
+        out["fused_kernel"] = {"mean_ms": roof.get("mean_ms", None), "frac": roof["frac"], "frac_of_sustained": (roof.get("sustained") or {}).get("frac")}
+    som = [k for k in line.get("kernels", []) if k["name"].startswith("som_assign")]
+    if som:
+        k = som[0]
+        t = k.get("traffic")
+        survey_bytes = (121280 + 300768) * B                  # SURVEY 8(d): som_assign 121,280 B + som_group 300,768 B per cloud
+        out["som_stage"] = {"ms_per_step": k["ms_per_step"], "hbm_frac": k.get("frac"),
+                            "hbm_frac_on_survey_8d_bytes": round(survey_bytes / (k["mean_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            "valu_frac": (k.get("valu") or {}).get("frac"),
+                            "pmc_over_algorithmic_bytes": round(t / (k["achieved"] * 1e9 * k["mean_ms"] * 1e-3), 2) if t and k.get("achieved") else None,
+                            "pmc_over_survey_8d_bytes": round(t / survey_bytes, 2) if t else None,
+                            "bound": "launch latency at this size: 60 % of 8 TB/s would be 5.6 us for both launches (SURVEY 8(d) bytes), below "
+                                     "the ~10 us a launch pair costs; neither roof is near (about 2.4 waves per SIMD)"}
+    for k in line.get("kernels_store_path", []):
+        if k["name"].startswith("index_max"):
+            out["index_max"] = {"in_step_frac_of_hbm": k.get("frac"), "standalone_frac_of_hbm": (k.get("standalone") or {}).get("frac")}
+    oc = line.get("other_configs") or {}
+    out["other_configs"] = {name: ({"ms_per_step": v.get("ms_per_step"), "clouds_per_s": v.get("clouds_per_s"),
+                                    "parity_ok": (v.get("parity_checked") or {}).get("ok")} if isinstance(v, dict) else None)
+                            for name, v in oc.items()}
+    pc = line.get("parity_checked") or {}
+    out["parity"] = {"ok": pc.get("ok"), "min_idx_bit_exact": pc.get("min_idx_bit_exact"), "feature_err_over_bound": pc.get("feature_err_over_bound")}
+    cb = line.get("cpu_baseline") or {}
+    out["cpu_baseline"] = {"clouds_per_s": cb.get("value"), "cores": cb.get("cores"), "kind": cb.get("kind")}
+    return out
 
 
 if __name__ == "__main__":
