@@ -324,6 +324,13 @@ int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, 
 int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t *gidx, const uint16_t *x2, int C2, const void *Wp,
                                const float *scale, const float *shift, int relu, uint16_t *y,
                                int B, int Cout, int L, sonet_stream_t stream);
+/* sonet_pointmlp_bf16 with an ACCUMULATING store: y = bf16(float(bf16(result)) + float(yadd)); yadd [B][Cout][L] bf16 = another gradient of the
+ * same tensor, computed earlier (models/layers.py:417-431: the first layer's output feeds the second layer and the last one) -- what autograd's
+ * accumulation of the two bf16 tensors would store, bit for bit, without its pass over three tensors.  yadd == y allowed.  Even L, 4-byte
+ * aligned rows. */
+int sonet_pointmlp_bf16_acc(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                            const float *scale, const float *shift, int relu, const uint16_t *yadd, uint16_t *y,
+                            int B, int Cout, int L, sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pointresnet_fused -- the encoder's first PointNet as ONE kernel (eval mode, 3xbf16-split arithmetic)
@@ -481,6 +488,21 @@ int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint16_t *x2, in
 int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
                              const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
                              int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream);
+/* Normalise-on-load (bf16 training forward, round 6): x1 / x2 hold the RAW (bf16) outputs of training-mode BatchNorm layers
+ * (models/layers.py:60-70, :282-296) whose normalise + ReLU pass was never run.  The operand load computes act(raw * xs[c] + xh[c]) in f32 and
+ * rounds to bf16 -- exactly what sonet_channel_affine_act_bf16 would have stored -- so the results equal the plain entry points on the
+ * normalised tensors bit for bit.  xs1, xh1 [C1] (xs2, xh2 [C2] when C2 > 0); xrelu bit 0 / 1: ReLU on x1 / x2.  Streaming-kernel shapes only
+ * ((C1 + C2) % 64 == 0, even L, 4-byte aligned rows; the statistics form: >= 8192 column groups): SONET_ERR_UNSUPPORTED otherwise. */
+int sonet_pointmlp_bf16_stats_xaff(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                   const float *scale, const float *shift, int relu, uint16_t *y,
+                                   int B, int Cout, int L, void *stats_ws, float *mean, float *var,
+                                   const float *xs1, const float *xh1, const float *xs2, const float *xh2, int xrelu,
+                                   sonet_stream_t stream);
+int sonet_pointmlp_bf16_pool_xaff(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                  const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                                  int32_t *out_idx, float *out_val, int B, int Cout, int L, int M,
+                                  const float *xs1, const float *xh1, const float *xs2, const float *xh2, int xrelu,
+                                  sonet_stream_t stream);
 
 /* f32-class twin on NODE-SORTED columns (sonet_som_sort_group_f32: ids_sorted [B][L] i32 non-decreasing per cloud, pos0 [B] = sorted position
  * of original column 0): the fp16-split layer (sonet_pointmlp_h3_f32) and the per-node arg-max pool of its output in one pass; the output is
@@ -525,6 +547,11 @@ int sonet_wgrad_x3_xaff_f32(const float *g, const float *x, float *dw, void *ws,
  * LDS-DMA ring, one workgroup per CU, (128 or 256) x 128 blocks of dw, partial blocks per column slice summed in a fixed order. */
 size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L);
 int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream);
+/* ... when x is the RAW (bf16) output of a BatchNorm layer whose normalise pass was never run (bf16 training, normalise-on-load): the x
+ * fragments go through act(raw * xs[c] + xh[c]) rounded to bf16, bit for bit what sonet_channel_affine_act_bf16 would have stored; xs, xh
+ * [Cin].  Streaming-kernel shapes only (L % 8 == 0, B * ceil(L / 64) >= 2048): SONET_ERR_UNSUPPORTED otherwise. */
+int sonet_wgrad_bf16_xaff(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L,
+                          const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 /* out[b][c][l] = act((z[b][c][gidx[b][l]] + sum_{i<NL} wl[c][i] * lead[b][i][l]) * scale[c] + shift[c]);  z [B][C][M] = the
  * layer applied to the M node features once (sonet_pointmlp_h3_f32 with unit scale), gidx [B][L] i32 (out of range: 0),
  * lead [B][NL][L] the per-column channels (NL <= 4: the 3 de-centred coordinates), wl [C][NL] their weight columns, exact f32
@@ -566,6 +593,9 @@ int sonet_pooled_dgrad_f32(const float *g_pooled, const int32_t *pos, const floa
 /* bf16 training path: x read as bfloat16 bits (sonet_pooled_wgrad_xbf16), gradients written as bfloat16 bits (sonet_pooled_dgrad_obf16) */
 int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
                              float *gw_partial, sonet_stream_t stream);
+/* ... with normalise-on-load of the bf16 rows (see sonet_pointmlp_bf16_stats_xaff): x = bf16(act(raw * xs[ci] + xh[ci])); xs, xh [Ci]. */
+int sonet_pooled_wgrad_xaff_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
+                                  float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream);
 int sonet_pooled_dgrad_obf16(const float *g_pooled, const int32_t *pos, const float *W, int B, int C, int M, int C1, int C2,
                              int L, void *ws, uint16_t *gx1, uint16_t *gx2, sonet_stream_t stream);
 /* ... the same gradient as a dense product on the matrix cores: the 64-column tile of the (never built) gradient of first_pn_out is

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
     int Cout, int L, int gpc /*64-column groups per cloud*/, long long ngroups, int CT, int KC, int ct_per_y,
     const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
-    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum / sum of squares of the STORED (bf16) output over this workgroup's columns*/)
+    double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum / sum of squares of the STORED (bf16) output over this workgroup's columns*/,
+    const uint16_t *__restrict__ yadd = nullptr /*optional [B][Cout][L] (PAIRED, no statistics): y = bf16(float(bf16(result)) + float(yadd)) -- what
+                                                  autograd's accumulation of two bf16 gradients of one tensor would store (models/layers.py _GradCarry)*/)
 {
     constexpr int NSL = S * MT;                              // 1 KiB W slices per stage
     constexpr int NS = (NSL + BF_WAVES - 1) / BF_WAVES;
@@ -317,6 +319,15 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
                     const unsigned so = so_tile + (unsigned)orow * rowB;
 #endif
                     if constexpr (PAIRED) {
+                        if (yadd != nullptr) {
+                            const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<uint16_t *>(yadd + b * (long long)Cout * L), 0, (int)((unsigned)Cout * rowB), 0x00020000);
+                            const unsigned ad = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra_, voya, so, 0);
+                            const unsigned sum = cvt_pk_bf16(__uint_as_float(pk << 16) + __uint_as_float(ad << 16),
+                                                             __uint_as_float(pk & 0xFFFF0000u) + __uint_as_float(ad & 0xFFFF0000u));
+                            __builtin_amdgcn_raw_buffer_store_b32((int)sum, ry, voya, so, 0);
+                            continue;
+                        }
                         __builtin_amdgcn_raw_buffer_store_b32((int)pk, ry, voya, so, 0);
                     } else {
                         __builtin_amdgcn_raw_buffer_store_b16((short)(pk & 0xFFFFu), ry, voya, so, 0);
@@ -340,6 +351,8 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
 // stores of an epilogue for the first four chunks after one, capped at 63).
 typedef int i32x4_t_ __attribute__((ext_vector_type(4)));
 
+struct BfrXaff { const float *xs1, *xh1, *xs2, *xh2; int xrelu; };     // normalise-on-load coefficients (see BfrArgs)
+
 struct BfrArgs {
     const uint16_t *x1, *x2;
     const uint4 *Wp;
@@ -356,6 +369,11 @@ struct BfrArgs {
     float *out_val;                       // [B][Cout][M] the stored (bf16) value at out_idx * row_max
     int M;
     int abl;                              // (variants build, POOL) 1: no epilogue at all, 2: no bin reads / updates (the arithmetic stays)
+    // (XAFF) normalise-on-load: x1 / x2 hold the RAW (bf16) outputs of BatchNorm layers; the operand is act(raw * xs[c] + xh[c]) rounded to
+    // bf16 -- what sonet_channel_affine_act_bf16 would have stored, bit for bit -- computed on the chunk's registers in front of the MFMAs
+    const float *xs1, *xh1, *xs2, *xh2;   // [C1], [C2] (x2's may be NULL when C2 == 0)
+    int xrelu;                            // bit 0: ReLU on x1, bit 1: on x2
+    unsigned xco_off;                     // byte offset of the coefficient table in the dynamic LDS
 };
 
 // (POOL) the order of the keys is that of index_max.hip -- bigger value wins, equal values: the smaller column wins, -0 counts as +0, a NaN never
@@ -402,7 +420,26 @@ __device__ __forceinline__ void bfr_wait_perm(const unsigned (&x)[8], unsigned (
                  : "memory");
 }
 
-template <int MT, bool STATS, bool POOL = false>
+// (XAFF) the four channel pairs of a B fragment (elements 2p, 2p + 1 of the chunk's half h, packed bf16) through act(raw * s + h): f32 fma,
+// one round-to-nearest-even back to bf16, ReLU -- sonet_channel_affine_act_bf16's arithmetic per element (there: ReLU in f32 in front of the
+// rounding; rounding is monotone and keeps the sign, so the order does not matter.  A -0.0 comes out as +0.0 here: as an operand of the
+// product that is the same number).  Five vector instructions per pair: two unpacks, v_pk_fma_f32, v_cvt_pk_bf16_f32, v_pk_max_i16 against
+// `floor` (0 with ReLU, the most negative i16 -- the identity -- without).  co[p] = (s of 2p, s of 2p + 1, h of 2p, h of 2p + 1).
+typedef float bfr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bfr_xaff(unsigned (&b)[4], const float4 (&co)[4], unsigned floor2) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bfr_f2 x = {__uint_as_float(b[p] << 16), __uint_as_float(b[p] & 0xFFFF0000u)};
+        const bfr_f2 sc = {co[p].x, co[p].y}, sh = {co[p].z, co[p].w};
+        bfr_f2 v;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(x), "v"(sc), "v"(sh));
+        unsigned r = cvt_pk_bf16(v[0], v[1]);
+        asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(r), "v"(floor2));
+        b[p] = r;
+    }
+}
+
+template <int MT, bool STATS, bool POOL = false, bool XAFF = false>
 __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
 {
     static_assert(!(STATS && POOL), "statistics belong to BatchNorm layers, the pool to the last (norm-free) layer");
@@ -417,6 +454,8 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
     float *shadow = reinterpret_cast<float *>(bins + (size_t)a.tps * 32 * (POOL ? a.M : 0));
     unsigned *v0s = reinterpret_cast<unsigned *>(shadow + (size_t)a.tps * 32 * (POOL ? a.M : 0));
     unsigned char *idb = reinterpret_cast<unsigned char *>(v0s + a.tps * 32);
+    // (XAFF) [KC][2 halves][4] float4 = (s, s, h, h) of elements 2p, 2p + 1: behind everything else (the launch adds KC * 128 bytes)
+    float4 *xco = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(bfr_lds) + a.xco_off);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -444,6 +483,20 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
         for (int o = threadIdx.x; o < a.tps * 32; o += 512) aff[o] = make_float2(a.scale[ct_begin * 32 + o], a.shift[ct_begin * 32 + o]);
         if constexpr (STATS)
             for (int o = threadIdx.x; o < 8 * a.tps * 32; o += 512) stl[o] = make_float2(0.f, 0.f);
+        if constexpr (XAFF) {
+            // entry (kc, hh, p): channels 16 kc + 8 hh + 2 p, + 1 of x1 (kc < KC1) or x2; rows past the panel's channel count read 0 and
+            // must stay 0 (their weights are 0 as well, but act(0 * s + h) need not be)
+            for (int o = threadIdx.x; o < KC * 8; o += 512) {
+                const int kc = o >> 3, hh = (o >> 2) & 1, pp = o & 3;
+                const bool second = kc >= a.KC1;
+                const int c = 16 * (second ? kc - a.KC1 : kc) + 8 * hh + 2 * pp, Cp = second ? a.C2 : a.C1;
+                const float *sp = second ? a.xs2 : a.xs1, *hp = second ? a.xh2 : a.xh1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < Cp) { v.x = sp[c]; v.z = hp[c]; }
+                if (c + 1 < Cp) { v.y = sp[c + 1]; v.w = hp[c + 1]; }
+                xco[o] = v;
+            }
+        }
         if constexpr (POOL) {
             // (the stream IS the cloud: every column group of cloud `stream` passes through this workgroup)
             for (int o = threadIdx.x; o < a.tps * 32 * a.M; o += 512) { bins[o] = BFP_INIT_KEY; shadow[o] = -1000.f; }
@@ -550,6 +603,13 @@ __global__ __launch_bounds__(512, 1) void pointmlp_bf16r_kernel(const BfrArgs a)
                     unsigned ba[4], bb[4];                                                              \
                     bfr_wait_perm<((FIRST4 && !POOL) ? (24 + 16 * MT > 63 ? 63 : 24 + 16 * MT) : 24)>(X[q], ba, bb); \
                     issue(X[q]);                                                                        \
+                    if constexpr (XAFF) {                                                               \
+                        const float4 *cp_ = xco + ((kc) * 2 + h) * 4;                                   \
+                        const float4 co_[4] = {cp_[0], cp_[1], cp_[2], cp_[3]};                         \
+                        const unsigned fl_ = ((((kc) >= a.KC1) ? (a.xrelu & 2) : (a.xrelu & 1)) != 0) ? 0u : 0x80008000u; \
+                        bfr_xaff(ba, co_, fl_);                                                         \
+                        bfr_xaff(bb, co_, fl_);                                                         \
+                    }                                                                                   \
                     const bf16x8 Ba = __builtin_bit_cast(bf16x8, make_uint4(ba[0], ba[1], ba[2], ba[3])); \
                     const bf16x8 Bb = __builtin_bit_cast(bf16x8, make_uint4(bb[0], bb[1], bb[2], bb[3])); \
                     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                 \
@@ -870,7 +930,8 @@ extern "C" int sonet_pointmlp_bf16_pack_strided(const float *W, long long row_st
 static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
                          const float *scale, const float *shift, int relu, uint16_t *y,
                          int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
-                         double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr)
+                         double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr, const BfrXaff *xaff = nullptr,
+                         const uint16_t *yadd = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -962,13 +1023,14 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
 #endif  // SONET_VARIANTS
     // big launches with dword-aligned rows: the streaming generation (W slab resident in LDS, persistent waves)
     {
-        bool want = paired && KC % 4 == 0 && CT % 2 == 0 && ngroups >= 8192 && ngroups < 0x7FFFFFFFll;
+        // (an accumulating store -- yadd -- runs on the staged kernel below: its epilogue loads would sit in the streaming kernel's hand-counted queue)
+        bool want = paired && KC % 4 == 0 && CT % 2 == 0 && ngroups >= 8192 && ngroups < 0x7FFFFFFFll && yadd == nullptr;
         if (const char *e = sonet::knob("SONET_BF16_STREAM")) want = want && atoi(e) != 0;
         int best_ns = 0, best_cost = 1 << 30;
         for (int ns = 1; want && ns <= CT / 2; ++ns) {
             if (CT % ns) continue;
             const int tps = CT / ns;
-            if (tps % 2 || (size_t)tps * KC * 1024 + (size_t)tps * 256 + (stats_ws ? (size_t)tps * 2048 : 0) > 158 * 1024) continue;   // W slab + affine + statistics rows
+            if (tps % 2 || (size_t)tps * KC * 1024 + (size_t)tps * 256 + (stats_ws ? (size_t)tps * 2048 : 0) + (xaff ? (size_t)KC * 128 : 0) > 158 * 1024) continue;   // W slab + affine + statistics rows (+ the normalise-on-load table)
             const int cost = ns * (tps / (tps % 4 == 0 ? 4 : 2));            // times X goes through the vector memory path
             if (cost < best_cost) { best_cost = cost; best_ns = ns; }
         }
@@ -985,7 +1047,13 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
             a.tps = CT / best_ns; a.nslab = best_ns; a.nstream = 8 * spx; a.ngroups = (int)ngroups;
             a.sync = ((unsigned)L * 2u) % 128u != 0 ? 2 : 0;
             if (const char *e = sonet::knob("SONET_BF16_SYNC")) a.sync = atoi(e);
-            const size_t lds = (size_t)a.tps * KC * 1024 + (size_t)a.tps * 32 * 8 + (stats_ws ? (size_t)8 * a.tps * 32 * 8 : 0);
+            size_t lds = (size_t)a.tps * KC * 1024 + (size_t)a.tps * 32 * 8 + (stats_ws ? (size_t)8 * a.tps * 32 * 8 : 0);
+            a.xs1 = a.xh1 = a.xs2 = a.xh2 = nullptr; a.xrelu = 0; a.xco_off = 0;
+            if (xaff) {
+                a.xs1 = xaff->xs1; a.xh1 = xaff->xh1; a.xs2 = xaff->xs2; a.xh2 = xaff->xh2; a.xrelu = xaff->xrelu;
+                a.xco_off = (unsigned)lds;
+                lds += (size_t)KC * 128;
+            }
             const dim3 gridr((unsigned)(8 * spx * best_ns)), blockr(512);
 #define BFR_LAUNCH(MM, SS) do { static bool attr_set = false;                                                                         \
                 if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pointmlp_bf16r_kernel<MM, SS>),             \
@@ -993,15 +1061,28 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
                                      return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
                                  attr_set = true; }                                                                                   \
                 hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, SS>), gridr, blockr, lds, st, a); } while (0)
-            if (a.tps % 4 == 0) { if (stats_ws) BFR_LAUNCH(4, true); else BFR_LAUNCH(4, false); }
-            else                { if (stats_ws) BFR_LAUNCH(2, true); else BFR_LAUNCH(2, false); }
+#define BFR_LAUNCH_X(MM) do { static bool attr_set = false;                                                                             \
+                if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pointmlp_bf16r_kernel<MM, true, false, true>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)       \
+                                     return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
+                                 attr_set = true; }                                                                                   \
+                hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, true, false, true>), gridr, blockr, lds, st, a); } while (0)
+            if (xaff) {                                        // (normalise-on-load: the training forward, i.e. with statistics)
+                if (!stats_ws) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: normalise-on-load comes with the statistics epilogue", what);
+                if (a.tps % 4 == 0) BFR_LAUNCH_X(4); else BFR_LAUNCH_X(2);
+            }
+            else if (a.tps % 4 == 0) { if (stats_ws) BFR_LAUNCH(4, true); else BFR_LAUNCH(4, false); }
+            else                     { if (stats_ws) BFR_LAUNCH(2, true); else BFR_LAUNCH(2, false); }
+#undef BFR_LAUNCH_X
 #undef BFR_LAUNCH
             if (stats_ws) sonet::launch_stats_finalize(stats_ws, a.nstream, Cout, 1.0 / ((double)B * L), mean, var, st);
             return sonet::launched(what);
         }
     }
+    if (xaff) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: normalise-on-load exists on the streaming kernel only (Cin %% 64 == 0, even L, >= 8192 column groups)", what);
+    if (yadd && (!paired || stats_ws)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the accumulating store needs even L, 4-byte aligned rows and no statistics", what);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
-#define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws
+#define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws, yadd
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, true>), BF_ARGS); } \
                            else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
@@ -1050,6 +1131,24 @@ extern "C" int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint1
                          reinterpret_cast<double *>(stats_ws), mean, var);
 }
 
+/* sonet_pointmlp_bf16_stats with NORMALISE-ON-LOAD (bf16 training forward, hidden layers of the first PointNet): x1 / x2 hold the RAW outputs
+ * of training-mode BatchNorm layers (models/layers.py:60-70, :282-296) whose normalise + ReLU pass was never run; the operand load computes
+ * act(raw * xs[c] + xh[c]) in f32 and rounds to bf16 -- exactly what sonet_channel_affine_act_bf16 would have stored -- so the outputs equal
+ * sonet_pointmlp_bf16_stats on the normalised tensors bit for bit.  xs1, xh1 [C1] (xs2, xh2 [C2] when C2 > 0); xrelu bit 0 / 1: ReLU on x1 / x2.
+ * Streaming-kernel shapes only ((C1 + C2) % 64 == 0, even L, 4-byte aligned rows, >= 8192 column groups): SONET_ERR_UNSUPPORTED otherwise. */
+extern "C" int sonet_pointmlp_bf16_stats_xaff(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                              const float *scale, const float *shift, int relu, uint16_t *y,
+                                              int B, int Cout, int L, void *stats_ws, float *mean, float *var,
+                                              const float *xs1, const float *xh1, const float *xs2, const float *xh2, int xrelu,
+                                              sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_stats_xaff";
+    SONET_REQUIRE(stats_ws && mean && var && xs1 && xh1 && (C2 == 0 || (xs2 && xh2)), "%s: NULL pointer", what);
+    const BfrXaff xa = {xs1, xh1, xs2, xh2, xrelu};
+    return bf16_run_impl(what, x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0,
+                         reinterpret_cast<double *>(stats_ws), mean, var, &xa);
+}
+
 /* The layer and the per-node arg-max pool of its output in ONE launch; the output itself is never written (the last layer of the first
  * PointNet in training, when only the pooled map is consumed: models/layers.py:431 + models/networks.py:180-185).
  * out_idx [B][Cout][M] = what sonet_index_max_bf16 reports on the tensor sonet_pointmlp_bf16 would have written (first maximum above -1000 in
@@ -1057,11 +1156,10 @@ extern "C" int sonet_pointmlp_bf16_stats(const uint16_t *x1, int C1, const uint1
  * A workgroup = (cloud, slab of output tiles) on the streaming kernel: W slab, the cloud's node ids (bytes) and the bins of its rows x M
  * nodes live in LDS, every column group of the cloud passes through it once.  ids [B][L] i32, row_max [B][M] i32 or NULL.
  * Needs: L even and < 65535 (a key holds the column in 16 bits), 4-byte aligned rows, (C1 + C2) % 64 == 0, Cout % 32 == 0 with a slab shape that fits the LDS, M <= 255. */
-extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
-                                        const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
-                                        int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream)
+static int bf16_pool_impl(const char *what, const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                          const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                          int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream, const BfrXaff *xaff)
 {
-    const char *what = "sonet_pointmlp_bf16_pool";
     SONET_REQUIRE(x1 && Wp && scale && shift && ids && out_idx && out_val, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && L > 0 && M > 0, "%s: non-positive size", what);
     SONET_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2 and C2 disagree", what);
@@ -1087,7 +1185,8 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
         const int tps = CT / ns;
         const int mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
         if (mt == 0) continue;
-        const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+        const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15)
+                           + (xaff ? (size_t)KC * 128 : 0);
         if (lds > 158 * 1024) continue;
         const long long cost = sonet::ceil_div64((long long)B * ns, cus) * tps;
         if (best_ns == 0 || cost < best_cost) { best_ns = ns; best_mt = mt; best_cost = cost; best_lds = lds; }
@@ -1097,7 +1196,8 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
         const int ns = atoi(e);
         if (ns >= 1 && CT % ns == 0) {
             const int tps = CT / ns, mt = tps % 4 == 0 ? 4 : tps % 3 == 0 ? 3 : tps % 2 == 0 ? 2 : 0;
-            const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15);
+            const size_t lds = (size_t)tps * KC * 1024 + (size_t)tps * 32 * 8 + (size_t)tps * 32 * M * 8 + (size_t)tps * 32 * 4 + (size_t)((L + 15) & ~15)
+                               + (xaff ? (size_t)KC * 128 : 0);
             if (mt && lds <= 158 * 1024) { best_ns = ns; best_mt = mt; best_lds = lds; }
         }
     }
@@ -1112,6 +1212,11 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
     //  under another's MFMAs: 559 -> 478 us at 64 x 15000 columns, tools/bench_pool_epilogue.py)
     a.sync = 0;
     a.ids = ids; a.row_max = row_max; a.out_idx = out_idx; a.out_val = out_val; a.M = M; a.abl = 0;
+    a.xs1 = a.xh1 = a.xs2 = a.xh2 = nullptr; a.xrelu = 0; a.xco_off = 0;
+    if (xaff) {
+        a.xs1 = xaff->xs1; a.xh1 = xaff->xh1; a.xs2 = xaff->xs2; a.xh2 = xaff->xh2; a.xrelu = xaff->xrelu;
+        a.xco_off = (unsigned)(best_lds - (size_t)KC * 128);             // (the table is the last item of the slab's LDS budget)
+    }
 #ifdef SONET_VARIANTS
     if (const char *e = sonet::knob("SONET_BF16_POOL_ABL")) a.abl = atoi(e);
     if (const char *e = sonet::knob("SONET_BF16_SYNC")) a.sync = atoi(e);
@@ -1125,9 +1230,39 @@ extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16
                              return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                           \
                          attr_set = true; }                                                                                           \
         hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, false, true>), gridr, blockr, best_lds, st, a); } while (0)
-    if (best_mt == 4) BFP_LAUNCH(4); else if (best_mt == 3) BFP_LAUNCH(3); else BFP_LAUNCH(2);
+#define BFP_LAUNCH_X(MM) do { static bool attr_set = false;                                                                           \
+        if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pointmlp_bf16r_kernel<MM, false, true, true>),      \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
+                             return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                           \
+                         attr_set = true; }                                                                                           \
+        hipLaunchKernelGGL((pointmlp_bf16r_kernel<MM, false, true, true>), gridr, blockr, best_lds, st, a); } while (0)
+    if (xaff) { if (best_mt == 4) BFP_LAUNCH_X(4); else if (best_mt == 3) BFP_LAUNCH_X(3); else BFP_LAUNCH_X(2); }
+    else if (best_mt == 4) BFP_LAUNCH(4); else if (best_mt == 3) BFP_LAUNCH(3); else BFP_LAUNCH(2);
+#undef BFP_LAUNCH_X
 #undef BFP_LAUNCH
     return sonet::launched(what);
+}
+
+extern "C" int sonet_pointmlp_bf16_pool(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                        const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                                        int32_t *out_idx, float *out_val, int B, int Cout, int L, int M, sonet_stream_t stream)
+{
+    return bf16_pool_impl("sonet_pointmlp_bf16_pool", x1, C1, x2, C2, Wp, scale, shift, relu, ids, row_max, out_idx, out_val, B, Cout, L, M, stream, nullptr);
+}
+
+/* sonet_pointmlp_bf16_pool with normalise-on-load of both input panels (see sonet_pointmlp_bf16_stats_xaff): the last layer of the first
+ * PointNet reading the RAW outputs of the first and third layer (models/layers.py:431).  Same positions and values, bit for bit, as the
+ * plain launch on the normalised tensors. */
+extern "C" int sonet_pointmlp_bf16_pool_xaff(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                             const float *scale, const float *shift, int relu, const int32_t *ids, const int32_t *row_max,
+                                             int32_t *out_idx, float *out_val, int B, int Cout, int L, int M,
+                                             const float *xs1, const float *xh1, const float *xs2, const float *xh2, int xrelu,
+                                             sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_pool_xaff";
+    SONET_REQUIRE(xs1 && xh1 && (C2 == 0 || (xs2 && xh2)), "%s: NULL pointer", what);
+    const BfrXaff xa = {xs1, xh1, xs2, xh2, xrelu};
+    return bf16_pool_impl(what, x1, C1, x2, C2, Wp, scale, shift, relu, ids, row_max, out_idx, out_val, B, Cout, L, M, stream, &xa);
 }
 
 extern "C" int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
@@ -1135,6 +1270,20 @@ extern "C" int sonet_pointmlp_bf16(const uint16_t *x1, int C1, const uint16_t *x
                                    int B, int Cout, int L, sonet_stream_t stream)
 {
     return bf16_run_impl("sonet_pointmlp_bf16", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream);
+}
+
+/* sonet_pointmlp_bf16 with an ACCUMULATING store: y = bf16(float(bf16(result)) + float(yadd)), yadd [B][Cout][L] bf16 -- another gradient of the
+ * same tensor, computed earlier (models/layers.py:417-431: the first layer's output feeds the second layer and the last one); exactly what
+ * autograd's accumulation of the two bf16 tensors would store, without its pass over three tensors.  yadd == y is allowed (every element is
+ * read and written by one lane).  Even L, 4-byte aligned rows. */
+extern "C" int sonet_pointmlp_bf16_acc(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
+                                       const float *scale, const float *shift, int relu, const uint16_t *yadd, uint16_t *y,
+                                       int B, int Cout, int L, sonet_stream_t stream)
+{
+    SONET_REQUIRE(yadd, "sonet_pointmlp_bf16_acc: NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(yadd) & 3) != 0) return sonet::fail(SONET_ERR_INVALID_ARG, "sonet_pointmlp_bf16_acc: yadd must be 4-byte aligned");
+    return bf16_run_impl("sonet_pointmlp_bf16_acc", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
+                         nullptr, yadd);
 }
 
 extern "C" int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t *gidx, const uint16_t *x2, int C2, const void *Wp,

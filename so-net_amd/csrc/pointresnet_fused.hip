@@ -1029,6 +1029,20 @@ int cu_count() {
     return cus;
 }
 
+// Persistent grid: one workgroup per CU.  A workgroup owns a whole CU (512 registers per lane), so nothing of another stream runs beside it.
+// Leaving CUs out for the other graphs' small launches was measured and is slower (docs/findings.md R6.1: 3776 tiles walk in 15 rounds on
+// 252 workgroups as on 256, and the headline still lost 1.5-2 %; 8 / 12 / 20 CUs out: -1 to -3 %), so the knob stays an experiment:
+// SONET_FUSED_FREE_CUS = k leaves at least k CUs out, -1 = the smallest grid with the same number of rounds.
+long long persistent_grid(long long ntiles, int cus) {
+    static const int free_cus = [] { const char *e = getenv("SONET_FUSED_FREE_CUS"); return e ? atoi(e) : 0; }();
+    if (ntiles <= cus) return ntiles;
+    if (free_cus == 0) return cus;
+    const long long rounds = (ntiles + cus - 1) / cus;
+    long long grid = (ntiles + rounds - 1) / rounds;
+    if (free_cus > 0 && grid > cus - free_cus) grid = cus - free_cus > 1 ? cus - free_cus : 1;
+    return free_cus > 0 || free_cus == -1 ? grid : cus;
+}
+
 }  // namespace
 
 extern "C" size_t sonet_pointresnet_pack_size(void) { return (size_t)NSLICE * 1024 + 64; }   // + trailer: word 0 = bits of max |w|
@@ -1056,7 +1070,7 @@ extern "C" int sonet_pointresnet_fused_f32(const float *x, int Cin0, const void 
     const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
     const int cus = cu_count();
-    const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
+    const long long grid = persistent_grid(ntiles, cus);
     hipLaunchKernelGGL((pointresnet_fused_kernel<false>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
                        x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log());
@@ -1075,7 +1089,7 @@ extern "C" int sonet_pointresnet_fused_p16_f32(const float *x, int Cin0, const v
     const int tpc = sonet::ceil_div(L, TPTS);
     const long long ntiles = (long long)B * tpc;
     const int cus = cu_count();
-    const long long grid = ntiles < cus ? ntiles : cus;        // persistent: one workgroup per CU
+    const long long grid = persistent_grid(ntiles, cus);
     hipLaunchKernelGGL((pointresnet_fused_kernel<false, true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, sonet::as_stream(stream),
                        x, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), y, L, tpc, ntiles,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (unsigned *)nullptr, (float *)nullptr, 0, (unsigned *)nullptr, sonet::range_log(), yp);
@@ -1105,7 +1119,7 @@ static int fused_pool_impl(const char *what, const float *x_sorted, int Cin0, co
     float *v0_ws = reinterpret_cast<float *>(partial_ws + ntiles * NPASS * SEG_SLOTS * PCH);
     hipLaunchKernelGGL(pooled_init_kernel, dim3((unsigned)sonet::ceil_div64(npool, 256)), dim3(256), 0, st, pooled_ws, npool);
     const int cus = cu_count();
-    const long long grid = ntiles < cus ? ntiles : cus;
+    const long long grid = persistent_grid(ntiles, cus);
     hipLaunchKernelGGL((pointresnet_fused_kernel<true>), dim3((unsigned)grid), dim3(PF_THREADS), 0, st,
                        x_sorted, Cin0, reinterpret_cast<const uint4 *>(wstream), reinterpret_cast<const float2 *>(affine), (float *)nullptr,
                        L, tpc, ntiles, ids_sorted, pos0, pooled_ws, v0_ws, M, partial_ws, sonet::range_log());

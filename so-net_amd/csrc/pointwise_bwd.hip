@@ -1587,6 +1587,37 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
                 copied = true;
             }
         }
+        if constexpr (sizeof(TX) == 2) {
+            if (xs != nullptr) {
+                // bf16 rows (PW_R == 2: channels ci0, ci0 + 1, back to back in memory and in LDS): act(raw * xs + xh) in f32, ReLU, one
+                // round-to-nearest-even back to bf16 -- sonet_channel_affine_act_bf16's arithmetic -- element by element (a 16-byte piece may
+                // straddle the two rows: the channel is chosen per element)
+                const float s0 = xs[ci0], h0 = xh[ci0];
+                const float s1 = nr > 1 ? xs[ci0 + 1] : 0.f, h1 = nr > 1 ? xh[ci0 + 1] : 0.f;
+                auto act16 = [&](unsigned v, bool second) -> unsigned {
+                    float f = __fmaf_rn(__uint_as_float(v << 16), second ? s1 : s0, second ? h1 : h0);
+                    if (xrelu && f < 0.f) f = 0.f;
+                    return bf_pack(f, 0.f) & 0xFFFFu;
+                };
+                if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
+                    const uint4 *x4 = reinterpret_cast<const uint4 *>(xb);
+                    uint4 *r4 = reinterpret_cast<uint4 *>(rows);
+                    for (int i = threadIdx.x; i < (int)(nbytes >> 4); i += blockDim.x) {
+                        const uint4 t = x4[i];
+                        unsigned d[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = 8 * i + 2 * k;
+                            d[k] = act16(d[k] & 0xFFFFu, e >= L) | (act16(d[k] >> 16, e + 1 >= L) << 16);
+                        }
+                        r4[i] = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = (TX)act16((unsigned)xb[i], i >= L);
+                }
+                copied = true;
+            }
+        }
         if (copied) {
         } else if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
             const uint4 *x4 = reinterpret_cast<const uint4 *>(xb);
@@ -1655,6 +1686,15 @@ extern "C" int sonet_pooled_wgrad_xbf16(const float *g_pooled, const int32_t *po
                                         float *gw_partial, sonet_stream_t stream)
 {
     return pooled_wgrad_impl<uint16_t>("sonet_pooled_wgrad_xbf16", g_pooled, pos, x, B, C, M, Ci, L, gw_partial, stream);
+}
+
+/* ... when x is the RAW (bf16) output of a BatchNorm layer (bf16 training with normalise-on-load, see sonet_pointmlp_bf16_stats_xaff): the rows
+ * are normalised on their way into the LDS, x = bf16(act(raw * xs[ci] + xh[ci])); xs, xh [Ci]. */
+extern "C" int sonet_pooled_wgrad_xaff_xbf16(const float *g_pooled, const int32_t *pos, const uint16_t *x, int B, int C, int M, int Ci, int L,
+                                             float *gw_partial, const float *xs, const float *xh, int xrelu, sonet_stream_t stream)
+{
+    SONET_REQUIRE(xs && xh, "sonet_pooled_wgrad_xaff_xbf16: NULL pointer");
+    return pooled_wgrad_impl<uint16_t>("sonet_pooled_wgrad_xaff_xbf16", g_pooled, pos, x, B, C, M, Ci, L, gw_partial, stream, xs, xh, xrelu);
 }
 
 template <typename TO>

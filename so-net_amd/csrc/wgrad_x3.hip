@@ -332,11 +332,37 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16_kernel(
 // per unit: "my DMAs of this unit have landed" (s_waitcnt vmcnt(N_DMA): the next unit's may be in flight) + barrier = everyone's
 // have, and everyone has finished the previous unit, whose slot the next request then overwrites.  f32 partial blocks per slice,
 // summed by wgrad_reduce_kernel in a fixed order.
+// XAFF (bf16 training with normalise-on-load): x holds the RAW output of a BatchNorm layer; a wave applies act(raw * xs[c] + xh[c]) -- f32 fma,
+// round to nearest even, ReLU: what sonet_channel_affine_act_bf16 would have stored -- to the x fragment it has just read from LDS (a lane's
+// eight values are one channel row: one coefficient pair per lane and x tile, held in registers for the whole launch).  Columns past L and
+// rows past Cin come from the zeroed 16 bytes and would turn into act(xh): their g partners are zero as well (same zeroed source), the
+// product is unchanged.
 constexpr int WS_UNIT = 64;
-template <int GT>
+typedef float ws_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ws_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint4 ws_xaff(uint4 v, float sc, float sh, unsigned floor2) {
+    unsigned d[4] = {v.x, v.y, v.z, v.w};
+    const ws_f2 s2 = {sc, sc}, h2 = {sh, sh};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const ws_f2 xx = {__uint_as_float(d[p] << 16), __uint_as_float(d[p] & 0xFFFF0000u)};
+        ws_f2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(xx), "v"(s2), "v"(h2));
+        unsigned o = ws_cvt_pk_bf16(r[0], r[1]);
+        asm("v_pk_max_i16 %0, %1, %2" : "=v"(o) : "v"(o), "v"(floor2));
+        d[p] = o;
+    }
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
+template <int GT, bool XAFF = false>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16s_kernel(const uint16_t *__restrict__ g, const uint16_t *__restrict__ x,
                                                              const uint4 *__restrict__ zero16, float *__restrict__ partial,
-                                                             int Cout, int Cin, int L, int nL, long long units, int nsplit, int oblocks, int cblocks)
+                                                             int Cout, int Cin, int L, int nL, long long units, int nsplit, int oblocks, int cblocks,
+                                                             const float *__restrict__ xs = nullptr, const float *__restrict__ xh = nullptr, int xrelu = 0)
 {
     constexpr int OBR = GT * 128, ROWS = OBR + 128, NDMA = ROWS / 32;   // DMA requests per wave and unit (64 lanes x 16 bytes = 8 rows each)
     extern __shared__ uint4 ws_ring[];                                   // [3][ROWS][8] 16-byte pieces
@@ -350,6 +376,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16s_kernel(const uint16_t *__r
     const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(ws_ring);
     const int nxt = min(4, (Cin - cb * 128 + 31) >> 5);                  // x tiles that exist
     const bool g_any = ob * OBR + wave * GT * 32 < Cout;
+    float xsc[4] = {0.f, 0.f, 0.f, 0.f}, xsh[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned xfloor = xrelu ? 0u : 0x80008000u;
+    if constexpr (XAFF) {
+#pragma unroll
+        for (int xt = 0; xt < 4; ++xt) {
+            const int c = cb * 128 + xt * 32 + m;
+            if (c < Cin) { xsc[xt] = xs[c]; xsh[xt] = xh[c]; }
+        }
+    }
 
     f32x16 acc[GT][4];
 #pragma unroll
@@ -405,7 +440,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16s_kernel(const uint16_t *__r
 #pragma unroll
                     for (int xt = 0; xt < 4; ++xt) {
                         if (xt < nxt) {
-                            const bf16x8 Bx = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sl + (OBR + xt * 32 + m) * 128 + pq));
+                            uint4 bx = *reinterpret_cast<const uint4 *>(sl + (OBR + xt * 32 + m) * 128 + pq);
+                            if constexpr (XAFF) bx = ws_xaff(bx, xsc[xt], xsh[xt], xfloor);
+                            const bf16x8 Bx = __builtin_bit_cast(bf16x8, bx);
 #pragma unroll
                             for (int gt = 0; gt < GT; ++gt)
                                 acc[gt][xt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[gt], Bx, acc[gt][xt], 0, 0, 0);
@@ -544,9 +581,9 @@ extern "C" size_t sonet_wgrad_bf16_ws_size(int B, int Cout, int Cin, int L)
     return a > b ? a : b;
 }
 
-extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
+static int wgrad_bf16_impl(const char *what, const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream,
+                           const float *xs, const float *xh, int xrelu)
 {
-    const char *what = "sonet_wgrad_bf16";
     SONET_REQUIRE(g && x && dw && ws, "%s: NULL pointer", what);
     SONET_REQUIRE(B > 0 && Cout > 0 && Cin > 0 && L > 0, "%s: non-positive size", what);
     if ((double)Cout * L * 2.0 >= 8.0e9 || (double)Cin * L * 2.0 >= 8.0e9) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: a per-cloud panel is too large", what);
@@ -569,7 +606,16 @@ extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw,
                                      return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
                                  attr_set = true; }                                                                                   \
                 hipLaunchKernelGGL(wgrad_bf16s_kernel<GG>, grid, block, lds, st, g, x, zero16, part, Cout, Cin, L, q.nL, q.units, q.nsplit, q.oblocks, q.cblocks); } while (0)
-            if (q.gt == 2) WS_LAUNCH(2); else WS_LAUNCH(1);
+#define WS_LAUNCH_X(GG) do { static bool attr_set = false;                                                                            \
+                if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16s_kernel<GG, true>),              \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)       \
+                                     return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: cannot reserve the LDS", what);                   \
+                                 attr_set = true; }                                                                                   \
+                hipLaunchKernelGGL((wgrad_bf16s_kernel<GG, true>), grid, block, lds, st, g, x, zero16, part, Cout, Cin, L, q.nL, q.units, q.nsplit, q.oblocks, q.cblocks, \
+                                   xs, xh, xrelu); } while (0)
+            if (xs) { if (q.gt == 2) WS_LAUNCH_X(2); else WS_LAUNCH_X(1); }
+            else if (q.gt == 2) WS_LAUNCH(2); else WS_LAUNCH(1);
+#undef WS_LAUNCH_X
 #undef WS_LAUNCH
             const long long n = (long long)Cout * Cin;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, part, dw,
@@ -577,6 +623,7 @@ extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw,
             return sonet::launched(what);
         }
     }
+    if (xs) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: normalise-on-load exists on the streaming kernel only (L %% 8 == 0, >= 2048 column units)", what);
     const WgPlan p = wg_plan(B, Cout, Cin, L, WB_UNIT);
     const long long nwg = (long long)p.oblocks * p.cblocks * p.nsplit;
     if (nwg > 0x7FFFFFFFll) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: too large", what);
@@ -590,4 +637,19 @@ extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw,
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)sonet::ceil_div64(n, 64)), dim3(256), 0, st, reinterpret_cast<const float *>(ws), dw,
                        Cout, Cin, p.nsplit, (size_t)p.oblocks * WG_BLK, p.cblocks * WG_BLK);
     return sonet::launched(what);
+}
+
+extern "C" int sonet_wgrad_bf16(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L, sonet_stream_t stream)
+{
+    return wgrad_bf16_impl("sonet_wgrad_bf16", g, x, dw, ws, B, Cout, Cin, L, stream, nullptr, nullptr, 0);
+}
+
+/* sonet_wgrad_bf16 when x is the RAW (bf16) output of a BatchNorm layer whose normalise pass was never run (bf16 training with
+ * normalise-on-load): x = act(raw * xs[c] + xh[c]) rounded to bf16 is applied to the fragments, bit for bit what sonet_channel_affine_act_bf16
+ * would have stored; xs, xh [Cin].  Streaming-kernel shapes only (L % 8 == 0, B * ceil(L / 64) >= 2048): SONET_ERR_UNSUPPORTED otherwise. */
+extern "C" int sonet_wgrad_bf16_xaff(const uint16_t *g, const uint16_t *x, float *dw, void *ws, int B, int Cout, int Cin, int L,
+                                     const float *xs, const float *xh, int xrelu, sonet_stream_t stream)
+{
+    SONET_REQUIRE(xs && xh, "sonet_wgrad_bf16_xaff: NULL pointer");
+    return wgrad_bf16_impl("sonet_wgrad_bf16_xaff", g, x, dw, ws, B, Cout, Cin, L, stream, xs, xh, xrelu);
 }

@@ -138,14 +138,21 @@ def _pack_transposed(weight2d, C1, C2):
     return out
 
 
-def _dgrad(g_raw, pack):
-    """W^T . g_raw through the fused 1x1-conv kernel (pack from _pack_transposed)."""
+def _dgrad(g_raw, pack, acc=None):
+    """W^T . g_raw through the fused 1x1-conv kernel (pack from _pack_transposed).  acc (bf16 packs; the caller checked ``_dgrad_acc_ok``):
+    another gradient of the same tensor, added by the store of the launch."""
     wpt, Ci, Cp = pack
     want = torch.bfloat16 if wpt.dtype == torch.int16 else torch.float32
     if g_raw.dtype != want:
         g_raw = g_raw.to(want)
-    y = _ops.pointmlp(g_raw, wpt, _ops.const_vec(Cp, 1.0, g_raw.device), _ops.const_vec(Cp, 0.0, g_raw.device), False, Cp)
+    y = _ops.pointmlp(g_raw, wpt, _ops.const_vec(Cp, 1.0, g_raw.device), _ops.const_vec(Cp, 0.0, g_raw.device), False, Cp, acc=acc)
     return y if Cp == Ci else y[:, :Ci]
+
+
+def _dgrad_acc_ok(g_raw, pack, acc):
+    wpt, Ci, Cp = pack
+    return (wpt.dtype == torch.int16 and Cp == Ci and acc.dtype == torch.bfloat16 and acc.is_contiguous() and g_raw.shape[2] % 2 == 0
+            and tuple(acc.shape) == (g_raw.shape[0], Cp, g_raw.shape[2]))
 
 
 def _wgrad(g_raw, x, xaff=None):
@@ -154,6 +161,13 @@ def _wgrad(g_raw, x, xaff=None):
     into three bf16 pieces on the matrix cores, partial blocks summed in a fixed order); exact-f32 mode and tiny problems: one
     batched hipBLASLt GEMM (K = L is the long axis); bf16 operands accumulate and come out in f32 (a bf16 per-cloud partial
     would cost three of the eight significand bits)."""
+    if xaff is not None and x.dtype == torch.bfloat16:
+        # bf16 training with normalise-on-load: the streaming weight-gradient kernel normalises its x fragments; other shapes write the
+        # activation out first (the values the normalise pass would have stored)
+        B_, Co_, L_ = g_raw.shape
+        if (g_raw.dtype == torch.bfloat16 and _ops.WGRAD_KERNEL and _ops.wgrad_bf16_xaff_ok(B_, Co_, x.shape[1], L_) and Co_ + x.shape[1] >= 192):
+            return _ops.wgrad_bf16(g_raw.contiguous(), x.contiguous(), xaff=xaff)
+        x, xaff = _ops.channel_affine_act(x.contiguous(), xaff[0], xaff[1], xaff[2]), None
     if xaff is not None:
         return _ops.wgrad_x3(g_raw.contiguous().float(), x.contiguous(), xaff=xaff)
     if g_raw.dtype == torch.bfloat16:
@@ -332,8 +346,8 @@ class _PointwiseFn(torch.autograd.Function):
             # bn_run = (running_mean, running_var, momentum, unbias) or None: the statistics launch below also writes the normalisation
             # coefficients and updates the running statistics (``ops.bn_rider``: one launch instead of three per layer and step)
             epi = _stats_epilogue_ok(x1, wp, Cout)
-            if xaff is not None and not (epi and wp.dtype == torch.int8):
-                raise RuntimeError("_PointwiseFn: normalise-on-load needs the h3 layer with the statistics epilogue")
+            if xaff is not None and not (epi and wp.dtype in (torch.int8, torch.int16)):
+                raise RuntimeError("_PointwiseFn: normalise-on-load needs the h3 or the bf16 layer with the statistics epilogue")
             if not epi:
                 raw = _ops.pointmlp(x1, wp, ones, bias, False, Cout, x2=x2)
             rm, rv, mom, unb = bn_run if bn_run is not None else (None, None, 0.0, 1.0)
@@ -442,11 +456,16 @@ class _PointwiseFn(torch.autograd.Function):
             ones_i = None
             packs = _pack_transposed(weight2d, x1.shape[1], x2.shape[1] if ctx.has_x2 else 0)
             outs = []
-            for need, pk in ((need1, packs[0]), (need2, packs[1])):
+            for i_, (need, pk) in enumerate(((need1, packs[0]), (need2, packs[1]))):
                 if not need or pk is None:
                     outs.append(None)
                     continue
-                outs.append(_dgrad(g_raw, pk))
+                # (bf16: a gradient the other consumer of x1 left in the carry is added by the store of this launch)
+                if i_ == 0 and carried is not None and _dgrad_acc_ok(g_raw, pk, carried):
+                    outs.append(_dgrad(g_raw, pk, acc=carried))
+                    carried = None
+                else:
+                    outs.append(_dgrad(g_raw, pk))
             g_x1, g_x2 = outs
         if carried is not None:                                           # (not taken by the launch above)
             g_x1 = carried if g_x1 is None else g_x1 + carried.to(g_x1.dtype)
@@ -474,8 +493,8 @@ class _PooledLastLayerFn(torch.autograd.Function):
         ctx.wleaf = _leaf_of(weight2d)
         ctx.use_token = _register_use(ctx.wleaf) if ctx.needs_input_grad[2] else None
         ctx.xaff = xaff                       # (sorted form only) x1 / x2 are RAW outputs of BatchNorm layers: see _PointwiseFn
-        if xaff is not None and pos0 is None:
-            raise RuntimeError("_PooledLastLayerFn: normalise-on-load comes with the node-sorted form")
+        if xaff is not None and pos0 is None and not (wp.dtype == torch.int16 and not need_dense and _ops.pointmlp_bf16_pool_ok(x1, x2, Cout, M)):
+            raise RuntimeError("_PooledLastLayerFn: normalise-on-load comes with the node-sorted form (f32-class) or the bf16 pool epilogue")
         if pos0 is not None:
             # NODE-SORTED columns (the caller ran the hidden layers on som_sort_group's copy; min_idx_i32 = its ids_sorted): the f32-class
             # layer pools its own output -- neither the B x 384 x kN tensor nor the index_max launch exists.  Positions are sorted
@@ -506,7 +525,7 @@ class _PooledLastLayerFn(torch.autograd.Function):
             # neither written nor read back (0.74 GB of HBM traffic each way at B = 64) and the index_max launch is gone; positions and
             # values are those of index_max_gather on the tensor the storing launch would have written, bit for bit
             y = None
-            idx, val = _ops.pointmlp_bf16_pool(x1, wp, ones, b, False, Cout, min_idx_i32, M, row_max, x2=x2)
+            idx, val = _ops.pointmlp_bf16_pool(x1, wp, ones, b, False, Cout, min_idx_i32, M, row_max, x2=x2, xaff=xaff)
         else:
             y = _ops.pointmlp(x1, wp, ones, b, False, Cout, x2=x2)
             idx, val = _ops.index_max_gather(y, min_idx_i32, M, row_max)
@@ -803,8 +822,11 @@ class _FusedPointwise(_PlainAttrs, nn.Module):
             x2 = x2.to(want)
         if (xaff is not None or defer or carry is not None) and not (train_bn and fuse_act):
             raise RuntimeError("deferred normalisation is a training-mode BatchNorm + ReLU layer's")
-        if xaff is not None and not (wp.dtype == torch.int8 and _stats_epilogue_ok(x1, wp, self.conv.out_channels)
-                                     and _ops.xaff_ok(x1.shape[1], x2.shape[1] if x2 is not None else 0, self.conv.out_channels)):
+        C2_ = x2.shape[1] if x2 is not None else 0
+        have_form = xaff is not None and _stats_epilogue_ok(x1, wp, self.conv.out_channels) and (
+            (wp.dtype == torch.int8 and _ops.xaff_ok(x1.shape[1], C2_, self.conv.out_channels))
+            or (wp.dtype == torch.int16 and _ops.bf16_xaff_ok(x1.shape[0], x1.shape[1], C2_, self.conv.out_channels, x1.shape[2])))
+        if xaff is not None and not have_form:
             # (the weight side of the range guard sent this layer to x3 between the caller's check and here, or a shape without the
             #  normalise-on-load form: its inputs are written out after all)
             x1 = _Materialise.apply(x1, xaff[0], xaff[1], xaff[2])
@@ -1270,6 +1292,26 @@ class PointResNet(nn.Module):
         last = self.layers[n - 1]
         return _ops.xaff_ok(self.out_channels_list[0], self.out_channels_list[n - 2], last.conv.out_channels)
 
+    def bf16_norm_on_load_ok(self, x, M):
+        """bf16 training, nobody reads first_pn_out (the pool is the last layer's epilogue): the hidden layers hand their RAW bf16 outputs on
+        and every consumer -- next layer, pooled last layer, weight gradients -- normalises in its operand path.  Decided before any layer
+        runs; the original column order (no sorted copy needed: the bf16 pool epilogue keeps its bins in LDS)."""
+        n = len(self.out_channels_list)
+        if not (_ops.BF16_NORM_ON_LOAD and _ops.WGRAD_KERNEL and _ops.STATS_EPILOGUE and _ops.POOLED_TRAIN_EPILOGUE
+                and _ops.POINTMLP_PRECISION == "bf16" and x.is_cuda):
+            return False
+        B, _, L = x.shape
+        for l in range(n - 1):
+            lay = self.layers[l]
+            if not (lay.normalization == 'batch' and lay.norm.training and lay.activation == 'relu' and lay._fusable()):
+                return False
+            if l >= 1 and not _ops.bf16_xaff_ok(B, lay.conv.in_channels, 0, lay.conv.out_channels, L):
+                return False
+        C1, C2, Cout = self.out_channels_list[0], self.out_channels_list[n - 2], self.layers[n - 1].conv.out_channels
+        if L % 2 or L > 65534 or (C1 + C2) % 64 or C1 % 16 or Cout % 32 or not 0 < M <= 255 or B > 65535:
+            return False
+        return _ops.wgrad_bf16_xaff_ok(B, Cout, C1, L)
+
     def forward_pooled(self, x, min_idx_i32, row_max, M, epoch=None, need_dense=True, pos0=None):
         """Training path of the encoder: hidden layers as usual, then the last layer and the per-node arg-max pool as one
         autograd node -> (first_pn_out, first_pn_out_masked_max, gather_index) or None when the layout does not allow it.
@@ -1298,6 +1340,20 @@ class PointResNet(nn.Module):
             skip, t = _Materialise.apply(skip[0], skip[1], skip[2], True), _Materialise.apply(h[0], h[1], h[2], True)
             return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M,
                                             bool(need_dense), pos0, None, carry)
+        elif pos0 is None and not need_dense and self.bf16_norm_on_load_ok(x, M):
+            # bf16: the same data flow in the original column order (round 6) -- the three normalise + ReLU passes over B x C x kN are gone
+            h, _ = self.layers[0]._run(_FusedPointwise._prep(x), None, epoch, defer=True)
+            skip = h
+            carry = _GradCarry() if (_ops.GRAD_CARRY and _ops._graph_task_id is not None and torch.is_grad_enabled() and skip[0].requires_grad) else None
+            for l in range(1, n - 1):
+                h, _ = self.layers[l]._run(h[0], None, epoch, xaff=(h[1], h[2], True), defer=True, carry=carry if l == 1 else None)
+            wp = last._packed(skip[0].shape[1], h[0].shape[1])
+            if wp.dtype == torch.int16 and _ops.pointmlp_bf16_pool_ok(skip[0], h[0], last.conv.out_channels, M):
+                return _PooledLastLayerFn.apply(skip[0], h[0], last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M, False, None,
+                                                (skip[1], skip[2], True, h[1], h[2], True), carry)
+            skip, t = _Materialise.apply(skip[0], skip[1], skip[2], True), _Materialise.apply(h[0], h[1], h[2], True)
+            return _PooledLastLayerFn.apply(skip.contiguous(), t.contiguous(), last._weight2d(), last._bias(), wp, min_idx_i32, row_max, M,
+                                            bool(need_dense), None, None, carry)
         else:
             skip = self.layers[0](x, epoch)
             t = skip

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sonet_som_assign_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sonet_som_assign_sort_ws_size": [_i, _i, _i, _i],
     "sonet_pointmlp_bf16_pool": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_pool_xaff": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sonet_pointmlp_h3_segpool_ws_size": [_i, _i, _i],
     "sonet_pointmlp_h3_segpool_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sonet_pointmlp_h3_stats_xaff_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
@@ -65,6 +66,7 @@ SIGNATURES = {
     "sonet_pointmlp_bf16_pack_size": [_i, _i],
     "sonet_pointmlp_bf16_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_acc": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_gather": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_index_max_gather_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_index_max_gather_p16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -75,11 +77,13 @@ SIGNATURES = {
     "sonet_pointmlp_x3_stats_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pointmlp_bf16_stats_ws_size": [_i, _i, _i],
     "sonet_pointmlp_bf16_stats": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sonet_pointmlp_bf16_stats_xaff": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sonet_pointmlp_h3_nodeadd_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "sonet_wgrad_x3_ws_size": [_i, _i, _i, _i],
     "sonet_wgrad_x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_wgrad_bf16_ws_size": [_i, _i, _i, _i],
     "sonet_wgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sonet_wgrad_bf16_xaff": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "sonet_pointmlp_x3_pack_size": [_i, _i],
     "sonet_pointmlp_x3_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_x3_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -124,6 +128,7 @@ SIGNATURES = {
     "sonet_linear_act_f32": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pooled_dgrad_ws_size": [_i, _i, _i, _i],
     "sonet_pooled_wgrad_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "sonet_pooled_wgrad_xaff_xbf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "sonet_pooled_dgrad_obf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sonet_pooled_dgrad_mfma_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

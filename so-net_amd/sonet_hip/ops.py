@@ -161,9 +161,10 @@ def pointmlp_bf16_pool_ok(x1, x2, Cout, M):
     return False
 
 
-def pointmlp_bf16_pool(x1, wp, scale, shift, relu, Cout, ids, M, row_max=None, x2=None):
+def pointmlp_bf16_pool(x1, wp, scale, shift, relu, Cout, ids, M, row_max=None, x2=None, xaff=None):
     """The bf16 layer and the per-node arg-max pool of its output in one launch (``sonet_pointmlp_bf16_pool``); the B x Cout x L output is
-    never written.  -> (idx i32, val f32) B x Cout x M: exactly ``index_max_gather(pointmlp(...), ids, M, row_max)``."""
+    never written.  -> (idx i32, val f32) B x Cout x M: exactly ``index_max_gather(pointmlp(...), ids, M, row_max)``.
+    xaff = (s1, h1, relu1[, s2, h2, relu2]): x1 / x2 are RAW outputs of BatchNorm layers, normalised by the operand load."""
     _chk(x1, "x", torch.bfloat16, 3)
     B, C1, L = x1.shape
     C2 = 0
@@ -187,9 +188,14 @@ def pointmlp_bf16_pool(x1, wp, scale, shift, relu, Cout, ids, M, row_max=None, x
         raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C1 + C2, Cout))
     idx = torch.empty((B, Cout, int(M)), dtype=torch.int32, device=dev)
     val = torch.empty((B, Cout, int(M)), dtype=torch.float32, device=dev)
-    with _lib.on_device(dev), _timed("pointmlpbf16_pool_%dx%d_L%d" % (C1 + C2, Cout, L)):
-        check(lib.sonet_pointmlp_bf16_pool(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(ids), ptr(row_max),
-                                           ptr(idx), ptr(val), B, Cout, L, int(M), stream_ptr()), "sonet_pointmlp_bf16_pool")
+    with _lib.on_device(dev), _timed("pointmlpbf16_pool_%dx%d_L%d%s" % (C1 + C2, Cout, L, "_xaff" if xaff is not None else "")):
+        if xaff is not None:
+            check(lib.sonet_pointmlp_bf16_pool_xaff(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(ids), ptr(row_max),
+                                                    ptr(idx), ptr(val), B, Cout, L, int(M), *_xaff_args(xaff, C1, C2, dev), stream_ptr()),
+                  "sonet_pointmlp_bf16_pool_xaff")
+        else:
+            check(lib.sonet_pointmlp_bf16_pool(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(ids), ptr(row_max),
+                                               ptr(idx), ptr(val), B, Cout, L, int(M), stream_ptr()), "sonet_pointmlp_bf16_pool")
     return idx, val
 
 
@@ -461,9 +467,15 @@ def wgrad_x3(g, x, xaff=None):
     return dw
 
 
-def wgrad_bf16(g, x):
+def wgrad_bf16_xaff_ok(B, Cout, Cin, L):
+    """Shapes ``wgrad_bf16(..., xaff=...)`` takes: the streaming generation of the kernel (16-byte aligned 8-column groups, a long reduction)."""
+    return L % 8 == 0 and B * ((L + 63) // 64) >= 2048
+
+
+def wgrad_bf16(g, x, xaff=None):
     """sum_b g[b] . x[b]^T for bfloat16 operands: g B x Cout x L, x B x Cin x L -> Cout x Cin f32 (one bf16 MFMA per product, f32
-    accumulation and partials, fixed-order reduction: ``sonet_wgrad_bf16``)."""
+    accumulation and partials, fixed-order reduction: ``sonet_wgrad_bf16``).  xaff = (scale, shift, relu): x holds the RAW output of a
+    BatchNorm layer, normalised by the operand path (``sonet_wgrad_bf16_xaff``; ``wgrad_bf16_xaff_ok`` shapes)."""
     _chk(g, "g", torch.bfloat16, 3)
     _chk(x, "x", torch.bfloat16, 3)
     dev = _same_device(g, x)
@@ -476,6 +488,17 @@ def wgrad_bf16(g, x):
     if g.numel() == 0 or x.numel() == 0:
         return dw.zero_()
     ws = torch.empty((lib.sonet_wgrad_bf16_ws_size(B, Cout, Cin, L),), dtype=torch.uint8, device=dev)
+    if xaff is not None:
+        xs, xh, xr = xaff
+        _chk(xs, "xaff scale", torch.float32, 1)
+        _chk(xh, "xaff shift", torch.float32, 1)
+        if xs.numel() != Cin or xh.numel() != Cin:
+            raise SonetHipError("wgrad_bf16: xaff needs Cin = %d coefficients" % Cin)
+        _same_device(x, xs, xh)
+        with _lib.on_device(dev), _timed("wgradbf16_%dx%d_L%d_xaff" % (Cout, Cin, L)):
+            check(lib.sonet_wgrad_bf16_xaff(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, ptr(xs), ptr(xh), int(bool(xr)), stream_ptr()),
+                  "sonet_wgrad_bf16_xaff")
+        return dw
     with _lib.on_device(dev), _timed("wgradbf16_%dx%d_L%d" % (Cout, Cin, L)):
         check(lib.sonet_wgrad_bf16(ptr(g), ptr(x), ptr(dw), ptr(ws), B, Cout, Cin, L, stream_ptr()), "sonet_wgrad_bf16")
     return dw
@@ -1088,8 +1111,10 @@ class _PackRegistry:
 packs = _PackRegistry()
 
 
-def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
+def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None, acc=None):
     """y = act((W . cat(x1, x2)) * scale + shift); x B x C x L f32.  The kernel follows the packing of ``wp``.
+    ``acc`` (bf16 packs, B x Cout x L bf16, even L): another gradient of the same tensor -- y = bf16(float(y) + float(acc)) from the store
+    of the launch (``sonet_pointmlp_bf16_acc``: autograd's accumulation without its pass).
     ``gidx`` (B x L i32, h3 packs only): column l of x1 (B x C1 x L1) is taken from x1[:, :, gidx[b, l]] -- zeros when the
     index is out of range -- i.e. the layer runs on the gathered tensor without materialising it."""
     bf16 = wp.dtype == torch.int16
@@ -1124,6 +1149,15 @@ def pointmlp(x1, wp, scale, shift, relu, Cout, x2=None, out=None, gidx=None):
     if bf16:
         if y.dtype != torch.bfloat16:
             raise SonetHipError("pointmlp: a bf16 pack writes a bfloat16 output")
+        if acc is not None:
+            _chk(acc, "acc", torch.bfloat16, 3)
+            if tuple(acc.shape) != (B, Cout, L) or gidx is not None or L % 2:
+                raise SonetHipError("pointmlp: acc must be B x Cout x L (even L, no gather index)")
+            _same_device(x1, acc)
+            with _lib.on_device(dev), _timed("pointmlpbf16_acc_%dx%d_L%d" % (C1 + C2, Cout, L)):
+                check(lib.sonet_pointmlp_bf16_acc(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(acc), ptr(y),
+                                                  B, Cout, L, stream_ptr()), "sonet_pointmlp_bf16_acc")
+            return y
         with _lib.on_device(dev), _timed("pointmlpbf16_%dx%d_L%d" % (C1 + C2, Cout, L)):
             if gidx is not None:
                 check(lib.sonet_pointmlp_bf16_gather(ptr(x1), C1, L1, ptr(gidx), ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)),
@@ -1353,6 +1387,18 @@ def _end_of_backward_join():
 STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: BatchNorm batch statistics by a separate pass (channel_stats)
 
 
+# bf16 training (BASELINE configs[1]): the same for the bf16 layers -- the normalise + ReLU pass of the first PointNet's hidden layers (three
+# streams over B x C x kN bf16 tensors per step) is gone; the streaming layer kernel, the pooled last layer and the two weight-gradient kernels
+# apply act(raw * scale + shift) to their operands (sonet_pointmlp_bf16_stats_xaff / _pool_xaff, sonet_wgrad_bf16_xaff, sonet_pooled_wgrad_xaff_xbf16)
+BF16_NORM_ON_LOAD = _os.environ.get("SONET_BF16_NORM_ON_LOAD", "1") != "0"
+
+
+def bf16_xaff_ok(B, C1, C2, Cout, L):
+    """Shapes the normalise-on-load form of the bf16 layer takes (the streaming kernel: ``sonet_pointmlp_bf16_stats_xaff``)."""
+    return ((C1 + C2) % 64 == 0 and (C2 == 0 or C1 % 16 == 0) and Cout % 64 == 0 and L % 2 == 0 and B * ((L + 63) // 64) >= 8192
+            and B * L * Cout * 4 >= (32 << 20))
+
+
 def xaff_ok(C1, C2, Cout):
     """Shapes the normalise-on-load form of the h3 layer takes (``sonet_pointmlp_h3_stats_xaff_f32`` / the xaff arguments of
     ``sonet_pointmlp_h3_segpool_f32``)."""
@@ -1402,9 +1448,14 @@ def pointmlp_stats(x1, wp, scale, shift, relu, Cout, x2=None, xaff=None):
     if bf16:
         ws = torch.empty((lib.sonet_pointmlp_bf16_stats_ws_size(B, Cout, L),), dtype=torch.uint8, device=dev)
         try:
-            with _lib.on_device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d" % (C1 + C2, Cout, L)):
-                check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
-                                                    ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
+            with _lib.on_device(dev), _timed("pointmlpbf16_stats_%dx%d_L%d%s" % (C1 + C2, Cout, L, "_xaff" if xaff is not None else "")):
+                if xaff is not None:
+                    check(lib.sonet_pointmlp_bf16_stats_xaff(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                             ptr(ws), ptr(mean), ptr(var), *_xaff_args(xaff, C1, C2, dev), stream_ptr()),
+                          "sonet_pointmlp_bf16_stats_xaff")
+                else:
+                    check(lib.sonet_pointmlp_bf16_stats(ptr(x1), C1, ptr(x2), C2, ptr(wp), ptr(scale), ptr(shift), int(bool(relu)), ptr(y), B, Cout, L,
+                                                        ptr(ws), ptr(mean), ptr(var), stream_ptr()), "sonet_pointmlp_bf16_stats")
         finally:
             _rider_done()
         return y, mean, var
@@ -2025,15 +2076,17 @@ def pooled_wgrad(g_pooled_t, pos_i32_t, x, xaff=None):
     lib = _lib.load()
     if xaff is not None:
         xs, xh, xr = xaff
-        _chk(x, "x", torch.float32, 3)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise SonetHipError("pooled_wgrad: float32 or bfloat16 rows")
         _chk(xs, "xaff scale", torch.float32, 1)
         _chk(xh, "xaff shift", torch.float32, 1)
         if xs.numel() != Ci or xh.numel() != Ci:
             raise SonetHipError("pooled_wgrad: xaff needs Ci = %d coefficients" % Ci)
         _same_device(x, xs, xh)
+        fnx = lib.sonet_pooled_wgrad_xaff_f32 if x.dtype == torch.float32 else lib.sonet_pooled_wgrad_xaff_xbf16
         with _lib.on_device(dev), _timed("pooled_wgrad_xaff"):
-            check(lib.sonet_pooled_wgrad_xaff_f32(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), ptr(xs), ptr(xh), int(bool(xr)),
-                                                  stream_ptr()), "sonet_pooled_wgrad_xaff_f32")
+            check(fnx(ptr(g_pooled_t), ptr(pos_i32_t), ptr(x), B, C, M, Ci, L, ptr(part), ptr(xs), ptr(xh), int(bool(xr)), stream_ptr()),
+                  "sonet_pooled_wgrad_xaff")
         return part.sum(0)
     fn = lib.sonet_pooled_wgrad_f32 if x.dtype == torch.float32 else lib.sonet_pooled_wgrad_xbf16
     with _lib.on_device(dev), _timed("pooled_wgrad"):

@@ -112,8 +112,8 @@ def main():
                                   stderr=subprocess.DEVNULL)
             txt = open(out).read()
     found, problems = audit(txt)
-    if found != 7:
-        problems.append('%d instantiations of pointmlp_bf16r_kernel (expected 7: four storing, three pooling)' % found)
+    if found != 12:
+        problems.append('%d instantiations of pointmlp_bf16r_kernel (expected 12: four storing, three pooling, two storing + three pooling with normalise-on-load)' % found)
     for p in problems[:20]:
         print('PROBLEM', p)
     print('check_bf16r_asm: %d kernels, %d problems' % (found, len(problems)))

@@ -54,6 +54,7 @@ def frame(stack):
 
 
 cnt = collections.Counter()
+allops = collections.defaultdict(lambda: [0, 0.0])
 kern = collections.Counter()
 for e in prof.events():
     if e.device_type != torch.autograd.DeviceType.CPU:
@@ -61,9 +62,19 @@ for e in prof.events():
         continue
     if e.name in ("aten::copy_", "aten::fill_", "aten::zero_") and e.device_time_total > 0:
         cnt[(e.name, str(e.input_shapes)[:60], frame(e.stack))] += 1
+    # every OUTERMOST aten operator that reached the device (library kernels of the step: the at:: / Cijk_ / rocclr share of the profile)
+    if e.name.startswith("aten::") and e.device_time_total > 0 and not (e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::")):
+        allops[(e.name, str(e.input_shapes)[:70], frame(e.stack))][0] += 1
+        allops[(e.name, str(e.input_shapes)[:70], frame(e.stack))][1] += e.device_time_total
 for (name, shp, fr), n in sorted(cnt.items(), key=lambda kv: (kv[0][2], kv[0][0])):
     print("%3d  %-12s %-60s %s" % (n, name, shp, fr))
 print(sum(cnt.values()), "device copies / fills per step")
 print("device activities by name (top 12):")
 for k, n in kern.most_common(12):
     print("%4d  %s" % (n, k))
+print("outermost aten operators with device time (count, device us, op, shapes, frame):")
+tot = 0.0
+for (name, shp, fr), (n, us) in sorted(allops.items(), key=lambda kv: -kv[1][1]):
+    tot += us
+    print("%3d %8.1f  %-28s %-70s %s" % (n, us, name, shp, fr))
+print("%.1f us of device time in aten operators per step" % tot)
