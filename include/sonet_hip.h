@@ -331,6 +331,16 @@ int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t
 int sonet_pointmlp_bf16_acc(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const void *Wp,
                             const float *scale, const float *shift, int relu, const uint16_t *yadd, uint16_t *y,
                             int B, int Cout, int L, sonet_stream_t stream);
+/* The input gradient of a bf16 layer behind a training-mode BatchNorm (+ ReLU), the BatchNorm / ReLU backward applied by the operand load
+ * (replaces autograd's backward of models/layers.py:60-70 + :282-296 for the layer below; bf16 twin of sonet_pointmlp_x3_bnb_f32 / _bnb_acc_f32):
+ *   y = bf16((W . g_raw) * scale + shift) [+ yadd],  g_raw[k] = bf16(a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k])
+ * gy, raw [B][C][L] bf16; a, b, c0 (sonet_bn_bwd_coeffs_f32) and sc, sh (the forward's normalisation) [C] f32.  Bit for bit what
+ * sonet_pointwise_bwd_apply_bf16 followed by sonet_pointmlp_bf16 (yadd NULL) or sonet_pointmlp_bf16_acc computes, in ONE pass over (gy, raw).
+ * g_raw_out [B][C][L] (or NULL) receives g_raw for the weight gradient.  Wp: sonet_pointmlp_bf16_pack of the C x Cout matrix.
+ * SONET_ERR_UNSUPPORTED unless L even, rows 4-byte aligned, C % 16 == 0, 32 <= C <= 512, Cout % 64 == 0. */
+int sonet_pointmlp_bf16_bnb(const uint16_t *gy, const uint16_t *raw, int C, const void *Wp, const float *scale, const float *shift,
+                            const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                            uint16_t *g_raw_out, const uint16_t *yadd, uint16_t *y, int B, int Cout, int L, sonet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * pointresnet_fused -- the encoder's first PointNet as ONE kernel (eval mode, 3xbf16-split arithmetic)

@@ -60,9 +60,16 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const float *__restrict_
     Wp[t] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// (BNB) BatchNorm / ReLU backward on the operand load: x1 holds gy and the operand of the product is
+//   g_raw[k] = bf16( a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k] )
+// -- sonet_pointwise_bwd_apply_bf16's arithmetic and rounding, element for element -- computed on the chunk's registers in front of the
+// MFMAs; the first pass of the first output slab also stores it (g_raw_out, for the weight gradient).  PAIRED, C1 % 16 == 0, C1 <= BNB_CMAX.
+struct BfBnb { const uint16_t *raw; const float *a, *b, *c0, *sc, *sh; uint16_t *g_raw_out; int relu; };
+constexpr int BNB_CMAX = 512;
+
 // PAIRED: L even -> one dword per (lane, channel row) covers the lane's two points.  Otherwise 2-byte accesses with two
 // independent column offsets per lane (odd L; the gather variant).
-template <int MT, int S, bool PAIRED, int NXB = 2>
+template <int MT, int S, bool PAIRED, int NXB = 2, bool BNB = false>
 __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_kernel(      // <= 4 tiles: two workgroups per CU (<= 256 VGPRs)
     const uint16_t *__restrict__ x1, int C1, const uint16_t *__restrict__ x2, int C2, const uint4 *__restrict__ Wp,
     const float *__restrict__ scale, const float *__restrict__ shift, int relu, uint16_t *__restrict__ y,
@@ -70,13 +77,17 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
     const int32_t *__restrict__ gidx /*optional [B][L]: column l of x1 is x1[:, gidx[b][l]]*/, int L1 /*row length of x1*/,
     double *__restrict__ stats_partial /*optional [gridDim.x][Cout][2]: sum / sum of squares of the STORED (bf16) output over this workgroup's columns*/,
     const uint16_t *__restrict__ yadd = nullptr /*optional [B][Cout][L] (PAIRED, no statistics): y = bf16(float(bf16(result)) + float(yadd)) -- what
-                                                  autograd's accumulation of two bf16 gradients of one tensor would store (models/layers.py _GradCarry)*/)
+                                                  autograd's accumulation of two bf16 gradients of one tensor would store (models/layers.py _GradCarry)*/,
+    const BfBnb bnb = BfBnb{})
 {
+    static_assert(!BNB || (PAIRED && NXB == 2), "the BatchNorm-backward load exists on the paired two-buffer pipeline");
     constexpr int NSL = S * MT;                              // 1 KiB W slices per stage
     constexpr int NS = (NSL + BF_WAVES - 1) / BF_WAVES;
     __shared__ uint4 wsm[2][NS * BF_WAVES][64];
     __shared__ float2 affine[1024];
     __shared__ float2 red[BF_WAVES][MT * 32];                   // (statistics epilogue)
+    __shared__ float4 bnb_abcs[BNB ? BNB_CMAX : 1];             // (BNB) (a, b, c0, sc) of input channel k
+    __shared__ float bnb_sh[BNB ? BNB_CMAX : 1];                //       sh
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -144,10 +155,33 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
         }
     };
 
+    // (BNB) the raw pre-activations beside gy: the same rows, the same lane offsets
+    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(BNB ? bnb.raw + b * (long long)C1 * L : x1), 0, (int)((unsigned)(BNB ? C1 : 0) * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(
+        (BNB && bnb.g_raw_out) ? bnb.g_raw_out + b * (long long)C1 * L : y, 0, (int)((unsigned)((BNB && bnb.g_raw_out) ? C1 : 0) * rowB), 0x00020000);
+    auto load_r = [&](unsigned (&rw_)[S][NR], int st) {
+        if constexpr (BNB) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const unsigned row0 = (unsigned)(16 * (st * S + i)) * rowB;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) rw_[i][t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rr_, voa, row0 + (unsigned)t * rowB, 0);
+            }
+        }
+    };
+
     const int ct_begin = blockIdx.y * ct_per_y;
     const int ct_end = min(CT, ct_begin + ct_per_y);
     for (int o = ct_begin * 32 + (int)threadIdx.x; o < ct_end * 32; o += BF_THREADS)
         affine[o - ct_begin * 32] = make_float2(scale[o], shift[o]);
+    if constexpr (BNB) {
+        for (int k = threadIdx.x; k < BNB_CMAX; k += BF_THREADS) {
+            const bool in = k < C1;
+            bnb_abcs[k] = in ? make_float4(bnb.a[k], bnb.b[k], bnb.c0[k], bnb.sc[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bnb_sh[k] = in ? bnb.sh[k] : 0.f;
+        }
+    }
 
     for (int ct0 = ct_begin; ct0 < ct_end; ct0 += MT) {
         f32x16 acc[MT][2];
@@ -173,10 +207,31 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
             for (int t = 0; t < NS; ++t)
                 wsm[slot][wave + t * BF_WAVES][lane] = __builtin_bit_cast(uint4, w[t]);
         };
-        auto compute = [&](const unsigned (&raw)[S][NR], int slot, int st) {
+        auto compute = [&](unsigned (&raw)[S][NR], const unsigned (&rawr)[S][NR], int slot, int st) {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 if (st * S + i >= KC) break;                  // (a padded last stage: its W slices repeat the last chunk)
+                if constexpr (BNB) {
+                    // gy -> g_raw on the chunk's eight dwords (channel rows 16 kc + 8 h + t; the lane's even | odd point)
+                    const int k0 = 16 * (st * S + i) + 8 * h;
+                    const bool st_out = bnb.g_raw_out != nullptr && blockIdx.y == 0 && ct0 == ct_begin && pva;
+                    const unsigned row0 = (unsigned)(16 * (st * S + i)) * rowB;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float4 co = bnb_abcs[k0 + t];
+                        const float shv = bnb_sh[k0 + t];
+                        const unsigned dg = raw[i][t], dr = rawr[i][t];
+                        const float r0 = __uint_as_float(dr << 16), r1 = __uint_as_float(dr & 0xFFFF0000u);
+                        float g0 = __uint_as_float(dg << 16), g1 = __uint_as_float(dg & 0xFFFF0000u);
+                        if (bnb.relu) {
+                            g0 = (__fmaf_rn(r0, co.w, shv) > 0.f) ? g0 : 0.f;
+                            g1 = (__fmaf_rn(r1, co.w, shv) > 0.f) ? g1 : 0.f;
+                        }
+                        const unsigned pk = cvt_pk_bf16(__fmaf_rn(co.x, g0, __fmaf_rn(co.y, r0, co.z)), __fmaf_rn(co.x, g1, __fmaf_rn(co.y, r1, co.z)));
+                        raw[i][t] = pk;
+                        if (st_out) __builtin_amdgcn_raw_buffer_store_b32((int)pk, rg_, voa, row0 + (unsigned)t * rowB, 0);
+                    }
+                }
                 unsigned ba[4], bb[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -201,26 +256,29 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
 
         i32x4_t wreg[NS];
         unsigned b0[S][NR], b1[S][NR];
+        unsigned q0[BNB ? S : 1][NR], q1[BNB ? S : 1][NR];          // (BNB) the raw pre-activations of the same chunks
         __syncthreads();
         if constexpr (NXB == 2) {
             stage_load(wreg, 0);
             load_b(b0, 0);
+            if constexpr (BNB) load_r(q0, 0);
             stage_write(wreg, 0);
             stage_load(wreg, nstage > 1 ? 1 : 0);
-#define BF_STAGE(st, bcur, bnxt, slot)                                        \
+#define BF_STAGE(st, bcur, bnxt, qcur, qnxt, slot)                            \
         {                                                                    \
             __syncthreads();                                                 \
             stage_write(wreg, (slot) ^ 1);                                   \
             stage_load(wreg, (st) + 2 < nstage ? (st) + 2 : nstage - 1);     \
             load_b(bnxt, (st) + 1);                                          \
-            compute(bcur, slot, st);                                         \
+            if constexpr (BNB) { load_r(qnxt, (st) + 1); compute(bcur, qcur, slot, st); } \
+            else compute(bcur, bcur, slot, st);                              \
         }
             int st = 0;
             for (; st + 2 <= nstage; st += 2) {
-                BF_STAGE(st, b0, b1, 0)
-                BF_STAGE(st + 1, b1, b0, 1)
+                BF_STAGE(st, b0, b1, q0, q1, 0)
+                BF_STAGE(st + 1, b1, b0, q1, q0, 1)
             }
-            if (st < nstage) BF_STAGE(st, b0, b1, 0)
+            if (st < nstage) BF_STAGE(st, b0, b1, q0, q1, 0)
 #undef BF_STAGE
         } else {
             // X AND W two stages ahead (three X register sets, two W sets).  One stage ahead, every stage top waited for the W slices
@@ -245,7 +303,7 @@ __global__ __launch_bounds__(BF_THREADS, (MT <= 4 ? 2 : 1)) void pointmlp_bf16_k
             stage_write(wset, slot_ ^ 1);                                    \
             stage_load(wset, clampst((st) + 3));                             \
             load_b(bfar, clampst((st) + 2));     /* (unconditional: a branch here makes hipcc wait for vmcnt(0)) */ \
-            compute(bcur, slot_, st);                                        \
+            compute(bcur, bcur, slot_, st);                                  \
         }
             int st = 0;
             for (; st + 6 <= nstage; st += 6) {
@@ -931,7 +989,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
                          const float *scale, const float *shift, int relu, uint16_t *y,
                          int B, int Cout, int L, sonet_stream_t stream, const int32_t *gidx = nullptr, int L1 = 0,
                          double *stats_ws = nullptr, float *mean = nullptr, float *var = nullptr, const BfrXaff *xaff = nullptr,
-                         const uint16_t *yadd = nullptr)
+                         const uint16_t *yadd = nullptr, const BfBnb *bnb = nullptr)
 {
     if (!gidx) L1 = L;
     SONET_REQUIRE(L1 > 0, "%s: non-positive size", what);
@@ -957,6 +1015,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     // node-level launches (a few thousand columns): with 4 tiles per group 515 -> 768 at 64 x 64 columns is 16 x 6 = 96 workgroups of
     // three groups each on 256 CUs; two tiles per group doubles the workgroups that can run side by side
     if (MT == 4 && nwg_x * (CT / 4) < 256 && CT % 2 == 0) MT = 2;
+    if (bnb && MT != 4 && MT != 2 && CT % 2 == 0) MT = 2;     // (the BatchNorm-backward load is instantiated for 4 and 2 tiles)
     if (const char *e = sonet::knob("SONET_BF16_MT")) {            // tuning knob (bench experiments only)
         const int want = atoi(e);
         if ((want == 12 || want == 6 || want == 4 || want == 2 || want == 1) && CT % want == 0) MT = want;
@@ -1024,7 +1083,7 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     // big launches with dword-aligned rows: the streaming generation (W slab resident in LDS, persistent waves)
     {
         // (an accumulating store -- yadd -- runs on the staged kernel below: its epilogue loads would sit in the streaming kernel's hand-counted queue)
-        bool want = paired && KC % 4 == 0 && CT % 2 == 0 && ngroups >= 8192 && ngroups < 0x7FFFFFFFll && yadd == nullptr;
+        bool want = paired && KC % 4 == 0 && CT % 2 == 0 && ngroups >= 8192 && ngroups < 0x7FFFFFFFll && yadd == nullptr && bnb == nullptr;
         if (const char *e = sonet::knob("SONET_BF16_STREAM")) want = want && atoi(e) != 0;
         int best_ns = 0, best_cost = 1 << 30;
         for (int ns = 1; want && ns <= CT / 2; ++ns) {
@@ -1083,6 +1142,15 @@ static int bf16_run_impl(const char *what, const uint16_t *x1, int C1, const uin
     if (yadd && (!paired || stats_ws)) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: the accumulating store needs even L, 4-byte aligned rows and no statistics", what);
     dim3 grid((unsigned)nwg_x, (unsigned)ysplit), block(BF_THREADS);
 #define BF_ARGS grid, block, 0, st, x1, C1, x2, C2, wp, scale, shift, relu, y, Cout, L, gpc, ngroups, CT, KC, ct_per_y, gidx, L1, stats_ws, yadd
+    if (bnb) {
+        // BatchNorm / ReLU backward on the operand load (the compiler-scheduled kernel: a second operand stream beside gy)
+        if (!paired || C2 != 0 || C1 % 16 != 0 || C1 > BNB_CMAX || stats_ws || S != 2 || (MT != 4 && MT != 2) ||
+            ((reinterpret_cast<uintptr_t>(bnb->raw) | reinterpret_cast<uintptr_t>(bnb->g_raw_out)) & 3) != 0)
+            return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: needs even L, 4-byte aligned rows, C %% 16 == 0, 32 <= C <= %d, Cout %% 64 == 0", what, BNB_CMAX);
+        if (MT == 4) hipLaunchKernelGGL((pointmlp_bf16_kernel<4, 2, true, 2, true>), BF_ARGS, *bnb);
+        else         hipLaunchKernelGGL((pointmlp_bf16_kernel<2, 2, true, 2, true>), BF_ARGS, *bnb);
+        return sonet::launched(what);
+    }
 #define BF_LAUNCH(MM) do { if (paired) { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, true>), BF_ARGS); \
                                          else        hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 1, true>), BF_ARGS); } \
                            else        { if (S == 2) hipLaunchKernelGGL((pointmlp_bf16_kernel<MM, 2, false>), BF_ARGS); \
@@ -1284,6 +1352,25 @@ extern "C" int sonet_pointmlp_bf16_acc(const uint16_t *x1, int C1, const uint16_
     if ((reinterpret_cast<uintptr_t>(yadd) & 3) != 0) return sonet::fail(SONET_ERR_INVALID_ARG, "sonet_pointmlp_bf16_acc: yadd must be 4-byte aligned");
     return bf16_run_impl("sonet_pointmlp_bf16_acc", x1, C1, x2, C2, Wp, scale, shift, relu, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr,
                          nullptr, yadd);
+}
+
+/* The input gradient of a bf16 layer behind a training-mode BatchNorm (+ ReLU) with the BatchNorm / ReLU backward applied by the operand load
+ * (models/layers.py:60-70, :282-296; the bf16 twin of sonet_pointmlp_x3_bnb_f32 / _bnb_acc_f32):
+ *   y = bf16((W . g_raw) * scale + shift) [+ yadd],   g_raw[k] = bf16(a[k] * (relu && !(raw * sc[k] + sh[k] > 0) ? 0 : gy) + b[k] * raw + c0[k])
+ * gy, raw [B][C][L] bf16, coefficients [C] f32 (sonet_bn_bwd_coeffs_f32's a, b, c0; the forward's normalisation sc, sh) -- what
+ * sonet_pointwise_bwd_apply_bf16 followed by sonet_pointmlp_bf16 (or _acc) computes, bit for bit, in ONE pass over (gy, raw).
+ * g_raw_out (or NULL) receives g_raw for the weight gradient; yadd (or NULL): another gradient of the same tensor, added by the store.
+ * Wp: the bf16 pack of the C x Cout matrix.  Needs even L, 4-byte aligned rows, C % 16 == 0, 32 <= C <= 512, Cout % 64 == 0. */
+extern "C" int sonet_pointmlp_bf16_bnb(const uint16_t *gy, const uint16_t *raw, int C, const void *Wp, const float *scale, const float *shift,
+                                       const float *a, const float *b, const float *c0, const float *sc, const float *sh, int relu,
+                                       uint16_t *g_raw_out, const uint16_t *yadd, uint16_t *y, int B, int Cout, int L, sonet_stream_t stream)
+{
+    const char *what = "sonet_pointmlp_bf16_bnb";
+    SONET_REQUIRE(gy && raw && a && b && c0 && sc && sh && y, "%s: NULL pointer", what);
+    if (yadd && (reinterpret_cast<uintptr_t>(yadd) & 3) != 0) return sonet::fail(SONET_ERR_INVALID_ARG, "%s: yadd must be 4-byte aligned", what);
+    if (C < 32) return sonet::fail(SONET_ERR_UNSUPPORTED, "%s: C=%d < 32", what, C);
+    const BfBnb bn = {raw, a, b, c0, sc, sh, g_raw_out, relu};
+    return bf16_run_impl(what, gy, C, nullptr, 0, Wp, scale, shift, 0, y, B, Cout, L, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, yadd, &bn);
 }
 
 extern "C" int sonet_pointmlp_bf16_gather(const uint16_t *x1, int C1, int L1, const int32_t *gidx, const uint16_t *x2, int C2, const void *Wp,

@@ -429,6 +429,22 @@ class _PointwiseFn(torch.autograd.Function):
                     fused_gx1 = yb if Cp == Ci else yb[:, :Ci]
                     if below is not None:
                         fused_gx1._sonet_bwd_sums = (res[2], x1.data_ptr(), fused_gx1._version, bool(xa_[2]))
+            # bf16, one input panel: the same on the compiler-scheduled bf16 layer kernel (``sonet_pointmlp_bf16_bnb``: one pass over
+            # (gy, raw) instead of the apply pass + the dgrad's read of g_raw; a gradient left in the carry is added by its store)
+            if (fused_gx1 is None and _ops.BF16_BNB_ON_LOAD and ctx.needs_input_grad[0] and not ctx.has_x2 and gy.dtype == torch.bfloat16
+                    and raw.dtype == torch.bfloat16 and gy.is_cuda and _ops.POINTMLP_PRECISION == "bf16"):
+                pk = _pack_transposed(weight2d, x1.shape[1], 0)[0]
+                if (pk is not None and pk[0].dtype == torch.int16 and pk[2] == pk[1]
+                        and _ops.pointmlp_bf16_bnb_ok(raw.shape[1], pk[2], raw.shape[2])
+                        and raw.shape[0] * raw.shape[2] >= 65536):
+                    wpt, Ci, Cp = pk
+                    dev = gy.device
+                    acc = None
+                    if (carried is not None and carried.dtype == torch.bfloat16 and carried.is_contiguous()
+                            and tuple(carried.shape) == (gy.shape[0], Cp, gy.shape[2])):
+                        acc, carried = carried, None
+                    fused_gx1, g_raw = _ops.pointmlp_bf16_bnb(gy, raw, wpt, _ops.const_vec(Cp, 1.0, dev), _ops.const_vec(Cp, 0.0, dev), a, b, c0, sc, sh,
+                                                              ctx.relu, Cp, want_g_raw=ctx.needs_input_grad[2], acc=acc)
             if fused_gx1 is None:
                 g_raw = _ops.pointwise_bwd_apply(gy, raw, sc, sh, ctx.relu, a, b, c0)
         g_w = None

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sonet_pointmlp_bf16_pack": [_vp, _vp, _i, _i, _vp],
     "sonet_pointmlp_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_acc": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "sonet_pointmlp_bf16_bnb": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sonet_pointmlp_bf16_gather": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sonet_index_max_gather_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sonet_index_max_gather_p16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

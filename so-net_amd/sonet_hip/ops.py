@@ -1261,6 +1261,51 @@ def pointmlp_x3_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, wa
     return y, g_raw
 
 
+def pointmlp_bf16_bnb_ok(C, Cout, L):
+    """Shapes ``pointmlp_bf16_bnb`` takes (``sonet_pointmlp_bf16_bnb``)."""
+    return C % 16 == 0 and 32 <= C <= 512 and Cout % 64 == 0 and L % 2 == 0
+
+
+def pointmlp_bf16_bnb(gy, raw, wpt, scale, shift, a, b, c0, sc, sh, relu, Cout, want_g_raw=True, acc=None):
+    """bf16((W . g_raw) * scale + shift) [+ acc] with g_raw = bf16(a * (gy masked by raw * sc + sh > 0 when relu) + b * raw + c0) per input
+    channel, in one pass over (gy, raw) -- ``pointwise_bwd_apply`` + ``pointmlp`` (or its ``acc`` form) on a bf16 pack, bit for bit
+    (``sonet_pointmlp_bf16_bnb``).  -> (y B x Cout x L bf16, g_raw or None)."""
+    _chk(gy, "gy", torch.bfloat16, 3)
+    _chk(raw, "raw", torch.bfloat16, 3)
+    if raw.shape != gy.shape:
+        raise SonetHipError("pointmlp_bf16_bnb: gy and raw must have the same shape")
+    B, C, L = gy.shape
+    if wpt.dtype != torch.int16:
+        raise SonetHipError("pointmlp_bf16_bnb: a bf16 pack")
+    for t in (scale, shift):
+        _chk(t, "scale / shift", torch.float32, 1)
+        if t.numel() != Cout:
+            raise SonetHipError("pointmlp_bf16_bnb: %d output coefficients expected" % Cout)
+    for t in (a, b, c0, sc, sh):
+        _chk(t, "coefficient", torch.float32, 1)
+        if t.numel() != C:
+            raise SonetHipError("pointmlp_bf16_bnb: %d coefficients expected" % C)
+    dev = _same_device(gy, raw, wpt, scale, shift, a, b, c0, sc, sh)
+    lib = _lib.load()
+    if wpt.numel() * wpt.element_size() != lib.sonet_pointmlp_bf16_pack_size(C, Cout):
+        raise SonetHipError("packed weight does not match Cin=%d Cout=%d" % (C, Cout))
+    if not pointmlp_bf16_bnb_ok(C, Cout, L):
+        raise SonetHipError("pointmlp_bf16_bnb: needs C %% 16 == 0, 32 <= C <= 512, Cout %% 64 == 0, even L (got C=%d Cout=%d L=%d)" % (C, Cout, L))
+    if acc is not None:
+        _chk(acc, "acc", torch.bfloat16, 3)
+        if tuple(acc.shape) != (B, Cout, L):
+            raise SonetHipError("pointmlp_bf16_bnb: acc must be B x Cout x L")
+        _same_device(gy, acc)
+    y = torch.empty((B, Cout, L), dtype=torch.bfloat16, device=dev)
+    g_raw = torch.empty_like(gy) if want_g_raw else None
+    if y.numel() == 0:
+        return y, g_raw
+    with _lib.on_device(dev), _timed("pointmlpbf16_bnb%s_%dx%d_L%d" % ("a" if acc is not None else "", C, Cout, L)):
+        check(lib.sonet_pointmlp_bf16_bnb(ptr(gy), ptr(raw), C, ptr(wpt), ptr(scale), ptr(shift), ptr(a), ptr(b), ptr(c0), ptr(sc), ptr(sh),
+                                          int(bool(relu)), ptr(g_raw), ptr(acc), ptr(y), B, Cout, L, stream_ptr()), "sonet_pointmlp_bf16_bnb")
+    return y, g_raw
+
+
 def pointmlp_nodeadd(x1, wp, scale, shift, relu, Cout, z, zidx, x2=None):
     """act((W . cat(x1, x2) + z[:, :, zidx]) * scale + shift) in one launch: z B x Cout x M f32 (the per-node block of the layer's
     pre-activation), zidx B x L i32 (out of range: + 0).  h3 packs only."""
@@ -1391,6 +1436,9 @@ STATS_EPILOGUE = _os.environ.get("SONET_STATS_EPILOGUE", "1") != "0"   # 0: Batc
 # streams over B x C x kN bf16 tensors per step) is gone; the streaming layer kernel, the pooled last layer and the two weight-gradient kernels
 # apply act(raw * scale + shift) to their operands (sonet_pointmlp_bf16_stats_xaff / _pool_xaff, sonet_wgrad_bf16_xaff, sonet_pooled_wgrad_xaff_xbf16)
 BF16_NORM_ON_LOAD = _os.environ.get("SONET_BF16_NORM_ON_LOAD", "1") != "0"
+# ... and the BatchNorm / ReLU backward of the bf16 hidden layers rides on the operand load of the input-gradient launch (sonet_pointmlp_bf16_bnb)
+# instead of being a pass over (gy, raw) that writes g_raw for the launch to read back
+BF16_BNB_ON_LOAD = _os.environ.get("SONET_BF16_BNB_ON_LOAD", "1") != "0"
 
 
 def bf16_xaff_ok(B, C1, C2, Cout, L):

@@ -141,3 +141,105 @@ def test_bf16_training_step_with_normalise_on_load_is_bit_identical():
             assert torch.equal(a[1][k], b[1][k]), (it, k)
         for k in a[2]:
             assert torch.equal(a[2][k], b[2][k]), (it, k)
+
+
+# ---- BatchNorm / ReLU backward on the operand load of the bf16 input-gradient launch (sonet_pointmlp_bf16_bnb) -----------------------------
+
+def _bnb_case(B, C, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    gy = (torch.randn(B, C, L, generator=g) * 1e-3).to(torch.bfloat16).to(DEV)
+    raw = (torch.randn(B, C, L, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    co = [(torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV), (torch.randn(C, generator=g) * 1e-4).to(DEV),
+          (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.4).to(DEV)]
+    return gy, raw, co
+
+
+@pytest.mark.parametrize("B,C,Cin,L", [(64, 256, 128, 15000), (64, 128, 64, 15000), (5, 64, 64, 1002), (3, 512, 192, 4098), (2, 32, 64, 66)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_bf16_dgrad_with_batchnorm_backward_on_load_equals_apply_pass_then_dgrad(B, C, Cin, L, acc):
+    """sonet_pointmlp_bf16_bnb == sonet_pointwise_bwd_apply_bf16 followed by sonet_pointmlp_bf16 (or _acc) on the transposed pack: the input
+    gradient AND the g_raw it stores for the weight gradient, bit for bit; with and without the ReLU mask, with and without the g_raw store."""
+    from sonet_hip import ops
+    gy, raw, (a, b, c0, sc, sh) = _bnb_case(B, C, L, C + L)
+    gen = torch.Generator().manual_seed(7 + Cin)
+    W = (torch.randn(C, Cin, generator=gen) * C ** -0.5).to(DEV)       # the layer's weight: C outputs, Cin inputs; the dgrad multiplies by W^T
+    addend = (torch.randn(B, Cin, L, generator=gen) * 1e-3).to(torch.bfloat16).to(DEV) if acc else None
+    assert ops.pointmlp_bf16_bnb_ok(C, Cin, L)
+    with ops.precision("bf16"):
+        wpt = ops.pointmlp_pack_transposed(W, 0, Cin, Cin, "bf16")
+        one, zero = ops.const_vec(Cin, 1.0, DEV), ops.const_vec(Cin, 0.0, DEV)
+        for relu in (True, False):
+            g_ref = ops.pointwise_bwd_apply(gy, raw, sc, sh, relu, a, b, c0)
+            y_ref = ops.pointmlp(g_ref, wpt, one, zero, False, Cin, acc=addend)
+            y, g = ops.pointmlp_bf16_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cin, want_g_raw=True, acc=addend)
+            assert y.dtype == torch.bfloat16 and g.dtype == torch.bfloat16
+            assert torch.equal(g.view(torch.int16), g_ref.view(torch.int16)), relu
+            assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), relu
+            y2, g2 = ops.pointmlp_bf16_bnb(gy, raw, wpt, one, zero, a, b, c0, sc, sh, relu, Cin, want_g_raw=False, acc=addend)
+            assert g2 is None and torch.equal(y2.view(torch.int16), y_ref.view(torch.int16))
+
+
+def test_bf16_bnb_rejects_shapes_it_does_not_take():
+    from sonet_hip import ops
+    from sonet_hip._lib import SonetHipError
+    gy, raw, (a, b, c0, sc, sh) = _bnb_case(2, 48, 65, 3)             # odd L
+    W = torch.randn(48, 64, device=DEV)
+    with ops.precision("bf16"):
+        wpt = ops.pointmlp_pack_transposed(W, 0, 64, 64, "bf16")
+        with pytest.raises(SonetHipError):
+            ops.pointmlp_bf16_bnb(gy, raw, wpt, ops.const_vec(64, 1.0, DEV), ops.const_vec(64, 0.0, DEV), a, b, c0, sc, sh, True, 64)
+
+
+def test_bf16_training_step_with_batchnorm_backward_on_load_is_bit_identical():
+    """ops.BF16_BNB_ON_LOAD on / off: the loss, every gradient and the running statistics of three consecutive steps are bit-identical, the
+    apply pass of the two hidden layers that have an input gradient is gone (the first layer's stays: it has no input gradient to ride on)."""
+    from argparse import Namespace
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    from sonet_hip.optim import FusedAdam
+    B, N = 64, 5000
+    out = {}
+    old = ops.BF16_BNB_ON_LOAD
+    try:
+        with ops.precision("bf16"):
+            for flag in (True, False):
+                ops.BF16_BNB_ON_LOAD = flag
+                opt = Namespace(gpu_id=0, device=torch.device(DEV), batch_size=B, input_pc_num=N, surface_normal=True, feature_num=1024,
+                                activation="relu", normalization="batch", dropout=0.0, node_num=64, k=3, som_k=9, som_k_type="avg", bn_momentum=0.1,
+                                bn_momentum_decay_step=None, bn_momentum_decay=0.6, classes=40)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                oe, oc = FusedAdam(enc.parameters(), lr=1e-3), FusedAdam(cls.parameters(), lr=1e-3)
+                inp = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                snaps = []
+                for it in range(3):
+                    with ops.kernel_timing() as rec:
+                        feat = enc(inp["pc"], inp["sn"], inp["node"], inp["node_knn_I"], is_train=True, epoch=0)
+                        enc.zero_grad(set_to_none=True)
+                        cls.zero_grad(set_to_none=True)
+                        loss = torch.nn.functional.cross_entropy(cls(feat, 0), inp["label"])
+                        loss.backward()
+                    names = [n for n, _, _ in rec.records]
+                    n_bnb = sum(1 for n in names if n.startswith("pointmlpbf16_bnb"))
+                    assert n_bnb == (2 if flag else 0), names
+                    snaps.append((loss.detach().clone(), {k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(cls.named_parameters()) if p.grad is not None},
+                                  {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}, names))
+                    oe.step()
+                    oc.step()
+                out[flag] = snaps
+    finally:
+        ops.BF16_BNB_ON_LOAD = old
+    for it in range(3):
+        a, b = out[True][it], out[False][it]
+        assert torch.equal(a[0], b[0])
+        assert a[1].keys() == b[1].keys()
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), (it, k)
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), (it, k)
+        big = lambda names: sum(1 for n in names if n.startswith("pointwise_bwd_apply"))      # noqa: E731
+        assert big(a[3]) == big(b[3]) - 2, (big(a[3]), big(b[3]))
