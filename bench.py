@@ -59,7 +59,7 @@ def parse():
                     help="forward = the BASELINE metric (default); train = forward+backward+gradient all-reduce+Adam "
                          "(BASELINE configs[4], reported under its own metric name)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,   # (3 -> 4: +2 % in three interleaved A/B pairs on two boxes, 5 and 6: no better -- docs/findings.md R6.2)
                     help="independent batches in flight: P HIP graphs replayed round-robin on P streams (1 = one stream; forward mode)")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-other-precisions", action="store_true", help="skip the x3 / exact-f32 throughput keys")
