@@ -261,13 +261,19 @@ def _grad_slot_empty(wleaf, token=None):
       * it will be STORED as the parameter's .grad, not added to an existing one (``p.grad is None``);
       * this node is the parameter's ONLY producer in the graphs alive now (a weight used twice -- a Siamese encoder, the encoder called
         twice before one backward -- has its two gradients summed by the engine on the MAIN stream as soon as both exist);
-      * the parameter carries no tensor hook and no post-accumulate-grad hook (they run on the main stream inside the pass).
+      * the parameter carries no tensor hook and no post-accumulate-grad hook (they run on the main stream inside the pass) -- except
+        hooks that declare ``_sonet_joins_side_streams`` (``sonet_hip.dp.GradientAllReducer``'s: it calls ``ops.join_side_streams()`` before it
+        touches any gradient: tests/dp_rccl_worker.py checks the step bit for bit against per-layer joins.  Measured on the final tree the
+        deferral is worth nothing either way any more -- 8.05-8.15 ms with and without, interleaved -- since the apply passes left the step).
     Hooks registered on the AccumulateGrad NODE from C++ (torch DistributedDataParallel's reducer) are not visible from here: under DDP
     set SONET_DEFER_WGRAD_JOIN=0 (training section); ``sonet_hip.dp.GradientAllReducer`` joins the side streams itself."""
     p = wleaf() if wleaf is not None else None
     if p is None or p.grad is not None:
         return False
-    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+    if getattr(p, "_backward_hooks", None):
+        return False
+    pah = getattr(p, "_post_accumulate_grad_hooks", None)
+    if pah and not all(getattr(h, "_sonet_joins_side_streams", False) for h in pah.values()):
         return False
     if token is None:
         return False

@@ -183,6 +183,9 @@ class GradientAllReducer:
                 _copy_all(self._views[self._next_launch], [self.params[j].grad for j in members])
                 self._work[self._next_launch] = dist.all_reduce(self._flat[bo:bo + bn], op=dist.ReduceOp.SUM, async_op=True)
                 self._next_launch += 1
+        # (models/layers.py ``_grad_slot_empty``: this hook joins the side streams before it reads a gradient, so a weight that carries it may
+        #  still leave its weight-gradient launch un-joined until the hook -- or the end of the pass -- comes)
+        hook._sonet_joins_side_streams = True
         return hook
 
     def no_sync(self):

@@ -58,6 +58,27 @@ def main():
         assert err <= 1e-6 * max(1.0, want.abs().max().item()), (step, err)
         if step >= 1:
             assert all(w is not None for w in red._work_done), "a bucket was not started from a gradient hook"
+    # The reducer's hooks sit on every weight: they join the side streams before they read a gradient, so the weight-gradient launches of the
+    # layers may still stay un-joined until then (models/layers.py _grad_slot_empty) -- the step must not change by a bit against per-layer joins.
+    from models import layers as L
+    from sonet_hip import ops
+    real, verdicts, res = L._grad_slot_empty, [], {}
+    L._grad_slot_empty = lambda w, t=None: (verdicts.append(real(w, t)) or verdicts[-1])
+    old = (ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL)
+    ops.H3_SEGPOOL = False                                                 # (the bit-reproducible form of the pooled layer)
+    try:
+        for flag in (True, False):
+            ops.DEFER_WGRAD_JOIN = flag
+            torch.manual_seed(7)                                           # the same dropout masks in both passes
+            del verdicts[:]
+            backward()
+            red.reduce()
+            res[flag] = (torch.cat([p.grad.reshape(-1) for p in live]).clone(), sum(verdicts))
+    finally:
+        L._grad_slot_empty = real
+        ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL = old
+    assert res[True][1] >= 4, "no weight deferred its join although only the reducer's own hooks are attached (%d)" % res[True][1]
+    assert torch.equal(res[True][0], res[False][0]), "deferred joins under the reducer's hooks changed the gradients"
     dead = [n for n, p in enc.named_parameters() if p.grad is None]
     assert dead and all(n.startswith("transformer.") for n in dead), dead[:3]
     ms = red.exposed_ms()

@@ -467,6 +467,19 @@ def test_deferred_join_only_for_single_producer_hook_free_weights():
     assert not L._grad_slot_empty(ref, t7)
     h2.remove()
     del t7
+    # ... unless the hook declares that it joins the side streams itself before it reads a gradient (sonet_hip.dp.GradientAllReducer's does)
+    t7b = L._register_use(ref)
+    joins = lambda q: None                                   # noqa: E731
+    joins._sonet_joins_side_streams = True
+    h3 = p.register_post_accumulate_grad_hook(joins)
+    assert L._grad_slot_empty(ref, t7b)
+    t7c = L._register_use(ref)
+    h4 = p.register_post_accumulate_grad_hook(lambda q: None)   # one undeclared hook beside it: no deferral
+    del t7b
+    assert not L._grad_slot_empty(ref, t7c)
+    h3.remove()
+    h4.remove()
+    del t7c
     t8 = L._register_use(ref)
     p.grad = torch.zeros_like(p)
     assert not L._grad_slot_empty(ref, t8)                   # accumulation into an existing .grad happens on the main stream
