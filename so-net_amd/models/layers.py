@@ -230,10 +230,11 @@ def _leaf_of(weight2d):
 class _UseToken:
     """One forward use of a weight by a node whose backward launches its weight gradient on the side stream.  It lives as long as the
     node's context (i.e. the autograd graph) does; ``done`` once that node's backward has run."""
-    __slots__ = ("done", "__weakref__")
+    __slots__ = ("done", "task", "__weakref__")
 
     def __init__(self):
         self.done = False
+        self.task = -1                        # id of the autograd pass (graph task) its backward ran in
 
 
 def _register_use(wleaf):
@@ -279,13 +280,17 @@ def _grad_slot_empty(wleaf, token=None):
         return False
     if token.done:                            # (a second backward through a retained graph: be conservative)
         return False
-    token.done = True
+    task = _ops._graph_task_id() if _ops._graph_task_id is not None else -1
+    token.done, token.task = True, task
     live = getattr(p, "_sonet_uses", None)
     if live is None:
         return False
-    # (ANY other live use counts, also one whose backward has already run in this pass: the engine adds the two gradients on the main stream
-    #  as soon as the second exists, so neither producer of a shared weight may leave its launch un-joined)
-    return not any(t is not token for t in live)
+    # Another live use counts when its backward has not run yet OR has run in THIS pass: the engine adds the two gradients on the main stream
+    # as soon as the second exists, so neither producer of a shared weight may leave its launch un-joined.  A use whose backward ran in an
+    # EARLIER pass does not count: an ordinary training loop keeps the previous step's loss -- and with it that step's graph nodes and their
+    # tokens -- alive while the next step runs (``loss, n = step()``), which switched the deferral off for every step but the first.
+    # (Outside an autograd pass, or on a torch without the graph-task query, passes cannot be told apart: every other live use counts.)
+    return not any((t is not token) and (not t.done or task == -1 or t.task == -1 or t.task == task) for t in live)
 
 
 class _Materialise(torch.autograd.Function):

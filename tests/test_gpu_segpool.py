@@ -422,6 +422,55 @@ def test_shared_weights_and_hooked_weights_join_their_side_streams_in_time():
         assert torch.equal(x, y)
 
 
+def test_deferred_join_survives_a_training_loop_that_keeps_the_previous_loss():
+    """``loss = step()`` keeps the previous step's loss -- its graph nodes and their use tokens -- alive while the next step runs.  Those uses ran
+    in an EARLIER pass and must not switch the deferral off (round 6: they did, for every step but the first); the gradients of every step
+    are bit-identical to per-layer joins."""
+    from models import layers as L
+    from models import networks as NW
+    from sonet_hip import ops, synth
+    B, N = 6, 2200
+    out, counts = {}, {}
+    real = L._grad_slot_empty
+    old = (ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL)
+    try:
+        ops.H3_SEGPOOL = False                                     # (bit-reproducible path)
+        with ops.precision("h3"):
+            for flag in (True, False):
+                ops.DEFER_WGRAD_JOIN = flag
+                verdicts = []
+                L._grad_slot_empty = lambda w, t=None, v=verdicts: (v.append(real(w, t)) or v[-1])
+                opt = _opt(B, N)
+                enc, cls = NW.Encoder(opt), NW.Classifier(opt)
+                enc.want_first_pn_out = False
+                synth.fill_state_dict_(enc.state_dict(), 3)
+                synth.fill_state_dict_(cls.state_dict(), 4)
+                enc.to(DEV).train()
+                cls.to(DEV).train()
+                a = synth.make_inputs(B, N, seed=9, device=torch.device(DEV))
+                torch.manual_seed(3)
+                loss, grads, per_step = None, [], []
+                for it in range(3):
+                    del verdicts[:]
+                    feat = enc(a["pc"], a["sn"], a["node"], a["node_knn_I"], is_train=True, epoch=0)
+                    enc.zero_grad(set_to_none=True)
+                    cls.zero_grad(set_to_none=True)
+                    new_loss = torch.nn.functional.cross_entropy(cls(feat, 0), a["label"])
+                    new_loss.backward()                            # (the previous step's ``loss`` is still alive here)
+                    loss = new_loss
+                    per_step.append(sum(verdicts))
+                    grads.append({k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(cls.named_parameters()) if p.grad is not None})
+                out[flag], counts[flag] = grads, per_step
+    finally:
+        L._grad_slot_empty = real
+        ops.DEFER_WGRAD_JOIN, ops.H3_SEGPOOL = old
+    assert counts[True][0] >= 4 and counts[True][1] == counts[True][0] and counts[True][2] == counts[True][0], counts
+    for it in range(3):
+        assert out[True][it].keys() == out[False][it].keys()
+        for k in out[True][it]:
+            assert torch.equal(out[True][it][k], out[False][it][k]), (it, k)
+
+
 # ------------------------------------------------------------------------------------------ BatchNorm backward on load
 @pytest.mark.parametrize("B,C,Cout,L,relu", [(64, 256, 128, 15000, True), (8, 128, 64, 4100, True), (3, 512, 512, 577, False), (2, 48, 96, 131, True)])
 def test_dgrad_with_batchnorm_backward_on_load_equals_apply_then_dgrad(B, C, Cout, L, relu):
