@@ -1031,10 +1031,10 @@ int cu_count() {
 
 // Persistent grid: one workgroup per CU.  A workgroup owns a whole CU (512 registers per lane), so nothing of another stream runs beside it.
 // Leaving CUs out for the other graphs' small launches was measured and is slower (docs/findings.md R6.1: 3776 tiles walk in 15 rounds on
-// 252 workgroups as on 256, and the headline still lost 1.5-2 %; 8 / 12 / 20 CUs out: -1 to -3 %), so the knob stays an experiment:
+// 252 workgroups as on 256, and the headline still lost 1.5-2 %; 8 / 12 / 20 CUs out: -1 to -3 %), so the knob stays an experiment of the VARIANTS build:
 // SONET_FUSED_FREE_CUS = k leaves at least k CUs out, -1 = the smallest grid with the same number of rounds.
 long long persistent_grid(long long ntiles, int cus) {
-    static const int free_cus = [] { const char *e = getenv("SONET_FUSED_FREE_CUS"); return e ? atoi(e) : 0; }();
+    static const int free_cus = [] { const char *e = sonet::knob("SONET_FUSED_FREE_CUS"); return e ? atoi(e) : 0; }();   // (variants build only)
     if (ntiles <= cus) return ntiles;
     if (free_cus == 0) return cus;
     const long long rounds = (ntiles + cus - 1) / cus;
