@@ -264,8 +264,8 @@ def _grad_slot_empty(wleaf, token=None):
         twice before one backward -- has its two gradients summed by the engine on the MAIN stream as soon as both exist);
       * the parameter carries no tensor hook and no post-accumulate-grad hook (they run on the main stream inside the pass) -- except
         hooks that declare ``_sonet_joins_side_streams`` (``sonet_hip.dp.GradientAllReducer``'s: it calls ``ops.join_side_streams()`` before it
-        touches any gradient: tests/dp_rccl_worker.py checks the step bit for bit against per-layer joins.  Measured on the final tree the
-        deferral is worth nothing either way any more -- 8.05-8.15 ms with and without, interleaved -- since the apply passes left the step).
+        touches any gradient: tests/dp_rccl_worker.py checks the step bit for bit against per-layer joins).  The deferral is worth 0.3 ms of
+        the 7.75 ms f32-class step and 0.1 ms of the bf16 step (docs/findings.md R6.5).
     Hooks registered on the AccumulateGrad NODE from C++ (torch DistributedDataParallel's reducer) are not visible from here: under DDP
     set SONET_DEFER_WGRAD_JOIN=0 (training section); ``sonet_hip.dp.GradientAllReducer`` joins the side streams itself."""
     p = wleaf() if wleaf is not None else None
