@@ -1588,35 +1588,41 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
             }
         }
         if constexpr (sizeof(TX) == 2) {
-            if (xs != nullptr) {
-                // bf16 rows (PW_R == 2: channels ci0, ci0 + 1, back to back in memory and in LDS): act(raw * xs + xh) in f32, ReLU, one
-                // round-to-nearest-even back to bf16 -- sonet_channel_affine_act_bf16's arithmetic -- element by element (a 16-byte piece may
-                // straddle the two rows: the channel is chosen per element)
-                const float s0 = xs[ci0], h0 = xh[ci0];
-                const float s1 = nr > 1 ? xs[ci0 + 1] : 0.f, h1 = nr > 1 ? xh[ci0 + 1] : 0.f;
-                auto act16 = [&](unsigned v, bool second) -> unsigned {
-                    float f = __fmaf_rn(__uint_as_float(v << 16), second ? s1 : s0, second ? h1 : h0);
-                    if (xrelu && f < 0.f) f = 0.f;
-                    return bf_pack(f, 0.f) & 0xFFFFu;
-                };
-                if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
-                    const uint4 *x4 = reinterpret_cast<const uint4 *>(xb);
-                    uint4 *r4 = reinterpret_cast<uint4 *>(rows);
-                    for (int i = threadIdx.x; i < (int)(nbytes >> 4); i += blockDim.x) {
-                        const uint4 t = x4[i];
-                        unsigned d[4] = {t.x, t.y, t.z, t.w};
+            // bf16 rows (PW_R == 2: channels ci0, ci0 + 1) sit INTERLEAVED in LDS, one dword per column = (row ci0 | row ci0 + 1 << 16): an entry
+            // costs ONE LDS read for both rows (round 6; two 2-byte reads before -- the multiply is bound by its LDS reads).  The values and
+            // the order of the fmas are unchanged: bit-identical sums.  With xs / xh the rows are normalised on the way in: act(raw * xs + xh)
+            // in f32, ReLU, one round-to-nearest-even back to bf16 -- sonet_channel_affine_act_bf16's arithmetic.
+            const float s0 = xs ? xs[ci0] : 1.f, h0 = xs ? xh[ci0] : 0.f;
+            const float s1 = (xs && nr > 1) ? xs[ci0 + 1] : 1.f, h1 = (xs && nr > 1) ? xh[ci0 + 1] : 0.f;
+            auto act16 = [&](unsigned v, bool second) -> unsigned {
+                if (xs == nullptr) return v;
+                float f = __fmaf_rn(__uint_as_float(v << 16), second ? s1 : s0, second ? h1 : h0);
+                if (xrelu && f < 0.f) f = 0.f;
+                return bf_pack(f, 0.f) & 0xFFFFu;
+            };
+            unsigned *pairs = reinterpret_cast<unsigned *>(rows_raw);
+            const uint16_t *x0 = reinterpret_cast<const uint16_t *>(xb), *x1r = x0 + L;
+            if ((L & 7) == 0 && ((size_t)xb & 15) == 0) {
+                const uint4 *a4 = reinterpret_cast<const uint4 *>(x0), *b4 = reinterpret_cast<const uint4 *>(x1r);
+                uint4 *p4 = reinterpret_cast<uint4 *>(pairs);
+                for (int i = threadIdx.x; i < (L >> 3); i += blockDim.x) {          // eight columns of both rows per thread
+                    const uint4 ta = a4[i];
+                    const uint4 tb = nr > 1 ? b4[i] : make_uint4(0u, 0u, 0u, 0u);
+                    const unsigned da[4] = {ta.x, ta.y, ta.z, ta.w}, db[4] = {tb.x, tb.y, tb.z, tb.w};
+                    unsigned o[8];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int e = 8 * i + 2 * k;
-                            d[k] = act16(d[k] & 0xFFFFu, e >= L) | (act16(d[k] >> 16, e + 1 >= L) << 16);
-                        }
-                        r4[i] = make_uint4(d[0], d[1], d[2], d[3]);
+                    for (int k = 0; k < 4; ++k) {
+                        o[2 * k] = act16(da[k] & 0xFFFFu, false) | ((nr > 1 ? act16(db[k] & 0xFFFFu, true) : 0u) << 16);
+                        o[2 * k + 1] = act16(da[k] >> 16, false) | ((nr > 1 ? act16(db[k] >> 16, true) : 0u) << 16);
                     }
-                } else {
-                    for (int i = threadIdx.x; i < nr * L; i += blockDim.x) rows[i] = (TX)act16((unsigned)xb[i], i >= L);
+                    p4[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+                    p4[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
                 }
-                copied = true;
+            } else {
+                for (int i = threadIdx.x; i < L; i += blockDim.x)
+                    pairs[i] = act16((unsigned)x0[i], false) | ((nr > 1 ? act16((unsigned)x1r[i], true) : 0u) << 16);
             }
+            copied = true;
         }
         if (copied) {
         } else if ((nbytes & 15) == 0 && ((size_t)xb & 15) == 0) {
@@ -1634,8 +1640,13 @@ __global__ __launch_bounds__(PW_T) void pooled_wgrad_kernel(const float *__restr
 #pragma unroll
             for (int m = 0; m < MH; ++m) {
                 if (pv[m] >= 0) {
-                    acc[0] = __fmaf_rn(gv[m], widen(rows[pv[m]]), acc[0]);
-                    if constexpr (PW_R > 1) { if (nr > 1) acc[1] = __fmaf_rn(gv[m], widen(rows[L + pv[m]]), acc[1]); }
+                    if constexpr (sizeof(TX) == 2) {
+                        const unsigned d = reinterpret_cast<const unsigned *>(rows_raw)[pv[m]];      // (row ci0 | row ci0 + 1 << 16) of this column
+                        acc[0] = __fmaf_rn(gv[m], bf_lo(d), acc[0]);
+                        if (nr > 1) acc[1] = __fmaf_rn(gv[m], bf_hi(d), acc[1]);
+                    } else {
+                        acc[0] = __fmaf_rn(gv[m], widen(rows[pv[m]]), acc[0]);
+                    }
                 }
             }
             if (half == 1) {
